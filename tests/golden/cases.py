@@ -1,0 +1,97 @@
+"""Shared definition of the golden cases: shapes, seeds and the deterministic numpy input
+generator.  Used by ``make_golden.py`` (which runs the real reference on these inputs, in
+the build container only) and by the tests (which regenerate the same inputs anywhere and
+compare against the committed expected outputs).  Inputs come from numpy's PCG64 stream so
+they do not depend on the torch version."""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+from typing import Dict
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class Case:
+    name: str
+    B: int
+    N: int
+    D: int
+    Q: int
+    C: int
+    d_out: int = 1
+    seed: int = 0
+    strided: bool = False       # x is a [:, 1:] view of a (B, N+1, D) buffer (models_more.py:24)
+    full: bool = True           # store full-size gradients (small shapes) or subsamples
+    steps: int = 3              # optimizer steps recorded
+    weight_decay: float = 0.0
+    big_scores: bool = False    # scale cls_token up so the softmax is far from uniform
+
+
+CASES = [
+    Case("tiny_q1", B=4, N=17, D=64, Q=1, C=10, seed=0),
+    Case("tiny_q4", B=4, N=17, D=64, Q=4, C=10, seed=1, weight_decay=1e-4),
+    Case("tiny_q8", B=4, N=17, D=64, Q=8, C=10, seed=0, big_scores=True),
+    Case("tiny_q4_dout2", B=4, N=17, D=64, Q=4, C=10, d_out=2, seed=1),
+    Case("tiny_strided", B=3, N=16, D=64, Q=4, C=7, seed=2, strided=True),
+    Case("vits_c100", B=4, N=196, D=384, Q=1, C=100, seed=0, full=False, steps=1),          # BASELINE config 1
+    Case("vitb16_q8", B=8, N=197, D=768, Q=8, C=1000, seed=0, full=False, steps=1),          # north-star shape
+    Case("vitb14_q8", B=4, N=256, D=768, Q=8, C=1000, seed=1, full=False, steps=1,
+         big_scores=True),                                                                  # BASELINE config 2
+    Case("so400m_q8", B=4, N=256, D=1152, Q=8, C=1000, seed=1, full=False, steps=1),         # BASELINE config 4
+    Case("vitl_q32_dout2", B=4, N=196, D=1024, Q=32, C=1000, d_out=2, seed=0, full=False, steps=1),
+]
+CASE_BY_NAME = {c.name: c for c in CASES}
+
+# subsampling strides for the large gradient tensors of ``full=False`` cases
+SUB_ROWS = 16
+
+
+def make_inputs(case: Case) -> Dict[str, np.ndarray]:
+    """Deterministic inputs + parameters for a case (float32; targets int64)."""
+    rng = np.random.default_rng(1000 + case.seed)
+    Dp = case.D // case.d_out
+    n_alloc = case.N + 1 if case.strided else case.N
+    x_buf = rng.standard_normal((case.B, n_alloc, case.D), dtype=np.float32)
+    cls_scale = 2.0 if case.big_scores else 0.02
+    cls_token = (cls_scale * rng.standard_normal((1, case.Q, case.D), dtype=np.float32)).astype(np.float32)
+    bound_v = 1.0 / np.sqrt(case.D)
+    v_weight = rng.uniform(-bound_v, bound_v, (Dp, case.D)).astype(np.float32)
+    bound_c = 1.0 / np.sqrt(Dp)
+    fc_weight = rng.uniform(-bound_c, bound_c, (case.C, Dp)).astype(np.float32)
+    fc_bias = rng.uniform(-bound_c, bound_c, (case.C,)).astype(np.float32)
+    targets = rng.integers(0, case.C, size=(case.B,), dtype=np.int64)
+    # a second batch for multi-step runs (steps alternate between the two batches)
+    x_buf2 = rng.standard_normal((case.B, n_alloc, case.D), dtype=np.float32)
+    targets2 = rng.integers(0, case.C, size=(case.B,), dtype=np.int64)
+    return dict(x_buf=x_buf, x_buf2=x_buf2, cls_token=cls_token, v_weight=v_weight,
+                fc_weight=fc_weight, fc_bias=fc_bias, targets=targets, targets2=targets2)
+
+
+def view_tokens(case: Case, x_buf: np.ndarray) -> np.ndarray:
+    """The token tensor the head sees: the whole buffer, or the patch-token view."""
+    return x_buf[:, 1:] if case.strided else x_buf
+
+
+def sub(a: np.ndarray) -> np.ndarray:
+    """Row subsample used for the big gradient / parameter tensors."""
+    return np.ascontiguousarray(a.reshape(-1, a.shape[-1])[::SUB_ROWS])
+
+
+# the lr schedule points pinned in the fixture: (epoch_float, lr, min_lr, warmup, epochs)
+LR_POINTS = [
+    (0.0, 1.6, 0.0, 10, 90), (0.5, 1.6, 0.0, 10, 90), (3.25, 1.6, 0.0, 10, 90),
+    (9.999, 1.6, 0.0, 10, 90), (10.0, 1.6, 0.0, 10, 90), (10.5, 1.6, 0.0, 10, 90),
+    (45.0, 1.6, 0.0, 10, 90), (89.99, 1.6, 0.0, 10, 90), (50.0, 0.8, 1e-3, 5, 100),
+    (0.0, 0.1, 0.0, 0, 30), (29.0, 0.1, 1e-6, 0, 30),
+]
+
+# step lrs used for the recorded optimizer steps (warm-up point, plateau, cosine point)
+STEP_LRS = [0.16, 1.6, 0.8]
+
+INIT_DIMS = [(384, 1, 1, 100), (768, 8, 1, 1000), (768, 32, 1, 1000), (1024, 8, 2, 1000),
+             (1152, 32, 1, 1000)]      # (dim, ep_queries, d_out, nb_classes)
+
+
+def case_dict(case: Case) -> dict:
+    return asdict(case)

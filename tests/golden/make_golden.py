@@ -1,0 +1,267 @@
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at /root/reference)
+on the deterministic inputs of ``cases.py``.
+
+Runs only in the build container (the reference does not travel to the GPU box); the
+committed ``.npz`` files are data: inputs are regenerated from seeds, expected outputs are
+stored.  Usage:  python tests/golden/make_golden.py
+
+What is imported from the reference: ``probe_heads`` (registry + build_probe_head, through
+a two-package import stub for the absent ``timm``/``torchvision``), ``poolings.ep``,
+``util.lars``, ``util.lr_sched``.  BatchNorm1d / Linear / CrossEntropyLoss / SGD /
+GradScaler are stock torch, exactly as the reference uses them.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = os.environ.get("EP_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub)  # noqa: E402
+
+
+def _stub_missing_packages():
+    """timm / torchvision are absent here; probe_heads only needs the names to exist
+    (SURVEY.md section 8c)."""
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+    timm = mod("timm"); models = mod("timm.models"); vt = mod("timm.models.vision_transformer")
+    layers = mod("timm.models.layers")
+    timm.models = models; models.vision_transformer = vt; models.layers = layers
+    vt.VisionTransformer = type("VisionTransformer", (torch.nn.Module,), {})
+    vt.Mlp = type("Mlp", (torch.nn.Module,), {})
+    layers.drop_path = lambda x, *a, **k: x
+    layers.DropPath = type("DropPath", (torch.nn.Module,), {})
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    tv = mod("torchvision"); ops = mod("torchvision.ops"); misc = mod("torchvision.ops.misc")
+    tv.ops = ops; ops.misc = misc
+    misc.FrozenBatchNorm2d = type("FrozenBatchNorm2d", (torch.nn.Module,), {})
+
+
+_stub_missing_packages()
+import probe_heads                                   # noqa: E402  (reference)
+from poolings.ep import EfficientProbing             # noqa: E402  (reference)
+from util.lars import LARS                           # noqa: E402  (reference)
+from util.lr_sched import adjust_learning_rate       # noqa: E402  (reference)
+
+
+class StubEncoder(torch.nn.Module):
+    """What build_probe_head needs from an encoder (tools/inv_heads.py:53-60)."""
+    def __init__(self, dim, nb_classes):
+        super().__init__()
+        self.embed_dim = dim
+        self.patch_embed = Namespace(num_patches=196)
+        self.head = torch.nn.Linear(dim, nb_classes)
+
+
+def ref_args(case_or=None, **kw):
+    a = Namespace(cls_features="ep", ep_queries=32, d_out=1, nb_classes=1000, num_heads=16,
+                  abmilp_sa="both", abmilp_act="tanh", abmilp_depth=2, abmilp_cond=None,
+                  abmilp_content="all", model="vit_base_patch16")
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def build_ref_head(dim, Q, d_out, C, cls_features="ep"):
+    enc = StubEncoder(dim, C)
+    probe_heads.build_probe_head(enc, ref_args(cls_features=cls_features, ep_queries=Q,
+                                               d_out=d_out, nb_classes=C))
+    return enc.head
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+
+def load_params(head, inp):
+    with torch.no_grad():
+        head[0].cls_token.copy_(torch.from_numpy(inp["cls_token"]))
+        head[0].v.weight.copy_(torch.from_numpy(inp["v_weight"]))
+        head[2].weight.copy_(torch.from_numpy(inp["fc_weight"]))
+        head[2].bias.copy_(torch.from_numpy(inp["fc_bias"]))
+
+
+def topk_acc(output, target, topk=(1, 5)):
+    """timm.utils.accuracy (timm 0.9.16), restated because timm is absent:
+    maxk = min(max(topk), C); topk -> compare -> correct[:k].sum() * 100 / B."""
+    maxk = min(max(topk), output.size(1))
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand_as(pred.t()))
+    return [float(correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100.0 / target.size(0)) for k in topk]
+
+
+def run_case(case, optimizer_name="lars"):
+    inp = make_inputs(case)
+    out = {}
+    torch.manual_seed(0)
+    head = build_ref_head(case.D, case.Q, case.d_out, case.C)
+    load_params(head, inp)
+    head.train()
+    if optimizer_name == "lars":
+        opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
+    else:
+        opt = torch.optim.SGD(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
+    crit = torch.nn.CrossEntropyLoss()
+    keep = (lambda a: a) if case.full else sub
+    names = ["cls_token", "v_weight", "fc_weight", "fc_bias"]
+    plist = [head[0].cls_token, head[0].v.weight, head[2].weight, head[2].bias]
+    for step in range(case.steps):
+        xb = inp["x_buf"] if step % 2 == 0 else inp["x_buf2"]
+        tg = inp["targets"] if step % 2 == 0 else inp["targets2"]
+        x = torch.from_numpy(view_tokens(case, xb))          # non-contiguous when strided
+        t = torch.from_numpy(tg)
+        lr = STEP_LRS[step % len(STEP_LRS)]
+        for g in opt.param_groups:
+            g["lr"] = lr
+        opt.zero_grad()
+        pooled = head[0](x)
+        z = head[1](pooled)
+        logits = head[2](z)
+        loss = crit(logits, t)
+        loss.backward()
+        if step == 0 and optimizer_name == "lars":
+            a1, a5 = topk_acc(logits, t)
+            attn = ((head[0].cls_token * case.D ** -0.5) @ x.transpose(1, 2)).softmax(-1)
+            out.update(pooled=pooled.detach().numpy(), z=z.detach().numpy(),
+                       logits=logits.detach().numpy(), loss=np.float32(loss.item()),
+                       acc1=np.float32(a1), acc5=np.float32(a5),
+                       attn=attn.detach().numpy())
+            for n, p in zip(names, plist):
+                g = p.grad.detach().numpy()
+                out[f"grad_{n}"] = g if n in ("cls_token", "fc_bias") else keep(g)
+                out[f"gradnorm_{n}"] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        tag = f"{optimizer_name}{step + 1}"
+        out[f"{tag}_loss"] = np.float32(loss.item())
+        for n, p in zip(names, plist):
+            a = p.detach().numpy().copy()
+            out[f"{tag}_{n}"] = a if n in ("cls_token", "fc_bias") else keep(a)
+            if optimizer_name == "lars":
+                mu = opt.state[p]["mu"].numpy().copy()
+                out[f"{tag}_mu_{n}"] = mu if n in ("cls_token", "fc_bias") else keep(mu)
+        out[f"{tag}_running_mean"] = head[1].running_mean.numpy().copy()
+        out[f"{tag}_running_var"] = head[1].running_var.numpy().copy()
+        out[f"{tag}_nbt"] = np.int64(head[1].num_batches_tracked.item())
+    if optimizer_name == "lars":
+        head.eval()
+        with torch.no_grad():
+            x = torch.from_numpy(view_tokens(case, inp["x_buf"]))
+            out["eval_logits"] = head(x).numpy()
+    return out
+
+
+def init_fixture():
+    """Initial weights of the head under torch.manual_seed(0), the way
+    tools/inv_heads.py:102-120 fingerprints them."""
+    rec = {}
+    for dim, Q, d_out, C in INIT_DIMS:
+        torch.manual_seed(0)
+        head = build_ref_head(dim, Q, d_out, C)
+        key = f"d{dim}_q{Q}_o{d_out}_c{C}"
+        sd = head.state_dict()
+        rec[key] = {
+            "repr": repr(head),
+            "keys": {k: list(v.shape) for k, v in sd.items()},
+            "sha256": {k: sha(v) for k, v in sd.items()},
+            "head8": {k: v.flatten()[:8].double().tolist() for k, v in sd.items()},
+            "n_trainable": int(sum(p.numel() for p in head.parameters())),
+        }
+    return rec
+
+
+def lr_fixture():
+    rows = []
+    for ep, lr, min_lr, warm, epochs in LR_POINTS:
+        opt = Namespace(param_groups=[{"lr": -1.0}, {"lr": -1.0, "lr_scale": 0.5}])
+        got = adjust_learning_rate(opt, ep, Namespace(lr=lr, min_lr=min_lr, warmup_epochs=warm, epochs=epochs))
+        rows.append(dict(epoch=ep, lr=lr, min_lr=min_lr, warmup=warm, epochs=epochs, out=got,
+                         group0=opt.param_groups[0]["lr"], group1=opt.param_groups[1]["lr"]))
+    return rows
+
+
+def lars_edge_fixture():
+    """util/lars.py:26-29 edge cases: zero update norm, zero param norm, 1-D tensors."""
+    out = {}
+    rng = np.random.default_rng(7)
+    p2 = torch.nn.Parameter(torch.from_numpy(rng.standard_normal((5, 6), dtype=np.float32)))
+    pz = torch.nn.Parameter(torch.zeros(4, 3))                      # ||p|| == 0 -> ratio 1
+    pg0 = torch.nn.Parameter(torch.from_numpy(rng.standard_normal((3, 4), dtype=np.float32)))  # grad 0
+    p1 = torch.nn.Parameter(torch.from_numpy(rng.standard_normal((9,), dtype=np.float32)))     # 1-D
+    p3 = torch.nn.Parameter(torch.from_numpy(rng.standard_normal((1, 2, 8), dtype=np.float32)))  # ndim 3
+    ps = [p2, pz, pg0, p1, p3]
+    gs = [rng.standard_normal(tuple(p.shape), dtype=np.float32) for p in ps]
+    gs[2] = np.zeros_like(gs[2])
+    opt = LARS(ps, lr=0.5, weight_decay=0.0)
+    for i, (p, g) in enumerate(zip(ps, gs)):
+        out[f"p{i}_before"] = p.detach().numpy().copy()
+        out[f"g{i}"] = g
+    for step in range(2):
+        for p, g in zip(ps, gs):
+            p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        for i, p in enumerate(ps):
+            out[f"p{i}_after{step + 1}"] = p.detach().numpy().copy()
+            out[f"mu{i}_after{step + 1}"] = opt.state[p]["mu"].numpy().copy()
+    # weight decay variant
+    ps2 = [torch.nn.Parameter(torch.from_numpy(out[f"p{i}_before"].copy())) for i in range(5)]
+    opt2 = LARS(ps2, lr=0.5, weight_decay=0.01)
+    for p, g in zip(ps2, gs):
+        p.grad = torch.from_numpy(g.copy())
+    opt2.step()
+    for i, p in enumerate(ps2):
+        out[f"wd_p{i}_after1"] = p.detach().numpy().copy()
+    return out
+
+
+def scaler_fixture():
+    """torch GradScaler (util/misc.py:263-277) scale trajectory with injected overflows."""
+    sc = torch.amp.GradScaler("cpu", init_scale=65536.0, growth_interval=4)
+    p = torch.nn.Parameter(torch.ones(3))
+    opt = torch.optim.SGD([p], lr=0.1)
+    traj, stepped = [], []
+    inf_at = {2, 3, 9}
+    for i in range(14):
+        opt.zero_grad()
+        coef = torch.full((3,), float("inf") if i in inf_at else 1.0)
+        before = p.detach().clone()
+        sc.scale((p * coef).sum()).backward()
+        sc.unscale_(opt)
+        sc.step(opt)
+        sc.update()
+        traj.append(sc.get_scale())
+        stepped.append(bool((p.detach() != before).any()))
+    return dict(scale=traj, stepped=stepped, inf_at=sorted(inf_at), growth_interval=4)
+
+
+def main():
+    meta = {"torch": torch.__version__, "reference": REF, "cases": [c.name for c in CASES]}
+    for case in CASES:
+        out = run_case(case, "lars")
+        if case.full:
+            sgd = run_case(case, "sgd")
+            out.update({k: v for k, v in sgd.items() if k.startswith("sgd")})
+        path = os.path.join(HERE, f"ep_{case.name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
+    np.savez_compressed(os.path.join(HERE, "lars_edges.npz"), **lars_edge_fixture())
+    with open(os.path.join(HERE, "host_fixtures.json"), "w") as f:
+        json.dump(dict(meta=meta, init=init_fixture(), lr=lr_fixture(), scaler=scaler_fixture()),
+                  f, indent=1, sort_keys=True)
+    print("wrote host_fixtures.json, lars_edges.npz")
+
+
+if __name__ == "__main__":
+    main()
