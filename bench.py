@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""EP-head throughput benchmark (BASELINE.json metric: EP-head images/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration of the probe head on one batch of synthetic tokens
+already resident in HBM: EP pooling forward, per-query value projection, BatchNorm, classifier,
+cross-entropy, the whole backward, [one RCCL all-reduce of the flat gradients when N > 1], LARS
+update.  Default workload: BASELINE.json configs[1] (DINOv2 ViT-B/14 tokens 256x768, Q=8,
+1000 classes); ``--workload ns`` is the north-star shape (ViT-B/16, 197x768).
+
+One JSON line is printed by rank 0 (see the driver contract in the task statement) with two extra
+objects: ``roofline`` for the dominant kernel (the EP pooling forward pass, HBM-bound) measured
+live with HIP events, and ``cpu_baseline`` = the op-for-op torch-CPU port of the reference step
+(oracle/torch_port.py) timed on this box's host cores for a bounded ~15 s sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N tokens, D, Q, classes, description)
+    "c2": (256, 768, 8, 1000, "DINOv2 ViT-B/14 tokens 256x768, EP q=8, 1000 classes (BASELINE configs[1])"),
+    "ns": (197, 768, 8, 1000, "ViT-B/16 tokens 197x768, EP q=8, 1000 classes (north-star shape)"),
+    "c1": (196, 384, 1, 100, "DINO ViT-S/16 tokens 196x384, EP q=1, 100 classes (BASELINE configs[0])"),
+    "c3": (196, 1024, 8, 1000, "MAE ViT-L/16 tokens 196x1024, EP q=8 (BASELINE configs[2])"),
+    "c4": (256, 1152, 8, 1000, "SigLIP2 SO400M/14 tokens 256x1152, EP q=8 (BASELINE configs[3])"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--buffers", type=int, default=4, help="distinct token buffers rotated through (HBM, not cache)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--kernel-iters", type=int, default=20)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from argparse import Namespace
+    from efficient_probing_amd import probe_heads, functional as F_
+    from efficient_probing_amd.engine import ProbeHeadEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    Nn, D, Q, Cc, desc = WORKLOADS[args.workload]
+    B = args.batch
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(D, Cc)
+    torch.manual_seed(0)                                   # same init on every rank (DDP broadcasts rank 0's)
+    enc = Enc()
+    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc))
+    head = enc.head.to(dev).train()
+    lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
+    eng = ProbeHeadEngine(head, optimizer="lars", lr=lr, weight_decay=0.0)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    xs = [torch.randn(B, Nn, D, device=dev, generator=gen) for _ in range(args.buffers)]
+    ts = [torch.randint(0, Cc, (B,), device=dev, generator=gen) for _ in range(args.buffers)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+    eng.read_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_sum, top1, _, bad = eng.read_stats()
+
+    # ---- dominant kernel: EP pooling passes, timed alone with HIP events on the launch stream ----
+    def time_kernel(fn, iters):
+        fn(0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+    cls = head[0].cls_token.detach()
+    scale = head[0].scale
+    keep = {}
+
+    def run_fwd(i):
+        keep["out"] = F_.pool_forward(xs[i % args.buffers], cls, scale)
+    t_fwd = time_kernel(run_fwd, args.kernel_iters)
+    P, S, ML = keep["out"]
+    dP = torch.randn_like(P)
+    ML[:, :, 2] = 0.0
+    ws_bytes = eng.lib.ep_pool_workspace_bytes(B, Nn, D, Q)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    dcls = torch.empty(Q, D, device=dev)
+    from efficient_probing_amd import _native as N_
+    stream = N_.current_stream_ptr(dev)
+
+    def run_bwd(i):
+        x = xs[i % args.buffers]
+        N_.check(eng.lib.ep_pool_backward(x.data_ptr(), 0, Nn * D, B, Nn, D, Q, float(scale), S.data_ptr(), ML.data_ptr(),
+                                          dP.data_ptr(), dcls.data_ptr(), 0, ws.data_ptr(), ws_bytes, stream), "bwd")
+    t_bwd = time_kernel(run_bwd, args.kernel_iters)
+
+    algo_bytes = B * Nn * D * 4                               # one streaming read of the fp32 tokens
+    fwd_gbs = algo_bytes / t_fwd / 1e9
+    bwd_gbs = algo_bytes / t_bwd / 1e9
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        out = {
+            "metric": "EP-head train images/sec", "value": round(value, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B,
+                       "global_batch": B * world, "optimizer": "lars", "token_buffers": args.buffers,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": "ep_pool_fwd_kernel", "achieved": round(fwd_gbs, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fwd_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes": algo_bytes,
+                         "bwd_kernel": {"kernel": "ep_pool_bwd_kernel", "achieved": round(bwd_gbs, 1),
+                                        "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
+                                        "us_per_launch": round(t_bwd * 1e6, 2)},
+                         "step_frac": round(value / world * 2 * Nn * D * 4 / 1e9 / HBM_PEAK_GBS, 4)},
+            "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, args.steps), 5),
+                      "nonfinite_rows": bad},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import torch_port
+            cb = max(8, min(128, B))
+            r = torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=args.cpu_seconds,
+                                            threads=os.cpu_count())
+            out["cpu_baseline"] = {"value": round(r["value"], 1), "unit": "images/s", "cores": r["threads"],
+                                   "kind": "port",
+                                   "sample": f"{r['steps']} train steps of batch {r['batch']} ({r['seconds']:.1f} s) "
+                                             f"of the same workload, torch-CPU op-for-op port of the reference step"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""ctypes binding of ``libep_hip.so`` (C ABI declared in ``include/ep_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing, or a kernel is asked
+to run without a GPU, this module raises -- loudly -- instead of silently computing the
+result some other way.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libep_hip.so")
+
+EP_DTYPE_F32 = 0
+EP_DTYPE_BF16 = 1
+
+c_f32p = C.c_void_p       # device pointers travel as integers (tensor.data_ptr())
+c_i64 = C.c_int64
+c_int = C.c_int
+c_float = C.c_float
+c_size = C.c_size_t
+c_void = C.c_void_p
+
+
+class EPSegment(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("apply_trust", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class EPHeadDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("Q", C.c_int32),
+                ("d_out", C.c_int32), ("C", C.c_int32)]
+
+
+class EPHeadStep(C.Structure):
+    _fields_ = [
+        ("dims", EPHeadDims),
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("targets", C.c_void_p),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("opt_state0", C.c_void_p), ("opt_state1", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("found_inf", C.c_void_p), ("grad_norm", C.c_void_p),
+        ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
+        ("grad_scale", C.c_float), ("inv_scale", C.c_float),
+        ("accumulate", C.c_int32), ("optimizer", C.c_int32),
+        ("lr", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float),
+        ("trust_coefficient", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("opt_step", C.c_int64),
+        ("phases", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ep_hip.h declares
+SIGNATURES = {
+    "ep_version": (c_int, []),
+    "ep_last_error_string": (C.c_char_p, []),
+    "ep_device_cu_count": (c_int, []),
+    "ep_debug_force_generic_pool": (c_int, [c_int]),
+    "ep_pool_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
+    "ep_pool_forward": (c_int, [c_void, c_int, c_i64, c_int, c_int, c_int, c_f32p, c_i64, c_int, c_float,
+                                c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),
+    "ep_pool_backward": (c_int, [c_void, c_int, c_i64, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p,
+                                 c_f32p, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_attention_from_scores": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_void]),
+    "ep_project_forward": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void]),
+    "ep_project_backward": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p,
+                                    c_f32p, c_f32p, c_int, c_void]),
+    "ep_bn_forward_train": (c_int, [c_f32p, c_int, c_int, c_float, c_float, c_f32p, c_f32p, c_f32p, c_f32p,
+                                    c_void, c_void]),
+    "ep_bn_forward_eval": (c_int, [c_f32p, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p, c_void]),
+    "ep_bn_backward": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_void]),
+    "ep_linear_forward": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_int, c_void]),
+    "ep_linear_backward": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p,
+                                   c_int, c_void]),
+    "ep_cross_entropy": (c_int, [c_f32p, c_int, c_void, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p, c_void]),
+    "ep_optim_workspace_bytes": (c_size, [c_i64, c_int]),
+    "ep_lars_step": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, C.POINTER(EPSegment), c_int, c_float, c_float,
+                             c_float, c_float, c_float, c_void, c_f32p, c_void, c_size, c_void]),
+    "ep_sgd_step": (c_int, [c_f32p, c_f32p, c_i64, c_float, c_float, c_float, c_void, c_f32p, c_void, c_size,
+                            c_void]),
+    "ep_adamw_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_float, c_float, c_float, c_float,
+                              c_float, c_float, c_void, c_f32p, c_void, c_size, c_void]),
+    "ep_head_param_offsets": (c_i64, [C.POINTER(EPHeadDims), C.POINTER(c_i64)]),
+    "ep_head_workspace_bytes": (c_size, [C.POINTER(EPHeadDims)]),
+    "ep_head_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),
+    "ep_head_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p,
+                                     c_float, c_f32p, c_int, c_void, c_size, c_void]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library.  Raises NativeLibraryError when it is absent:
+    build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+    ``efficient_probing_amd/csrc/build.sh``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run efficient_probing_amd/csrc/build.sh). "
+            "There is no CPU fallback for the EP head kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ep_last_error_string().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = "invalid argument" if rc < 0 else "HIP error"
+        raise RuntimeError(f"{what} failed ({kind} {rc}): {last_error()}")
+
+
+def require_gpu_tensor(t, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the EP head kernels have no CPU path "
+                           f"(got device {t.device})")
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

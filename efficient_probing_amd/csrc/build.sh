@@ -1,0 +1,19 @@
+#!/usr/bin/env bash
+# Build libep_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../libep_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -Wno-unused-variable"
+objs=()
+for f in ep_pool ep_gemm ep_tail ep_optim ep_api; do
+  src="${here}/${f}.hip"; obj="${here}/${f}.o"
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "${here}/ep_common.h" -nt "$obj" || "${here}/ep_internal.h" -nt "$obj" || "${here}/../../include/ep_hip.h" -nt "$obj" ]]; then
+    echo "[build] hipcc ${f}.hip" >&2
+    "$HIPCC" $FLAGS ${EP_EXTRA_FLAGS:-} -c "$src" -o "$obj" &
+  fi
+  objs+=("$obj")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "[build] $out" >&2

@@ -1,0 +1,354 @@
+// extern "C" entry points of libep_hip.so (declared in include/ep_hip.h).
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include "ep_common.h"
+#include "ep_internal.h"
+
+namespace ep {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int cu_count() {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  cached = n;
+  return n;
+}
+
+static int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q) {
+  EP_REQUIRE(x != nullptr, EP_E_ARG, "x is null");
+  EP_REQUIRE(B > 0 && N > 0 && D > 0 && Q > 0, EP_E_ARG, "B, N, D, Q must be positive (got %d %d %d %d)", B, N, D, Q);
+  EP_REQUIRE(x_dtype == EP_DTYPE_F32, EP_E_UNSUPPORTED, "token dtype %d not implemented (fp32 only in this build)", x_dtype);
+  EP_REQUIRE(D % 4 == 0, EP_E_SHAPE, "D = %d must be a multiple of 4", D);
+  EP_REQUIRE(x_bstride >= (int64_t)N * D, EP_E_SHAPE, "batch stride %lld smaller than N*D", (long long)x_bstride);
+  EP_REQUIRE(aligned16(x) && x_bstride % 4 == 0, EP_E_ALIGN, "token buffer / batch stride must be 16-byte aligned");
+  return 0;
+}
+
+struct HeadWs {
+  float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *loss_rows, *dz, *dy, *dP;
+  void* pool_ws; size_t pool_ws_bytes;
+  void* opt_ws; size_t opt_ws_bytes;
+  int ldl;
+  size_t total;
+};
+
+static HeadWs carve(const ep_head_dims& d, void* base) {
+  HeadWs w{};
+  const int Dp = d.D / d.d_out;
+  w.ldl = (d.C + 3) / 4 * 4;
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += round_up(nfloat * sizeof(float), 256);
+    return p;
+  };
+  const size_t B = d.B;
+  w.P = take(B * d.Q * d.D);
+  w.S = take(B * d.Q * d.N);
+  w.ML = take(B * d.Q * 4);
+  w.y = take(B * Dp);
+  w.z = take(B * Dp);
+  w.rstd = take(Dp);
+  w.logits = take(B * w.ldl);
+  w.dlogits = take(B * w.ldl);
+  w.loss_rows = take(B);
+  w.dz = take(B * Dp);
+  w.dy = take(B * Dp);
+  w.dP = take(B * d.Q * d.D);
+  w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.Q);
+  w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
+  int64_t offs[4];
+  const int64_t total = ep_head_param_offsets(&d, offs);
+  w.opt_ws_bytes = optim_workspace_bytes(total, 4);
+  w.opt_ws = take(w.opt_ws_bytes / sizeof(float));
+  w.total = off;
+  return w;
+}
+
+static int check_dims(const ep_head_dims& d) {
+  EP_REQUIRE(d.B > 0 && d.N > 0 && d.D > 0 && d.Q > 0 && d.C > 0 && d.d_out > 0, EP_E_ARG, "head dims must be positive");
+  EP_REQUIRE(d.D % (d.d_out * d.Q) == 0, EP_E_SHAPE, "D %% (d_out*Q) != 0 (D=%d d_out=%d Q=%d) -- same constraint as reference ep.py:40", d.D, d.d_out, d.Q);
+  EP_REQUIRE((d.D / d.d_out) % 4 == 0 && d.D % 4 == 0, EP_E_SHAPE, "D and D/d_out must be multiples of 4");
+  return 0;
+}
+
+static PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale) {
+  PoolParams p{};
+  p.x = static_cast<const float*>(x); p.x_bstride = x_bstride; p.B = B; p.N = N; p.D = D; p.Q = Q; p.scale = scale;
+  return p;
+}
+
+static int project_forward(const float* P, const float* Wv, int B, int D, int Dp, int Q, float* y, hipStream_t st) {
+  const int Dq = Dp / Q;
+  GemmParams g{};
+  g.A = P; g.lda = (int64_t)Q * D; g.sAz = D;
+  g.B = Wv; g.ldb = D; g.sBz = (int64_t)Dq * D;
+  g.C = y; g.ldc = Dp; g.sCz = Dq;
+  g.M = B; g.N = Dq; g.K = D; g.alpha = 1.f; g.extA = D; g.extB = D;
+  return gemm(true, true, g, Q, st);
+}
+
+static int project_backward(const float* dy, const float* y, const float* P, const float* Wv, int B, int D, int Dp,
+                            int Q, float* dP, float* dWv, float* ML, int accumulate, hipStream_t st) {
+  const int Dq = Dp / Q;
+  if (ML && y) EP_TRY(delta_rows(dy, y, B * Q, Dq, ML, st));
+  if (dP) {
+    GemmParams g{};
+    g.A = dy; g.lda = Dp; g.sAz = Dq;
+    g.B = Wv; g.ldb = D; g.sBz = (int64_t)Dq * D; g.extB = D;
+    g.C = dP; g.ldc = (int64_t)Q * D; g.sCz = D;
+    g.M = B; g.N = D; g.K = Dq; g.alpha = 1.f;
+    EP_TRY(gemm(true, false, g, Q, st));
+  }
+  if (dWv) {
+    GemmParams g{};
+    g.A = dy; g.lda = Dp; g.sAz = Dq; g.extA = Dq;
+    g.B = P; g.ldb = (int64_t)Q * D; g.sBz = D; g.extB = D;
+    g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
+    g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate;
+    EP_TRY(gemm(false, false, g, Q, st));
+  }
+  return 0;
+}
+
+static int linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits,
+                          int ldl, hipStream_t st) {
+  GemmParams g{};
+  g.A = z; g.lda = Dp; g.B = Wc; g.ldb = Dp; g.C = logits; g.ldc = ldl; g.bias = bc;
+  g.M = B; g.N = C; g.K = Dp; g.alpha = 1.f;
+  return gemm(true, true, g, 1, st);
+}
+
+static int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, int B, int Dp, int C,
+                           float* dz, float* dWc, float* dbc, int accumulate, hipStream_t st) {
+  if (dz) {
+    GemmParams g{};
+    g.A = dl; g.lda = ldl; g.B = Wc; g.ldb = Dp; g.extB = Dp; g.C = dz; g.ldc = Dp;
+    g.M = B; g.N = Dp; g.K = C; g.alpha = 1.f;
+    EP_TRY(gemm(true, false, g, 1, st));
+  }
+  if (dWc) {
+    GemmParams g{};
+    g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
+    g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate;
+    EP_TRY(gemm(false, false, g, 1, st));
+  }
+  if (dbc) EP_TRY(colsum(dl, B, C, ldl, accumulate, dbc, st));
+  return 0;
+}
+
+}  // namespace ep
+
+using namespace ep;
+
+extern "C" {
+
+int ep_version(void) { return EP_ABI_VERSION; }
+const char* ep_last_error_string(void) { return g_err; }
+int ep_device_cu_count(void) { return cu_count(); }
+int ep_debug_force_generic_pool(int on) { return debug_force_generic(on); }
+
+size_t ep_pool_workspace_bytes(int B, int N, int D, int Q) { return pool_workspace_bytes(B, N, D, Q); }
+
+int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, const float* cls_token,
+                    int64_t cls_bstride, int Q, float scale, float* P, float* S, float* ML, void* workspace,
+                    size_t workspace_bytes, ep_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  EP_REQUIRE(cls_token && P && S && ML, EP_E_ARG, "ep_pool_forward: null pointer");
+  EP_REQUIRE(aligned16(cls_token) && aligned16(P) && aligned16(ML) && cls_bstride % 4 == 0, EP_E_ALIGN,
+             "ep_pool_forward: cls_token / P / ML must be 16-byte aligned");
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale);
+  p.cls = cls_token; p.cls_bstride = cls_bstride; p.P = P; p.S = S; p.ML = ML;
+  return pool_forward(p, (hipStream_t)stream);
+}
+
+int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q, float scale,
+                     const float* S, const float* ML, const float* dP, float* dcls, int accumulate, void* workspace,
+                     size_t workspace_bytes, ep_stream_t stream) {
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  EP_REQUIRE(S && ML && dP && dcls && workspace, EP_E_ARG, "ep_pool_backward: null pointer");
+  EP_REQUIRE(aligned16(dP) && aligned16(dcls) && aligned16(ML) && aligned16(workspace), EP_E_ALIGN,
+             "ep_pool_backward: dP / dcls / ML / workspace must be 16-byte aligned");
+  EP_REQUIRE(workspace_bytes >= pool_workspace_bytes(B, N, D, Q), EP_E_WORKSPACE,
+             "ep_pool_backward: workspace %zu < %zu", workspace_bytes, pool_workspace_bytes(B, N, D, Q));
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale);
+  p.S = const_cast<float*>(S); p.ML = const_cast<float*>(ML); p.dP = dP; p.Gpart = static_cast<float*>(workspace);
+  return pool_backward(p, dcls, accumulate, (hipStream_t)stream);
+}
+
+int ep_attention_from_scores(const float* S, const float* ML, int B, int Q, int N, float* A, ep_stream_t stream) {
+  EP_REQUIRE(S && ML && A && B > 0 && Q > 0 && N > 0, EP_E_ARG, "ep_attention_from_scores: bad argument");
+  return attention_from_scores(S, ML, B * Q, N, A, (hipStream_t)stream);
+}
+
+int ep_project_forward(const float* P, const float* Wv, int B, int D, int Dp, int Q, float* y, ep_stream_t stream) {
+  EP_REQUIRE(P && Wv && y && B > 0 && D > 0 && Dp > 0 && Q > 0, EP_E_ARG, "ep_project_forward: bad argument");
+  EP_REQUIRE(Dp % Q == 0, EP_E_SHAPE, "Dp %% Q != 0");
+  return project_forward(P, Wv, B, D, Dp, Q, y, (hipStream_t)stream);
+}
+
+int ep_project_backward(const float* dy, const float* y, const float* P, const float* Wv, int B, int D, int Dp,
+                        int Q, float* dP, float* dWv, float* ML, int accumulate, ep_stream_t stream) {
+  EP_REQUIRE(dy && P && Wv && B > 0 && D > 0 && Dp > 0 && Q > 0, EP_E_ARG, "ep_project_backward: bad argument");
+  EP_REQUIRE(Dp % Q == 0, EP_E_SHAPE, "Dp %% Q != 0");
+  return project_backward(dy, y, P, Wv, B, D, Dp, Q, dP, dWv, ML, accumulate, (hipStream_t)stream);
+}
+
+int ep_bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, ep_stream_t stream) {
+  EP_REQUIRE(y && z && rstd && running_mean && running_var && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_forward_train: bad argument");
+  return bn_forward_train(y, B, Dp, eps, momentum, z, rstd, running_mean, running_var, num_batches_tracked,
+                          (hipStream_t)stream);
+}
+int ep_bn_forward_eval(const float* y, int B, int Dp, float eps, const float* running_mean, const float* running_var,
+                       float* z, ep_stream_t stream) {
+  EP_REQUIRE(y && z && running_mean && running_var && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_forward_eval: bad argument");
+  return bn_forward_eval(y, B, Dp, eps, running_mean, running_var, z, (hipStream_t)stream);
+}
+int ep_bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, ep_stream_t stream) {
+  EP_REQUIRE(dz && z && rstd && dy && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_backward: bad argument");
+  return bn_backward(dz, z, rstd, B, Dp, dy, (hipStream_t)stream);
+}
+
+int ep_linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits, int ldl,
+                      ep_stream_t stream) {
+  EP_REQUIRE(z && Wc && logits && B > 0 && Dp > 0 && C > 0 && ldl >= C, EP_E_ARG, "ep_linear_forward: bad argument");
+  return linear_forward(z, Wc, bc, B, Dp, C, logits, ldl, (hipStream_t)stream);
+}
+int ep_linear_backward(const float* dlogits, int ldl, const float* z, const float* Wc, int B, int Dp, int C,
+                       float* dz, float* dWc, float* dbc, int accumulate, ep_stream_t stream) {
+  EP_REQUIRE(dlogits && z && Wc && B > 0 && Dp > 0 && C > 0 && ldl >= C, EP_E_ARG, "ep_linear_backward: bad argument");
+  return linear_backward(dlogits, ldl, z, Wc, B, Dp, C, dz, dWc, dbc, accumulate, (hipStream_t)stream);
+}
+
+int ep_cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
+                     float* loss_rows, float* dlogits, float* stats, ep_stream_t stream) {
+  EP_REQUIRE(logits && targets && B > 0 && C > 0 && ldl >= C, EP_E_ARG, "ep_cross_entropy: bad argument");
+  return cross_entropy(logits, ldl, targets, B, C, grad_scale, loss_rows, dlogits, stats, (hipStream_t)stream);
+}
+
+size_t ep_optim_workspace_bytes(int64_t total_numel, int num_segments) {
+  return optim_workspace_bytes(total_numel, num_segments);
+}
+int ep_lars_step(float* params, const float* grads, float* mu, int64_t total_numel, const ep_segment* segs_host,
+                 int num_segments, float lr, float weight_decay, float momentum, float trust_coefficient,
+                 float inv_scale, int32_t* found_inf, float* grad_norm_out, void* workspace, size_t workspace_bytes,
+                 ep_stream_t stream) {
+  return optim_step(0, params, grads, mu, nullptr, total_numel, segs_host, num_segments, lr, weight_decay, momentum,
+                    trust_coefficient, inv_scale, 0.f, 0.f, 0.f, 0, found_inf, grad_norm_out, workspace,
+                    workspace_bytes, (hipStream_t)stream);
+}
+int ep_sgd_step(float* params, const float* grads, int64_t total_numel, float lr, float weight_decay, float inv_scale,
+                int32_t* found_inf, float* grad_norm_out, void* workspace, size_t workspace_bytes, ep_stream_t stream) {
+  return optim_step(1, params, grads, nullptr, nullptr, total_numel, nullptr, 0, lr, weight_decay, 0.f, 0.f, inv_scale,
+                    0.f, 0.f, 0.f, 0, found_inf, grad_norm_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int ep_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t total_numel,
+                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float inv_scale,
+                  int32_t* found_inf, float* grad_norm_out, void* workspace, size_t workspace_bytes,
+                  ep_stream_t stream) {
+  return optim_step(2, params, grads, exp_avg, exp_avg_sq, total_numel, nullptr, 0, lr, weight_decay, 0.f, 0.f,
+                    inv_scale, beta1, beta2, eps, step, found_inf, grad_norm_out, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}
+
+int64_t ep_head_param_offsets(const ep_head_dims* d, int64_t offsets[4]) {
+  const int64_t Dp = d->D / d->d_out;
+  const int64_t sizes[4] = {(int64_t)d->Q * d->D, Dp * d->D, (int64_t)d->C * Dp, (int64_t)d->C};
+  int64_t off = 0;
+  for (int i = 0; i < 4; ++i) {
+    offsets[i] = off;
+    off += (sizes[i] + 3) / 4 * 4;
+  }
+  return off;
+}
+
+size_t ep_head_workspace_bytes(const ep_head_dims* dims) {
+  if (!dims || check_dims(*dims) != 0) return 0;
+  return carve(*dims, nullptr).total;
+}
+
+int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(s && ws, EP_E_ARG, "ep_head_train_step: null pointer");
+  const ep_head_dims& d = s->dims;
+  EP_TRY(check_dims(d));
+  EP_REQUIRE(aligned16(ws), EP_E_ALIGN, "workspace must be 16-byte aligned");
+  HeadWs w = carve(d, ws);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_train_step: workspace %zu < %zu", ws_bytes, w.total);
+  EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  hipStream_t st = (hipStream_t)stream;
+  const int Dp = d.D / d.d_out;
+  int64_t offs[4];
+  const int64_t total = ep_head_param_offsets(&d, offs);
+  float* cls = s->params + offs[0]; float* Wv = s->params + offs[1];
+  float* Wc = s->params + offs[2]; float* bc = s->params + offs[3];
+  const float scale = (float)pow((double)d.D, -0.5);   // head_dim ** -0.5 with num_heads = 1 (ep.py:19-20)
+  if (s->phases & 1) {
+    EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
+    EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.Q));
+    PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale);
+    p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML;
+    EP_TRY(pool_forward(p, st));
+    EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
+    EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
+                            s->num_batches_tracked, st));
+    EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
+    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, w.loss_rows, w.dlogits, s->stats, st));
+    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, s->grads + offs[2], s->grads + offs[3],
+                           s->accumulate, st));
+    EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, st));
+    EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, s->grads + offs[1], w.ML, s->accumulate, st));
+    p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
+    EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st));
+  }
+  if (s->phases & 2) {
+    EP_REQUIRE(s->found_inf, EP_E_ARG, "optimizer phase needs found_inf");
+    ep_segment segs[4];
+    const int64_t sizes[4] = {(int64_t)d.Q * d.D, (int64_t)Dp * d.D, (int64_t)d.C * Dp, (int64_t)d.C};
+    for (int i = 0; i < 4; ++i) segs[i] = ep_segment{offs[i], sizes[i], i < 3 ? 1 : 0, 0};   // bias: ndim 1
+    EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
+                      s->optimizer == 0 ? segs : nullptr, s->optimizer == 0 ? 4 : 0, s->lr, s->weight_decay,
+                      s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,
+                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st));
+  }
+  return 0;
+}
+
+int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, int64_t x_bstride, const float* params,
+                         const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
+                         void* ws, size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(dims && x && params && running_mean && running_var && logits && ws, EP_E_ARG, "ep_head_eval_forward: null pointer");
+  const ep_head_dims& d = *dims;
+  EP_TRY(check_dims(d));
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, d.B, d.N, d.D, d.Q));
+  HeadWs w = carve(d, ws);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_eval_forward: workspace %zu < %zu", ws_bytes, w.total);
+  EP_REQUIRE(ldl >= d.C, EP_E_ARG, "ldl < C");
+  hipStream_t st = (hipStream_t)stream;
+  const int Dp = d.D / d.d_out;
+  int64_t offs[4];
+  ep_head_param_offsets(&d, offs);
+  const float scale = (float)pow((double)d.D, -0.5);
+  PoolParams p = pool_params(x, x_bstride, d.B, d.N, d.D, d.Q, scale);
+  p.cls = params + offs[0]; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML;
+  EP_TRY(pool_forward(p, st));
+  EP_TRY(project_forward(w.P, params + offs[1], d.B, d.D, Dp, d.Q, w.y, st));
+  EP_TRY(bn_forward_eval(w.y, d.B, Dp, bn_eps, running_mean, running_var, w.z, st));
+  EP_TRY(linear_forward(w.z, params + offs[2], params + offs[3], d.B, Dp, d.C, logits, ldl, st));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Shared host/device helpers for the EP HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ep_hip.h"
+
+namespace ep {
+
+void set_error(const char* fmt, ...);
+
+#define EP_REQUIRE(cond, code, ...)        \
+  do {                                     \
+    if (!(cond)) {                         \
+      ep::set_error(__VA_ARGS__);          \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+#define EP_LAUNCH_CHECK(what)                                            \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      ep::set_error("%s: %s", (what), hipGetErrorString(e__));           \
+      return (int)e__;                                                   \
+    }                                                                    \
+  } while (0)
+
+#define EP_TRY(expr)          \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int cu_count();
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// ---- wave64 helpers -------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id_uniform() {
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+
+// DPP row operations (16-lane rows).  ctrl: quad_perm [1,0,3,2]=0xB1, [2,3,0,1]=0x4E,
+// row_half_mirror=0x141, row_mirror=0x140.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float(
+      __builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+// sum of the 16 lanes of each row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+// fold two registers across the 32-lane halves: result lanes 0-31 = sum over both halves of
+// a, lanes 32-63 = sum over both halves of b  (v_permlane32_swap, gfx950).
+__device__ __forceinline__ float fold32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// fold two registers across adjacent 16-lane rows: rows of the result hold
+// [a0+a1, b0+b1, a2+a3, b2+b3]  (v_permlane16_swap, gfx950).
+__device__ __forceinline__ float fold16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// full-wave sum, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v = fold16(v, v);   // rows: [r0+r1, r0+r1, r2+r3, r2+r3]
+  v = fold32(v, v);   // all lanes: total
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+}  // namespace ep

@@ -1,0 +1,59 @@
+// Internal (non-ABI) interfaces between the translation units of libep_hip.so.
+#pragma once
+#include "ep_common.h"
+
+namespace ep {
+
+struct PoolParams {
+  const float* x;        // tokens
+  int64_t x_bstride;     // elements between images
+  int B, N, D, Q;
+  const float* cls;      // fwd: (Q,D) or (B,Q,D)
+  int64_t cls_bstride;   // 0 when shared
+  float scale;
+  float* P;              // fwd out (B,Q,D)
+  float* S;              // fwd out / bwd in (B,Q,N)
+  float* ML;             // (B,Q,4)
+  const float* dP;       // bwd in (B,Q,D)
+  float* Gpart;          // bwd out (n_workgroups, Q, D)
+  int nslot;             // ring depth
+  int slot_bytes;        // TT*D*4
+  int kdma;              // 16-byte DMA instructions per wave per ring item
+};
+
+struct GemmParams {
+  const float* A; const float* B; float* C; const float* bias;
+  int M, N, K;
+  int64_t lda, ldb, ldc;            // leading dimensions (elements)
+  int64_t sAz, sBz, sCz;            // batch strides (elements)
+  int extA, extB;                   // readable extent of the contiguous dim of a T-layout operand
+  float alpha;
+  int accumulate;
+};
+
+size_t pool_workspace_bytes(int B, int N, int D, int Q);
+int pool_forward(const PoolParams& p, hipStream_t st);
+int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st);
+int debug_force_generic(int on);
+int attention_from_scores(const float* S, const float* ML, int rows, int N, float* A, hipStream_t st);
+
+// a_k / b_k: operand contiguous along K (true) or along its free dimension (false)
+int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
+
+int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
+                     float* rmean, float* rvar, int64_t* nbt, hipStream_t st);
+int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean, const float* rvar, float* z,
+                    hipStream_t st);
+int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, hipStream_t st);
+int colsum(const float* src, int B, int ncol, int ld, int accumulate, float* out, hipStream_t st);
+int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st);
+int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
+                  float* loss_rows, float* dlogits, float* stats, hipStream_t st);
+
+size_t optim_workspace_bytes(int64_t total, int nseg);
+int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,
+               int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
+               float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
+               hipStream_t st);
+
+}  // namespace ep

@@ -1,0 +1,177 @@
+// Fused optimizer step over one flat fp32 parameter buffer (gfx950).
+//
+// Replaces reference util/lars.py:13-37 (LARS), torch.optim.SGD / AdamW as selected in
+// main_linprobe.py:403-408, the GradScaler unscale + inf/nan skip of util/misc.py:267-277 and
+// get_grad_norm_ (util/misc.py:289-301).  Two launches:
+//   1. ep_opt_norms_kernel : per-chunk partial sums  ||p||^2, ||g*inv + wd*p||^2, ||g*inv||^2 and
+//      a non-finite flag (one pass over p and g);
+//   2. ep_opt_update_kernel: every chunk re-reduces the partials of its tensor in a fixed order
+//      (deterministic), forms the trust ratio, checks the global non-finite flag and updates
+//      p / state in place (one pass over p, g, state).
+#include "ep_common.h"
+#include "ep_internal.h"
+
+namespace ep {
+
+constexpr int OPT_CHUNK = 4096;      // elements per workgroup
+constexpr int OPT_MAX_SEG = 32;
+
+struct OptSegs {
+  int n;
+  int64_t off[OPT_MAX_SEG];
+  int64_t numel[OPT_MAX_SEG];
+  int first_chunk[OPT_MAX_SEG + 1];   // chunk index range of each segment
+  int trust[OPT_MAX_SEG];
+};
+
+struct OptParams {
+  float* p; const float* g; float* s0; float* s1;
+  float lr, wd, momentum, tc, inv_scale, beta1, beta2, eps, bc1, bc2;
+  int mode;                           // 0 LARS, 1 SGD, 2 AdamW
+  float* partial;                     // [nchunks][4]
+  int nchunks;
+  int32_t* found_inf; float* grad_norm;
+};
+
+__device__ __forceinline__ int seg_of_chunk(const OptSegs& s, int chunk) {
+  int k = 0;
+  while (k + 1 < s.n && chunk >= s.first_chunk[k + 1]) ++k;
+  return k;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs segs) {
+  __shared__ float sm[4];
+  const int chunk = blockIdx.x;
+  const int k = seg_of_chunk(segs, chunk);
+  const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
+  const int64_t end = segs.off[k] + segs.numel[k];
+  const bool decay = (o.mode == 0) ? (segs.trust[k] != 0) : (o.mode == 1);
+  float pp = 0.f, uu = 0.f, gg = 0.f, bad = 0.f;
+  for (int e = threadIdx.x; e < OPT_CHUNK; e += 256) {
+    const int64_t i = base + e;
+    if (i < end) {
+      const float pv = o.p[i];
+      const float gv = o.g[i] * o.inv_scale;
+      const float u = decay ? fmaf(o.wd, pv, gv) : gv;
+      pp = fmaf(pv, pv, pp); uu = fmaf(u, u, uu); gg = fmaf(gv, gv, gg);
+      bad += (fabsf(gv) <= 3.4028234664e38f) ? 0.f : 1.f;
+    }
+  }
+  pp = block_sum(pp, sm); uu = block_sum(uu, sm); gg = block_sum(gg, sm); bad = block_sum(bad, sm);
+  if (threadIdx.x == 0) {
+    float* out = o.partial + (int64_t)chunk * 4;
+    out[0] = pp; out[1] = uu; out[2] = gg; out[3] = bad;
+  }
+}
+
+__global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs segs) {
+  __shared__ float sm[4];
+  const int chunk = blockIdx.x;
+  const int k = seg_of_chunk(segs, chunk);
+  // global non-finite flag and gradient norm (fixed order over all chunks)
+  float bad = 0.f, gg = 0.f;
+  for (int c = threadIdx.x; c < o.nchunks; c += 256) { bad += o.partial[(int64_t)c * 4 + 3]; gg += o.partial[(int64_t)c * 4 + 2]; }
+  bad = block_sum(bad, sm);
+  gg = block_sum(gg, sm);
+  if (chunk == 0 && threadIdx.x == 0) {
+    *o.found_inf = bad > 0.f ? 1 : 0;
+    if (o.grad_norm) *o.grad_norm = sqrtf(gg);
+  }
+  if (bad > 0.f) return;                                 // GradScaler.step: skip the update
+  float q = 1.0f;
+  if (o.mode == 0 && segs.trust[k]) {
+    float pp = 0.f, uu = 0.f;
+    for (int c = segs.first_chunk[k] + threadIdx.x; c < segs.first_chunk[k + 1]; c += 256) {
+      pp += o.partial[(int64_t)c * 4 + 0]; uu += o.partial[(int64_t)c * 4 + 1];
+    }
+    pp = block_sum(pp, sm); uu = block_sum(uu, sm);
+    const float pn = sqrtf(pp), un = sqrtf(uu);
+    q = (pn > 0.f && un > 0.f) ? o.tc * pn / un : 1.0f;  // util/lars.py:26-29
+  }
+  const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
+  const int64_t end = segs.off[k] + segs.numel[k];
+  const bool decay = (o.mode == 0) ? (segs.trust[k] != 0) : (o.mode == 1);
+  for (int e = threadIdx.x; e < OPT_CHUNK; e += 256) {
+    const int64_t i = base + e;
+    if (i >= end) continue;
+    const float pv = o.p[i];
+    const float gv = o.g[i] * o.inv_scale;
+    if (o.mode == 0) {                                   // LARS (util/lars.py:21-37)
+      float dp = decay ? fmaf(o.wd, pv, gv) : gv;
+      dp *= q;
+      const float mu = fmaf(o.s0[i], o.momentum, dp);
+      o.s0[i] = mu;
+      o.p[i] = pv - o.lr * mu;
+    } else if (o.mode == 1) {                            // SGD, no momentum (main_linprobe.py:407)
+      const float d = (o.wd != 0.f) ? fmaf(o.wd, pv, gv) : gv;
+      o.p[i] = pv - o.lr * d;
+    } else {                                             // AdamW (torch defaults, decoupled decay)
+      float pw = pv * (1.0f - o.lr * o.wd);
+      const float m = o.s0[i] * o.beta1 + (1.0f - o.beta1) * gv;
+      const float v = o.s1[i] * o.beta2 + (1.0f - o.beta2) * gv * gv;
+      o.s0[i] = m; o.s1[i] = v;
+      const float denom = sqrtf(v) / o.bc2 + o.eps;      // bc2 = sqrt(1 - beta2^t)
+      o.p[i] = pw - (o.lr / o.bc1) * (m / denom);        // bc1 = 1 - beta1^t
+    }
+  }
+}
+
+static int build_segs(const ep_segment* segs, int nseg, int64_t total, OptSegs& out, int& nchunks) {
+  EP_REQUIRE(nseg >= 1 && nseg <= OPT_MAX_SEG, EP_E_ARG, "optimizer: 1..%d segments supported, got %d", OPT_MAX_SEG, nseg);
+  out.n = nseg;
+  int c = 0;
+  for (int k = 0; k < nseg; ++k) {
+    EP_REQUIRE(segs[k].offset >= 0 && segs[k].numel > 0 && segs[k].offset + segs[k].numel <= total, EP_E_ARG,
+               "optimizer: segment %d out of range", k);
+    out.off[k] = segs[k].offset; out.numel[k] = segs[k].numel; out.trust[k] = segs[k].apply_trust;
+    out.first_chunk[k] = c;
+    c += (int)((segs[k].numel + OPT_CHUNK - 1) / OPT_CHUNK);
+  }
+  out.first_chunk[nseg] = c;
+  nchunks = c;
+  return 0;
+}
+
+size_t optim_workspace_bytes(int64_t total, int nseg) {
+  return round_up(((size_t)(total / OPT_CHUNK) + (size_t)nseg + 1) * 4 * sizeof(float), 256);
+}
+
+int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,
+               int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
+               float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
+               hipStream_t st) {
+  EP_REQUIRE(p && g && found_inf && ws, EP_E_ARG, "optimizer: null pointer");
+  EP_REQUIRE(mode != 0 || s0, EP_E_ARG, "LARS needs the momentum buffer");
+  EP_REQUIRE(mode != 2 || (s0 && s1), EP_E_ARG, "AdamW needs exp_avg and exp_avg_sq");
+  OptSegs S{};
+  int nchunks = 0;
+  ep_segment whole{0, total, 0, 0};
+  if (!segs) { segs = &whole; nseg = 1; }
+  EP_TRY(build_segs(segs, nseg, total, S, nchunks));
+  EP_REQUIRE(ws_bytes >= (size_t)nchunks * 4 * sizeof(float), EP_E_WORKSPACE, "optimizer workspace too small");
+  OptParams o{};
+  o.p = p; o.g = g; o.s0 = s0; o.s1 = s1; o.lr = lr; o.wd = wd; o.momentum = momentum; o.tc = tc;
+  o.inv_scale = inv_scale; o.beta1 = beta1; o.beta2 = beta2; o.eps = eps; o.mode = mode;
+  if (mode == 2) {
+    o.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    o.bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  }
+  o.partial = (float*)ws; o.nchunks = nchunks; o.found_inf = found_inf; o.grad_norm = grad_norm;
+  hipLaunchKernelGGL(ep_opt_norms_kernel, dim3(nchunks), dim3(256), 0, st, o, S);
+  EP_LAUNCH_CHECK("ep_opt_norms_kernel");
+  hipLaunchKernelGGL(ep_opt_update_kernel, dim3(nchunks), dim3(256), 0, st, o, S);
+  EP_LAUNCH_CHECK("ep_opt_update_kernel");
+  return 0;
+}
+
+}  // namespace ep

@@ -1,0 +1,187 @@
+"""Fused train / eval step of the EP probe head: one C call per phase, no host sync.
+
+``ProbeHeadEngine`` owns the flat fp32 parameter / gradient / optimizer-state buffers of a
+``Sequential(EfficientProbing, BatchNorm1d, Linear)`` head (the module's parameters become
+views of the flat buffer, so ``state_dict()`` / checkpoints keep working) and runs the body of
+the reference hot loop (reference engine_finetune.py:52-77: forward, CE, backward, optimizer)
+through ``ep_head_train_step``.
+
+Data parallelism (reference main_linprobe.py:581-583 wraps the model in DDP): every rank holds
+a full replica and its own images; per step there is exactly ONE all-reduce (RCCL over xGMI when
+the backend is "nccl") of the flat gradient buffer between the backward and the optimizer
+phase.  The 1/world averaging is folded into the optimizer's ``inv_scale`` -- no extra pass.
+BatchNorm statistics stay per-rank (the reference does not use SyncBN); running stats are
+broadcast from rank 0 on ``sync_buffers()`` (eval / checkpoint time).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _native as N
+from . import functional as F_
+
+OPTIMIZERS = {"lars": 0, "sgd": 1, "adamw": 2}
+
+
+class ProbeHeadEngine:
+    def __init__(self, head: nn.Sequential, optimizer: str = "lars", lr: float = 0.0, weight_decay: float = 0.0,
+                 momentum: float = 0.9, trust_coefficient: float = 0.001, betas=(0.9, 0.999), adam_eps: float = 1e-8,
+                 process_group=None, loss_scale: float = 1.0, accum_iter: int = 1, broadcast_from_rank0: bool = True):
+        from .probe_heads import is_native_ep_head
+        if not is_native_ep_head(head):
+            raise TypeError("ProbeHeadEngine needs Sequential(EfficientProbing, BatchNorm1d, Linear)")
+        if optimizer not in OPTIMIZERS:
+            raise ValueError(f"optimizer must be one of {sorted(OPTIMIZERS)}")
+        self.head = head
+        self.pool, self.bn, self.fc = head[0], head[1], head[2]
+        dev = self.fc.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("ProbeHeadEngine: the head must be on the GPU (.to('cuda')); there is no CPU path")
+        self.device = dev
+        self.lib = N.load()
+        self.optimizer_name = optimizer
+        self.lr, self.weight_decay, self.momentum, self.trust_coefficient = lr, weight_decay, momentum, trust_coefficient
+        self.betas, self.adam_eps = betas, adam_eps
+        self.loss_scale = float(loss_scale)
+        self.accum_iter = int(accum_iter)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.opt_step = 0
+        self._micro = 0
+
+        D = self.pool.v.in_features
+        self.dims = N.EPHeadDims(B=0, N=0, D=D, Q=self.pool.num_queries, d_out=self.pool.d_out,
+                                 C=self.fc.out_features)
+        offs = (C.c_int64 * 4)()
+        self.total = int(self.lib.ep_head_param_offsets(C.byref(self.dims), offs))
+        self.offsets = list(offs)
+        self.params_list = [self.pool.cls_token, self.pool.v.weight, self.fc.weight, self.fc.bias]
+        self.flat_p = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        n_state = {"lars": 1, "sgd": 0, "adamw": 2}[optimizer]
+        self.state = [torch.zeros(self.total, device=dev, dtype=torch.float32) for _ in range(n_state)]
+        with torch.no_grad():
+            for p, o in zip(self.params_list, self.offsets):
+                v = self.flat_p[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.stats = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.found_inf = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._ws = None
+        self._ws_key = None
+        if broadcast_from_rank0 and self.world > 1:
+            dist.broadcast(self.flat_p, src=0, group=self.group)     # what DDP does at wrap time
+            self.sync_buffers()
+
+    # ------------------------------------------------------------------------------------
+    def mu_views(self):
+        """LARS momentum buffers per parameter (reference state[p]['mu'])."""
+        return [self.state[0][o:o + p.numel()].view(p.shape) for p, o in zip(self.params_list, self.offsets)]
+
+    def sync_buffers(self):
+        if self.world > 1:
+            for b in (self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked):
+                dist.broadcast(b, src=0, group=self.group)
+
+    def _workspace(self, B: int, Nn: int):
+        key = (B, Nn)
+        if self._ws_key != key:
+            self.dims.B, self.dims.N = B, Nn
+            nbytes = self.lib.ep_head_workspace_bytes(C.byref(self.dims))
+            if nbytes == 0:
+                raise RuntimeError(f"ep_head_workspace_bytes: {N.last_error()}")
+            self._ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+            self._ws_key = key
+        return self._ws
+
+    def _step_struct(self, x, bstride, targets, phases, accumulate, lr) -> N.EPHeadStep:
+        s = N.EPHeadStep()
+        s.dims = self.dims
+        s.x = x.data_ptr() if x is not None else 0
+        s.x_dtype = N.EP_DTYPE_F32
+        s.x_bstride = bstride
+        s.targets = targets.data_ptr() if targets is not None else 0
+        s.params = self.flat_p.data_ptr(); s.grads = self.flat_g.data_ptr()
+        s.opt_state0 = self.state[0].data_ptr() if len(self.state) > 0 else 0
+        s.opt_state1 = self.state[1].data_ptr() if len(self.state) > 1 else 0
+        s.running_mean = self.bn.running_mean.data_ptr(); s.running_var = self.bn.running_var.data_ptr()
+        s.num_batches_tracked = self.bn.num_batches_tracked.data_ptr()
+        s.stats = self.stats.data_ptr()
+        s.found_inf = self.found_inf.data_ptr(); s.grad_norm = self.grad_norm.data_ptr()
+        s.bn_eps = self.bn.eps; s.bn_momentum = self.bn.momentum
+        s.grad_scale = self.loss_scale / self.accum_iter
+        s.inv_scale = 1.0 / (self.loss_scale * self.world)
+        s.accumulate = int(accumulate)
+        s.optimizer = OPTIMIZERS[self.optimizer_name]
+        s.lr = self.lr if lr is None else lr
+        s.weight_decay = self.weight_decay; s.momentum = self.momentum
+        s.trust_coefficient = self.trust_coefficient
+        s.beta1, s.beta2 = self.betas; s.adam_eps = self.adam_eps
+        s.opt_step = self.opt_step
+        s.phases = phases
+        return s
+
+    # ------------------------------------------------------------------------------------
+    def forward_backward(self, x: torch.Tensor, targets: torch.Tensor) -> None:
+        """Phase 1: forward + CE + backward into the flat gradient buffer (accumulating across
+        micro-steps when accum_iter > 1).  Adds to ``self.stats``."""
+        xv, bstride = F_.as_token_view(x)
+        B, Nn, D = xv.shape
+        ws = self._workspace(B, Nn)
+        targets = targets.to(device=self.device, dtype=torch.int64)
+        s = self._step_struct(xv, bstride, targets, 1, self._micro > 0, None)
+        N.check(self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
+                                            N.current_stream_ptr(self.device)), "ep_head_train_step(fwd+bwd)")
+        self._micro += 1
+
+    def all_reduce_grads(self) -> None:
+        """THE collective of a data-parallel step: one sum all-reduce of the flat gradients."""
+        if self.world > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def optimizer_step(self, lr: Optional[float] = None) -> None:
+        self.opt_step += 1
+        ws = self._ws
+        if ws is None:
+            raise RuntimeError("optimizer_step before any forward_backward")
+        s = self._step_struct(None, 0, None, 2, False, lr)
+        N.check(self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
+                                            N.current_stream_ptr(self.device)), "ep_head_train_step(optimizer)")
+        self._micro = 0
+
+    def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None) -> None:
+        """One full iteration (accum_iter == 1): forward/backward, gradient all-reduce, update."""
+        self.forward_backward(x, targets)
+        if self._micro >= self.accum_iter:
+            self.all_reduce_grads()
+            self.optimizer_step(lr)
+
+    @torch.no_grad()
+    def eval_logits(self, x: torch.Tensor) -> torch.Tensor:
+        xv, bstride = F_.as_token_view(x)
+        B, Nn, D = xv.shape
+        ws = self._workspace(B, Nn)
+        Cc = self.dims.C
+        ldl = F_.padded_ld(Cc)
+        out = torch.empty((B, ldl), device=self.device, dtype=torch.float32)
+        N.check(self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride,
+                                              self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                              self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                              ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)),
+                "ep_head_eval_forward")
+        return out[:, :Cc]
+
+    def read_stats(self, reset: bool = True):
+        """(mean loss summed over the steps since the last reset, #top-1 hits, #top-5 hits,
+        #non-finite rows) -- ONE host sync, at logging frequency rather than per step."""
+        vals = self.stats.tolist()
+        if reset:
+            self.stats.zero_()
+        return vals

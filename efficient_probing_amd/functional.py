@@ -1,0 +1,366 @@
+"""Torch-facing wrappers over the C ABI (``include/ep_hip.h``): tensors in, tensors out.
+
+Each function enqueues HIP kernels on torch's current stream and returns without
+synchronising.  Tensors must be CUDA (ROCm) tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+BN_EPS = 1e-6          # probe_heads.py:109-110 of the reference
+BN_MOMENTUM = 0.1
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    N.require_gpu_tensor(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def as_token_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """Return (x', batch_stride) with x' fp32, inner two dims contiguous.  A view such as
+    ``feat[:, 1:]`` (reference models_more.py:24) is passed through without a copy."""
+    N.require_gpu_tensor(x, "tokens")
+    if x.dim() != 3:
+        raise ValueError(f"tokens must be (B, N, D), got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        x = x.float()          # bf16/fp16 autocast outputs: widened once (native bf16 path: later round)
+    B, Nn, D = x.shape
+    ok = x.stride(2) == 1 and x.stride(1) == D and (B == 1 or x.stride(0) >= Nn * D) \
+        and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+    if not ok:
+        x = x.contiguous()
+    return x, (x.stride(0) if B > 1 else Nn * D)
+
+
+def pool_forward(x: torch.Tensor, cls_token: torch.Tensor, scale: float,
+                 per_image_queries: bool = False):
+    """EP pooling forward.  x (B,N,D); cls_token (Q,D) / (1,Q,D) or, with
+    ``per_image_queries``, (B,Q,D).  Returns P (B,Q,D), S (B,Q,N), ML (B,Q,4)."""
+    lib = N.load()
+    x, bstride = as_token_view(x)
+    B, Nn, D = x.shape
+    cls = _f32c(cls_token, "cls_token")
+    Q = cls.shape[-2]
+    cls_bstride = Q * D if per_image_queries else 0
+    P = torch.empty((B, Q, D), device=x.device, dtype=torch.float32)
+    S = torch.empty((B, Q, Nn), device=x.device, dtype=torch.float32)
+    ML = torch.empty((B, Q, 4), device=x.device, dtype=torch.float32)
+    rc = lib.ep_pool_forward(x.data_ptr(), N.EP_DTYPE_F32, bstride, B, Nn, D, cls.data_ptr(), cls_bstride, Q,
+                             float(scale), P.data_ptr(), S.data_ptr(), ML.data_ptr(), 0, 0,
+                             N.current_stream_ptr(x.device))
+    N.check(rc, "ep_pool_forward")
+    return P, S, ML
+
+
+def pool_backward(x: torch.Tensor, S: torch.Tensor, ML: torch.Tensor, dP: torch.Tensor, scale: float,
+                  dcls: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    lib = N.load()
+    x, bstride = as_token_view(x)
+    B, Nn, D = x.shape
+    Q = S.shape[1]
+    dP = _f32c(dP, "dP")
+    if dcls is None:
+        dcls = torch.empty((Q, D), device=x.device, dtype=torch.float32)
+        accumulate = False
+    nbytes = lib.ep_pool_workspace_bytes(B, Nn, D, Q)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    rc = lib.ep_pool_backward(x.data_ptr(), N.EP_DTYPE_F32, bstride, B, Nn, D, Q, float(scale), S.data_ptr(),
+                              ML.data_ptr(), dP.data_ptr(), dcls.data_ptr(), int(accumulate), ws.data_ptr(), nbytes,
+                              N.current_stream_ptr(x.device))
+    N.check(rc, "ep_pool_backward")
+    return dcls
+
+
+def attention_from_scores(S: torch.Tensor, ML: torch.Tensor) -> torch.Tensor:
+    lib = N.load()
+    B, Q, Nn = S.shape
+    A = torch.empty_like(S)
+    N.check(lib.ep_attention_from_scores(S.data_ptr(), ML.data_ptr(), B, Q, Nn, A.data_ptr(),
+                                         N.current_stream_ptr(S.device)), "ep_attention_from_scores")
+    return A
+
+
+def project_forward(P: torch.Tensor, Wv: torch.Tensor) -> torch.Tensor:
+    lib = N.load()
+    B, Q, D = P.shape
+    Wv = _f32c(Wv, "v.weight")
+    Dp = Wv.shape[0]
+    y = torch.empty((B, Dp), device=P.device, dtype=torch.float32)
+    N.check(lib.ep_project_forward(P.data_ptr(), Wv.data_ptr(), B, D, Dp, Q, y.data_ptr(),
+                                   N.current_stream_ptr(P.device)), "ep_project_forward")
+    return y
+
+
+def project_backward(dy: torch.Tensor, y: Optional[torch.Tensor], P: torch.Tensor, Wv: torch.Tensor,
+                     ML: Optional[torch.Tensor], need_dP: bool = True, dWv: Optional[torch.Tensor] = None,
+                     accumulate: bool = False, need_dWv: bool = True):
+    lib = N.load()
+    B, Q, D = P.shape
+    Wv = _f32c(Wv, "v.weight")
+    dy = _f32c(dy, "dy")
+    Dp = Wv.shape[0]
+    dP = torch.empty_like(P) if need_dP else None
+    if need_dWv and dWv is None:
+        dWv = torch.empty_like(Wv)
+        accumulate = False
+    N.check(lib.ep_project_backward(dy.data_ptr(), _ptr(y), P.data_ptr(), Wv.data_ptr(), B, D, Dp, Q, _ptr(dP),
+                                    _ptr(dWv) if need_dWv else 0, _ptr(ML), int(accumulate),
+                                    N.current_stream_ptr(P.device)), "ep_project_backward")
+    return dP, dWv
+
+
+def bn_forward_train(y, running_mean, running_var, num_batches_tracked, eps=BN_EPS, momentum=BN_MOMENTUM):
+    lib = N.load()
+    y = _f32c(y, "y")
+    B, Dp = y.shape
+    z = torch.empty_like(y)
+    rstd = torch.empty((Dp,), device=y.device, dtype=torch.float32)
+    N.check(lib.ep_bn_forward_train(y.data_ptr(), B, Dp, eps, momentum, z.data_ptr(), rstd.data_ptr(),
+                                    running_mean.data_ptr(), running_var.data_ptr(), _ptr(num_batches_tracked),
+                                    N.current_stream_ptr(y.device)), "ep_bn_forward_train")
+    return z, rstd
+
+
+def bn_forward_eval(y, running_mean, running_var, eps=BN_EPS):
+    lib = N.load()
+    y = _f32c(y, "y")
+    B, Dp = y.shape
+    z = torch.empty_like(y)
+    N.check(lib.ep_bn_forward_eval(y.data_ptr(), B, Dp, eps, running_mean.data_ptr(), running_var.data_ptr(),
+                                   z.data_ptr(), N.current_stream_ptr(y.device)), "ep_bn_forward_eval")
+    return z
+
+
+def bn_backward(dz, z, rstd):
+    lib = N.load()
+    dz = _f32c(dz, "dz")
+    B, Dp = z.shape
+    dy = torch.empty_like(z)
+    N.check(lib.ep_bn_backward(dz.data_ptr(), z.data_ptr(), rstd.data_ptr(), B, Dp, dy.data_ptr(),
+                               N.current_stream_ptr(z.device)), "ep_bn_backward")
+    return dy
+
+
+def padded_ld(C_: int) -> int:
+    return (C_ + 3) // 4 * 4
+
+
+def linear_forward(z, Wc, bc) -> torch.Tensor:
+    """Returns logits as a (B, C) view of a (B, ldl) buffer (ldl = C rounded up to 4)."""
+    lib = N.load()
+    z = _f32c(z, "z")
+    Wc = _f32c(Wc, "weight")
+    B, Dp = z.shape
+    C_ = Wc.shape[0]
+    ldl = padded_ld(C_)
+    buf = torch.empty((B, ldl), device=z.device, dtype=torch.float32)
+    N.check(lib.ep_linear_forward(z.data_ptr(), Wc.data_ptr(), _ptr(bc), B, Dp, C_, buf.data_ptr(), ldl,
+                                  N.current_stream_ptr(z.device)), "ep_linear_forward")
+    return buf[:, :C_]
+
+
+def _padded_rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """(B, C) tensor -> storage with a leading dimension that is a multiple of 4 and zero pad."""
+    B, C_ = t.shape
+    ldl = padded_ld(C_)
+    if t.stride(1) == 1 and t.stride(0) == ldl and t.dtype == torch.float32 and ldl == C_:
+        return t, ldl
+    buf = torch.zeros((B, ldl), device=t.device, dtype=torch.float32)
+    buf[:, :C_] = t
+    return buf, ldl
+
+
+def linear_backward(dlogits, z, Wc, need_dz=True, dWc=None, dbc=None, accumulate=False):
+    lib = N.load()
+    dl, ldl = _padded_rows(dlogits)
+    z = _f32c(z, "z")
+    Wc = _f32c(Wc, "weight")
+    B, Dp = z.shape
+    C_ = Wc.shape[0]
+    dz = torch.empty_like(z) if need_dz else None
+    if dWc is None:
+        dWc = torch.empty_like(Wc); dbc = torch.empty((C_,), device=z.device, dtype=torch.float32)
+        accumulate = False
+    N.check(lib.ep_linear_backward(dl.data_ptr(), ldl, z.data_ptr(), Wc.data_ptr(), B, Dp, C_, _ptr(dz),
+                                   dWc.data_ptr(), _ptr(dbc), int(accumulate),
+                                   N.current_stream_ptr(z.device)), "ep_linear_backward")
+    return dz, dWc, dbc
+
+
+def cross_entropy(logits, targets, grad_scale: float = 1.0, need_grad: bool = True, stats=None):
+    """Mean CE + accuracy counts.  Returns (loss_rows (B,), dlogits (B,C) view or None, stats (4,))."""
+    lib = N.load()
+    lg, ldl = _padded_rows(logits) if not (logits.stride(1) == 1 and logits.stride(0) % 4 == 0
+                                           and logits.dtype == torch.float32) else (logits, logits.stride(0))
+    B, C_ = logits.shape
+    targets = targets.to(device=logits.device, dtype=torch.int64).contiguous()
+    loss_rows = torch.empty((B,), device=logits.device, dtype=torch.float32)
+    dl = torch.empty((B, ldl), device=logits.device, dtype=torch.float32) if need_grad else None
+    if stats is None:
+        stats = torch.zeros((4,), device=logits.device, dtype=torch.float32)
+    N.check(lib.ep_cross_entropy(lg.data_ptr(), ldl, targets.data_ptr(), B, C_, float(grad_scale),
+                                 loss_rows.data_ptr(), _ptr(dl), stats.data_ptr(),
+                                 N.current_stream_ptr(logits.device)), "ep_cross_entropy")
+    return loss_rows, (dl[:, :C_] if dl is not None else None), stats
+
+
+# --------------------------------------------------------------------------------------------
+# optimizers on flat buffers
+# --------------------------------------------------------------------------------------------
+def make_segments(entries: Sequence[Tuple[int, int, bool]]):
+    arr = (N.EPSegment * len(entries))()
+    for i, (off, numel, trust) in enumerate(entries):
+        arr[i].offset = off; arr[i].numel = numel; arr[i].apply_trust = 1 if trust else 0
+    return arr
+
+
+def optim_workspace(total: int, nseg: int, device) -> torch.Tensor:
+    nbytes = N.load().ep_optim_workspace_bytes(total, nseg)
+    return torch.empty(nbytes, device=device, dtype=torch.uint8)
+
+
+def lars_step(params, grads, mu, segments, lr, weight_decay=0.0, momentum=0.9, trust_coefficient=0.001,
+              inv_scale=1.0, found_inf=None, grad_norm=None, workspace=None):
+    lib = N.load()
+    total = params.numel()
+    if found_inf is None:
+        found_inf = torch.zeros((1,), device=params.device, dtype=torch.int32)
+    if workspace is None:
+        workspace = optim_workspace(total, len(segments), params.device)
+    N.check(lib.ep_lars_step(params.data_ptr(), grads.data_ptr(), mu.data_ptr(), total, segments, len(segments),
+                             lr, weight_decay, momentum, trust_coefficient, inv_scale, found_inf.data_ptr(),
+                             _ptr(grad_norm), workspace.data_ptr(), workspace.numel(),
+                             N.current_stream_ptr(params.device)), "ep_lars_step")
+    return found_inf
+
+
+def sgd_step(params, grads, lr, weight_decay=0.0, inv_scale=1.0, found_inf=None, grad_norm=None, workspace=None):
+    lib = N.load()
+    total = params.numel()
+    if found_inf is None:
+        found_inf = torch.zeros((1,), device=params.device, dtype=torch.int32)
+    if workspace is None:
+        workspace = optim_workspace(total, 1, params.device)
+    N.check(lib.ep_sgd_step(params.data_ptr(), grads.data_ptr(), total, lr, weight_decay, inv_scale,
+                            found_inf.data_ptr(), _ptr(grad_norm), workspace.data_ptr(), workspace.numel(),
+                            N.current_stream_ptr(params.device)), "ep_sgd_step")
+    return found_inf
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+               inv_scale=1.0, found_inf=None, grad_norm=None, workspace=None):
+    lib = N.load()
+    total = params.numel()
+    if found_inf is None:
+        found_inf = torch.zeros((1,), device=params.device, dtype=torch.int32)
+    if workspace is None:
+        workspace = optim_workspace(total, 1, params.device)
+    N.check(lib.ep_adamw_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), total,
+                              int(step), lr, betas[0], betas[1], eps, weight_decay, inv_scale, found_inf.data_ptr(),
+                              _ptr(grad_norm), workspace.data_ptr(), workspace.numel(),
+                              N.current_stream_ptr(params.device)), "ep_adamw_step")
+    return found_inf
+
+
+# --------------------------------------------------------------------------------------------
+# autograd glue (module-level drop-in path)
+# --------------------------------------------------------------------------------------------
+class _EPPoolProject(torch.autograd.Function):
+    """pooled = EfficientProbing(x) with gradients for cls_token and v.weight (x is frozen in
+    the probing protocol; a gradient w.r.t. x is not provided)."""
+
+    @staticmethod
+    def forward(ctx, x, cls_token, v_weight, scale, per_image):
+        P, S, ML = pool_forward(x, cls_token, scale, per_image_queries=per_image)
+        y = project_forward(P, v_weight)
+        ctx.save_for_backward(x, P, S, ML, y, v_weight)
+        ctx.scale = scale
+        ctx.per_image = per_image
+        ctx.cls_shape = cls_token.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, P, S, ML, y, v_weight = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("EfficientProbing (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        need_cls = ctx.needs_input_grad[1] and not ctx.per_image
+        dy = dy.contiguous()
+        dP, dWv = project_backward(dy, y, P, v_weight, ML, need_dP=need_cls,
+                                   need_dWv=ctx.needs_input_grad[2])
+        dcls = None
+        if need_cls:
+            dcls = pool_backward(x, S, ML, dP, ctx.scale).reshape(ctx.cls_shape)
+        elif ctx.needs_input_grad[1]:
+            raise RuntimeError("gradient w.r.t. per-image queries (cls=...) is not implemented")
+        return None, dcls, dWv, None, None
+
+
+def ep_pool_project(x, cls_token, v_weight, scale, per_image=False):
+    return _EPPoolProject.apply(x, cls_token, v_weight, scale, per_image)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, running_mean, running_var, nbt, eps, momentum):
+        z, rstd = bn_forward_train(y, running_mean, running_var, nbt, eps, momentum)
+        ctx.save_for_backward(z, rstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        z, rstd = ctx.saved_tensors
+        return bn_backward(dz, z, rstd), None, None, None, None, None
+
+
+def batch_norm_train(y, running_mean, running_var, nbt, eps=BN_EPS, momentum=BN_MOMENTUM):
+    return _BatchNormTrain.apply(y, running_mean, running_var, nbt, eps, momentum)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, weight, bias):
+        ctx.save_for_backward(z, weight)
+        ctx.has_bias = bias is not None
+        return linear_forward(z, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        z, weight = ctx.saved_tensors
+        dz, dW, db = linear_backward(dlogits, z, weight, need_dz=ctx.needs_input_grad[0])
+        return dz, dW, (db if ctx.has_bias else None)
+
+
+def linear(z, weight, bias):
+    return _Linear.apply(z, weight, bias)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        loss_rows, dl, stats = cross_entropy(logits, targets, 1.0, need_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, gloss, _gstats):
+        (dl,) = ctx.saved_tensors
+        return dl * gloss, None
+
+
+def cross_entropy_loss(logits, targets):
+    """(loss, stats) with stats = [mean loss, #top1, #top5, #non-finite rows]."""
+    return _CrossEntropy.apply(logits, targets)

@@ -1,0 +1,160 @@
+"""Probe-head registry: ``--cls_features`` name -> how to build the pooling module and which
+classifier sits behind it.  Call surface of reference probe_heads.py:60-110:
+
+    POOLINGS[name] = (make_pooling(dim, args, model) -> nn.Module,
+                      make_classifier(dim, args) -> nn.Linear | None)
+    build_probe_head(model, args)   # model.head <- Sequential(pooling, BatchNorm1d, classifier)
+
+Invariants kept from the reference (published numbers depend on them):
+  * the pooling module is constructed BEFORE the classifier, so the RNG draws happen in the
+    same order under a fixed seed (reference probe_heads.py:14-16,104);
+  * only EP builds a fresh classifier (its width is dim // d_out); every other pooling keeps the
+    encoder's own ``model.head`` object, which the --finetune checkpoint already wrote into
+    (reference probe_heads.py:17-20,105);
+  * a ``_all`` suffix selects the same pooling over [CLS]+patch tokens (reference :95);
+  * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
+
+Native on MI355X: ``ep`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of
+libep_hip.so).  The other thirteen names resolve to the reference's own PyTorch modules when the
+reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
+``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
+"""
+from __future__ import annotations
+
+import importlib
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from .poolings.ep import EfficientProbing
+from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
+
+BN_EPS = 1e-6
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d(width, affine=False, eps=1e-6) whose GPU fp32 path is the native kernel
+    (batch statistics per GPU, running stats with momentum 0.1 and unbiased variance; same
+    buffers / state-dict keys).  The class keeps the torch name so ``repr(head)`` is unchanged."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        native = x.is_cuda and x.dim() == 2 and not self.affine and self.track_running_stats \
+            and self.momentum is not None
+        if not native:
+            return super().forward(x)
+        out_dtype = x.dtype
+        if self.training:
+            z = F_.batch_norm_train(x, self.running_mean, self.running_var, self.num_batches_tracked,
+                                    self.eps, self.momentum)
+        else:
+            z = F_.bn_forward_eval(x, self.running_mean, self.running_var, self.eps)
+        return z if out_dtype == torch.float32 else z.to(out_dtype)
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose GPU path is the native f32-MFMA kernel (same init, same state dict)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not (x.is_cuda and x.dim() == 2):
+            return super().forward(x)
+        out_dtype = x.dtype
+        y = F_.linear(x, self.weight, self.bias)
+        return y if out_dtype == torch.float32 else y.to(out_dtype)
+
+
+def _batchnorm(width: int) -> nn.Module:
+    return BatchNorm1d(width, affine=False, eps=BN_EPS)
+
+
+PoolingFactory = Callable[[int, object, nn.Module], nn.Module]
+ClassifierFactory = Optional[Callable[[int, object], nn.Linear]]
+
+# how the reference builds the pooling modules we do not (yet) run natively:
+# name -> (module path, class name, kwargs(dim, args, model))
+_REFERENCE_SPECS = {
+    "abmilp": ("poolings.abmilp", "ABMILPHead",
+               lambda dim, a, m: dict(dim=dim, self_attention_apply_to=a.abmilp_sa, activation=a.abmilp_act,
+                                      depth=a.abmilp_depth, cond=a.abmilp_cond, content=a.abmilp_content,
+                                      num_patches=m.patch_embed.num_patches)),
+    "simpool": ("poolings.simpool", "SimPool",
+                lambda dim, a, m: dict(dim=dim, num_heads=1, qkv_bias=False, qk_scale=None, gamma=None,
+                                       use_beta=False)),
+    "esimpool": ("poolings.simpool", "SimPool_nolinears",
+                 lambda dim, a, m: dict(dim=dim, num_heads=12, qk_scale=None, gamma=None, use_beta=False)),
+    "clip": ("poolings.clip.attention_pool2d", "AttentionPool2d",
+             lambda dim, a, m: dict(in_features=dim, feat_size=16 if a.model == "capi_vitl14_in1k" else 14)),
+    "siglip": ("poolings.clip.attention_pool", "AttentionPoolLatent", lambda dim, a, m: dict(in_features=dim)),
+    "aim": ("poolings.aim", "AttentionPoolingClassifier", lambda dim, a, m: dict(dim=dim, num_heads=a.num_heads)),
+    "cbam": ("poolings.cbam", "CbamPooling", lambda dim, a, m: dict(channels=dim, spatial_kernel_size=7)),
+    "coca": ("poolings.coca_pytorch", "CrossAttention", lambda dim, a, m: dict(dim=dim)),
+    "cait": ("poolings.other_pool", "CAPooling", lambda dim, a, m: dict(embed_dim=dim)),
+    "dinovit": ("poolings.other_pool", "DinoViTBlockPooling", lambda dim, a, m: dict(d_model=dim)),
+    "jepa": ("poolings.jepa.attentive_pooler", "AttentivePooler",
+             lambda dim, a, m: dict(embed_dim=dim, num_heads=a.num_heads)),
+    "dolg": ("poolings.dolg.dolg", "SpatialAttention2d",
+             lambda dim, a, m: dict(in_c=dim, s3_dim=dim, with_aspp=False)),
+    "cae": ("poolings.cae_att", "CAEAttentiveBlock", lambda dim, a, m: dict(dim=dim)),
+}
+
+
+def _reference_pooling(name: str) -> PoolingFactory:
+    mod_name, cls_name, kwargs = _REFERENCE_SPECS[name]
+
+    def make(dim, args, model):
+        try:
+            cls = getattr(importlib.import_module(mod_name), cls_name)
+        except Exception as e:  # the reference repo is not on sys.path
+            raise NotImplementedError(
+                f"--cls_features {name}: no native MI355X kernel yet and the reference module "
+                f"{mod_name}.{cls_name} is not importable ({e}); put the reference repository on sys.path or "
+                f"register a factory with efficient_probing_amd.probe_heads.register_pooling().") from e
+        return cls(**kwargs(dim, args, model))
+    return make
+
+
+def _make_ep(dim, args, model):
+    return EfficientProbing(dim=dim, num_queries=args.ep_queries, d_out=args.d_out)
+
+
+def _make_ep_classifier(dim, args):
+    return Linear(dim // args.d_out, args.nb_classes, bias=True)
+
+
+POOLINGS: Dict[str, Tuple[PoolingFactory, ClassifierFactory]] = {
+    name: (_reference_pooling(name), None) for name in _REFERENCE_SPECS
+}
+POOLINGS["ep"] = (_make_ep, _make_ep_classifier)
+
+
+def register_pooling(name: str, make_pooling: PoolingFactory, make_classifier: ClassifierFactory = None) -> None:
+    """Plug another pooling (or a native re-implementation) into the registry."""
+    if name not in ATTENTIVE_POOLINGS:
+        raise KeyError(f"{name!r} is not an attentive pooling known to map_cls_features()")
+    POOLINGS[name] = (make_pooling, make_classifier)
+
+
+def build_probe_head(model: nn.Module, args) -> None:
+    """Replace ``model.head`` in place with the probe selected by ``args.cls_features``.
+    Must run after the --finetune checkpoint load and before --resume
+    (reference probe_heads.py:87-106, main_linprobe.py:496-500)."""
+    base = base_pooling_name(args.cls_features)
+    dim = model.head.in_features
+    if base not in POOLINGS:
+        model.head = nn.Sequential(_batchnorm(dim), model.head)       # plain linear probing
+        return
+    make_pooling, make_classifier = POOLINGS[base]
+    pooling = make_pooling(dim, args, model)                           # first: fixes the RNG order
+    classifier = make_classifier(dim, args) if make_classifier is not None else model.head
+    model.head = nn.Sequential(pooling, _batchnorm(classifier.in_features), classifier)
+
+
+def is_native_ep_head(head: nn.Module) -> bool:
+    """True for Sequential(EfficientProbing, BatchNorm1d, Linear) built by this registry -- the
+    shape the fused train step (engine.ProbeHeadEngine) accelerates."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], EfficientProbing)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
+assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

@@ -1,0 +1,216 @@
+/* ep_hip.h -- C ABI of the MI355X-native efficient-probing (EP) head engine.
+ *
+ * Drop-in boundary for the hot path of billpsomas/efficient-probing.  The reference has no
+ * FFI of its own: its boundary is the Python module protocol
+ *     model.head = Sequential(pooling, BatchNorm1d(affine=False, eps=1e-6), Linear)
+ * (reference probe_heads.py:87-110) driven by engine_finetune.py:22-103 and util/lars.py.
+ * Each entry point below replaces the torch ops behind one piece of that protocol; the
+ * reference file:line it replaces is cited on every declaration.  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a CALLER-OWNED DEVICE buffer (hipMalloc / torch tensor storage); the
+ *     library never allocates persistent memory and never frees caller memory.  Scratch is
+ *     passed in explicitly; its size comes from the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns
+ *     without synchronising the device (safe to capture into a hipGraph).
+ *   - return value: 0 = ok; negative = invalid argument / unsupported shape (EP_E_*);
+ *     positive = hipError_t of a failed launch.  Nothing throws across the boundary.
+ *     ep_last_error_string() returns a thread-local description of the last failure.
+ *   - stateless and re-entrant: distinct host threads may call concurrently on distinct streams.
+ *   - all tensors are row-major float32 unless a dtype argument says otherwise; token tensors
+ *     `x` are (B, N, D) with the last two dimensions contiguous and an explicit batch stride
+ *     (in elements), so the `feat[:, 1:]` patch-token view of reference models_more.py:24 is
+ *     accepted without a copy.
+ */
+#ifndef EP_HIP_H
+#define EP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EP_ABI_VERSION 1
+
+#define EP_DTYPE_F32 0
+#define EP_DTYPE_BF16 1
+
+#define EP_OK 0
+#define EP_E_ARG (-1)         /* null pointer / non-positive size / bad enum            */
+#define EP_E_SHAPE (-2)       /* shape constraint violated (e.g. D % (d_out*Q) != 0)     */
+#define EP_E_ALIGN (-3)       /* pointer or stride not 16-byte aligned where required    */
+#define EP_E_WORKSPACE (-4)   /* workspace too small                                     */
+#define EP_E_UNSUPPORTED (-5) /* dtype / mode not implemented                            */
+
+typedef void* ep_stream_t;
+
+int ep_version(void);
+const char* ep_last_error_string(void);
+/* number of compute units of the current device (used by callers to size persistent grids) */
+int ep_device_cu_count(void);
+/* test hook: route ep_pool_forward/backward through the generic (non-streaming) kernels so the
+ * two independent implementations can be compared on identical inputs.  Returns the old value. */
+int ep_debug_force_generic_pool(int on);
+
+/* ------------------------------------------------------------------------------------------
+ * EP attentive pooling, forward.   Replaces reference poolings/ep.py:35-44 (scores q.k^T,
+ * softmax over tokens, attention-weighted reduction), in the pool-then-project form:
+ *     S[b,q,n]  = sum_d (cls_token[q,d]*scale) * x[b,n,d]
+ *     A[b,q,:]  = softmax_n S[b,q,:]
+ *     P[b,q,:]  = sum_n A[b,q,n] * x[b,n,:]                       (B,Q,D)
+ * One streaming read of x.  Saved for backward: S (B,Q,N) raw scores and
+ * ML (B,Q,4) = {row max m, sum exp(S-m), reserved(delta), 0}.
+ * `cls_token` is the learned (Q,D) query block (state_dict key 0.cls_token) or, when
+ * cls_bstride != 0, a per-image (B,Q,D) override (the `cls=` argument of ep.py:32-33).
+ */
+size_t ep_pool_workspace_bytes(int B, int N, int D, int Q);
+int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D,
+                    const float* cls_token, int64_t cls_bstride, int Q, float scale,
+                    float* P, float* S, float* ML,
+                    void* workspace, size_t workspace_bytes, ep_stream_t stream);
+
+/* EP pooling, backward w.r.t. cls_token (x is frozen: reference main_linprobe.py:393-400).
+ * Replaces autograd of ep.py:39-44.  Second streaming read of x.
+ *     dA[b,q,n] = dP[b,q,:] . x[b,n,:] ;  dS = A * (dA - delta[b,q]) ;  delta = ML[b,q,2]
+ *     dcls[q,:] (+)= scale * sum_b sum_n dS[b,q,n] * x[b,n,:]
+ * accumulate != 0 adds into dcls (gradient accumulation, engine_finetune.py:72-77).      */
+int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D,
+                     int Q, float scale, const float* S, const float* ML, const float* dP,
+                     float* dcls, int accumulate,
+                     void* workspace, size_t workspace_bytes, ep_stream_t stream);
+
+/* Attention maps A = softmax(S) from the saved scores (reference tools/ep_attention_maps.py:52-58). */
+int ep_attention_from_scores(const float* S, const float* ML, int B, int Q, int N, float* A,
+                             ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-query value projection.  Replaces `self.v(x)` + the slice/concat of ep.py:40,44-45:
+ *     y[b, q*Dq + c] = sum_d P[b,q,d] * Wv[q*Dq + c, d]       Dq = Dp / Q, Dp = D / d_out
+ * backward:  dP[b,q,d] = sum_c dy[b,q*Dq+c] * Wv[q*Dq+c, d]
+ *            dWv[q*Dq+c, d] (+)= sum_b dy[b,q*Dq+c] * P[b,q,d]
+ *            ML[b,q,2] = delta[b,q] = sum_c dy[b,q*Dq+c] * y[b,q*Dq+c]                     */
+int ep_project_forward(const float* P, const float* Wv, int B, int D, int Dp, int Q, float* y,
+                       ep_stream_t stream);
+int ep_project_backward(const float* dy, const float* y, const float* P, const float* Wv,
+                        int B, int D, int Dp, int Q, float* dP, float* dWv, float* ML,
+                        int accumulate, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d(Dp, affine=False, eps) -- reference probe_heads.py:109-110 (torch semantics:
+ * biased batch variance for normalisation, unbiased for the running estimate, momentum 0.1).
+ * train: z = (y-mu)*rstd ; saves rstd (Dp) ; updates running_mean/var in place and
+ *        *num_batches_tracked (int64, device) += 1.
+ * backward: dy = rstd * (dz - mean_b dz - z * mean_b(dz*z)).                               */
+int ep_bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z,
+                        float* rstd, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, ep_stream_t stream);
+int ep_bn_forward_eval(const float* y, int B, int Dp, float eps, const float* running_mean,
+                       const float* running_var, float* z, ep_stream_t stream);
+int ep_bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy,
+                   ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Classifier Linear(Dp, C) -- reference probe_heads.py:76.  logits has leading dimension ldl
+ * (>= C, multiple of 4; pad columns are written as 0).
+ * backward: dz = dlogits Wc ; dWc (+)= dlogits^T z ; dbc (+)= sum_b dlogits.               */
+int ep_linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C,
+                      float* logits, int ldl, ep_stream_t stream);
+int ep_linear_backward(const float* dlogits, int ldl, const float* z, const float* Wc, int B,
+                       int Dp, int C, float* dz, float* dWc, float* dbc, int accumulate,
+                       ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CrossEntropyLoss() mean reduction + timm accuracy counts -- reference
+ * main_linprobe.py:589, engine_finetune.py:62-63.
+ *   loss_rows[b] = -log softmax(logits[b])[target[b]]
+ *   stats[0] += sum_b loss_rows[b] / B  (mean loss), stats[1] += #top-1 hits, stats[2] += #top-5
+ *   hits, stats[3] += 1 if any logit is non-finite (the sys.exit(1) test of
+ *   engine_finetune.py:66-70).  `stats` (4 floats) must be zeroed by the caller when a new
+ *   accounting window starts.
+ *   dlogits[b,k] = (softmax - onehot) * grad_scale / B   (grad_scale = loss_scale / accum_iter)
+ * dlogits may be NULL (evaluation).                                                        */
+int ep_cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C,
+                     float grad_scale, float* loss_rows, float* dlogits, float* stats,
+                     ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizers over ONE flat float32 parameter buffer (params, grads, state have the same
+ * layout; `segs` describes the tensors inside it).  Replaces reference util/lars.py:13-37 and
+ * torch.optim.SGD / AdamW as selected by main_linprobe.py:403-408, plus the GradScaler
+ * unscale / inf-skip of util/misc.py:267-277:
+ *   g = grad * inv_scale ; if any g is non-finite: *found_inf = 1 and NOTHING is updated.
+ *   LARS, for segments with apply_trust (tensor ndim > 1): dp = g + wd*p ;
+ *       dp *= tc*||p||/||dp|| if both norms > 0 ; then mu = momentum*mu + dp ; p -= lr*mu.
+ * grad_norm_out (optional, 1 float) receives the global L2 norm of the unscaled gradient
+ * (util/misc.py:289-301).  found_inf (1 int32, device) is written every call (0 or 1).     */
+typedef struct ep_segment {
+  int64_t offset;      /* first element of the tensor in the flat buffer (multiple of 4)   */
+  int64_t numel;
+  int32_t apply_trust; /* 1: weight decay + LARS trust ratio (ndim > 1); 0: plain momentum */
+  int32_t reserved;
+} ep_segment;
+
+size_t ep_optim_workspace_bytes(int64_t total_numel, int num_segments);
+int ep_lars_step(float* params, const float* grads, float* mu, int64_t total_numel,
+                 const ep_segment* segs_host, int num_segments, float lr, float weight_decay,
+                 float momentum, float trust_coefficient, float inv_scale, int32_t* found_inf,
+                 float* grad_norm_out, void* workspace, size_t workspace_bytes,
+                 ep_stream_t stream);
+int ep_sgd_step(float* params, const float* grads, int64_t total_numel, float lr,
+                float weight_decay, float inv_scale, int32_t* found_inf, float* grad_norm_out,
+                void* workspace, size_t workspace_bytes, ep_stream_t stream);
+int ep_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  int64_t total_numel, int64_t step, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float inv_scale, int32_t* found_inf,
+                  float* grad_norm_out, void* workspace, size_t workspace_bytes,
+                  ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole train step of Sequential(EP, BN, Linear) + CE (+ optimizer) as one call: the hot loop
+ * body of reference engine_finetune.py:52-77.  All buffers caller-owned; `ws` from
+ * ep_head_workspace_bytes().  The flat parameter buffer holds, in nn.Module.parameters()
+ * order, cls_token (Q*D) | v.weight (Dp*D) | fc.weight (C*Dp) | fc.bias (C); each tensor
+ * starts at a multiple of 4 elements (ep_head_param_offsets fills the four offsets and returns
+ * the total element count).
+ * phases: 1 = forward+loss+backward into `grads` (accumulating if accumulate != 0);
+ *         2 = optimizer only; 3 = both.  Between 1 and 2 the caller may all-reduce `grads`
+ *         (the single RCCL all-reduce per step that replaces DDP, main_linprobe.py:581-583).  */
+typedef struct ep_head_dims {
+  int32_t B, N, D, Q, d_out, C;
+} ep_head_dims;
+
+typedef struct ep_head_step {
+  ep_head_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;          /* 4 floats, see ep_cross_entropy                                  */
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale;      /* loss_scale / accum_iter applied to dlogits                      */
+  float inv_scale;       /* 1 / loss_scale applied by the optimizer                         */
+  int32_t accumulate;
+  int32_t optimizer;     /* 0 = LARS, 1 = SGD, 2 = AdamW                                    */
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+} ep_head_step;
+
+int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);
+size_t ep_head_workspace_bytes(const ep_head_dims* dims);
+int ep_head_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+/* eval forward: logits (B, ldl) from tokens using running statistics
+ * (reference engine_finetune.py:106-166 inner forward).                                    */
+int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const float* params, const float* running_mean,
+                         const float* running_var, float bn_eps, float* logits, int ldl,
+                         void* ws, size_t ws_bytes, ep_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EP_HIP_H */

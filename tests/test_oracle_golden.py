@@ -131,3 +131,26 @@ def test_refactoring_identity():
     Wq = inp["v_weight"].reshape(case.Q, dq, case.D)
     alt = np.einsum("bqd,qcd->bqc", P, Wq).reshape(case.B, -1)
     np.testing.assert_allclose(alt, out, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny_q4", "tiny_q8", "vitb16_q8"])
+def test_torch_port_matches_golden(name):
+    """The CPU-baseline port (oracle/torch_port.py) computes what the reference computes."""
+    import torch
+    from cases import CASE_BY_NAME
+    from oracle import torch_port as TP
+    case = CASE_BY_NAME[name]
+    g, inp = load(case), make_inputs(case)
+    head = TP.make_head(case.D, case.Q, case.C, case.d_out).train()
+    with torch.no_grad():
+        head[0].cls_token.copy_(torch.from_numpy(inp["cls_token"]))
+        head[0].v.weight.copy_(torch.from_numpy(inp["v_weight"]))
+        head[2].weight.copy_(torch.from_numpy(inp["fc_weight"]))
+        head[2].bias.copy_(torch.from_numpy(inp["fc_bias"]))
+    mus = [torch.zeros_like(p) for p in head.parameters()]
+    x = torch.from_numpy(view_tokens(case, inp["x_buf"]))
+    loss = TP.train_step(head, mus, x, torch.from_numpy(inp["targets"]), STEP_LRS[0])
+    assert float(loss) == pytest.approx(float(g["lars1_loss"]), rel=1e-6)
+    keep = (lambda a: a) if case.full else sub
+    np.testing.assert_allclose(head[0].cls_token.detach().numpy(), g["lars1_cls_token"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(keep(head[2].weight.detach().numpy()), g["lars1_fc_weight"], rtol=1e-5, atol=1e-7)
