@@ -111,25 +111,21 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
 
-  f4v ra[2], rb[2];
-  auto gload = [&](int k0) {
-    if (A_K) load_K<VEC>(A, p.lda, p.M, p.K, m0, k0, tid, ra);
-    else load_T<VEC>(A, p.lda, p.extA, p.K, m0, k0, tid, ra);
-    if (B_K) load_K<VEC>(B, p.ldb, p.N, p.K, n0, k0, tid, rb);
-    else load_T<VEC>(B, p.ldb, p.extB, p.K, n0, k0, tid, rb);
+  // Register ring of depth 3: the global loads of K-tile it+3 are issued while tile `it` is
+  // multiplied, so a load has ~2-3 iterations (2-3k cycles of MFMA) to land before it is copied
+  // into LDS one iteration ahead of its use.  R[j] indices are static (loop unrolled by 3).
+  f4v ra[3][2], rb[3][2];
+  auto gload = [&](int k0, f4v (&xa)[2], f4v (&xb)[2]) {
+    if (A_K) load_K<VEC>(A, p.lda, p.M, p.K, m0, k0, tid, xa);
+    else load_T<VEC>(A, p.lda, p.extA, p.K, m0, k0, tid, xa);
+    if (B_K) load_K<VEC>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
+    else load_T<VEC>(B, p.ldb, p.extB, p.K, n0, k0, tid, xb);
   };
-  auto lstore = [&](int buf) {
-    if (A_K) store_K(lds[buf][0], tid, ra); else store_T(lds[buf][0], tid, ra);
-    if (B_K) store_K(lds[buf][1], tid, rb); else store_T(lds[buf][1], tid, rb);
+  auto lstore = [&](int buf, const f4v (&xa)[2], const f4v (&xb)[2]) {
+    if (A_K) store_K(lds[buf][0], tid, xa); else store_T(lds[buf][0], tid, xa);
+    if (B_K) store_K(lds[buf][1], tid, xb); else store_T(lds[buf][1], tid, xb);
   };
-
-  const int nk = (p.K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk) gload((it + 1) * BK);
+  auto compute = [&](int buf) {
     const float* As = lds[buf][0];
     const float* Bs = lds[buf][1];
 #pragma unroll
@@ -151,9 +147,27 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (it + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0, ra[0], rb[0]);
+  lstore(0, ra[0], rb[0]);
+  if (nk > 1) gload(BK, ra[1], rb[1]);
+  if (nk > 2) gload(2 * BK, ra[2], rb[2]);
+  __syncthreads();
+#define EP_GEMM_STEP(IT, J)                                                   \
+  if ((IT) < nk) {                                                            \
+    if ((IT) + 3 < nk) gload(((IT) + 3) * BK, ra[J], rb[J]);                  \
+    compute((IT) & 1);                                                        \
+    if ((IT) + 1 < nk) lstore(((IT) + 1) & 1, ra[((J) + 1) % 3], rb[((J) + 1) % 3]); \
+    __syncthreads();                                                          \
   }
+  for (int it = 0; it < nk; it += 3) {
+    EP_GEMM_STEP(it, 0)
+    EP_GEMM_STEP(it + 1, 1)
+    EP_GEMM_STEP(it + 2, 2)
+  }
+#undef EP_GEMM_STEP
   // epilogue: D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)

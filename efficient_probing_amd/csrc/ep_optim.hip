@@ -57,14 +57,20 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
   const int64_t end = segs.off[k] + segs.numel[k];
   const bool decay = (o.mode == 0) ? (segs.trust[k] != 0) : (o.mode == 1);
   float pp = 0.f, uu = 0.f, gg = 0.f, bad = 0.f;
-  for (int e = threadIdx.x; e < OPT_CHUNK; e += 256) {
+  auto acc1 = [&](float pv, float graw) {
+    const float gv = graw * o.inv_scale;
+    const float u = decay ? fmaf(o.wd, pv, gv) : gv;
+    pp = fmaf(pv, pv, pp); uu = fmaf(u, u, uu); gg = fmaf(gv, gv, gg);
+    bad += (fabsf(gv) <= 3.4028234664e38f) ? 0.f : 1.f;
+  };
+  for (int e = threadIdx.x * 4; e < OPT_CHUNK; e += 1024) {     // segment offsets are multiples of 4
     const int64_t i = base + e;
-    if (i < end) {
-      const float pv = o.p[i];
-      const float gv = o.g[i] * o.inv_scale;
-      const float u = decay ? fmaf(o.wd, pv, gv) : gv;
-      pp = fmaf(pv, pv, pp); uu = fmaf(u, u, uu); gg = fmaf(gv, gv, gg);
-      bad += (fabsf(gv) <= 3.4028234664e38f) ? 0.f : 1.f;
+    if (i + 3 < end) {
+      const f4 pv = *reinterpret_cast<const f4*>(o.p + i);
+      const f4 gv = *reinterpret_cast<const f4*>(o.g + i);
+      acc1(pv.x, gv.x); acc1(pv.y, gv.y); acc1(pv.z, gv.z); acc1(pv.w, gv.w);
+    } else {
+      for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
     }
   }
   pp = block_sum(pp, sm); uu = block_sum(uu, sm); gg = block_sum(gg, sm); bad = block_sum(bad, sm);
@@ -101,27 +107,45 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
   const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
   const int64_t end = segs.off[k] + segs.numel[k];
   const bool decay = (o.mode == 0) ? (segs.trust[k] != 0) : (o.mode == 1);
-  for (int e = threadIdx.x; e < OPT_CHUNK; e += 256) {
-    const int64_t i = base + e;
-    if (i >= end) continue;
-    const float pv = o.p[i];
-    const float gv = o.g[i] * o.inv_scale;
+  auto upd1 = [&](int64_t i, float pv, float graw, float& s0v, float& s1v) -> float {
+    const float gv = graw * o.inv_scale;
     if (o.mode == 0) {                                   // LARS (util/lars.py:21-37)
       float dp = decay ? fmaf(o.wd, pv, gv) : gv;
       dp *= q;
-      const float mu = fmaf(o.s0[i], o.momentum, dp);
-      o.s0[i] = mu;
-      o.p[i] = pv - o.lr * mu;
+      s0v = fmaf(s0v, o.momentum, dp);
+      return pv - o.lr * s0v;
     } else if (o.mode == 1) {                            // SGD, no momentum (main_linprobe.py:407)
       const float d = (o.wd != 0.f) ? fmaf(o.wd, pv, gv) : gv;
-      o.p[i] = pv - o.lr * d;
+      return pv - o.lr * d;
     } else {                                             // AdamW (torch defaults, decoupled decay)
-      float pw = pv * (1.0f - o.lr * o.wd);
-      const float m = o.s0[i] * o.beta1 + (1.0f - o.beta1) * gv;
-      const float v = o.s1[i] * o.beta2 + (1.0f - o.beta2) * gv * gv;
-      o.s0[i] = m; o.s1[i] = v;
-      const float denom = sqrtf(v) / o.bc2 + o.eps;      // bc2 = sqrt(1 - beta2^t)
-      o.p[i] = pw - (o.lr / o.bc1) * (m / denom);        // bc1 = 1 - beta1^t
+      const float pw = pv * (1.0f - o.lr * o.wd);
+      s0v = s0v * o.beta1 + (1.0f - o.beta1) * gv;
+      s1v = s1v * o.beta2 + (1.0f - o.beta2) * gv * gv;
+      const float denom = sqrtf(s1v) / o.bc2 + o.eps;    // bc2 = sqrt(1 - beta2^t)
+      return pw - (o.lr / o.bc1) * (s0v / denom);        // bc1 = 1 - beta1^t
+    }
+  };
+  for (int e = threadIdx.x * 4; e < OPT_CHUNK; e += 1024) {
+    const int64_t i = base + e;
+    if (i + 3 < end) {
+      f4 pv = *reinterpret_cast<const f4*>(o.p + i);
+      const f4 gv = *reinterpret_cast<const f4*>(o.g + i);
+      f4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
+      if (o.mode != 1) av = *reinterpret_cast<const f4*>(o.s0 + i);
+      if (o.mode == 2) bv = *reinterpret_cast<const f4*>(o.s1 + i);
+      float a[4] = {av.x, av.y, av.z, av.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
+      pv.x = upd1(i, pv.x, gv.x, a[0], b[0]); pv.y = upd1(i + 1, pv.y, gv.y, a[1], b[1]);
+      pv.z = upd1(i + 2, pv.z, gv.z, a[2], b[2]); pv.w = upd1(i + 3, pv.w, gv.w, a[3], b[3]);
+      *reinterpret_cast<f4*>(o.p + i) = pv;
+      if (o.mode != 1) *reinterpret_cast<f4*>(o.s0 + i) = f4{a[0], a[1], a[2], a[3]};
+      if (o.mode == 2) *reinterpret_cast<f4*>(o.s1 + i) = f4{b[0], b[1], b[2], b[3]};
+    } else {
+      for (int64_t t = i; t < end && t < i + 4; ++t) {
+        float a = o.mode != 1 ? o.s0[t] : 0.f, b = o.mode == 2 ? o.s1[t] : 0.f;
+        o.p[t] = upd1(t, o.p[t], o.g[t], a, b);
+        if (o.mode != 1) o.s0[t] = a;
+        if (o.mode == 2) o.s1[t] = b;
+      }
     }
   }
 }

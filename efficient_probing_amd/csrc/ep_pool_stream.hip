@@ -1,0 +1,501 @@
+// EP attentive pooling: the two streaming passes over the frozen tokens (gfx950 / CDNA4).
+//
+//   forward  (reference poolings/ep.py:35-44):  S = (cls*scale) x^T ; A = softmax_n S ; P = A x
+//   backward (autograd of the same lines)     :  dA = dP x^T ; dS = A (dA - delta) ;
+//                                                dcls = scale * sum_b dS x
+//
+// Design (DESIGN.md "pool kernels"):
+//   * one workgroup streams whole images; the image's tokens are copied HBM -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a ring of NSLOT tiles of 4
+//     tokens, several tiles ahead of the compute, so x is read from HBM exactly once per pass
+//     and never touches a VGPR on the way in;
+//   * the Q queries are split over the NW waves of the workgroup (QW queries per wave); every
+//     wave reads every token row from LDS (lane = 16-byte chunk of the row, conflict-free
+//     ds_read_b128) and owns the FULL D-dimension for its queries, so there is no cross-wave
+//     reduction at all -- the only synchronisation is one s_barrier per tile for the ring;
+//   * scores: lane-local packed FMAs (v_pk_fma_f32), then a v_permlane32_swap /
+//     v_permlane16_swap / DPP butterfly that leaves score (q, t) replicated in the 16 lanes of row
+//     t of register q;
+//   * softmax: lazy-max online softmax evaluated lane-parallel (row = token), weights broadcast
+//     to SGPRs with v_readlane and used as the scalar operand of the pooling FMAs;
+//   * LDS-DMA completion is tracked with a counted s_waitcnt vmcnt(N) whose N is a compile-time
+//     constant in steady state (never 0 inside the stream).
+#include "ep_common.h"
+#include "ep_internal.h"
+#include "ep_pool_stream.h"
+
+namespace ep {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+constexpr int TB = 4;                 // tokens per butterfly mini-batch (one per 16-lane row)
+constexpr int TT = STREAM_TT;         // tokens per ring tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LAZY_MAX_THR = 12.0f; // rescale only when a score exceeds the running max by this
+
+// s_waitcnt vmcnt(n) with a runtime (wave-uniform) n -- used only at the head/tail of a stream
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define EP_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    EP_W(0) EP_W(1) EP_W(2) EP_W(3) EP_W(4) EP_W(5) EP_W(6) EP_W(7) EP_W(8) EP_W(9)
+    EP_W(10) EP_W(11) EP_W(12) EP_W(13) EP_W(14) EP_W(15) EP_W(16) EP_W(17) EP_W(18) EP_W(19)
+    EP_W(20) EP_W(21) EP_W(22) EP_W(23) EP_W(24) EP_W(25) EP_W(26) EP_W(27) EP_W(28) EP_W(29)
+    EP_W(30) EP_W(31) EP_W(32) EP_W(33) EP_W(34) EP_W(35) EP_W(36) EP_W(37) EP_W(38) EP_W(39)
+    EP_W(40) EP_W(41) EP_W(42) EP_W(43) EP_W(44) EP_W(45) EP_W(46) EP_W(47) EP_W(48)
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+  }
+#undef EP_W
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate out of range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void ring_barrier() {
+  // this wave's LDS reads of the previous tile have retired (their results were consumed) and
+  // its own DMA pieces of the next tile have landed (counted vmcnt just before).
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Issue the LDS-DMA copy of one ring item: valid bytes [0, limit+16) of `src`; lanes past the end
+// re-copy the last 16 bytes (finite duplicates that are never consumed as valid rows).
+template <int NW, int KDMA>
+__device__ __forceinline__ void dma_rows(const char* src, unsigned limit, char* slot, int npiece, int w,
+                                         unsigned lane16) {
+#pragma unroll
+  for (int j = 0; j < KDMA; ++j) {
+    int pc = w + NW * j;                       // wave-uniform piece index
+    pc = pc < npiece ? pc : npiece - 1;        // surplus instructions re-copy the last piece
+    unsigned off = (unsigned)pc * 1024u + lane16;
+    off = off < limit ? off : limit;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// lane-local partial dot products of TB token rows with QW query rows (packed FMAs)
+template <int QW, int KP>
+__device__ __forceinline__ void partial_scores(const f4 (&w)[QW][KP], const f4 (&xv)[TB][KP], float (&part)[QW][TB]) {
+#pragma unroll
+  for (int j = 0; j < QW; ++j)
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      f2 s = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        s = fma2(w[j][k].xy, xv[t][k].xy, s);
+        s = fma2(w[j][k].zw, xv[t][k].zw, s);
+      }
+      part[j][t] = s.x + s.y;
+    }
+}
+
+// butterfly reduction: on return u[q] holds, in every lane of row t (lanes 16t..16t+15), the
+// 64-lane sum of part[q][t].
+template <int QW>
+__device__ __forceinline__ void butterfly(const float (&part)[QW][TB], float (&u)[QW]) {
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    // fold32(a,b): lanes<32 <- a, lanes>=32 <- b.  fold16(r0,r1): rows <- [r0.lo, r1.lo, r0.hi, r1.hi]
+    // rows [t0,t1,t2,t3]  <=  r0 = fold32(t0,t2), r1 = fold32(t1,t3)
+    const float r0 = fold32(part[q][0], part[q][2]);
+    const float r1 = fold32(part[q][1], part[q][3]);
+    u[q] = row16_sum(fold16(r0, r1));
+  }
+}
+
+template <int QW, int KP>
+__device__ __forceinline__ void load_rows(const char* tile, int rowbytes, const int (&coff)[KP], f4 (&xv)[TB][KP]) {
+#pragma unroll
+  for (int t = 0; t < TB; ++t)
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      xv[t][k] = *reinterpret_cast<const f4*>(tile + t * rowbytes + coff[k]);
+}
+
+template <int QW, int KP>
+__device__ __forceinline__ void accumulate_rows(const float (&wrow)[QW], const f4 (&xv)[TB][KP], f4 (&acc)[QW][KP]) {
+#pragma unroll
+  for (int j = 0; j < QW; ++j)
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const float a = readlane_f(wrow[j], 16 * t);      // SGPR broadcast of weight (q_j, token t)
+#pragma unroll
+      for (int k = 0; k < KP; ++k) acc[j][k] += a * xv[t][k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <int QW, int KP, int NW, int DFIX>
+__global__ __launch_bounds__(NW * 64, 2) void ep_pool_fwd_kernel(PoolParams p) {
+  using Cfg = StreamCfgT<QW, KP, NW>;
+  constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA;
+  extern __shared__ __attribute__((aligned(1024))) char ring[];
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int D = DFIX ? DFIX : p.D;
+  const int N = p.N, Q = p.Q;
+  const int rowbytes = D * 4;
+  const int nchunk = D >> 2;                    // 16-byte chunks per row
+  const int slot_bytes = TT * rowbytes;
+  const int npiece = slot_bytes >> 10;
+  const int tiles_per_img = (N + TT - 1) / TT;
+  const int G = gridDim.x;
+  const int wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;     // images b = wg + j*G
+  const int n_items = n_img * tiles_per_img;
+  if (n_items <= 0) return;
+  const int q0 = w * QW;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // byte offset of this lane's 16-byte chunk k inside a token row; lanes past the end of the row
+  // (last piece, D % 256 != 0) re-read chunk 0: finite data that meets a zero query weight.
+  int coff[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) coff[k] = ((lane + 64 * k) < nchunk ? (lane + 64 * k) : 0) * 16;
+
+  // queries of this wave, pre-scaled like the reference (q = cls_token * scale, ep.py:39)
+  f4 cq[QW][KP];
+  auto load_cls = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < QW; ++j)
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        const int c = lane + 64 * i;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + j < Q && c < nchunk)
+          v = *reinterpret_cast<const f4*>(p.cls + (int64_t)b * p.cls_bstride + (int64_t)(q0 + j) * D + 4 * c);
+        cq[j][i] = v * p.scale;
+      }
+  };
+  load_cls(wg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight before the ring starts
+
+  // ---- producer: one ring item = one tile of TT token rows -------------------------------
+  int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+  const char* psrc = reinterpret_cast<const char*>(p.x + (int64_t)wg * p.x_bstride);
+  auto produce = [&]() {
+    if (pi < n_items) {
+      const int left = N - ptile * TT;
+      const unsigned limit = (unsigned)((left < TT ? left : TT) * rowbytes - 16);
+      dma_rows<NW, KDMA>(psrc, limit, ring + pslot * slot_bytes, npiece, w, lane16);
+      ++pi;
+      pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+      if (++ptile == tiles_per_img) {
+        ptile = 0; ++pimg;
+        psrc = reinterpret_cast<const char*>(p.x + (int64_t)(wg + pimg * G) * p.x_bstride);
+      } else {
+        psrc += slot_bytes;
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+  f4 acc[QW][KP];
+  float m[QW], mL[QW], lsum[QW];
+  int cimg = 0, ctile = 0, cslot = 0;
+  for (int i = 0; i < n_items; ++i) {
+    // ---- wait for item i, free the slot of item i-1, refill it ---------------------------
+    // Outstanding VMEM ops of this wave, oldest first: DMA of items i..pi-1 (KDMA each), then the
+    // S / P stores of the previous iteration.  Requiring <= (pi-1-i)*KDMA outstanding retires
+    // item i (and, harmlessly early, a few ops of item i+1 in place of the stores).
+    const int ahead = pi - 1 - i;
+    if (ahead == NSLOT - 2) wait_vmcnt_imm<(NSLOT - 2) * KDMA>();
+    else wait_vmcnt(ahead * KDMA);
+    ring_barrier();
+    produce();
+    const int b = wg + cimg * G;
+    const int n0 = ctile * TT;
+    const int nvalid = (N - n0) < TT ? (N - n0) : TT;
+    const char* tile = ring + cslot * slot_bytes;
+    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+    if (ctile == 0) {
+      if (p.cls_bstride != 0 && cimg != 0) load_cls(b);   // per-image query override (rare path)
+#pragma unroll
+      for (int j = 0; j < QW; ++j) {
+        m[j] = -INFINITY; mL[j] = -INFINITY; lsum[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // ---- compute (TT == TB: one butterfly mini-batch per tile) ----------------------------
+    if (p.ablate != 1) {
+      f4 xv[TB][KP];
+      load_rows<QW, KP>(tile, rowbytes, coff, xv);
+      float part[QW][TB];
+      partial_scores<QW, KP>(cq, xv, part);
+      float u[QW];
+      butterfly<QW>(part, u);
+      const int row = lane >> 4;
+      const bool rowvalid = row < nvalid;
+      float ue[QW];
+      bool need = false;
+#pragma unroll
+      for (int j = 0; j < QW; ++j) {
+        ue[j] = rowvalid ? u[j] : -INFINITY;
+        need |= ue[j] > m[j] + LAZY_MAX_THR;
+      }
+      if (__builtin_amdgcn_ballot_w64(need) != 0ull) {     // wave-uniform, rare
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+          const float mx = fmaxf(fmaxf(readlane_f(ue[j], 0), readlane_f(ue[j], 16)),
+                                 fmaxf(readlane_f(ue[j], 32), readlane_f(ue[j], 48)));
+          const float mn = fmaxf(m[j], mx);
+          const float f = __builtin_amdgcn_exp2f((m[j] - mn) * LOG2E);   // m = -inf -> 0
+          m[j] = mn; mL[j] = mn * LOG2E;
+          lsum[j] *= f;
+#pragma unroll
+          for (int k = 0; k < KP; ++k) acc[j][k] *= f;
+        }
+      }
+      float pr[QW];
+#pragma unroll
+      for (int j = 0; j < QW; ++j) {
+        pr[j] = __builtin_amdgcn_exp2f(fmaf(ue[j], LOG2E, -mL[j]));      // invalid rows: exp2(-inf) = 0
+        lsum[j] += pr[j];
+      }
+      // raw scores for backward / attention maps
+      if ((lane & 15) == 0 && rowvalid) {
+#pragma unroll
+        for (int j = 0; j < QW; ++j)
+          if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + row)] = u[j];
+      }
+      if (p.ablate != 3) accumulate_rows<QW, KP>(pr, xv, acc);
+    }
+    // ---- image epilogue -------------------------------------------------------------------
+    if (ctile == tiles_per_img - 1) {
+#pragma unroll
+      for (int j = 0; j < QW; ++j) {
+        const float l = readlane_f(lsum[j], 0) + readlane_f(lsum[j], 16) +
+                        readlane_f(lsum[j], 32) + readlane_f(lsum[j], 48);
+        const float inv = 1.0f / l;
+        if (q0 + j < Q) {
+          float* Pq = p.P + ((int64_t)b * Q + q0 + j) * D;
+#pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nchunk) *reinterpret_cast<f4*>(Pq + 4 * c) = acc[j][k] * inv;
+          }
+          if (lane == 0) {
+            const f4 rec = {m[j], l, 0.f, 0.f};
+            *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + q0 + j) * 4) = rec;
+          }
+        }
+      }
+      ctile = 0; ++cimg;
+    } else {
+      ++ctile;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward (gradient of cls_token)
+// ring items per image: H = ceil(Q/TT) header items holding rows of dP[b], then the token tiles.
+// Every item additionally carries one 4-byte-per-lane DMA per wave into a private 256-byte area:
+// header items fetch ML[b,q,0:4] of the wave's queries, token items fetch S[b,q,n0:n0+TT].
+// ---------------------------------------------------------------------------------------
+template <int QW, int KP, int NW, int DFIX>
+__global__ __launch_bounds__(NW * 64, 2) void ep_pool_bwd_kernel(PoolParams p) {
+  using Cfg = StreamCfgT<QW, KP, NW>;
+  constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA;
+  extern __shared__ __attribute__((aligned(1024))) char ring[];
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int D = DFIX ? DFIX : p.D;
+  const int N = p.N, Q = p.Q;
+  const int rowbytes = D * 4;
+  const int nchunk = D >> 2;
+  const int slot_bytes = TT * rowbytes;
+  const int npiece = slot_bytes >> 10;
+  const int tiles_per_img = (N + TT - 1) / TT;
+  const int H = (Q + TT - 1) / TT;
+  const int items_per_img = H + tiles_per_img;
+  const int G = gridDim.x;
+  const int wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * items_per_img;
+  const int q0 = w * QW;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  char* small_base = ring + NSLOT * slot_bytes;          // [NSLOT][NW][64 floats]
+  int coff[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) coff[k] = ((lane + 64 * k) < nchunk ? (lane + 64 * k) : 0) * 16;
+
+  f4 gacc[QW][KP];
+#pragma unroll
+  for (int j = 0; j < QW; ++j)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) gacc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
+
+  if (n_items > 0) {
+    // lane -> element of the per-item small DMA
+    int hq = q0 + (lane >> 2); hq = hq < Q ? hq : Q - 1;           // header: ML[b, hq, lane & 3]
+    int sq = q0 + lane / TT; sq = sq < Q ? sq : Q - 1;             // tile:   S[b, sq, n0 + lane % TT]
+    const int st = lane % TT;
+    int pi = 0, pimg = 0, pidx = 0, pslot = 0;
+    auto produce = [&]() {
+      if (pi < n_items) {
+        const int b = wg + pimg * G;
+        char* small = small_base + (pslot * NW + w) * 256;
+        char* slot = ring + pslot * slot_bytes;
+        if (pidx < H) {                                   // header: rows of dP[b]
+          const int r0 = pidx * TT;
+          const int rows = (Q - r0) < TT ? (Q - r0) : TT;
+          const char* src = reinterpret_cast<const char*>(p.dP + ((int64_t)b * Q + r0) * D);
+          dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
+          const float* ms = p.ML + ((int64_t)b * Q + hq) * 4 + (lane & 3);
+          __builtin_amdgcn_global_load_lds((gptr_t)ms, (lds_ptr_t)small, 4, 0, 0);
+        } else {
+          const int n0 = (pidx - H) * TT;
+          const int rows = (N - n0) < TT ? (N - n0) : TT;
+          const char* src = reinterpret_cast<const char*>(p.x + (int64_t)b * p.x_bstride + (int64_t)n0 * D);
+          dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
+          int nn = n0 + st; nn = nn < N ? nn : N - 1;
+          const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;
+          __builtin_amdgcn_global_load_lds((gptr_t)ss, (lds_ptr_t)small, 4, 0, 0);
+        }
+        ++pi;
+        pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+        if (++pidx == items_per_img) { pidx = 0; ++pimg; }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+    f4 gq[QW][KP];                  // dP rows of this wave's queries for the current image
+    float mLq[QW], il[QW], dl[QW];  // row max * log2e, 1/l, delta of this wave's queries
+    int cidx = 0, cslot = 0;
+    constexpr int KD = KDMA + 1;
+    for (int i = 0; i < n_items; ++i) {
+      const int ahead = pi - 1 - i;
+      if (ahead == NSLOT - 2) wait_vmcnt_imm<(NSLOT - 2) * KD>();
+      else wait_vmcnt(ahead * KD);
+      ring_barrier();
+      produce();
+      const char* tile = ring + cslot * slot_bytes;
+      const float* small = reinterpret_cast<const float*>(small_base + (cslot * NW + w) * 256);
+      cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+      if (cidx < H) {
+        // header item: pick up the dP rows of my queries that live in this item
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+          const int q = q0 + j;
+          if (q < Q && q / TT == cidx) {
+            const int r = q % TT;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+              f4 v = *reinterpret_cast<const f4*>(tile + r * rowbytes + coff[k]);
+              if (lane + 64 * k >= nchunk) v = f4{0.f, 0.f, 0.f, 0.f};
+              gq[j][k] = v;
+            }
+          } else if (q >= Q && cidx == 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) gq[j][k] = f4{0.f, 0.f, 0.f, 0.f};
+          }
+          mLq[j] = small[4 * j + 0] * LOG2E;
+          il[j] = 1.0f / small[4 * j + 1];
+          dl[j] = small[4 * j + 2];
+        }
+      } else {
+        const int n0 = (cidx - H) * TT;
+        const int nvalid = (N - n0) < TT ? (N - n0) : TT;
+        f4 xv[TB][KP];
+        load_rows<QW, KP>(tile, rowbytes, coff, xv);
+        float part[QW][TB];
+        partial_scores<QW, KP>(gq, xv, part);
+        float u[QW];
+        butterfly<QW>(part, u);                       // dA[q][t] in row t
+        const int row = lane >> 4;
+        const bool rowvalid = row < nvalid;
+        float wgt[QW];
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+          const float s = small[j * TT + row];
+          const float a = __builtin_amdgcn_exp2f(fmaf(s, LOG2E, -mLq[j])) * il[j];
+          wgt[j] = rowvalid ? a * (u[j] - dl[j]) : 0.f;
+        }
+        accumulate_rows<QW, KP>(wgt, xv, gacc);
+      }
+      if (++cidx == items_per_img) cidx = 0;
+    }
+  }
+  // per-workgroup partial of sum_b sum_n dS x  (reduced + scaled by ep_reduce_partials)
+#pragma unroll
+  for (int j = 0; j < QW; ++j)
+    if (q0 + j < Q) {
+      float* Gq = p.Gpart + ((int64_t)wg * Q + q0 + j) * D;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nchunk) *reinterpret_cast<f4*>(Gq + 4 * c) = gacc[j][k];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------
+template <int QW, int KP, int NW, int DFIX>
+static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  using Cfg = StreamCfgT<QW, KP, NW>;
+  const int D = p.D;
+  const size_t slot = (size_t)TT * D * 4;
+  const size_t lds = bwd ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
+  auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX>;
+  auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX>;
+  const void* fn = bwd ? (const void*)kb : (const void*)kf;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+  if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(NW * 64), lds, st, p);
+  else hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, st, p);
+  EP_LAUNCH_CHECK(bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel");
+  return 0;
+}
+
+template <int QW, int KP, int NW>
+static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  using Cfg = StreamCfgT<QW, KP, NW>;
+  if constexpr (!Cfg::VALID) {
+    set_error("no streaming kernel for qw=%d kp=%d nw=%d", QW, KP, NW);
+    return EP_E_UNSUPPORTED;
+  } else {
+    // compile-time D for the shapes the benchmark configs use (immediate LDS offsets)
+    if constexpr ((QW == 2 && NW == 4 && (KP == 3 || KP == 4)) || (QW == 4 && NW == 8 && KP == 3)) {
+      if (p.D == 256 * KP) return launch_one<QW, KP, NW, 256 * KP>(bwd, p, grid, st);
+    }
+    return launch_one<QW, KP, NW, 0>(bwd, p, grid, st);
+  }
+}
+
+template <int QW, int NW>
+static int dispatch_kp(bool bwd, int kp, const PoolParams& p, int grid, hipStream_t st) {
+  switch (kp) {
+    case 1: return launch_cfg<QW, 1, NW>(bwd, p, grid, st);
+    case 2: return launch_cfg<QW, 2, NW>(bwd, p, grid, st);
+    case 3: return launch_cfg<QW, 3, NW>(bwd, p, grid, st);
+    case 4: return launch_cfg<QW, 4, NW>(bwd, p, grid, st);
+    case 5: return launch_cfg<QW, 5, NW>(bwd, p, grid, st);
+    case 6: return launch_cfg<QW, 6, NW>(bwd, p, grid, st);
+  }
+  set_error("no streaming kernel for kp=%d", kp);
+  return EP_E_UNSUPPORTED;
+}
+
+int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st) {
+  if (c.qw == 1 && c.nw == 1) return dispatch_kp<1, 1>(bwd, c.kp, p, c.grid, st);
+  if (c.qw == 1 && c.nw == 2) return dispatch_kp<1, 2>(bwd, c.kp, p, c.grid, st);
+  if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st);
+  if (c.qw == 2 && c.nw == 4) return dispatch_kp<2, 4>(bwd, c.kp, p, c.grid, st);
+  if (c.qw == 2 && c.nw == 8) return dispatch_kp<2, 8>(bwd, c.kp, p, c.grid, st);
+  if (c.qw == 4 && c.nw == 8) return dispatch_kp<4, 8>(bwd, c.kp, p, c.grid, st);
+  set_error("no streaming kernel for qw=%d nw=%d", c.qw, c.nw);
+  return EP_E_UNSUPPORTED;
+}
+
+}  // namespace ep
