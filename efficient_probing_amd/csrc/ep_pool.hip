@@ -167,7 +167,7 @@ StreamPlan stream_plan(int B, int N, int D, int Q) {
   if (Q == 1) { c.qw = 1; c.nw = 1; }
   else if (Q == 2) { c.qw = 1; c.nw = 2; }
   else if (Q <= 4) { c.qw = 1; c.nw = 4; }
-  else if (Q <= 8) { c.qw = 2; c.nw = 4; }
+  else if (Q <= 8) { if (c.kp >= 5) { c.qw = 1; c.nw = 8; } else { c.qw = 2; c.nw = 4; } }   // wide rows: 1 query per wave
   else if (Q <= 16) { c.qw = 2; c.nw = 8; }
   else { c.qw = 4; c.nw = 8; }
   if (!stream_valid(c.qw, c.kp, c.nw)) return c;

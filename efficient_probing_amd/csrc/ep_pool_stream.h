@@ -20,7 +20,7 @@ constexpr int stream_nslot(int kp, int nw, bool bwd) {
 constexpr bool stream_valid(int qw, int kp, int nw) {
   return stream_nslot(kp, nw, false) >= 3 && stream_nslot(kp, nw, true) >= 3 &&
          (stream_nslot(kp, nw, true) - 2) * (stream_kdma(kp, nw) + 1) <= 60 &&
-         !(qw == 4 && kp > 3);                                     // register budget (spills beyond)
+         !(qw == 4 && kp > 3) && !(qw == 2 && kp > 5);             // register budget (spills beyond)
 }
 
 template <int QW, int KP, int NW>

@@ -491,6 +491,7 @@ int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_
   if (c.qw == 1 && c.nw == 1) return dispatch_kp<1, 1>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 1 && c.nw == 2) return dispatch_kp<1, 2>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st);
+  if (c.qw == 1 && c.nw == 8) return dispatch_kp<1, 8>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 2 && c.nw == 4) return dispatch_kp<2, 4>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 2 && c.nw == 8) return dispatch_kp<2, 8>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 4 && c.nw == 8) return dispatch_kp<4, 8>(bwd, c.kp, p, c.grid, st);
