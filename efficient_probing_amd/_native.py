@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libep_hip.so")
+LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
@@ -50,6 +50,7 @@ class EPHeadStep(C.Structure):
         ("trust_coefficient", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("opt_step", C.c_int64),
         ("phases", C.c_int32),
+        ("aux_stream", C.c_void_p),
     ]
 
 
@@ -68,10 +69,11 @@ SIGNATURES = {
     "ep_project_forward": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_project_backward": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p,
                                     c_f32p, c_f32p, c_int, c_void]),
+    "ep_bn_workspace_bytes": (c_size, [c_int, c_int]),
     "ep_bn_forward_train": (c_int, [c_f32p, c_int, c_int, c_float, c_float, c_f32p, c_f32p, c_f32p, c_f32p,
-                                    c_void, c_void]),
+                                    c_void, c_void, c_size, c_void]),
     "ep_bn_forward_eval": (c_int, [c_f32p, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p, c_void]),
-    "ep_bn_backward": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_void]),
+    "ep_bn_backward": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_void, c_size, c_void]),
     "ep_linear_forward": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_int, c_void]),
     "ep_linear_backward": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                    c_int, c_void]),

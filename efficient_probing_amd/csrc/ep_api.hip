@@ -26,6 +26,26 @@ int cu_count() {
   return n;
 }
 
+#define EP_HIP(expr)                                                     \
+  do {                                                                   \
+    hipError_t e__ = (expr);                                             \
+    if (e__ != hipSuccess) {                                             \
+      ep::set_error("%s: %s", #expr, hipGetErrorString(e__));            \
+      return (int)e__;                                                   \
+    }                                                                    \
+  } while (0)
+
+// Fork/join events for the optional aux stream: a small per-thread pool created on first use and
+// reused (events carry no data; the library otherwise keeps no state).
+static int get_events(hipEvent_t* out, int n) {
+  static thread_local hipEvent_t pool[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n; ++i) {
+    if (!pool[i]) EP_HIP(hipEventCreateWithFlags(&pool[i], hipEventDisableTiming));
+    out[i] = pool[i];
+  }
+  return 0;
+}
+
 static int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q) {
   EP_REQUIRE(x != nullptr, EP_E_ARG, "x is null");
   EP_REQUIRE(B > 0 && N > 0 && D > 0 && Q > 0, EP_E_ARG, "B, N, D, Q must be positive (got %d %d %d %d)", B, N, D, Q);
@@ -37,7 +57,7 @@ static int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, in
 }
 
 struct HeadWs {
-  float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *loss_rows, *dz, *dy, *dP;
+  float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
   void* pool_ws; size_t pool_ws_bytes;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
@@ -63,7 +83,8 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   w.rstd = take(Dp);
   w.logits = take(B * w.ldl);
   w.dlogits = take(B * w.ldl);
-  w.loss_rows = take(B);
+  w.rowstat = take(B * 4);
+  w.bnpart = take(bn_workspace_bytes(d.B, Dp) / sizeof(float));
   w.dz = take(B * Dp);
   w.dy = take(B * Dp);
   w.dP = take(B * d.Q * d.D);
@@ -207,20 +228,25 @@ int ep_project_backward(const float* dy, const float* y, const float* P, const f
   return project_backward(dy, y, P, Wv, B, D, Dp, Q, dP, dWv, ML, accumulate, (hipStream_t)stream);
 }
 
+size_t ep_bn_workspace_bytes(int B, int Dp) { return bn_workspace_bytes(B, Dp); }
 int ep_bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
-                        float* running_mean, float* running_var, int64_t* num_batches_tracked, ep_stream_t stream) {
-  EP_REQUIRE(y && z && rstd && running_mean && running_var && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_forward_train: bad argument");
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace,
+                        size_t workspace_bytes, ep_stream_t stream) {
+  EP_REQUIRE(y && z && rstd && running_mean && running_var && workspace && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_forward_train: bad argument");
+  EP_REQUIRE(workspace_bytes >= bn_workspace_bytes(B, Dp), EP_E_WORKSPACE, "ep_bn_forward_train: workspace too small");
   return bn_forward_train(y, B, Dp, eps, momentum, z, rstd, running_mean, running_var, num_batches_tracked,
-                          (hipStream_t)stream);
+                          static_cast<float*>(workspace), (hipStream_t)stream);
 }
 int ep_bn_forward_eval(const float* y, int B, int Dp, float eps, const float* running_mean, const float* running_var,
                        float* z, ep_stream_t stream) {
   EP_REQUIRE(y && z && running_mean && running_var && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_forward_eval: bad argument");
   return bn_forward_eval(y, B, Dp, eps, running_mean, running_var, z, (hipStream_t)stream);
 }
-int ep_bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, ep_stream_t stream) {
-  EP_REQUIRE(dz && z && rstd && dy && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_backward: bad argument");
-  return bn_backward(dz, z, rstd, B, Dp, dy, (hipStream_t)stream);
+int ep_bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, void* workspace,
+                   size_t workspace_bytes, ep_stream_t stream) {
+  EP_REQUIRE(dz && z && rstd && dy && workspace && B > 0 && Dp > 0, EP_E_ARG, "ep_bn_backward: bad argument");
+  EP_REQUIRE(workspace_bytes >= bn_workspace_bytes(B, Dp), EP_E_WORKSPACE, "ep_bn_backward: workspace too small");
+  return bn_backward(dz, z, rstd, B, Dp, dy, static_cast<float*>(workspace), (hipStream_t)stream);
 }
 
 int ep_linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits, int ldl,
@@ -235,9 +261,13 @@ int ep_linear_backward(const float* dlogits, int ldl, const float* z, const floa
 }
 
 int ep_cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
-                     float* loss_rows, float* dlogits, float* stats, ep_stream_t stream) {
+                     float* row_stats, float* dlogits, float* stats, ep_stream_t stream) {
   EP_REQUIRE(logits && targets && B > 0 && C > 0 && ldl >= C, EP_E_ARG, "ep_cross_entropy: bad argument");
-  return cross_entropy(logits, ldl, targets, B, C, grad_scale, loss_rows, dlogits, stats, (hipStream_t)stream);
+  EP_REQUIRE(row_stats || !stats, EP_E_ARG, "ep_cross_entropy: stats needs the row_stats scratch (B*4 floats)");
+  EP_REQUIRE(!row_stats || aligned16(row_stats), EP_E_ALIGN, "row_stats must be 16-byte aligned");
+  EP_TRY(cross_entropy(logits, ldl, targets, B, C, grad_scale, nullptr, dlogits, row_stats, (hipStream_t)stream));
+  if (stats) EP_TRY(ce_stats(row_stats, B, stats, (hipStream_t)stream));
+  return 0;
 }
 
 size_t ep_optim_workspace_bytes(int64_t total_numel, int num_segments) {
@@ -304,15 +334,37 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     EP_TRY(pool_forward(p, st));
     EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
-                            s->num_batches_tracked, st));
+                            s->num_batches_tracked, w.bnpart, st));
     EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
-    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, w.loss_rows, w.dlogits, s->stats, st));
-    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, s->grads + offs[2], s->grads + offs[3],
-                           s->accumulate, st));
-    EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, st));
-    EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, s->grads + offs[1], w.ML, s->accumulate, st));
+    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
+    // The weight gradients dWc / dbc / dWv and the statistics feed nothing before the optimizer:
+    // with an aux stream they run beside the critical path (dz -> BN backward -> dP -> second
+    // token pass), which is HBM/VALU-bound while these are MFMA-bound.
+    hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    if (side != st) {
+      EP_TRY(get_events(ev, 3));
+      EP_HIP(hipEventRecord(ev[0], st));
+      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    }
+    EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
+    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
+                           s->accumulate, side));
+    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
+    EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
+    if (side != st) {
+      EP_HIP(hipEventRecord(ev[1], st));
+      EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
+    }
+    EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
+                            s->accumulate, side));
+    EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
     EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st));
+    if (side != st) {
+      EP_HIP(hipEventRecord(ev[2], side));
+      EP_HIP(hipStreamWaitEvent(st, ev[2], 0));           // join: grads complete on `stream`
+    }
   }
   if (s->phases & 2) {
     EP_REQUIRE(s->found_inf, EP_E_ARG, "optimizer phase needs found_inf");

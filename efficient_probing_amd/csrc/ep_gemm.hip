@@ -197,7 +197,14 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
     return aligned16(ptr) && ld % 4 == 0 && sz % 4 == 0 && inner % 4 == 0;
   };
   const bool vec = vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
-#define EP_GEMM_LAUNCH(AK, BK_, V) hipLaunchKernelGGL((ep_gemm_kernel<AK, BK_, V>), grid, dim3(256), 0, st, p)
+  size_t pad = 0;
+  if (const char* e = getenv("EP_GEMM_PADLDS")) pad = (size_t)atoi(e) * 1024;
+  if (pad) {
+#define EP_GEMM_ATTR(AK, BK_, V) hipFuncSetAttribute((const void*)ep_gemm_kernel<AK, BK_, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad)
+    EP_GEMM_ATTR(true, true, true); EP_GEMM_ATTR(true, false, true); EP_GEMM_ATTR(false, true, true); EP_GEMM_ATTR(false, false, true);
+#undef EP_GEMM_ATTR
+  }
+#define EP_GEMM_LAUNCH(AK, BK_, V) hipLaunchKernelGGL((ep_gemm_kernel<AK, BK_, V>), grid, dim3(256), pad, st, p)
   if (vec) {
     if (a_k && b_k) EP_GEMM_LAUNCH(true, true, true);
     else if (a_k && !b_k) EP_GEMM_LAUNCH(true, false, true);

@@ -41,15 +41,18 @@ int attention_from_scores(const float* S, const float* ML, int rows, int N, floa
 // a_k / b_k: operand contiguous along K (true) or along its free dimension (false)
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
 
+size_t bn_workspace_bytes(int B, int Dp);
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
-                     float* rmean, float* rvar, int64_t* nbt, hipStream_t st);
+                     float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st);
 int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean, const float* rvar, float* z,
                     hipStream_t st);
-int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, hipStream_t st);
+int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, float* partial,
+                hipStream_t st);
 int colsum(const float* src, int B, int ncol, int ld, int accumulate, float* out, hipStream_t st);
 int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st);
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
-                  float* loss_rows, float* dlogits, float* stats, hipStream_t st);
+                  float* loss_rows, float* dlogits, float* rowstat, hipStream_t st);
+int ce_stats(const float* rowstat, int B, float* stats, hipStream_t st);
 
 size_t optim_workspace_bytes(int64_t total, int nseg);
 int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,

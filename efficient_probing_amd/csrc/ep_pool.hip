@@ -164,14 +164,12 @@ StreamPlan stream_plan(int B, int N, int D, int Q) {
   if (D % 64 != 0 || D > 1536 || Q < 1 || Q > 32) return c;
   c.kp = (D + 255) / 256;
   // queries per wave (QW) x waves per workgroup (NW) >= Q; 8 waves per CU (2 per SIMD)
-  if (Q == 1) { c.qw = 1; c.nw = 1; }
-  else if (Q == 2) { c.qw = 1; c.nw = 2; }
-  else if (Q <= 4) { c.qw = 1; c.nw = 4; }
+  if (Q <= 4) { c.qw = 1; c.nw = 4; }               // waves without a query only feed the DMA ring
   else if (Q <= 8) { if (c.kp >= 5) { c.qw = 1; c.nw = 8; } else { c.qw = 2; c.nw = 4; } }   // wide rows: 1 query per wave
   else if (Q <= 16) { c.qw = 2; c.nw = 8; }
   else { c.qw = 4; c.nw = 8; }
   if (!stream_valid(c.qw, c.kp, c.nw)) return c;
-  int wg_per_cu = 8 / c.nw;
+  int wg_per_cu = STREAM_WAVES_PER_CU / c.nw;
   if (const char* e = getenv("EP_POOL_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }
   int grid = cu_count() * wg_per_cu;
   if (grid > B) grid = B;

@@ -5,14 +5,28 @@
 
 namespace ep {
 
-constexpr int STREAM_TT = 4;                       // tokens per ring tile
+// build-time tuning knobs (A/B variants are built with -D...; defaults are the shipped values)
+#ifndef EP_STREAM_TT
+#define EP_STREAM_TT 8
+#endif
+#ifndef EP_STREAM_NSLOT_CAP
+#define EP_STREAM_NSLOT_CAP 8
+#endif
+#ifndef EP_STREAM_WAVES_PER_CU
+#define EP_STREAM_WAVES_PER_CU 8
+#endif
+#ifndef EP_DMA_AUX
+#define EP_DMA_AUX 2              // cache-policy bits of the LDS-DMA loads (2 = nt: streamed once)
+#endif
+constexpr int STREAM_TT = EP_STREAM_TT;            // tokens per ring tile
+constexpr int STREAM_WAVES_PER_CU = EP_STREAM_WAVES_PER_CU;
 
 constexpr int stream_kdma(int kp, int nw) { return (STREAM_TT * kp + nw - 1) / nw; }
 constexpr int stream_nslot(int kp, int nw, bool bwd) {
   const int slot = STREAM_TT * kp * 1024 + (bwd ? nw * 256 : 0);   // worst case D = 256*kp
-  const int budget = 160 * 1024 / (8 / nw);                        // 8 waves per CU
+  const int budget = 160 * 1024 / (STREAM_WAVES_PER_CU / nw);      // resident workgroups share the LDS
   int ns = budget / slot;
-  if (ns > 8) ns = 8;
+  if (ns > EP_STREAM_NSLOT_CAP) ns = EP_STREAM_NSLOT_CAP;
   const int kd = stream_kdma(kp, nw) + (bwd ? 1 : 0);
   while (ns > 3 && (ns - 2) * kd > 60) --ns;                       // vmcnt is a 6-bit counter
   return ns;

@@ -70,7 +70,7 @@ __device__ __forceinline__ void dma_rows(const char* src, unsigned limit, char* 
     pc = pc < npiece ? pc : npiece - 1;        // surplus instructions re-copy the last piece
     unsigned off = (unsigned)pc * 1024u + lane16;
     off = off < limit ? off : limit;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, EP_DMA_AUX);
   }
 }
 
@@ -132,7 +132,7 @@ __device__ __forceinline__ void accumulate_rows(const float (&wrow)[QW], const f
 // forward
 // ---------------------------------------------------------------------------------------
 template <int QW, int KP, int NW, int DFIX>
-__global__ __launch_bounds__(NW * 64, 2) void ep_pool_fwd_kernel(PoolParams p) {
+__global__ __launch_bounds__(NW * 64, STREAM_WAVES_PER_CU / 4) void ep_pool_fwd_kernel(PoolParams p) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA;
   extern __shared__ __attribute__((aligned(1024))) char ring[];
@@ -223,49 +223,53 @@ __global__ __launch_bounds__(NW * 64, 2) void ep_pool_fwd_kernel(PoolParams p) {
         for (int k = 0; k < KP; ++k) acc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    // ---- compute (TT == TB: one butterfly mini-batch per tile) ----------------------------
-    if (p.ablate != 1) {
-      f4 xv[TB][KP];
-      load_rows<QW, KP>(tile, rowbytes, coff, xv);
-      float part[QW][TB];
-      partial_scores<QW, KP>(cq, xv, part);
-      float u[QW];
-      butterfly<QW>(part, u);
-      const int row = lane >> 4;
-      const bool rowvalid = row < nvalid;
-      float ue[QW];
-      bool need = false;
+    // ---- compute: TT/TB butterfly mini-batches per tile ------------------------------------
+    if (p.ablate != 1 && q0 < Q) {
 #pragma unroll
-      for (int j = 0; j < QW; ++j) {
-        ue[j] = rowvalid ? u[j] : -INFINITY;
-        need |= ue[j] > m[j] + LAZY_MAX_THR;
-      }
-      if (__builtin_amdgcn_ballot_w64(need) != 0ull) {     // wave-uniform, rare
+      for (int t0 = 0; t0 < TT; t0 += TB) {
+        if (t0 >= nvalid) break;
+        f4 xv[TB][KP];
+        load_rows<QW, KP>(tile + t0 * rowbytes, rowbytes, coff, xv);
+        float part[QW][TB];
+        partial_scores<QW, KP>(cq, xv, part);
+        float u[QW];
+        butterfly<QW>(part, u);
+        const int row = lane >> 4;
+        const bool rowvalid = (t0 + row) < nvalid;
+        float ue[QW];
+        bool need = false;
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
-          const float mx = fmaxf(fmaxf(readlane_f(ue[j], 0), readlane_f(ue[j], 16)),
-                                 fmaxf(readlane_f(ue[j], 32), readlane_f(ue[j], 48)));
-          const float mn = fmaxf(m[j], mx);
-          const float f = __builtin_amdgcn_exp2f((m[j] - mn) * LOG2E);   // m = -inf -> 0
-          m[j] = mn; mL[j] = mn * LOG2E;
-          lsum[j] *= f;
-#pragma unroll
-          for (int k = 0; k < KP; ++k) acc[j][k] *= f;
+          ue[j] = rowvalid ? u[j] : -INFINITY;
+          need |= ue[j] > m[j] + LAZY_MAX_THR;
         }
-      }
-      float pr[QW];
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {     // wave-uniform, rare
 #pragma unroll
-      for (int j = 0; j < QW; ++j) {
-        pr[j] = __builtin_amdgcn_exp2f(fmaf(ue[j], LOG2E, -mL[j]));      // invalid rows: exp2(-inf) = 0
-        lsum[j] += pr[j];
-      }
-      // raw scores for backward / attention maps
-      if ((lane & 15) == 0 && rowvalid) {
+          for (int j = 0; j < QW; ++j) {
+            const float mx = fmaxf(fmaxf(readlane_f(ue[j], 0), readlane_f(ue[j], 16)),
+                                   fmaxf(readlane_f(ue[j], 32), readlane_f(ue[j], 48)));
+            const float mn = fmaxf(m[j], mx);
+            const float f = __builtin_amdgcn_exp2f((m[j] - mn) * LOG2E);   // m = -inf -> 0
+            m[j] = mn; mL[j] = mn * LOG2E;
+            lsum[j] *= f;
 #pragma unroll
-        for (int j = 0; j < QW; ++j)
-          if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + row)] = u[j];
+            for (int k = 0; k < KP; ++k) acc[j][k] *= f;
+          }
+        }
+        float pr[QW];
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+          pr[j] = __builtin_amdgcn_exp2f(fmaf(ue[j], LOG2E, -mL[j]));      // invalid rows: exp2(-inf) = 0
+          lsum[j] += pr[j];
+        }
+        // raw scores for backward / attention maps
+        if ((lane & 15) == 0 && rowvalid) {
+#pragma unroll
+          for (int j = 0; j < QW; ++j)
+            if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + t0 + row)] = u[j];
+        }
+        if (p.ablate != 3) accumulate_rows<QW, KP>(pr, xv, acc);
       }
-      if (p.ablate != 3) accumulate_rows<QW, KP>(pr, xv, acc);
     }
     // ---- image epilogue -------------------------------------------------------------------
     if (ctile == tiles_per_img - 1) {
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ep_pool_fwd_kernel(PoolParams p) {
 // header items fetch ML[b,q,0:4] of the wave's queries, token items fetch S[b,q,n0:n0+TT].
 // ---------------------------------------------------------------------------------------
 template <int QW, int KP, int NW, int DFIX>
-__global__ __launch_bounds__(NW * 64, 2) void ep_pool_bwd_kernel(PoolParams p) {
+__global__ __launch_bounds__(NW * 64, STREAM_WAVES_PER_CU / 4) void ep_pool_bwd_kernel(PoolParams p) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA;
   extern __shared__ __attribute__((aligned(1024))) char ring[];
@@ -404,23 +408,27 @@ __global__ __launch_bounds__(NW * 64, 2) void ep_pool_bwd_kernel(PoolParams p) {
         }
       } else {
         const int n0 = (cidx - H) * TT;
-        const int nvalid = (N - n0) < TT ? (N - n0) : TT;
-        f4 xv[TB][KP];
-        load_rows<QW, KP>(tile, rowbytes, coff, xv);
-        float part[QW][TB];
-        partial_scores<QW, KP>(gq, xv, part);
-        float u[QW];
-        butterfly<QW>(part, u);                       // dA[q][t] in row t
-        const int row = lane >> 4;
-        const bool rowvalid = row < nvalid;
-        float wgt[QW];
+        const int nvalid = q0 < Q ? ((N - n0) < TT ? (N - n0) : TT) : 0;   // waves without a query skip
 #pragma unroll
-        for (int j = 0; j < QW; ++j) {
-          const float s = small[j * TT + row];
-          const float a = __builtin_amdgcn_exp2f(fmaf(s, LOG2E, -mLq[j])) * il[j];
-          wgt[j] = rowvalid ? a * (u[j] - dl[j]) : 0.f;
+        for (int t0 = 0; t0 < TT; t0 += TB) {
+          if (t0 >= nvalid) break;
+          f4 xv[TB][KP];
+          load_rows<QW, KP>(tile + t0 * rowbytes, rowbytes, coff, xv);
+          float part[QW][TB];
+          partial_scores<QW, KP>(gq, xv, part);
+          float u[QW];
+          butterfly<QW>(part, u);                       // dA[q][t] in row t
+          const int row = lane >> 4;
+          const bool rowvalid = (t0 + row) < nvalid;
+          float wgt[QW];
+#pragma unroll
+          for (int j = 0; j < QW; ++j) {
+            const float s = small[j * TT + t0 + row];
+            const float a = __builtin_amdgcn_exp2f(fmaf(s, LOG2E, -mLq[j])) * il[j];
+            wgt[j] = rowvalid ? a * (u[j] - dl[j]) : 0.f;
+          }
+          accumulate_rows<QW, KP>(wgt, xv, gacc);
         }
-        accumulate_rows<QW, KP>(wgt, xv, gacc);
       }
       if (++cidx == items_per_img) cidx = 0;
     }
@@ -488,8 +496,6 @@ static int dispatch_kp(bool bwd, int kp, const PoolParams& p, int grid, hipStrea
 }
 
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st) {
-  if (c.qw == 1 && c.nw == 1) return dispatch_kp<1, 1>(bwd, c.kp, p, c.grid, st);
-  if (c.qw == 1 && c.nw == 2) return dispatch_kp<1, 2>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 1 && c.nw == 8) return dispatch_kp<1, 8>(bwd, c.kp, p, c.grid, st);
   if (c.qw == 2 && c.nw == 4) return dispatch_kp<2, 4>(bwd, c.kp, p, c.grid, st);

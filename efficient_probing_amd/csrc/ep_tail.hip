@@ -24,70 +24,85 @@ __device__ __forceinline__ float colreduce(float v, float (*sm)[CG], int tx, int
   return s;
 }
 
-// Register-resident column tile: a workgroup owns CG columns and ALL B rows (B <= RL*RPT); each
-// thread keeps its RPT rows of one column in registers, so y is read from memory exactly once and
-// all loads of a thread are in flight together.
-constexpr int RPT = 64;   // rows per thread  -> B <= 1024 on the fast path
+// BatchNorm over the batch axis in two launches with whole-chip parallelism:
+//   stage 1: grid (Dp/CG, RS): per row-chunk, per column: (mean_chunk, M2_chunk) [train] or
+//            (sum dz, sum dz*z) [backward]  ->  partial[rs][which][col]
+//   stage 2: same grid: every workgroup combines the RS partials of its columns in a FIXED order
+//            (Chan's parallel variance formula -- as stable as the two-pass form), then normalises /
+//            back-propagates its own row-chunk.  Deterministic, no atomics.
+constexpr int RS_MAX = 32;
 
-template <bool FAST>
-__global__ __launch_bounds__(256) void ep_bn_train_kernel(const float* __restrict__ y, int B, int Dp,
-                                                        float eps, float momentum,
+__device__ __forceinline__ void chunk_rows(int B, int nrs, int rs, int& r0, int& r1) {
+  const int per = (B + nrs - 1) / nrs;
+  r0 = rs * per;
+  r1 = (r0 + per) < B ? (r0 + per) : B;
+  if (r0 > B) r0 = B;
+}
+
+__global__ __launch_bounds__(256) void ep_bn_stats_kernel(const float* __restrict__ y, int B, int Dp,
+                                                        float* __restrict__ partial) {
+  __shared__ float sm[RL][CG];
+  __shared__ float bc[CG];
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int col = blockIdx.x * CG + tx;
+  const bool ok = col < Dp;
+  int r0, r1;
+  chunk_rows(B, gridDim.y, blockIdx.y, r0, r1);
+  const int n = r1 - r0;
+  float s = 0.f;
+  if (ok) for (int b = r0 + ty; b < r1; b += RL) s += y[(int64_t)b * Dp + col];
+  s = colreduce(s, sm, tx, ty);
+  if (ty == 0) bc[tx] = n > 0 ? s / (float)n : 0.f;
+  __syncthreads();
+  const float mu = bc[tx];
+  float q = 0.f;
+  if (ok) for (int b = r0 + ty; b < r1; b += RL) { const float d = y[(int64_t)b * Dp + col] - mu; q = fmaf(d, d, q); }
+  q = colreduce(q, sm, tx, ty);
+  if (ty == 0 && ok) {
+    partial[((int64_t)blockIdx.y * 2 + 0) * Dp + col] = mu;
+    partial[((int64_t)blockIdx.y * 2 + 1) * Dp + col] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void ep_bn_apply_kernel(const float* __restrict__ y, int B, int Dp, float eps,
+                                                        float momentum, const float* __restrict__ partial,
                                                         float* __restrict__ z, float* __restrict__ rstd_out,
                                                         float* __restrict__ rmean, float* __restrict__ rvar,
                                                         int64_t* __restrict__ nbt) {
-  __shared__ float sm[RL][CG];
   __shared__ float bc[2][CG];
   const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
   const int col = blockIdx.x * CG + tx;
   const bool ok = col < Dp;
-  float v[FAST ? RPT : 1];
-  float s = 0.f;
-  if (FAST) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const int b = ty + r * RL;
-      v[r] = (ok && b < B) ? y[(int64_t)b * Dp + col] : 0.f;
+  const int nrs = gridDim.y;
+  if (ty == 0 && ok) {
+    float tot = 0.f;
+    for (int r = 0; r < nrs; ++r) {
+      int a0, a1; chunk_rows(B, nrs, r, a0, a1);
+      tot += (float)(a1 - a0) * partial[((int64_t)r * 2 + 0) * Dp + col];
     }
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) s += v[r];
-  } else {
-    if (ok) for (int b = ty; b < B; b += RL) s += y[(int64_t)b * Dp + col];
-  }
-  s = colreduce(s, sm, tx, ty);
-  if (ty == 0) bc[0][tx] = s / (float)B;
-  __syncthreads();
-  const float mu = bc[0][tx];
-  float q = 0.f;
-  if (FAST) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) { const float d = (ty + r * RL < B) ? v[r] - mu : 0.f; q = fmaf(d, d, q); }
-  } else {
-    if (ok) for (int b = ty; b < B; b += RL) { const float d = y[(int64_t)b * Dp + col] - mu; q = fmaf(d, d, q); }
-  }
-  q = colreduce(q, sm, tx, ty);
-  if (ty == 0) {
-    const float var = q / (float)B;                      // biased: used for normalisation
+    const float mu = tot / (float)B;
+    float m2 = 0.f;
+    for (int r = 0; r < nrs; ++r) {
+      int a0, a1; chunk_rows(B, nrs, r, a0, a1);
+      const float d = partial[((int64_t)r * 2 + 0) * Dp + col] - mu;
+      m2 += partial[((int64_t)r * 2 + 1) * Dp + col] + (float)(a1 - a0) * d * d;
+    }
+    const float var = m2 / (float)B;                       // biased: used for normalisation
     const float rs = 1.0f / sqrtf(var + eps);
-    bc[1][tx] = rs;
-    if (ok) {
+    bc[0][tx] = mu; bc[1][tx] = rs;
+    if (blockIdx.y == 0) {
       rstd_out[col] = rs;
       const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
       rmean[col] = (1.0f - momentum) * rmean[col] + momentum * mu;
       rvar[col] = (1.0f - momentum) * rvar[col] + momentum * unbiased;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   __syncthreads();
-  const float rs = bc[1][tx];
-  if (FAST) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const int b = ty + r * RL;
-      if (ok && b < B) z[(int64_t)b * Dp + col] = (v[r] - mu) * rs;
-    }
-  } else {
-    if (ok) for (int b = ty; b < B; b += RL) z[(int64_t)b * Dp + col] = (y[(int64_t)b * Dp + col] - mu) * rs;
-  }
+  const float mu = bc[0][tx], rs = bc[1][tx];
+  int r0, r1;
+  chunk_rows(B, nrs, blockIdx.y, r0, r1);
+  if (ok) for (int b = r0 + ty; b < r1; b += RL) z[(int64_t)b * Dp + col] = (y[(int64_t)b * Dp + col] - mu) * rs;
 }
 
 __global__ void ep_bn_eval_kernel(const float* __restrict__ y, int64_t total, int Dp, float eps,
@@ -99,52 +114,53 @@ __global__ void ep_bn_eval_kernel(const float* __restrict__ y, int64_t total, in
   z[i] = (y[i] - rmean[col]) / sqrtf(rvar[col] + eps);
 }
 
-template <bool FAST>
-__global__ __launch_bounds__(256) void ep_bn_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
-                                                      const float* __restrict__ rstd, int B, int Dp,
-                                                      float* __restrict__ dy) {
+__global__ __launch_bounds__(256) void ep_bn_bwd_stats_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                            int B, int Dp, float* __restrict__ partial) {
   __shared__ float sm[RL][CG];
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int col = blockIdx.x * CG + tx;
+  const bool ok = col < Dp;
+  int r0, r1;
+  chunk_rows(B, gridDim.y, blockIdx.y, r0, r1);
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) for (int b = r0 + ty; b < r1; b += RL) {
+    const float g = dz[(int64_t)b * Dp + col];
+    s1 += g;
+    s2 = fmaf(g, z[(int64_t)b * Dp + col], s2);
+  }
+  s1 = colreduce(s1, sm, tx, ty);
+  s2 = colreduce(s2, sm, tx, ty);
+  if (ty == 0 && ok) {
+    partial[((int64_t)blockIdx.y * 2 + 0) * Dp + col] = s1;
+    partial[((int64_t)blockIdx.y * 2 + 1) * Dp + col] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void ep_bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                            const float* __restrict__ rstd, int B, int Dp,
+                                                            const float* __restrict__ partial, float* __restrict__ dy) {
   __shared__ float bc[2][CG];
   const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
   const int col = blockIdx.x * CG + tx;
   const bool ok = col < Dp;
-  float g[FAST ? RPT : 1], zz[FAST ? RPT : 1];
-  float s1 = 0.f, s2 = 0.f;
-  if (FAST) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const int b = ty + r * RL;
-      const bool in = ok && b < B;
-      g[r] = in ? dz[(int64_t)b * Dp + col] : 0.f;
-      zz[r] = in ? z[(int64_t)b * Dp + col] : 0.f;
+  const int nrs = gridDim.y;
+  if (ty == 0 && ok) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nrs; ++r) {
+      s1 += partial[((int64_t)r * 2 + 0) * Dp + col];
+      s2 += partial[((int64_t)r * 2 + 1) * Dp + col];
     }
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) { s1 += g[r]; s2 = fmaf(g[r], zz[r], s2); }
-  } else if (ok) {
-    for (int b = ty; b < B; b += RL) {
-      const float gv = dz[(int64_t)b * Dp + col];
-      s1 += gv;
-      s2 = fmaf(gv, z[(int64_t)b * Dp + col], s2);
-    }
+    bc[0][tx] = s1 / (float)B; bc[1][tx] = s2 / (float)B;
   }
-  s1 = colreduce(s1, sm, tx, ty);
-  s2 = colreduce(s2, sm, tx, ty);
-  if (ty == 0) { bc[0][tx] = s1 / (float)B; bc[1][tx] = s2 / (float)B; }
   __syncthreads();
   const float m1 = bc[0][tx], m2 = bc[1][tx];
+  int r0, r1;
+  chunk_rows(B, nrs, blockIdx.y, r0, r1);
   if (ok) {
     const float rs = rstd[col];
-    if (FAST) {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const int b = ty + r * RL;
-        if (b < B) dy[(int64_t)b * Dp + col] = rs * (g[r] - m1 - zz[r] * m2);
-      }
-    } else {
-      for (int b = ty; b < B; b += RL) {
-        const int64_t i = (int64_t)b * Dp + col;
-        dy[i] = rs * (dz[i] - m1 - z[i] * m2);
-      }
+    for (int b = r0 + ty; b < r1; b += RL) {
+      const int64_t i = (int64_t)b * Dp + col;
+      dy[i] = rs * (dz[i] - m1 - z[i] * m2);
     }
   }
 }
@@ -190,7 +206,7 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void ep_ce_kernel(const float* __restrict__ logits, int ldl,
                                                   const int64_t* __restrict__ targets, int B, int C,
                                                   float grad_scale, float* __restrict__ loss_rows,
-                                                  float* __restrict__ dlogits, float* __restrict__ stats) {
+                                                  float* __restrict__ dlogits, float* __restrict__ rowstat) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
@@ -255,25 +271,45 @@ __global__ __launch_bounds__(256) void ep_ce_kernel(const float* __restrict__ lo
   }
   if (lane == 0) {
     if (loss_rows) loss_rows[b] = loss;
-    if (stats) {
-      atomicAdd(&stats[0], loss / (float)B);
-      if (fr < 0.5f) atomicAdd(&stats[1], 1.0f);
-      if (fr < 4.5f) atomicAdd(&stats[2], 1.0f);
-      if (fb > 0.5f || !(fabsf(loss) <= 3.4028234664e38f)) atomicAdd(&stats[3], 1.0f);
+    if (rowstat) {
+      const float isbad = (fb > 0.5f || !(fabsf(loss) <= 3.4028234664e38f)) ? 1.f : 0.f;
+      *reinterpret_cast<f4*>(rowstat + (int64_t)b * 4) =
+          f4{loss / (float)B, fr < 0.5f ? 1.f : 0.f, fr < 4.5f ? 1.f : 0.f, isbad};
     }
   }
 }
 
+// stats[0..3] += sum_b rowstat[b][0..3]   (one workgroup, fixed order: reproducible)
+__global__ __launch_bounds__(256) void ep_ce_stats_kernel(const float* __restrict__ rowstat, int B,
+                                                        float* __restrict__ stats) {
+  __shared__ f4 sm[4];
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < B; b += 256) s += *reinterpret_cast<const f4*>(rowstat + (int64_t)b * 4);
+  s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const f4 t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    stats[0] += t.x; stats[1] += t.y; stats[2] += t.z; stats[3] += t.w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
+static int bn_row_splits(int B) {
+  int rs = B / 64;                       // ~64 rows per workgroup
+  if (rs < 1) rs = 1;
+  if (rs > RS_MAX) rs = RS_MAX;
+  return rs;
+}
+size_t bn_workspace_bytes(int B, int Dp) { (void)B; return round_up((size_t)RS_MAX * 2 * Dp * sizeof(float), 256); }
+
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
-                     float* rmean, float* rvar, int64_t* nbt, hipStream_t st) {
-  if (B <= RL * RPT)
-    hipLaunchKernelGGL(ep_bn_train_kernel<true>, dim3((Dp + CG - 1) / CG), dim3(256), 0, st, y, B, Dp, eps,
-                       momentum, z, rstd, rmean, rvar, nbt);
-  else
-    hipLaunchKernelGGL(ep_bn_train_kernel<false>, dim3((Dp + CG - 1) / CG), dim3(256), 0, st, y, B, Dp, eps,
-                       momentum, z, rstd, rmean, rvar, nbt);
-  EP_LAUNCH_CHECK("ep_bn_train_kernel");
+                     float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st) {
+  const dim3 grid((Dp + CG - 1) / CG, bn_row_splits(B));
+  hipLaunchKernelGGL(ep_bn_stats_kernel, grid, dim3(256), 0, st, y, B, Dp, partial);
+  hipLaunchKernelGGL(ep_bn_apply_kernel, grid, dim3(256), 0, st, y, B, Dp, eps, momentum, partial, z, rstd, rmean,
+                     rvar, nbt);
+  EP_LAUNCH_CHECK("ep_bn_train kernels");
   return 0;
 }
 int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean, const float* rvar, float* z,
@@ -284,12 +320,12 @@ int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean
   EP_LAUNCH_CHECK("ep_bn_eval_kernel");
   return 0;
 }
-int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, hipStream_t st) {
-  if (B <= RL * RPT)
-    hipLaunchKernelGGL(ep_bn_bwd_kernel<true>, dim3((Dp + CG - 1) / CG), dim3(256), 0, st, dz, z, rstd, B, Dp, dy);
-  else
-    hipLaunchKernelGGL(ep_bn_bwd_kernel<false>, dim3((Dp + CG - 1) / CG), dim3(256), 0, st, dz, z, rstd, B, Dp, dy);
-  EP_LAUNCH_CHECK("ep_bn_bwd_kernel");
+int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, float* partial,
+                hipStream_t st) {
+  const dim3 grid((Dp + CG - 1) / CG, bn_row_splits(B));
+  hipLaunchKernelGGL(ep_bn_bwd_stats_kernel, grid, dim3(256), 0, st, dz, z, B, Dp, partial);
+  hipLaunchKernelGGL(ep_bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, z, rstd, B, Dp, partial, dy);
+  EP_LAUNCH_CHECK("ep_bn_bwd kernels");
   return 0;
 }
 int colsum(const float* src, int B, int ncol, int ld, int accumulate, float* out, hipStream_t st) {
@@ -304,14 +340,19 @@ int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hip
   return 0;
 }
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
-                  float* loss_rows, float* dlogits, float* stats, hipStream_t st) {
+                  float* loss_rows, float* dlogits, float* rowstat, hipStream_t st) {
   if (ldl <= 64 * CE_RPT)
     hipLaunchKernelGGL(ep_ce_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, st, logits, ldl, targets, B, C,
-                       grad_scale, loss_rows, dlogits, stats);
+                       grad_scale, loss_rows, dlogits, rowstat);
   else
     hipLaunchKernelGGL(ep_ce_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, st, logits, ldl, targets, B, C,
-                       grad_scale, loss_rows, dlogits, stats);
+                       grad_scale, loss_rows, dlogits, rowstat);
   EP_LAUNCH_CHECK("ep_ce_kernel");
+  return 0;
+}
+int ce_stats(const float* rowstat, int B, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(ep_ce_stats_kernel, dim3(1), dim3(256), 0, st, rowstat, B, stats);
+  EP_LAUNCH_CHECK("ep_ce_stats_kernel");
   return 0;
 }
 

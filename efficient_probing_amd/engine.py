@@ -31,7 +31,8 @@ OPTIMIZERS = {"lars": 0, "sgd": 1, "adamw": 2}
 class ProbeHeadEngine:
     def __init__(self, head: nn.Sequential, optimizer: str = "lars", lr: float = 0.0, weight_decay: float = 0.0,
                  momentum: float = 0.9, trust_coefficient: float = 0.001, betas=(0.9, 0.999), adam_eps: float = 1e-8,
-                 process_group=None, loss_scale: float = 1.0, accum_iter: int = 1, broadcast_from_rank0: bool = True):
+                 process_group=None, loss_scale: float = 1.0, accum_iter: int = 1, broadcast_from_rank0: bool = True,
+                 overlap: bool = True):
         from .probe_heads import is_native_ep_head
         if not is_native_ep_head(head):
             raise TypeError("ProbeHeadEngine needs Sequential(EfficientProbing, BatchNorm1d, Linear)")
@@ -76,6 +77,7 @@ class ProbeHeadEngine:
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self._ws = None
         self._ws_key = None
+        self.aux_stream = torch.cuda.Stream(device=dev) if overlap else None
         if broadcast_from_rank0 and self.world > 1:
             dist.broadcast(self.flat_p, src=0, group=self.group)     # what DDP does at wrap time
             self.sync_buffers()
@@ -126,6 +128,7 @@ class ProbeHeadEngine:
         s.beta1, s.beta2 = self.betas; s.adam_eps = self.adam_eps
         s.opt_step = self.opt_step
         s.phases = phases
+        s.aux_stream = self.aux_stream.cuda_stream if self.aux_stream is not None else 0
         return s
 
     # ------------------------------------------------------------------------------------

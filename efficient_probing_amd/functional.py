@@ -126,9 +126,10 @@ def bn_forward_train(y, running_mean, running_var, num_batches_tracked, eps=BN_E
     B, Dp = y.shape
     z = torch.empty_like(y)
     rstd = torch.empty((Dp,), device=y.device, dtype=torch.float32)
+    ws = torch.empty(lib.ep_bn_workspace_bytes(B, Dp), device=y.device, dtype=torch.uint8)
     N.check(lib.ep_bn_forward_train(y.data_ptr(), B, Dp, eps, momentum, z.data_ptr(), rstd.data_ptr(),
                                     running_mean.data_ptr(), running_var.data_ptr(), _ptr(num_batches_tracked),
-                                    N.current_stream_ptr(y.device)), "ep_bn_forward_train")
+                                    ws.data_ptr(), ws.numel(), N.current_stream_ptr(y.device)), "ep_bn_forward_train")
     return z, rstd
 
 
@@ -147,8 +148,9 @@ def bn_backward(dz, z, rstd):
     dz = _f32c(dz, "dz")
     B, Dp = z.shape
     dy = torch.empty_like(z)
+    ws = torch.empty(lib.ep_bn_workspace_bytes(B, Dp), device=z.device, dtype=torch.uint8)
     N.check(lib.ep_bn_backward(dz.data_ptr(), z.data_ptr(), rstd.data_ptr(), B, Dp, dy.data_ptr(),
-                               N.current_stream_ptr(z.device)), "ep_bn_backward")
+                               ws.data_ptr(), ws.numel(), N.current_stream_ptr(z.device)), "ep_bn_backward")
     return dy
 
 
@@ -199,13 +201,14 @@ def linear_backward(dlogits, z, Wc, need_dz=True, dWc=None, dbc=None, accumulate
 
 
 def cross_entropy(logits, targets, grad_scale: float = 1.0, need_grad: bool = True, stats=None):
-    """Mean CE + accuracy counts.  Returns (loss_rows (B,), dlogits (B,C) view or None, stats (4,))."""
+    """Mean CE + accuracy counts.  Returns (row_stats (B,4), dlogits (B,C) view or None, stats (4,));
+    row_stats[b] = [loss_b / B, top-1 hit, top-5 hit, non-finite]."""
     lib = N.load()
     lg, ldl = _padded_rows(logits) if not (logits.stride(1) == 1 and logits.stride(0) % 4 == 0
                                            and logits.dtype == torch.float32) else (logits, logits.stride(0))
     B, C_ = logits.shape
     targets = targets.to(device=logits.device, dtype=torch.int64).contiguous()
-    loss_rows = torch.empty((B,), device=logits.device, dtype=torch.float32)
+    loss_rows = torch.empty((B, 4), device=logits.device, dtype=torch.float32)
     dl = torch.empty((B, ldl), device=logits.device, dtype=torch.float32) if need_grad else None
     if stats is None:
         stats = torch.zeros((4,), device=logits.device, dtype=torch.float32)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 1
+#define EP_ABI_VERSION 2
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -104,13 +104,15 @@ int ep_project_backward(const float* dy, const float* y, const float* P, const f
  * train: z = (y-mu)*rstd ; saves rstd (Dp) ; updates running_mean/var in place and
  *        *num_batches_tracked (int64, device) += 1.
  * backward: dy = rstd * (dz - mean_b dz - z * mean_b(dz*z)).                               */
+size_t ep_bn_workspace_bytes(int B, int Dp);
 int ep_bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z,
                         float* rstd, float* running_mean, float* running_var,
-                        int64_t* num_batches_tracked, ep_stream_t stream);
+                        int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
+                        ep_stream_t stream);
 int ep_bn_forward_eval(const float* y, int B, int Dp, float eps, const float* running_mean,
                        const float* running_var, float* z, ep_stream_t stream);
 int ep_bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy,
-                   ep_stream_t stream);
+                   void* workspace, size_t workspace_bytes, ep_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Classifier Linear(Dp, C) -- reference probe_heads.py:76.  logits has leading dimension ldl
@@ -125,15 +127,15 @@ int ep_linear_backward(const float* dlogits, int ldl, const float* z, const floa
 /* ------------------------------------------------------------------------------------------
  * CrossEntropyLoss() mean reduction + timm accuracy counts -- reference
  * main_linprobe.py:589, engine_finetune.py:62-63.
- *   loss_rows[b] = -log softmax(logits[b])[target[b]]
- *   stats[0] += sum_b loss_rows[b] / B  (mean loss), stats[1] += #top-1 hits, stats[2] += #top-5
- *   hits, stats[3] += 1 if any logit is non-finite (the sys.exit(1) test of
- *   engine_finetune.py:66-70).  `stats` (4 floats) must be zeroed by the caller when a new
- *   accounting window starts.
+ *   row_stats[b] = { -log softmax(logits[b])[target[b]] / B, top-1 hit, top-5 hit, non-finite }
+ *   (B x 4 floats, caller-owned scratch / output); then, in a fixed order (reproducible),
+ *   stats[0] += mean loss, stats[1] += #top-1 hits, stats[2] += #top-5 hits, stats[3] += #rows
+ *   with a non-finite logit or loss (the sys.exit(1) test of engine_finetune.py:66-70).
+ *   `stats` (4 floats, may be NULL) must be zeroed by the caller when an accounting window starts.
  *   dlogits[b,k] = (softmax - onehot) * grad_scale / B   (grad_scale = loss_scale / accum_iter)
  * dlogits may be NULL (evaluation).                                                        */
 int ep_cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C,
-                     float grad_scale, float* loss_rows, float* dlogits, float* stats,
+                     float grad_scale, float* row_stats, float* dlogits, float* stats,
                      ep_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -198,6 +200,9 @@ typedef struct ep_head_step {
   float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
   int64_t opt_step;
   int32_t phases;
+  ep_stream_t aux_stream; /* optional second caller-owned stream: the weight-gradient contractions
+                             (dWc, dWv, dbc) that nothing else in the step depends on run there,
+                             concurrently with the second token pass; NULL = everything on `stream` */
 } ep_head_step;
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);
