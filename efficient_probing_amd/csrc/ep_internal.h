@@ -19,6 +19,7 @@ struct PoolParams {
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
   int kdma;              // 16-byte DMA instructions per wave per ring item
+  unsigned long long* dbg;  // diagnostic only (EP_MF_STAMP): per-wave phase cycle counters
   int ablate;            // diagnostic only (EP_POOL_ABLATE): 1 ring only, 2 +LDS reads, 3 no pooling FMAs
 };
 

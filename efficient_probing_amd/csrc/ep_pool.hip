@@ -178,25 +178,40 @@ StreamPlan stream_plan(int B, int N, int D, int Q) {
   return c;
 }
 
-static int g_force_generic = -1;
-int debug_force_generic(int on) { int old = g_force_generic == 1; g_force_generic = on ? 1 : 0; return old; }
-static bool force_generic() {
-  if (g_force_generic < 0) {
-    const char* e = getenv("EP_POOL_FORCE_GENERIC");
-    g_force_generic = (e && e[0] == '1') ? 1 : 0;
+// kernel selection: 0 = automatic (matrix-core kernel where supported, else the vector-ALU
+// streaming kernel, else generic), 1 = generic only, 2 = skip the matrix-core kernel.
+static int g_pool_mode = -1;
+static int pool_mode() {
+  if (g_pool_mode < 0) {
+    const char* e = getenv("EP_POOL_MODE");
+    g_pool_mode = e ? atoi(e) : 0;
   }
-  return g_force_generic == 1;
+  return g_pool_mode;
 }
+int debug_force_generic(int mode) { int old = pool_mode(); g_pool_mode = mode; return old; }
+static bool force_generic() { return pool_mode() == 1; }
+// Measured on MI355X (tools/compare_modes.sh): the matrix-core kernel wins or ties for Q >= 5; with
+// few queries the vector-ALU kernel is purely memory-bound (6.2 TB/s at Q = 1) and wins; at
+// D = 1152 the matrix-core backward only fits a 2-deep ring and loses to the vector-ALU one.
+static bool use_mf(const PoolParams& p, bool bwd) {
+  if (pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
+  const bool valu_ok = stream_plan(p.B, p.N, p.D, p.Q).ok;
+  if (valu_ok && p.Q <= 4) return false;
+  if (valu_ok && bwd && p.D == 1152) return false;
+  return true;
+}
+static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 
 size_t pool_workspace_bytes(int B, int N, int D, int Q) {
   // Gpart: one (Q,D) partial per workgroup of the backward; the generic kernel uses one per
   // image, the streaming kernel one per resident workgroup (<= B).
   (void)N;
-  return round_up((size_t)(B + 16) * Q * D * sizeof(float), 256);
+  return round_up((size_t)(2 * B + 16) * Q * D * sizeof(float), 256);
 }
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
+  if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (c.ok && !force_generic()) {
     if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
@@ -212,7 +227,11 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   PoolParams p = p0;
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   int nparts;
-  if (c.ok && !force_generic()) {
+  if (use_mf(p, true)) {
+    const int grid = mf_grid(p.B);
+    nparts = 2 * grid;                         // one partial per token half of every workgroup
+    EP_TRY(mf_launch(true, p, grid, st));
+  } else if (c.ok && !force_generic()) {
     EP_TRY(stream_launch(true, c, p, st));
     nparts = c.grid;
   } else {

@@ -51,9 +51,11 @@ int ep_version(void);
 const char* ep_last_error_string(void);
 /* number of compute units of the current device (used by callers to size persistent grids) */
 int ep_device_cu_count(void);
-/* test hook: route ep_pool_forward/backward through the generic (non-streaming) kernels so the
- * two independent implementations can be compared on identical inputs.  Returns the old value. */
-int ep_debug_force_generic_pool(int on);
+/* test hook: select the pooling kernel family so the independent implementations can be compared
+ * on identical inputs: 0 = automatic (matrix-core streaming kernel where supported, else the
+ * vector-ALU streaming kernel, else generic), 1 = generic only, 2 = no matrix-core kernel.
+ * Returns the old value. */
+int ep_debug_force_generic_pool(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * EP attentive pooling, forward.   Replaces reference poolings/ep.py:35-44 (scores q.k^T,

@@ -59,7 +59,7 @@ def gtol(want, rtol=1e-4, k=2e-5):
 def test_native_library_is_loaded():
     from efficient_probing_amd import _native
     lib = _native.load()
-    assert lib.ep_version() == 1
+    assert lib.ep_version() >= 2
     assert lib.ep_device_cu_count() > 0
 
 
@@ -89,8 +89,8 @@ def test_streaming_and_generic_kernels_agree(case):
     rng = np.random.default_rng(5)
     dP = torch.from_numpy(rng.standard_normal((case.B, case.Q, case.D), dtype=np.float32)).to(DEV)
     outs = []
-    for generic in (0, 1):
-        lib.ep_debug_force_generic_pool(generic)
+    for mode in (1, 0, 2):       # generic (reference of this test), automatic (matrix-core), vector-ALU streaming
+        lib.ep_debug_force_generic_pool(mode)
         try:
             P, S, ML = F_.pool_forward(x, cls, scale)
             ML2 = ML.clone()
@@ -100,8 +100,10 @@ def test_streaming_and_generic_kernels_agree(case):
             outs.append([t.cpu().numpy() for t in (P, S, dcls)] + [F_.attention_from_scores(S, ML).cpu().numpy()])
         finally:
             lib.ep_debug_force_generic_pool(0)
-    for a, b, name in zip(outs[0], outs[1], ("P", "S", "dcls", "A")):
-        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(b).max())), err_msg=name)
+    for which, other in (("auto", outs[1]), ("valu-stream", outs[2])):
+        for a, b, name in zip(other, outs[0], ("P", "S", "dcls", "A")):
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(b).max())),
+                                       err_msg=f"{which} {name}")
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
