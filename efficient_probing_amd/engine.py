@@ -145,9 +145,10 @@ class ProbeHeadEngine:
         self._micro += 1
 
     def all_reduce_grads(self) -> None:
-        """THE collective of a data-parallel step: one sum all-reduce of the flat gradients."""
-        if self.world > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+        """THE collective of a data-parallel step: one sum all-reduce of the flat gradients
+        (parallel.all_reduce_flat_grads); the 1/world factor rides on the optimizer's inv_scale."""
+        from .parallel import all_reduce_flat_grads
+        all_reduce_flat_grads(self.flat_g, self.group)
 
     def optimizer_step(self, lr: Optional[float] = None) -> None:
         self.opt_step += 1

@@ -1,0 +1,255 @@
+"""Train / eval loops with the reference's call surface (reference engine_finetune.py:22-166):
+
+    train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler,
+                    max_norm=0, mixup_fn=None, log_writer=None, args=None) -> {name: global_avg}
+    evaluate(data_loader, model, device, *, return_targets_and_preds=False,
+             cls_features="cls", return_block=None) -> {"loss", "acc1", "acc5"[, "targets", "preds"]}
+
+Two execution paths, chosen per call:
+  * FUSED  -- ``model`` is (or wraps, as ``model.head``) a native ``Sequential(EfficientProbing,
+    BatchNorm1d, Linear)`` and the loader yields token tensors ``(B, N, D)`` (live encoder output
+    via ``token_fn`` or pre-dumped tokens): one ``ProbeHeadEngine`` step per batch -- forward, loss,
+    backward, [one all-reduce], optimizer in the HIP kernels, no host sync inside the step; loss /
+    accuracy are read back every ``print_freq`` steps instead of three ``.item()`` per step.
+  * MODULE -- anything else: the reference's loop (autocast, criterion, loss scaler, optimizer)
+    driving whatever modules ``model`` contains; the native modules run their kernels through
+    autograd.  Non-finite loss stops the run with exit code 1 like the reference
+    (engine_finetune.py:66-70).
+"""
+from __future__ import annotations
+
+import math
+import sys
+import time
+from collections import defaultdict, deque
+from typing import Callable, Iterable, Optional
+
+import torch
+
+from .util import lr_sched
+from .util import misc
+from .util.misc import AMP_PRECISIONS
+
+
+class SmoothedValue:
+    """Windowed / global running average (the subset of reference util/misc.py:22-81 the loops use)."""
+
+    def __init__(self, window_size: int = 20, fmt: str = "{median:.4f} ({global_avg:.4f})"):
+        self.deque = deque(maxlen=window_size)
+        self.total, self.count, self.fmt = 0.0, 0, fmt
+
+    def update(self, value, n: int = 1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        if not misc.is_dist_avail_and_initialized():
+            return
+        dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        torch.distributed.barrier()
+        torch.distributed.all_reduce(t)
+        self.count, self.total = int(t[0].item()), float(t[1].item())
+
+    @property
+    def median(self):
+        return float(torch.tensor(list(self.deque)).median()) if self.deque else 0.0
+
+    @property
+    def global_avg(self):
+        return self.total / max(self.count, 1)
+
+    @property
+    def value(self):
+        return self.deque[-1] if self.deque else 0.0
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, global_avg=self.global_avg, value=self.value)
+
+
+class MetricLogger:
+    def __init__(self, delimiter: str = "  "):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            self.meters[k].update(float(v))
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def synchronize_between_processes(self):
+        for m in self.meters.values():
+            m.synchronize_between_processes()
+
+    def __getattr__(self, attr):
+        if attr in self.__dict__.get("meters", {}):
+            return self.meters[attr]
+        raise AttributeError(attr)
+
+    def __str__(self):
+        return self.delimiter.join(f"{k}: {v}" for k, v in self.meters.items())
+
+    def log_every(self, iterable, print_freq, header=""):
+        t0 = time.time()
+        for i, obj in enumerate(iterable):
+            yield obj
+            if print_freq and i % print_freq == 0 and misc.get_rank() == 0:
+                print(f"{header} [{i}] {self}  elapsed {time.time() - t0:.1f}s")
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1, 5)):
+    """timm.utils.accuracy: percentage of rows whose target is among the k largest logits."""
+    maxk = min(max(topk), output.size(1))
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand_as(pred.t()))
+    return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100.0 / target.size(0) for k in topk]
+
+
+def _native_head(model):
+    from .probe_heads import is_native_ep_head
+    m = model.module if hasattr(model, "module") else model
+    head = m if is_native_ep_head(m) else getattr(m, "head", None)
+    return head if (head is not None and is_native_ep_head(head)) else None
+
+
+def get_engine(model, optimizer=None, args=None):
+    """The fused engine attached to ``model`` (created on first use from the optimizer's
+    hyper-parameters; LARS / SGD / AdamW as selected by reference main_linprobe.py:403-408)."""
+    from .engine import ProbeHeadEngine
+    m = model.module if hasattr(model, "module") else model
+    eng = getattr(m, "_ep_engine", None)
+    if eng is None:
+        head = _native_head(model)
+        if head is None:
+            return None
+        name, kw = "lars", {}
+        if optimizer is not None:
+            g = optimizer.param_groups[0]
+            cls = type(optimizer).__name__.lower()
+            name = "lars" if "lars" in cls else ("adamw" if "adamw" in cls else "sgd")
+            kw = dict(lr=g.get("lr", 0.0), weight_decay=g.get("weight_decay", 0.0))
+            if name == "lars":
+                kw.update(momentum=g.get("momentum", 0.9), trust_coefficient=g.get("trust_coefficient", 0.001))
+            if name == "adamw":
+                kw.update(betas=g.get("betas", (0.9, 0.999)), adam_eps=g.get("eps", 1e-8))
+        accum = getattr(args, "accum_iter", 1) if args is not None else 1
+        eng = ProbeHeadEngine(head, optimizer=name, accum_iter=accum, **kw)
+        if optimizer is not None and name == "lars":
+            # keep optimizer.state_dict() interchangeable with the reference's (state[p]['mu']):
+            # the optimizer's momentum entries become views of the engine's flat buffer
+            for p, mu in zip(eng.params_list, eng.mu_views()):
+                st = optimizer.state[p]
+                if "mu" in st:
+                    mu.copy_(st["mu"])                      # resumed from a checkpoint
+                st["mu"] = mu
+        m._ep_engine = eng
+    return eng
+
+
+def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
+                    optimizer: torch.optim.Optimizer, device: torch.device, epoch: int, loss_scaler,
+                    max_norm: float = 0, mixup_fn=None, log_writer=None, args=None,
+                    token_fn: Optional[Callable] = None):
+    """``token_fn(samples) -> (B, N, D) tokens`` (the frozen encoder) enables the fused path for image
+    loaders; loaders that already yield 3-D token tensors take it directly."""
+    model.train(True)
+    metric_logger = MetricLogger()
+    metric_logger.add_meter("lr", SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    header = f"Epoch: [{epoch}]"
+    print_freq = 20
+    accum_iter = getattr(args, "accum_iter", 1)
+    amp = getattr(args, "amp", "none")
+    n_iter = len(data_loader)
+    engine = get_engine(model, optimizer, args) if mixup_fn is None else None
+    optimizer.zero_grad()
+    pending = 0                                   # fused steps whose statistics are still on the GPU
+
+    def flush_stats(n_steps):
+        loss_sum, top1, top5, bad = engine.read_stats()
+        if bad > 0 or not math.isfinite(loss_sum):
+            print(f"Loss is non-finite ({loss_sum}), stopping training")
+            sys.exit(1)
+        bsz = engine.dims.B
+        metric_logger.meters["loss"].update(loss_sum / n_steps, n_steps)
+        metric_logger.meters["acc1"].update(top1 * 100.0 / (bsz * n_steps), n_steps)
+        metric_logger.meters["acc5"].update(top5 * 100.0 / (bsz * n_steps), n_steps)
+
+    for step, (samples, targets) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+        if step % accum_iter == 0:
+            lr = lr_sched.adjust_learning_rate(optimizer, step / n_iter + epoch, args)
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        fused = engine is not None and (samples.dim() == 3 or token_fn is not None)
+        if fused:
+            tokens = samples if samples.dim() == 3 else token_fn(samples)
+            engine.forward_backward(tokens.detach(), targets)
+            if (step + 1) % accum_iter == 0:
+                engine.all_reduce_grads()
+                engine.optimizer_step(lr=max(g["lr"] for g in optimizer.param_groups))
+            pending += 1
+            if pending == print_freq or step == n_iter - 1:
+                flush_stats(pending)
+                pending = 0
+        else:
+            if mixup_fn is not None:
+                samples, targets = mixup_fn(samples, targets)
+            with torch.autocast("cuda", enabled=(amp != "none" and samples.is_cuda), dtype=AMP_PRECISIONS[amp]):
+                outputs = model(samples)
+                loss = criterion(outputs, targets)
+            acc1, acc5 = accuracy(outputs.float(), targets if targets.dim() == 1 else targets.argmax(1))
+            metric_logger.update(acc1=acc1.item(), acc5=acc5.item())
+            loss_value = loss.item()
+            if not math.isfinite(loss_value):
+                print(f"Loss is {loss_value}, stopping training")
+                sys.exit(1)
+            loss = loss / accum_iter
+            loss_scaler(loss, optimizer, clip_grad=max_norm if max_norm else None, parameters=model.parameters(),
+                        create_graph=False, update_grad=(step + 1) % accum_iter == 0)
+            if (step + 1) % accum_iter == 0:
+                optimizer.zero_grad()
+            metric_logger.update(loss=loss_value)
+        metric_logger.update(lr=max(g["lr"] for g in optimizer.param_groups))
+        if log_writer is not None and (step + 1) % accum_iter == 0 and "loss" in metric_logger.meters:
+            epoch_1000x = int((step / n_iter + epoch) * 1000)
+            log_writer.add_scalar("loss", misc.all_reduce_mean(metric_logger.meters["loss"].value), epoch_1000x)
+            log_writer.add_scalar("lr", metric_logger.meters["lr"].value, epoch_1000x)
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: m.global_avg for k, m in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = False, cls_features: str = "cls",
+             return_block: Optional[int] = None, token_fn: Optional[Callable] = None):
+    model.eval()
+    metric_logger = MetricLogger()
+    engine = get_engine(model)
+    if engine is not None:
+        engine.sync_buffers()                      # rank 0's running statistics, as DDP's buffer broadcast gives
+    all_t, all_p = [], []
+    for batch in metric_logger.log_every(data_loader, 10, "Test:"):
+        images, target = batch[0].to(device, non_blocking=True), batch[-1].to(device, non_blocking=True)
+        if engine is not None and (images.dim() == 3 or token_fn is not None):
+            output = engine.eval_logits(images if images.dim() == 3 else token_fn(images))
+        else:
+            output = model(images).float()
+        loss = torch.nn.functional.cross_entropy(output, target)
+        acc1, acc5 = accuracy(output, target)
+        n = images.shape[0]
+        metric_logger.update(loss=loss.item())
+        metric_logger.meters["acc1"].update(acc1.item(), n=n)
+        metric_logger.meters["acc5"].update(acc5.item(), n=n)
+        if return_targets_and_preds:
+            all_t.append(target.cpu())
+            all_p.append(output.argmax(1).cpu())
+    metric_logger.synchronize_between_processes()
+    stats = {k: m.global_avg for k, m in metric_logger.meters.items()}
+    print("* Acc@1 {:.3f} Acc@5 {:.3f} loss {:.3f}".format(stats.get("acc1", 0), stats.get("acc5", 0), stats.get("loss", 0)))
+    if return_targets_and_preds:
+        stats["targets"], stats["preds"] = torch.cat(all_t), torch.cat(all_p)
+    return stats

@@ -1,0 +1,137 @@
+"""engine_finetune on the GPU: the fused path and the module (autograd) path of train_one_epoch
+produce the same head, gradient accumulation matches one big step's gradients, and evaluate() agrees
+with the oracle.  Needs an MI355X (pytest -m gpu)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from cases import Case, make_inputs
+from oracle import ep_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Enc(torch.nn.Module):
+    def __init__(self, dim, classes):
+        super().__init__()
+        self.head = torch.nn.Linear(dim, classes)
+
+    def forward(self, tokens):
+        return self.head(tokens)
+
+
+def make_model(case, inp):
+    from efficient_probing_amd import probe_heads
+    torch.manual_seed(0)
+    m = Enc(case.D, case.C)
+    probe_heads.build_probe_head(m, Namespace(cls_features="ep", ep_queries=case.Q, d_out=1, nb_classes=case.C))
+    with torch.no_grad():
+        m.head[0].cls_token.copy_(torch.from_numpy(inp["cls_token"]))
+        m.head[0].v.weight.copy_(torch.from_numpy(inp["v_weight"]))
+        m.head[2].weight.copy_(torch.from_numpy(inp["fc_weight"]))
+        m.head[2].bias.copy_(torch.from_numpy(inp["fc_bias"]))
+    return m.to(DEV)
+
+
+def loader_of(case, inp, n_batches):
+    xs = [inp["x_buf"], inp["x_buf2"]]
+    ts = [inp["targets"], inp["targets2"]]
+    return [(torch.from_numpy(xs[i % 2]), torch.from_numpy(ts[i % 2])) for i in range(n_batches)]
+
+
+ARGS = Namespace(accum_iter=1, amp="none", lr=0.4, min_lr=0.0, warmup_epochs=1, epochs=3)
+
+
+def run(case, inp, fused, accum=1, n_batches=4):
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd.util.lars import LARS
+    from efficient_probing_amd.util.misc import NativeScalerWithGradNormCount
+    from efficient_probing_amd import functional as F_
+    model = make_model(case, inp)
+    opt = LARS(model.head.parameters(), lr=0.0, weight_decay=1e-4)
+    args = Namespace(**{**vars(ARGS), "accum_iter": accum})
+    loader = loader_of(case, inp, n_batches)
+    if fused:
+        stats = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), loader, opt, torch.device(DEV), 1,
+                                   NativeScalerWithGradNormCount(), args=args)
+    else:
+        class Wrapped(torch.nn.Module):           # hides the head from the fused-path detection
+            def __init__(self, m):
+                super().__init__()
+                self.inner = m
+
+            def forward(self, x):
+                return self.inner(x)
+        crit = lambda out, t: F_.cross_entropy_loss(out, t)[0]
+        stats = EF.train_one_epoch(Wrapped(model), crit, loader, opt, torch.device(DEV), 1,
+                                   NativeScalerWithGradNormCount(), args=args)
+    return model, opt, stats
+
+
+def test_fused_and_module_paths_agree():
+    case = Case("ef", B=16, N=40, D=256, Q=8, C=20, seed=5)
+    inp = make_inputs(case)
+    m1, o1, s1 = run(case, inp, fused=True)
+    m2, o2, s2 = run(case, inp, fused=False)
+    for (n1, p1), (n2, p2) in zip(m1.head.named_parameters(), m2.head.named_parameters()):
+        np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=n1)
+    assert s1["loss"] == pytest.approx(s2["loss"], rel=1e-4)
+    assert s1["acc1"] == pytest.approx(s2["acc1"]) and s1["lr"] == pytest.approx(s2["lr"])
+    np.testing.assert_allclose(m1.head[1].running_var.cpu().numpy(), m2.head[1].running_var.cpu().numpy(), rtol=1e-5)
+    # optimizer state is exposed in the reference's format on both paths
+    for p in m1.head.parameters():
+        assert "mu" in o1.state[p] and o1.state[p]["mu"].shape == p.shape
+    sd = o1.state_dict()
+    assert all("mu" in st for st in sd["state"].values())
+
+
+def test_gradient_accumulation_matches_reference_semantics():
+    """accum_iter = 2: gradients of the two micro-batches (each loss / 2) add up before one LARS step
+    (reference engine_finetune.py:72-77); BatchNorm sees each micro-batch separately."""
+    case = Case("acc", B=8, N=24, D=128, Q=4, C=12, seed=9)
+    inp = make_inputs(case)
+    m, opt, _ = run(case, inp, fused=True, accum=2, n_batches=2)
+    st = O.HeadState(cls_token=inp["cls_token"].copy(), v_weight=inp["v_weight"].copy(),
+                     fc_weight=inp["fc_weight"].copy(), fc_bias=inp["fc_bias"].copy(),
+                     running_mean=np.zeros(case.D, np.float32), running_var=np.ones(case.D, np.float32),
+                     num_queries=case.Q, d_out=1)
+    grads = None
+    for xb, tg in ((inp["x_buf"], inp["targets"]), (inp["x_buf2"], inp["targets2"])):
+        out, cache = O.head_forward_train(st, xb, tg)
+        g = O.head_backward(st, cache, loss_scale=0.5)
+        gl = [g[k] for k in O.PARAM_ORDER]
+        grads = gl if grads is None else [a + b for a, b in zip(grads, gl)]
+        st.running_mean, st.running_var, st.num_batches_tracked = cache["new_bn"]
+    from efficient_probing_amd.util.lr_sched import lr_at
+    lr = lr_at(1.0, 0.4, 0.0, 1, 3)                 # schedule point of micro-step 0 of epoch 1
+    ps, _ = O.lars_step(st.params(), grads, [None] * 4, lr=lr, weight_decay=1e-4)
+    for got, want, n in zip(m.head.parameters(), ps, O.PARAM_ORDER):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-4, atol=2e-6, err_msg=n)
+    assert int(m.head[1].num_batches_tracked) == 2
+
+
+def test_evaluate_matches_oracle():
+    from efficient_probing_amd import engine_finetune as EF
+    case = Case("ev", B=16, N=33, D=256, Q=8, C=20, seed=2)
+    inp = make_inputs(case)
+    model = make_model(case, inp)
+    with torch.no_grad():
+        model.head[1].running_mean.normal_(0, 0.1)
+        model.head[1].running_var.uniform_(0.5, 1.5)
+    st = O.HeadState(cls_token=inp["cls_token"], v_weight=inp["v_weight"], fc_weight=inp["fc_weight"],
+                     fc_bias=inp["fc_bias"], running_mean=model.head[1].running_mean.cpu().numpy(),
+                     running_var=model.head[1].running_var.cpu().numpy(), num_queries=case.Q, d_out=1)
+    loader = loader_of(case, inp, 2)
+    stats = EF.evaluate(loader, model, torch.device(DEV), return_targets_and_preds=True)
+    accs, losses = [], []
+    for xb, tg in ((inp["x_buf"], inp["targets"]), (inp["x_buf2"], inp["targets2"])):
+        logits = O.head_forward_eval(st, xb)
+        loss, _ = O.cross_entropy(logits, tg)
+        accs.append(O.accuracy(logits, tg)); losses.append(float(loss))
+    assert stats["loss"] == pytest.approx(np.mean(losses), rel=1e-4)
+    assert stats["acc1"] == pytest.approx(np.mean([a[0] for a in accs]))
+    assert stats["acc5"] == pytest.approx(np.mean([a[1] for a in accs]))
+    assert stats["preds"].shape == (2 * case.B,)
