@@ -182,6 +182,7 @@ int ep_device_cu_count(void) { return cu_count(); }
 int ep_debug_force_generic_pool(int on) { return debug_force_generic(on); }
 
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q) { return pool_workspace_bytes(B, N, D, Q); }
+const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward) { return pool_kernel_family(B, N, D, Q, backward); }
 
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, const float* cls_token,
                     int64_t cls_bstride, int Q, float scale, float* P, float* S, float* ML, void* workspace,

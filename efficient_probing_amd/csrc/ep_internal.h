@@ -34,6 +34,7 @@ struct GemmParams {
 };
 
 size_t pool_workspace_bytes(int B, int N, int D, int Q);
+const char* pool_kernel_family(int B, int N, int D, int Q, int bwd);
 int pool_forward(const PoolParams& p, hipStream_t st);
 int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st);
 int debug_force_generic(int on);

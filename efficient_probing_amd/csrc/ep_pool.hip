@@ -202,6 +202,14 @@ static bool use_mf(const PoolParams& p, bool bwd) {
 }
 static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 
+const char* pool_kernel_family(int B, int N, int D, int Q, int bwd) {
+  PoolParams p{};
+  p.B = B; p.N = N; p.D = D; p.Q = Q;
+  if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
+  if (stream_plan(B, N, D, Q).ok && !force_generic()) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
+  return bwd ? "ep_pool_bwd_generic_kernel" : "ep_pool_fwd_generic_kernel";
+}
+
 size_t pool_workspace_bytes(int B, int N, int D, int Q) {
   // Gpart: one (Q,D) partial per workgroup of the backward; the generic kernel uses one per
   // image, the streaming kernel one per resident workgroup (<= B).

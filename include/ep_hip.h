@@ -69,6 +69,9 @@ int ep_debug_force_generic_pool(int mode);
  * cls_bstride != 0, a per-image (B,Q,D) override (the `cls=` argument of ep.py:32-33).
  */
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q);
+/* name of the device kernel ep_pool_forward / ep_pool_backward will launch for this shape (for
+ * matching profiler output; static string) */
+const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward);
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D,
                     const float* cls_token, int64_t cls_bstride, int Q, float scale,
                     float* P, float* S, float* ML,

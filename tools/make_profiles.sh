@@ -1,0 +1,38 @@
+#!/usr/bin/env bash
+# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + HBM traffic counters of bench.py.
+# usage: tools/make_profiles.sh TAG [bench args...]   -> gpurun_out/profiles_TAG/*
+set -uo pipefail
+tag="$1"; shift
+out="gpurun_out/profiles_$tag"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+args="--steps 30 --warmup 5 --no-cpu-baseline --kernel-iters 10 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py $args > "$out/bench_under_trace.json" 2> "$out/trace.log"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $args > /dev/null 2> "$out/pmc_fetch.log"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py $args > /dev/null 2> "$out/pmc_write.log"
+python3 tools/prof_summary.py "$out/trace" > "$out/kernel_stats_summary.txt"
+python3 - "$out" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ep::", "")
+                agg[k].append(float(r["Counter_Value"]))
+    res[name] = {k: {"launches": len(v), "avg_KiB": sum(v) / len(v)} for k, v in agg.items() if "ep_" in k}
+# gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM)
+summary = {}
+for k, v in res["FETCH_SIZE"].items():
+    w = res["WRITE_SIZE"].get(k, {"avg_KiB": 0.0})
+    summary[k] = {"fetch_bytes_corrected": v["avg_KiB"] * 1024 * 2, "write_bytes": w["avg_KiB"] * 1024,
+                  "hbm_bytes_per_launch": v["avg_KiB"] * 1024 * 2 + w["avg_KiB"] * 1024, "launches": v["launches"]}
+json.dump({"raw": res, "per_kernel": summary,
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); WRITE_SIZE as is"},
+          open(f"{out}/hbm_traffic.json", "w"), indent=1)
+for k, v in summary.items():
+    if "pool" in k: print(k[:50], {a: round(b) for a, b in v.items()})
+PY
+rm -rf "$out"/pmc_fetch/*/*agent_info.csv "$out"/pmc_write/*/*agent_info.csv
+cat "$out/kernel_stats_summary.txt" | head -30
