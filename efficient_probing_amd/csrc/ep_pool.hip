@@ -201,10 +201,18 @@ static bool use_mf(const PoolParams& p, bool bwd) {
   return true;
 }
 static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
+// all-matrix-core kernel: forced with mode 3; chosen automatically only where it measured fastest
+// (backward at D = 1152, where the other two kernels run short of LDS / registers)
+static bool use_mm(const PoolParams& p, bool bwd) {
+  if (!mm_supported(p.D, p.Q, p.cls_bstride)) return false;
+  if (pool_mode() == 3) return true;
+  return pool_mode() == 0 && bwd && p.D == 1152 && p.Q >= 5;
+}
 
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd) {
   PoolParams p{};
   p.B = B; p.N = N; p.D = D; p.Q = Q;
+  if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
   if (stream_plan(B, N, D, Q).ok && !force_generic()) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
   return bwd ? "ep_pool_bwd_generic_kernel" : "ep_pool_fwd_generic_kernel";
@@ -219,6 +227,7 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
+  if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (c.ok && !force_generic()) {
@@ -235,7 +244,10 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   PoolParams p = p0;
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   int nparts;
-  if (use_mf(p, true)) {
+  if (use_mm(p, true)) {
+    nparts = mf_grid(p.B);
+    EP_TRY(mm_launch(true, p, nparts, st));
+  } else if (use_mf(p, true)) {
     const int grid = mf_grid(p.B);
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));

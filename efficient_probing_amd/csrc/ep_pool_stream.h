@@ -54,6 +54,9 @@ StreamPlan stream_plan(int B, int N, int D, int Q);
 // matrix-core variant (ep_pool_mfma.hip)
 bool mf_supported(int D, int Q, int64_t cls_bstride);
 int mf_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
+// all-matrix-core variant (ep_pool_mm.hip)
+bool mm_supported(int D, int Q, int64_t cls_bstride);
+int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st);
 
 }  // namespace ep

@@ -89,7 +89,7 @@ def test_streaming_and_generic_kernels_agree(case):
     rng = np.random.default_rng(5)
     dP = torch.from_numpy(rng.standard_normal((case.B, case.Q, case.D), dtype=np.float32)).to(DEV)
     outs = []
-    for mode in (1, 0, 2):       # generic (reference of this test), automatic (matrix-core), vector-ALU streaming
+    for mode in (1, 0, 2, 3):    # generic (reference of this test), automatic, vector-ALU streaming, all-matrix-core
         lib.ep_debug_force_generic_pool(mode)
         try:
             P, S, ML = F_.pool_forward(x, cls, scale)
@@ -100,7 +100,7 @@ def test_streaming_and_generic_kernels_agree(case):
             outs.append([t.cpu().numpy() for t in (P, S, dcls)] + [F_.attention_from_scores(S, ML).cpu().numpy()])
         finally:
             lib.ep_debug_force_generic_pool(0)
-    for which, other in (("auto", outs[1]), ("valu-stream", outs[2])):
+    for which, other in (("auto", outs[1]), ("valu-stream", outs[2]), ("all-mfma", outs[3])):
         for a, b, name in zip(other, outs[0], ("P", "S", "dcls", "A")):
             np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(b).max())),
                                        err_msg=f"{which} {name}")
