@@ -27,87 +27,100 @@ constexpr int LDT = BM + 16;   // T-layout row stride (floats)
 
 // ---- global -> register tile loads ---------------------------------------------------------
 // K layout: 64 rows x 32 k ; thread handles float4 (row = idx/8, kq = idx%8), idx = tid + 256 r
-template <bool VEC>
+template <bool VEC, int RT>
 __device__ __forceinline__ void load_K(const float* __restrict__ base, int64_t ld, int rows, int K,
                                        int r0, int k0, int tid, f4v (&reg)[2]) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RT / 32; ++r) {
     const int idx = tid + 256 * r;
     const int row = r0 + (idx >> 3), k = k0 + 4 * (idx & 7);
     f4v v = {0.f, 0.f, 0.f, 0.f};
-    if (row < rows) {
+    if (VEC) {
+      // branch-free: out-of-range lanes load a valid address and are zeroed afterwards, so the
+      // prefetch loads stay straight-line code and the compiler can count them exactly (vmcnt(N))
+      const int rowc = row < rows ? row : rows - 1;
+      v = *reinterpret_cast<const f4v*>(base + (int64_t)rowc * ld + (k < K ? k : 0));   // zeroed in store_K
+    } else if (row < rows) {
       const float* ptr = base + (int64_t)row * ld + k;
-      if (VEC) {
-        if (k < K) v = *reinterpret_cast<const f4v*>(ptr);
-      } else {
-        if (k + 0 < K) v.x = ptr[0];
-        if (k + 1 < K) v.y = ptr[1];
-        if (k + 2 < K) v.z = ptr[2];
-        if (k + 3 < K) v.w = ptr[3];
-      }
+      if (k + 0 < K) v.x = ptr[0];
+      if (k + 1 < K) v.y = ptr[1];
+      if (k + 2 < K) v.z = ptr[2];
+      if (k + 3 < K) v.w = ptr[3];
     }
     reg[r] = v;
   }
 }
 // T layout: 32 k-rows x 64 r ; thread handles float4 (krow = idx/16, rq = idx%16)
-template <bool VEC>
+template <bool VEC, int RT>
 __device__ __forceinline__ void load_T(const float* __restrict__ base, int64_t ld, int ext, int K,
                                        int r0, int k0, int tid, f4v (&reg)[2]) {
+  constexpr int QPR = RT / 4;             // float4 per k-row (16 or 8)
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RT / 32; ++r) {
     const int idx = tid + 256 * r;
-    const int k = k0 + (idx >> 4), rr = r0 + 4 * (idx & 15);
+    const int k = k0 + idx / QPR, rr = r0 + 4 * (idx % QPR);
     f4v v = {0.f, 0.f, 0.f, 0.f};
-    if (k < K) {
+    if (VEC) {
+      const int kc = k < K ? k : K - 1;
+      v = *reinterpret_cast<const f4v*>(base + (int64_t)kc * ld + (rr < ext ? rr : 0));  // zeroed in store_T
+    } else if (k < K) {
       const float* ptr = base + (int64_t)k * ld + rr;
-      if (VEC) {
-        if (rr < ext) v = *reinterpret_cast<const f4v*>(ptr);
-      } else {
-        if (rr + 0 < ext) v.x = ptr[0];
-        if (rr + 1 < ext) v.y = ptr[1];
-        if (rr + 2 < ext) v.z = ptr[2];
-        if (rr + 3 < ext) v.w = ptr[3];
-      }
+      if (rr + 0 < ext) v.x = ptr[0];
+      if (rr + 1 < ext) v.y = ptr[1];
+      if (rr + 2 < ext) v.z = ptr[2];
+      if (rr + 3 < ext) v.w = ptr[3];
     }
     reg[r] = v;
   }
 }
-__device__ __forceinline__ void store_K(float* lds, int tid, const f4v (&reg)[2]) {
+// the out-of-range mask is applied here, at the point the loaded registers are consumed anyway
+// (a select right after the load would force the load to complete immediately)
+template <int RT>
+__device__ __forceinline__ void store_K(float* lds, int tid, const f4v (&reg)[2], int rows, int K, int r0, int k0) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RT / 32; ++r) {
     const int idx = tid + 256 * r;
+    const bool ok = (r0 + (idx >> 3)) < rows && (k0 + 4 * (idx & 7)) < K;
+    const f4v v = ok ? reg[r] : f4v{0.f, 0.f, 0.f, 0.f};
     float* d = lds + (idx >> 3) * LDK + 4 * (idx & 7);
-    *reinterpret_cast<f2*>(d) = f2{reg[r].x, reg[r].y};
-    *reinterpret_cast<f2*>(d + 2) = f2{reg[r].z, reg[r].w};
+    *reinterpret_cast<f2*>(d) = f2{v.x, v.y};
+    *reinterpret_cast<f2*>(d + 2) = f2{v.z, v.w};
   }
 }
-__device__ __forceinline__ void store_T(float* lds, int tid, const f4v (&reg)[2]) {
+template <int RT>
+__device__ __forceinline__ void store_T(float* lds, int tid, const f4v (&reg)[2], int ext, int K, int r0, int k0) {
+  constexpr int QPR = RT / 4;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RT / 32; ++r) {
     const int idx = tid + 256 * r;
-    *reinterpret_cast<f4v*>(lds + (idx >> 4) * LDT + 4 * (idx & 15)) = reg[r];
+    const bool ok = (k0 + idx / QPR) < K && (r0 + 4 * (idx % QPR)) < ext;
+    const f4v v = ok ? reg[r] : f4v{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4v*>(lds + (idx / QPR) * LDT + 4 * (idx % QPR)) = v;
   }
 }
 
 constexpr int LDS_OPERAND = (64 * LDK > 32 * LDT) ? 64 * LDK : 32 * LDT;   // floats per operand image
 
-template <bool A_K, bool B_K, bool VEC>
+// BMT = rows of the output tile (64, or 32 when a 64-row tiling would leave CUs with a single
+// workgroup: two resident workgroups per CU hide each other's LDS / barrier latency)
+template <bool A_K, bool B_K, bool VEC, int BMT>
 __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
+  constexpr int MI = BMT / 32;            // 16-row MFMA blocks per wave along M
   __shared__ __attribute__((aligned(16))) float lds[2][2][LDS_OPERAND];   // [buffer][A|B]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BMT, n0 = blockIdx.x * BN;
   const int z = blockIdx.z;
   const float* A = p.A + (int64_t)z * p.sAz;
   const float* B = p.B + (int64_t)z * p.sBz;
   float* C = p.C + (int64_t)z * p.sCz;
   const int i16 = lane & 15, kk = lane >> 4;
 
-  f4v acc[2][2];
+  f4v acc[MI][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MI; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
 
@@ -116,24 +129,24 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
   // into LDS one iteration ahead of its use.  R[j] indices are static (loop unrolled by 3).
   f4v ra[3][2], rb[3][2];
   auto gload = [&](int k0, f4v (&xa)[2], f4v (&xb)[2]) {
-    if (A_K) load_K<VEC>(A, p.lda, p.M, p.K, m0, k0, tid, xa);
-    else load_T<VEC>(A, p.lda, p.extA, p.K, m0, k0, tid, xa);
-    if (B_K) load_K<VEC>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
-    else load_T<VEC>(B, p.ldb, p.extB, p.K, n0, k0, tid, xb);
+    if (A_K) load_K<VEC, BMT>(A, p.lda, p.M, p.K, m0, k0, tid, xa);
+    else load_T<VEC, BMT>(A, p.lda, p.extA, p.K, m0, k0, tid, xa);
+    if (B_K) load_K<VEC, BN>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
+    else load_T<VEC, BN>(B, p.ldb, p.extB, p.K, n0, k0, tid, xb);
   };
-  auto lstore = [&](int buf, const f4v (&xa)[2], const f4v (&xb)[2]) {
-    if (A_K) store_K(lds[buf][0], tid, xa); else store_T(lds[buf][0], tid, xa);
-    if (B_K) store_K(lds[buf][1], tid, xb); else store_T(lds[buf][1], tid, xb);
+  auto lstore = [&](int buf, const f4v (&xa)[2], const f4v (&xb)[2], int k0) {
+    if (A_K) store_K<BMT>(lds[buf][0], tid, xa, p.M, p.K, m0, k0); else store_T<BMT>(lds[buf][0], tid, xa, p.extA, p.K, m0, k0);
+    if (B_K) store_K<BN>(lds[buf][1], tid, xb, p.N, p.K, n0, k0); else store_T<BN>(lds[buf][1], tid, xb, p.extB, p.K, n0, k0);
   };
   auto compute = [&](int buf) {
     const float* As = lds[buf][0];
     const float* Bs = lds[buf][1];
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      float af[2], bf[2];
+      float af[MI], bf[2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int row = wm * 32 + mi * 16 + i16;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (16 * MI) + mi * 16 + i16;
         af[mi] = A_K ? As[row * LDK + 4 * s + kk] : As[(4 * s + kk) * LDT + row];
       }
 #pragma unroll
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
         bf[ni] = B_K ? Bs[col * LDK + 4 * s + kk] : Bs[(4 * s + kk) * LDT + col];
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
@@ -150,27 +163,35 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
   };
 
   const int nk = (p.K + BK - 1) / BK;
+  auto tile_k0 = [&](int it) { return (it < nk ? it : nk - 1) * BK; };   // clamped: redundant, never out of range
   gload(0, ra[0], rb[0]);
-  lstore(0, ra[0], rb[0]);
-  if (nk > 1) gload(BK, ra[1], rb[1]);
-  if (nk > 2) gload(2 * BK, ra[2], rb[2]);
+  lstore(0, ra[0], rb[0], 0);
+  gload(tile_k0(1), ra[1], rb[1]);
+  gload(tile_k0(2), ra[2], rb[2]);
   __syncthreads();
-#define EP_GEMM_STEP(IT, J)                                                   \
-  if ((IT) < nk) {                                                            \
-    if ((IT) + 3 < nk) gload(((IT) + 3) * BK, ra[J], rb[J]);                  \
-    compute((IT) & 1);                                                        \
-    if ((IT) + 1 < nk) lstore(((IT) + 1) & 1, ra[((J) + 1) % 3], rb[((J) + 1) % 3]); \
-    __syncthreads();                                                          \
+  // One step = prefetch tile it+3 (unconditionally: straight-line code lets the compiler wait with an
+  // exact vmcnt(N) instead of draining), multiply tile it, stage tile it+1 into the other LDS buffer.
+#define EP_GEMM_STEP(IT, J)                                                 \
+  {                                                                         \
+    gload(tile_k0((IT) + 3), ra[J], rb[J]);                                 \
+    compute((IT) & 1);                                                      \
+    lstore(((IT) + 1) & 1, ra[((J) + 1) % 3], rb[((J) + 1) % 3], ((IT) + 1) * BK); \
+    __syncthreads();                                                        \
   }
-  for (int it = 0; it < nk; it += 3) {
+  int it = 0;
+  for (; it + 2 < nk; it += 3) {
     EP_GEMM_STEP(it, 0)
     EP_GEMM_STEP(it + 1, 1)
     EP_GEMM_STEP(it + 2, 2)
   }
+  if (it < nk) {
+    EP_GEMM_STEP(it, 0)
+    if (it + 1 < nk) EP_GEMM_STEP(it + 1, 1)
+  }
 #undef EP_GEMM_STEP
   // epilogue: D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + wn * 32 + ni * 16 + i16;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
       const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + mi * 16 + kk * 4 + r;
+        const int row = m0 + wm * (16 * MI) + mi * 16 + kk * 4 + r;
         if (row < p.M) {
           float* c = C + (int64_t)row * p.ldc + col;
           float v = p.alpha * acc[mi][ni][r] + bv;
@@ -189,22 +210,10 @@ __global__ __launch_bounds__(256) void ep_gemm_kernel(GemmParams p) {
     }
 }
 
-int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
-  if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch);
-  // vector loads need 16-byte aligned rows on every operand
-  auto vec_ok = [](const float* ptr, int64_t ld, int64_t sz, int inner) {
-    return aligned16(ptr) && ld % 4 == 0 && sz % 4 == 0 && inner % 4 == 0;
-  };
-  const bool vec = vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
-  size_t pad = 0;
-  if (const char* e = getenv("EP_GEMM_PADLDS")) pad = (size_t)atoi(e) * 1024;
-  if (pad) {
-#define EP_GEMM_ATTR(AK, BK_, V) hipFuncSetAttribute((const void*)ep_gemm_kernel<AK, BK_, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad)
-    EP_GEMM_ATTR(true, true, true); EP_GEMM_ATTR(true, false, true); EP_GEMM_ATTR(false, true, true); EP_GEMM_ATTR(false, false, true);
-#undef EP_GEMM_ATTR
-  }
-#define EP_GEMM_LAUNCH(AK, BK_, V) hipLaunchKernelGGL((ep_gemm_kernel<AK, BK_, V>), grid, dim3(256), pad, st, p)
+template <int BMT>
+static void gemm_launch(bool a_k, bool b_k, bool vec, const GemmParams& p, int batch, hipStream_t st) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BMT - 1) / BMT, batch);
+#define EP_GEMM_LAUNCH(AK, BK_, V) hipLaunchKernelGGL((ep_gemm_kernel<AK, BK_, V, BMT>), grid, dim3(256), 0, st, p)
   if (vec) {
     if (a_k && b_k) EP_GEMM_LAUNCH(true, true, true);
     else if (a_k && !b_k) EP_GEMM_LAUNCH(true, false, true);
@@ -217,6 +226,21 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
     else EP_GEMM_LAUNCH(false, false, false);
   }
 #undef EP_GEMM_LAUNCH
+}
+
+int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
+  // vector loads need 16-byte aligned rows on every operand
+  auto vec_ok = [](const float* ptr, int64_t ld, int64_t sz, int inner) {
+    return aligned16(ptr) && ld % 4 == 0 && sz % 4 == 0 && inner % 4 == 0;
+  };
+  const bool vec = vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
+  const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;
+  static int force_bm = -1;
+  if (force_bm < 0) { const char* e = getenv("EP_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
+  const bool small = force_bm ? (force_bm == 32) : (tiles64 < 2L * cu_count());
+  if (small) gemm_launch<32>(a_k, b_k, vec, p, batch, st);
+  else gemm_launch<64>(a_k, b_k, vec, p, batch, st);
   EP_LAUNCH_CHECK("ep_gemm_kernel");
   return 0;
 }

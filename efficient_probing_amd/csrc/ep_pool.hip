@@ -169,7 +169,7 @@ StreamPlan stream_plan(int B, int N, int D, int Q) {
   else if (Q <= 16) { c.qw = 2; c.nw = 8; }
   else { c.qw = 4; c.nw = 8; }
   if (!stream_valid(c.qw, c.kp, c.nw)) return c;
-  int wg_per_cu = STREAM_WAVES_PER_CU / c.nw;
+  int wg_per_cu = stream_waves_per_cu(c.qw, c.kp, c.nw) / c.nw;
   if (const char* e = getenv("EP_POOL_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }
   int grid = cu_count() * wg_per_cu;
   if (grid > B) grid = B;
@@ -190,14 +190,14 @@ static int pool_mode() {
 }
 int debug_force_generic(int mode) { int old = pool_mode(); g_pool_mode = mode; return old; }
 static bool force_generic() { return pool_mode() == 1; }
-// Measured on MI355X (tools/compare_modes.sh): the matrix-core kernel wins or ties for Q >= 5; with
-// few queries the vector-ALU kernel is purely memory-bound (6.2 TB/s at Q = 1) and wins; at
-// D = 1152 the matrix-core backward only fits a 2-deep ring and loses to the vector-ALU one.
+// Measured on MI355X (tools/compare_modes.sh, bench.py): the vector-ALU kernel wins when it can keep
+// three workgroups per CU (Q <= 8 and D <= 768) and for few queries (purely memory-bound: 6.2 TB/s at
+// Q = 1); the matrix-core kernel wins for wider rows and more queries.
 static bool use_mf(const PoolParams& p, bool bwd) {
+  (void)bwd;
   if (pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
-  const bool valu_ok = stream_plan(p.B, p.N, p.D, p.Q).ok;
-  if (valu_ok && p.Q <= 4) return false;
-  if (valu_ok && bwd && p.D == 1152) return false;
+  const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+  if (c.ok && (p.Q <= 4 || stream_waves_per_cu(c.qw, c.kp, c.nw) == 12)) return false;   // vector-ALU kernel wins
   return true;
 }
 static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }

@@ -6,42 +6,45 @@
 namespace ep {
 
 // build-time tuning knobs (A/B variants are built with -D...; defaults are the shipped values)
-#ifndef EP_STREAM_TT
-#define EP_STREAM_TT 8
-#endif
 #ifndef EP_STREAM_NSLOT_CAP
 #define EP_STREAM_NSLOT_CAP 8
-#endif
-#ifndef EP_STREAM_WAVES_PER_CU
-#define EP_STREAM_WAVES_PER_CU 8
 #endif
 #ifndef EP_DMA_AUX
 #define EP_DMA_AUX 2              // cache-policy bits of the LDS-DMA loads (2 = nt: streamed once)
 #endif
-constexpr int STREAM_TT = EP_STREAM_TT;            // tokens per ring tile
-constexpr int STREAM_WAVES_PER_CU = EP_STREAM_WAVES_PER_CU;
 
-constexpr int stream_kdma(int kp, int nw) { return (STREAM_TT * kp + nw - 1) / nw; }
-constexpr int stream_nslot(int kp, int nw, bool bwd) {
-  const int slot = STREAM_TT * kp * 1024 + (bwd ? nw * 256 : 0);   // worst case D = 256*kp
-  const int budget = 160 * 1024 / (STREAM_WAVES_PER_CU / nw);      // resident workgroups share the LDS
+// Geometry per configuration (measured on MI355X, tools/ab_variants.sh):
+//  * 2 queries per wave and D <= 768 (<= 168 VGPRs, compute-heavy): 12 waves per CU = three 4-wave
+//    workgroups with rings of 4-token tiles -- the third workgroup hides the other two's barrier and
+//    LDS latency (152 us vs 164 us per pass at 256x768, Q = 8);
+//  * otherwise 8 waves per CU with 8-token tiles (fewer barriers per byte; with 1 query per wave the
+//    kernel is memory-bound and the longer DMA bursts win: 0.76 vs 0.62 of peak at Q = 1).
+constexpr int stream_waves_per_cu(int qw, int kp, int nw) { return (nw == 4 && qw == 2 && kp <= 3) ? 12 : 8; }
+constexpr int stream_tt(int qw, int kp, int nw) { return stream_waves_per_cu(qw, kp, nw) == 12 ? 4 : 8; }
+
+constexpr int stream_kdma(int qw, int kp, int nw) { return (stream_tt(qw, kp, nw) * kp + nw - 1) / nw; }
+constexpr int stream_nslot(int qw, int kp, int nw, bool bwd) {
+  const int slot = stream_tt(qw, kp, nw) * kp * 1024 + (bwd ? nw * 256 : 0);   // worst case D = 256*kp
+  const int budget = 160 * 1024 / (stream_waves_per_cu(qw, kp, nw) / nw);    // resident workgroups share the LDS
   int ns = budget / slot;
   if (ns > EP_STREAM_NSLOT_CAP) ns = EP_STREAM_NSLOT_CAP;
-  const int kd = stream_kdma(kp, nw) + (bwd ? 1 : 0);
+  const int kd = stream_kdma(qw, kp, nw) + (bwd ? 1 : 0);
   while (ns > 3 && (ns - 2) * kd > 60) --ns;                       // vmcnt is a 6-bit counter
   return ns;
 }
 constexpr bool stream_valid(int qw, int kp, int nw) {
-  return stream_nslot(kp, nw, false) >= 3 && stream_nslot(kp, nw, true) >= 3 &&
-         (stream_nslot(kp, nw, true) - 2) * (stream_kdma(kp, nw) + 1) <= 60 &&
+  return stream_nslot(qw, kp, nw, false) >= 3 && stream_nslot(qw, kp, nw, true) >= 3 &&
+         (stream_nslot(qw, kp, nw, true) - 2) * (stream_kdma(qw, kp, nw) + 1) <= 60 &&
          !(qw == 4 && kp > 3) && !(qw == 2 && kp > 5);             // register budget (spills beyond)
 }
 
 template <int QW, int KP, int NW>
 struct StreamCfgT {
-  static constexpr int KDMA = stream_kdma(KP, NW);
-  static constexpr int NSLOT_F = stream_nslot(KP, NW, false);
-  static constexpr int NSLOT_B = stream_nslot(KP, NW, true);
+  static constexpr int TT = stream_tt(QW, KP, NW);                 // tokens per ring tile
+  static constexpr int WPC = stream_waves_per_cu(QW, KP, NW);      // resident waves per CU
+  static constexpr int KDMA = stream_kdma(QW, KP, NW);
+  static constexpr int NSLOT_F = stream_nslot(QW, KP, NW, false);
+  static constexpr int NSLOT_B = stream_nslot(QW, KP, NW, true);
   static constexpr bool VALID = stream_valid(QW, KP, NW);
 };
 

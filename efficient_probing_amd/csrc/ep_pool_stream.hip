@@ -30,7 +30,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
 constexpr int TB = 4;                 // tokens per butterfly mini-batch (one per 16-lane row)
-constexpr int TT = STREAM_TT;         // tokens per ring tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LAZY_MAX_THR = 12.0f; // rescale only when a score exceeds the running max by this
 
@@ -132,9 +131,9 @@ __device__ __forceinline__ void accumulate_rows(const float (&wrow)[QW], const f
 // forward
 // ---------------------------------------------------------------------------------------
 template <int QW, int KP, int NW, int DFIX>
-__global__ __launch_bounds__(NW * 64, STREAM_WAVES_PER_CU / 4) void ep_pool_fwd_kernel(PoolParams p) {
+__global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_fwd_kernel(PoolParams p) {
   using Cfg = StreamCfgT<QW, KP, NW>;
-  constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA;
+  constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA, TT = Cfg::TT;
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int lane = lane_id();
   const int w = wave_id_uniform();
@@ -305,9 +304,9 @@ __global__ __launch_bounds__(NW * 64, STREAM_WAVES_PER_CU / 4) void ep_pool_fwd_
 // header items fetch ML[b,q,0:4] of the wave's queries, token items fetch S[b,q,n0:n0+TT].
 // ---------------------------------------------------------------------------------------
 template <int QW, int KP, int NW, int DFIX>
-__global__ __launch_bounds__(NW * 64, STREAM_WAVES_PER_CU / 4) void ep_pool_bwd_kernel(PoolParams p) {
+__global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_bwd_kernel(PoolParams p) {
   using Cfg = StreamCfgT<QW, KP, NW>;
-  constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA;
+  constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA, TT = Cfg::TT;
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int lane = lane_id();
   const int w = wave_id_uniform();
@@ -453,7 +452,7 @@ template <int QW, int KP, int NW, int DFIX>
 static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   const int D = p.D;
-  const size_t slot = (size_t)TT * D * 4;
+  const size_t slot = (size_t)Cfg::TT * D * 4;
   const size_t lds = bwd ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
   auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX>;
   auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX>;
