@@ -137,7 +137,7 @@ def main():
 
     def run_bwd(i):
         x = xs[i % args.buffers]
-        N_.check(eng.lib.ep_pool_backward(x.data_ptr(), 0, Nn * D, B, Nn, D, Q, float(scale), S.data_ptr(), ML.data_ptr(),
+        N_.check(eng.lib.ep_pool_backward(x.data_ptr(), 0, Nn * D, 0, B, Nn, D, Q, float(scale), S.data_ptr(), ML.data_ptr(),
                                           dP.data_ptr(), dcls.data_ptr(), 0, ws.data_ptr(), ws_bytes, stream), "bwd")
     t_bwd = time_kernel(run_bwd, args.kernel_iters)
 

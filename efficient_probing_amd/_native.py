@@ -38,6 +38,7 @@ class EPHeadStep(C.Structure):
     _fields_ = [
         ("dims", EPHeadDims),
         ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("image_index", C.c_void_p),
         ("targets", C.c_void_p),
         ("params", C.c_void_p), ("grads", C.c_void_p), ("opt_state0", C.c_void_p), ("opt_state1", C.c_void_p),
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
@@ -62,9 +63,9 @@ SIGNATURES = {
     "ep_debug_force_generic_pool": (c_int, [c_int]),
     "ep_pool_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "ep_pool_kernel_name": (C.c_char_p, [c_int, c_int, c_int, c_int, c_int]),
-    "ep_pool_forward": (c_int, [c_void, c_int, c_i64, c_int, c_int, c_int, c_f32p, c_i64, c_int, c_float,
+    "ep_pool_forward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_i64, c_int, c_float,
                                 c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),
-    "ep_pool_backward": (c_int, [c_void, c_int, c_i64, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p,
+    "ep_pool_backward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p,
                                  c_f32p, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_attention_from_scores": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_project_forward": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void]),
@@ -89,7 +90,7 @@ SIGNATURES = {
     "ep_head_param_offsets": (c_i64, [C.POINTER(EPHeadDims), C.POINTER(c_i64)]),
     "ep_head_workspace_bytes": (c_size, [C.POINTER(EPHeadDims)]),
     "ep_head_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),
-    "ep_head_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p,
+    "ep_head_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p,
                                      c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }
 

@@ -184,22 +184,22 @@ int ep_debug_force_generic_pool(int on) { return debug_force_generic(on); }
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q) { return pool_workspace_bytes(B, N, D, Q); }
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward) { return pool_kernel_family(B, N, D, Q, backward); }
 
-int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, const float* cls_token,
-                    int64_t cls_bstride, int Q, float scale, float* P, float* S, float* ML, void* workspace,
-                    size_t workspace_bytes, ep_stream_t stream) {
+int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                    const float* cls_token, int64_t cls_bstride, int Q, float scale, float* P, float* S, float* ML,
+                    void* workspace, size_t workspace_bytes, ep_stream_t stream) {
   (void)workspace; (void)workspace_bytes;
   EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
   EP_REQUIRE(cls_token && P && S && ML, EP_E_ARG, "ep_pool_forward: null pointer");
   EP_REQUIRE(aligned16(cls_token) && aligned16(P) && aligned16(ML) && cls_bstride % 4 == 0, EP_E_ALIGN,
              "ep_pool_forward: cls_token / P / ML must be 16-byte aligned");
   PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale);
-  p.cls = cls_token; p.cls_bstride = cls_bstride; p.P = P; p.S = S; p.ML = ML;
+  p.cls = cls_token; p.cls_bstride = cls_bstride; p.P = P; p.S = S; p.ML = ML; p.index = image_index;
   return pool_forward(p, (hipStream_t)stream);
 }
 
-int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q, float scale,
-                     const float* S, const float* ML, const float* dP, float* dcls, int accumulate, void* workspace,
-                     size_t workspace_bytes, ep_stream_t stream) {
+int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                     int Q, float scale, const float* S, const float* ML, const float* dP, float* dcls, int accumulate,
+                     void* workspace, size_t workspace_bytes, ep_stream_t stream) {
   EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
   EP_REQUIRE(S && ML && dP && dcls && workspace, EP_E_ARG, "ep_pool_backward: null pointer");
   EP_REQUIRE(aligned16(dP) && aligned16(dcls) && aligned16(ML) && aligned16(workspace), EP_E_ALIGN,
@@ -208,6 +208,7 @@ int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, int B, int N
              "ep_pool_backward: workspace %zu < %zu", workspace_bytes, pool_workspace_bytes(B, N, D, Q));
   PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale);
   p.S = const_cast<float*>(S); p.ML = const_cast<float*>(ML); p.dP = dP; p.Gpart = static_cast<float*>(workspace);
+  p.index = image_index;
   return pool_backward(p, dcls, accumulate, (hipStream_t)stream);
 }
 
@@ -331,7 +332,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
     EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.Q));
     PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale);
-    p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML;
+    p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
     EP_TRY(pool_forward(p, st));
     EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
@@ -380,7 +381,8 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   return 0;
 }
 
-int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, int64_t x_bstride, const float* params,
+int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* params,
                          const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
                          void* ws, size_t ws_bytes, ep_stream_t stream) {
   EP_REQUIRE(dims && x && params && running_mean && running_var && logits && ws, EP_E_ARG, "ep_head_eval_forward: null pointer");
@@ -396,7 +398,7 @@ int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, i
   ep_head_param_offsets(&d, offs);
   const float scale = (float)pow((double)d.D, -0.5);
   PoolParams p = pool_params(x, x_bstride, d.B, d.N, d.D, d.Q, scale);
-  p.cls = params + offs[0]; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML;
+  p.cls = params + offs[0]; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = image_index;
   EP_TRY(pool_forward(p, st));
   EP_TRY(project_forward(w.P, params + offs[1], d.B, d.D, Dp, d.Q, w.y, st));
   EP_TRY(bn_forward_eval(w.y, d.B, Dp, bn_eps, running_mean, running_var, w.z, st));

@@ -16,6 +16,7 @@ struct PoolParams {
   float* ML;             // (B,Q,4)
   const float* dP;       // bwd in (B,Q,D)
   float* Gpart;          // bwd out (n_workgroups, Q, D)
+  const int* index;      // optional (B,) image indices into x: image b is x[index[b]] (resident token store)
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
   int kdma;              // 16-byte DMA instructions per wave per ring item
@@ -32,6 +33,9 @@ struct GemmParams {
   float alpha;
   int accumulate;
 };
+
+// element offset of image b of the batch inside the token buffer
+#define EP_IMG_OFF(p, b) ((int64_t)((p).index ? (p).index[(b)] : (b)) * (p).x_bstride)
 
 size_t pool_workspace_bytes(int B, int N, int D, int Q);
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
-  const float* xb = p.x + (int64_t)b * p.x_bstride;
+  const float* xb = p.x + EP_IMG_OFF(p, b);
   float* red = sm + N;
   for (int q = 0; q < Q; ++q) {
     const float* cq = p.cls + (int64_t)b * p.cls_bstride + (int64_t)q * D;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) 
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
-  const float* xb = p.x + (int64_t)b * p.x_bstride;
+  const float* xb = p.x + EP_IMG_OFF(p, b);
   for (int q = 0; q < Q; ++q) {
     const float* g = p.dP + ((int64_t)b * Q + q) * D;
     const float* ml = p.ML + ((int64_t)b * Q + q) * 4;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_fwd_kernel(PoolParam
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
-  const char* psrc = reinterpret_cast<const char*>(p.x + (int64_t)wg * p.x_bstride);
+  const char* psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, wg));
   auto produce = [&]() {
     if (pi < n_items) {
       const int left = N - ptile * MF_TT;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_fwd_kernel(PoolParam
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
       if (++ptile == tiles_per_img) {
         ptile = 0; ++pimg;
-        psrc = reinterpret_cast<const char*>(p.x + (int64_t)(wg + pimg * G) * p.x_bstride);
+        psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
       } else {
         psrc += SLOT;
       }
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_bwd_kernel(PoolParam
         } else {
           const int n0 = (pidx - 1) * MF_TT;
           const int rows = (N - n0) < MF_TT ? (N - n0) : MF_TT;
-          const char* src = reinterpret_cast<const char*>(p.x + (int64_t)b * p.x_bstride + (int64_t)n0 * D);
+          const char* src = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, b) + (int64_t)n0 * D);
           mf_dma_tile<NG>(src, (unsigned)(rows * ROWB - 16), slot, w, soff);
           int nn = n0 + t_l; nn = nn < N ? nn : N - 1;
           const float* ss = p.S + ((int64_t)b * Q + q_l) * N + nn;              // lane = 8*qi + tt

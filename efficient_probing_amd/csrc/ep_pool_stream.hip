@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 
   // ---- producer: one ring item = one tile of TT token rows -------------------------------
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
-  const char* psrc = reinterpret_cast<const char*>(p.x + (int64_t)wg * p.x_bstride);
+  const char* psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, wg));
   auto produce = [&]() {
     if (pi < n_items) {
       const int left = N - ptile * TT;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
       if (++ptile == tiles_per_img) {
         ptile = 0; ++pimg;
-        psrc = reinterpret_cast<const char*>(p.x + (int64_t)(wg + pimg * G) * p.x_bstride);
+        psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
       } else {
         psrc += slot_bytes;
       }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         } else {
           const int n0 = (pidx - H) * TT;
           const int rows = (N - n0) < TT ? (N - n0) : TT;
-          const char* src = reinterpret_cast<const char*>(p.x + (int64_t)b * p.x_bstride + (int64_t)n0 * D);
+          const char* src = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, b) + (int64_t)n0 * D);
           dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
           int nn = n0 + st; nn = nn < N ? nn : N - 1;
           const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;

@@ -132,14 +132,18 @@ class ProbeHeadEngine:
         return s
 
     # ------------------------------------------------------------------------------------
-    def forward_backward(self, x: torch.Tensor, targets: torch.Tensor) -> None:
+    def forward_backward(self, x: torch.Tensor, targets: torch.Tensor,
+                         image_index: Optional[torch.Tensor] = None) -> None:
         """Phase 1: forward + CE + backward into the flat gradient buffer (accumulating across
-        micro-steps when accum_iter > 1).  Adds to ``self.stats``."""
+        micro-steps when accum_iter > 1).  Adds to ``self.stats``.  With ``image_index`` (int32 (B,)),
+        ``x`` is a token store resident in HBM and the batch is read from it in place."""
         xv, bstride = F_.as_token_view(x)
-        B, Nn, D = xv.shape
+        _, Nn, D = xv.shape
+        iptr, B = F_._index_arg(image_index, xv)
         ws = self._workspace(B, Nn)
         targets = targets.to(device=self.device, dtype=torch.int64)
         s = self._step_struct(xv, bstride, targets, 1, self._micro > 0, None)
+        s.image_index = iptr
         N.check(self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
                                             N.current_stream_ptr(self.device)), "ep_head_train_step(fwd+bwd)")
         self._micro += 1
@@ -160,22 +164,24 @@ class ProbeHeadEngine:
                                             N.current_stream_ptr(self.device)), "ep_head_train_step(optimizer)")
         self._micro = 0
 
-    def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None) -> None:
+    def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None,
+                   image_index: Optional[torch.Tensor] = None) -> None:
         """One full iteration (accum_iter == 1): forward/backward, gradient all-reduce, update."""
-        self.forward_backward(x, targets)
+        self.forward_backward(x, targets, image_index)
         if self._micro >= self.accum_iter:
             self.all_reduce_grads()
             self.optimizer_step(lr)
 
     @torch.no_grad()
-    def eval_logits(self, x: torch.Tensor) -> torch.Tensor:
+    def eval_logits(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         xv, bstride = F_.as_token_view(x)
-        B, Nn, D = xv.shape
+        _, Nn, D = xv.shape
+        iptr, B = F_._index_arg(image_index, xv)
         ws = self._workspace(B, Nn)
         Cc = self.dims.C
         ldl = F_.padded_ld(Cc)
         out = torch.empty((B, ldl), device=self.device, dtype=torch.float32)
-        N.check(self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride,
+        N.check(self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, iptr,
                                               self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                               self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
                                               ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)),

@@ -43,20 +43,32 @@ def as_token_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     return x, (x.stride(0) if B > 1 else Nn * D)
 
 
+def _index_arg(image_index, x):
+    """(pointer, batch size) for the optional in-place batch selection from a resident token store."""
+    if image_index is None:
+        return 0, x.shape[0]
+    if image_index.dtype != torch.int32 or not image_index.is_cuda or not image_index.is_contiguous():
+        raise ValueError("image_index must be a contiguous int32 CUDA tensor")
+    return image_index.data_ptr(), image_index.numel()
+
+
 def pool_forward(x: torch.Tensor, cls_token: torch.Tensor, scale: float,
-                 per_image_queries: bool = False):
+                 per_image_queries: bool = False, image_index: Optional[torch.Tensor] = None):
     """EP pooling forward.  x (B,N,D); cls_token (Q,D) / (1,Q,D) or, with
-    ``per_image_queries``, (B,Q,D).  Returns P (B,Q,D), S (B,Q,N), ML (B,Q,4)."""
+    ``per_image_queries``, (B,Q,D).  Returns P (B,Q,D), S (B,Q,N), ML (B,Q,4).
+    With ``image_index`` (int32, (B,)), x is a resident token store (M,N,D) and image b of the batch
+    is x[image_index[b]], read in place."""
     lib = N.load()
     x, bstride = as_token_view(x)
-    B, Nn, D = x.shape
+    _, Nn, D = x.shape
+    iptr, B = _index_arg(image_index, x)
     cls = _f32c(cls_token, "cls_token")
     Q = cls.shape[-2]
     cls_bstride = Q * D if per_image_queries else 0
     P = torch.empty((B, Q, D), device=x.device, dtype=torch.float32)
     S = torch.empty((B, Q, Nn), device=x.device, dtype=torch.float32)
     ML = torch.empty((B, Q, 4), device=x.device, dtype=torch.float32)
-    rc = lib.ep_pool_forward(x.data_ptr(), N.EP_DTYPE_F32, bstride, B, Nn, D, cls.data_ptr(), cls_bstride, Q,
+    rc = lib.ep_pool_forward(x.data_ptr(), N.EP_DTYPE_F32, bstride, iptr, B, Nn, D, cls.data_ptr(), cls_bstride, Q,
                              float(scale), P.data_ptr(), S.data_ptr(), ML.data_ptr(), 0, 0,
                              N.current_stream_ptr(x.device))
     N.check(rc, "ep_pool_forward")
@@ -64,10 +76,12 @@ def pool_forward(x: torch.Tensor, cls_token: torch.Tensor, scale: float,
 
 
 def pool_backward(x: torch.Tensor, S: torch.Tensor, ML: torch.Tensor, dP: torch.Tensor, scale: float,
-                  dcls: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+                  dcls: Optional[torch.Tensor] = None, accumulate: bool = False,
+                  image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = N.load()
     x, bstride = as_token_view(x)
-    B, Nn, D = x.shape
+    _, Nn, D = x.shape
+    iptr, B = _index_arg(image_index, x)
     Q = S.shape[1]
     dP = _f32c(dP, "dP")
     if dcls is None:
@@ -75,7 +89,7 @@ def pool_backward(x: torch.Tensor, S: torch.Tensor, ML: torch.Tensor, dP: torch.
         accumulate = False
     nbytes = lib.ep_pool_workspace_bytes(B, Nn, D, Q)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    rc = lib.ep_pool_backward(x.data_ptr(), N.EP_DTYPE_F32, bstride, B, Nn, D, Q, float(scale), S.data_ptr(),
+    rc = lib.ep_pool_backward(x.data_ptr(), N.EP_DTYPE_F32, bstride, iptr, B, Nn, D, Q, float(scale), S.data_ptr(),
                               ML.data_ptr(), dP.data_ptr(), dcls.data_ptr(), int(accumulate), ws.data_ptr(), nbytes,
                               N.current_stream_ptr(x.device))
     N.check(rc, "ep_pool_backward")

@@ -1,0 +1,166 @@
+"""Pre-dumped token store and feeder.
+
+The reference can dump frozen-backbone tokens only as one small ``.npz`` (``tokens (n,N,C) float32``,
+``images``, ``names``; reference tools/dump_tokens.py:95-98).  Training a probe on a 7B-parameter
+encoder (BASELINE config 5) needs the whole dataset's tokens on disk once and then a reader that
+keeps the head kernels fed.  This module provides
+
+  * a sharded on-disk format: ``meta.json`` + ``tokens-XXXXX.bin`` (raw row-major ``(n_i, N, D)`` fp32)
+    + ``labels-XXXXX.npy``; shards are independent, so ranks partition them with no communication;
+  * ``TokenStoreWriter`` / ``read_reference_npz`` (imports the reference's ``.npz`` dump);
+  * ``ResidentTokenStore``: a rank's shard loaded ONCE into HBM (288 GB per MI355X: 163 k images of
+    256x768 fp32 tokens per GPU, the whole 1.28 M-image ImageNet train set on 8 GPUs) and batches
+    drawn as an int32 index vector -- the pooling kernels read the selected images IN PLACE
+    (``image_index`` of the C ABI), so an epoch never copies or re-uploads a token;
+  * ``StreamingTokenLoader``: for stores larger than HBM, double-buffered pinned-host -> device
+    copies on a side stream (PCIe-bound, ~80 k img/s at 256x768 fp32).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+META = "meta.json"
+
+
+class TokenStoreWriter:
+    def __init__(self, out_dir: str, num_tokens: int, dim: int, shard_images: int = 8192, dtype: str = "float32"):
+        if dtype != "float32":
+            raise NotImplementedError("token store dtype: float32 only in this build")
+        os.makedirs(out_dir, exist_ok=True)
+        self.out_dir, self.N, self.D, self.shard_images = out_dir, num_tokens, dim, shard_images
+        self.shards: List[dict] = []
+        self._tok: List[np.ndarray] = []
+        self._lab: List[np.ndarray] = []
+        self._n = 0
+
+    def add(self, tokens: np.ndarray, labels: np.ndarray) -> None:
+        tokens = np.ascontiguousarray(tokens, dtype=np.float32)
+        assert tokens.ndim == 3 and tokens.shape[1:] == (self.N, self.D), tokens.shape
+        assert len(labels) == len(tokens)
+        self._tok.append(tokens); self._lab.append(np.asarray(labels, dtype=np.int64)); self._n += len(tokens)
+        while self._n >= self.shard_images:
+            self._flush(self.shard_images)
+
+    def _flush(self, n: int) -> None:
+        tok = np.concatenate(self._tok); lab = np.concatenate(self._lab)
+        idx = len(self.shards)
+        tok[:n].tofile(os.path.join(self.out_dir, f"tokens-{idx:05d}.bin"))
+        np.save(os.path.join(self.out_dir, f"labels-{idx:05d}.npy"), lab[:n])
+        self.shards.append({"index": idx, "images": int(n)})
+        self._tok, self._lab, self._n = ([tok[n:]] if len(tok) > n else []), ([lab[n:]] if len(lab) > n else []), len(tok) - n
+
+    def close(self) -> dict:
+        if self._n:
+            self._flush(self._n)
+        meta = {"format": "ep-token-store-v1", "num_tokens": self.N, "dim": self.D, "dtype": "float32",
+                "shards": self.shards, "total_images": int(sum(s["images"] for s in self.shards))}
+        with open(os.path.join(self.out_dir, META), "w") as f:
+            json.dump(meta, f, indent=1)
+        return meta
+
+
+def read_reference_npz(path: str) -> Tuple[np.ndarray, List[str]]:
+    """Tokens and names of a reference dump (tools/dump_tokens.py:95-98: keys tokens/images/names)."""
+    z = np.load(path, allow_pickle=True)
+    return np.asarray(z["tokens"], dtype=np.float32), [str(n) for n in z["names"]]
+
+
+def load_meta(store_dir: str) -> dict:
+    with open(os.path.join(store_dir, META)) as f:
+        meta = json.load(f)
+    if meta.get("format") != "ep-token-store-v1":
+        raise ValueError(f"{store_dir}: not an ep token store")
+    return meta
+
+
+def shards_of_rank(meta: dict, world: int, rank: int) -> List[dict]:
+    """Round-robin shard ownership: independent units, no data-path collective."""
+    return [s for s in meta["shards"] if s["index"] % world == rank]
+
+
+def open_shard(store_dir: str, meta: dict, shard: dict) -> Tuple[np.memmap, np.ndarray]:
+    tok = np.memmap(os.path.join(store_dir, f"tokens-{shard['index']:05d}.bin"), dtype=np.float32, mode="r",
+                    shape=(shard["images"], meta["num_tokens"], meta["dim"]))
+    lab = np.load(os.path.join(store_dir, f"labels-{shard['index']:05d}.npy"))
+    return tok, lab
+
+
+class ResidentTokenStore:
+    """This rank's shards, resident in HBM.  ``batches(batch_size, epoch)`` yields
+    ``(store_tensor, image_index int32 (B,), targets int64 (B,))``: pass ``store_tensor`` as the tokens and
+    ``image_index`` to ``ProbeHeadEngine.train_step`` -- no per-batch copy happens."""
+
+    def __init__(self, store_dir: str, device, world: int = 1, rank: int = 0, seed: int = 0):
+        meta = load_meta(store_dir)
+        mine = shards_of_rank(meta, world, rank)
+        n = sum(s["images"] for s in mine)
+        self.N, self.D, self.seed, self.rank = meta["num_tokens"], meta["dim"], seed, rank
+        self.tokens = torch.empty((max(n, 1), self.N, self.D), device=device, dtype=torch.float32)
+        labels = []
+        off = 0
+        for s in mine:
+            tok, lab = open_shard(store_dir, meta, s)
+            self.tokens[off:off + s["images"]].copy_(torch.from_numpy(np.ascontiguousarray(tok)))
+            labels.append(lab); off += s["images"]
+        self.num_images = n
+        self.labels = torch.from_numpy(np.concatenate(labels) if labels else np.zeros(0, np.int64)).to(device)
+
+    def batches(self, batch_size: int, epoch: int = 0, shuffle: bool = True, drop_last: bool = True):
+        g = torch.Generator(device="cpu").manual_seed(self.seed * 1000003 + epoch * 101 + self.rank)
+        order = torch.randperm(self.num_images, generator=g) if shuffle else torch.arange(self.num_images)
+        order = order.to(dtype=torch.int32, device=self.tokens.device)
+        stop = self.num_images - (self.num_images % batch_size if drop_last else 0)
+        for lo in range(0, stop, batch_size):
+            idx = order[lo:lo + batch_size].contiguous()
+            yield self.tokens, idx, self.labels[idx.long()]
+
+
+class StreamingTokenLoader:
+    """Shards larger than HBM: memmap -> pinned staging -> device on a copy stream, two batches deep."""
+
+    def __init__(self, store_dir: str, device, batch_size: int, world: int = 1, rank: int = 0):
+        self.dir, self.device, self.B = store_dir, device, batch_size
+        self.meta = load_meta(store_dir)
+        self.shards = shards_of_rank(self.meta, world, rank)
+        self.stream = torch.cuda.Stream(device=device)
+        N, D = self.meta["num_tokens"], self.meta["dim"]
+        self.stage = [torch.empty((batch_size, N, D), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.dev = [torch.empty((batch_size, N, D), dtype=torch.float32, device=device) for _ in range(2)]
+
+    def __len__(self):
+        return sum(s["images"] // self.B for s in self.shards)
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        k = 0
+        pending = None
+        copied = [None, None]     # H2D-complete events per buffer (host staging may be rewritten after them)
+        consumed = [None, None]   # main-stream events: the consumer's kernels on a device buffer are enqueued before them
+        main = torch.cuda.current_stream(self.device)
+        for s in self.shards:
+            tok, lab = open_shard(self.dir, self.meta, s)
+            for lo in range(0, s["images"] - self.B + 1, self.B):
+                buf = k & 1
+                if copied[buf] is not None:
+                    copied[buf].synchronize()                     # previous H2D out of this staging buffer is done
+                self.stage[buf].copy_(torch.from_numpy(np.ascontiguousarray(tok[lo:lo + self.B])))
+                with torch.cuda.stream(self.stream):
+                    if consumed[buf] is not None:
+                        self.stream.wait_event(consumed[buf])     # consumer finished with this device buffer
+                    self.dev[buf].copy_(self.stage[buf], non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(self.stream)
+                copied[buf] = ev
+                cur = (buf, torch.from_numpy(lab[lo:lo + self.B]).to(self.device), ev)
+                if pending is not None:
+                    main.wait_event(pending[2])
+                    yield self.dev[pending[0]], pending[1]
+                    done = torch.cuda.Event(); done.record(main); consumed[pending[0]] = done
+                pending = cur
+                k += 1
+        if pending is not None:
+            main.wait_event(pending[2])
+            yield self.dev[pending[0]], pending[1]

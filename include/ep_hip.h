@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 2
+#define EP_ABI_VERSION 3
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -67,12 +67,16 @@ int ep_debug_force_generic_pool(int mode);
  * ML (B,Q,4) = {row max m, sum exp(S-m), reserved(delta), 0}.
  * `cls_token` is the learned (Q,D) query block (state_dict key 0.cls_token) or, when
  * cls_bstride != 0, a per-image (B,Q,D) override (the `cls=` argument of ep.py:32-33).
+ * `image_index` (optional, NULL = identity): (B,) int32 device array; image b of the batch is
+ * x + image_index[b] * x_bstride -- batches are read IN PLACE from a token store resident in HBM
+ * (288 GB per GPU), no gather copy.
  */
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q);
 /* name of the device kernel ep_pool_forward / ep_pool_backward will launch for this shape (for
  * matching profiler output; static string) */
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward);
-int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D,
+int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
+                    int B, int N, int D,
                     const float* cls_token, int64_t cls_bstride, int Q, float scale,
                     float* P, float* S, float* ML,
                     void* workspace, size_t workspace_bytes, ep_stream_t stream);
@@ -82,7 +86,8 @@ int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, int B, int N,
  *     dA[b,q,n] = dP[b,q,:] . x[b,n,:] ;  dS = A * (dA - delta[b,q]) ;  delta = ML[b,q,2]
  *     dcls[q,:] (+)= scale * sum_b sum_n dS[b,q,n] * x[b,n,:]
  * accumulate != 0 adds into dcls (gradient accumulation, engine_finetune.py:72-77).      */
-int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D,
+int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
+                     int B, int N, int D,
                      int Q, float scale, const float* S, const float* ML, const float* dP,
                      float* dcls, int accumulate,
                      void* workspace, size_t workspace_bytes, ep_stream_t stream);
@@ -192,6 +197,7 @@ typedef struct ep_head_dims {
 typedef struct ep_head_step {
   ep_head_dims dims;
   const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;   /* optional, see ep_pool_forward */
   const int64_t* targets;
   float* params; float* grads; float* opt_state0; float* opt_state1;
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
@@ -216,7 +222,7 @@ int ep_head_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_s
 /* eval forward: logits (B, ldl) from tokens using running statistics
  * (reference engine_finetune.py:106-166 inner forward).                                    */
 int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
-                         const float* params, const float* running_mean,
+                         const int32_t* image_index, const float* params, const float* running_mean,
                          const float* running_var, float bn_eps, float* logits, int ldl,
                          void* ws, size_t ws_bytes, ep_stream_t stream);
 
