@@ -1,0 +1,89 @@
+"""GPU: batches drawn in place from a resident token store (image_index) give exactly what a gathered
+batch gives, for every pooling kernel family; the streaming loader delivers the stored data."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape", [(40, 37, 64, 4), (48, 50, 768, 8), (24, 33, 1024, 8), (24, 20, 384, 1)],
+                         ids=["generic-D64", "valu-768", "mfma-1024", "valu-q1"])
+def test_indexed_pool_matches_gathered(shape):
+    from efficient_probing_amd import functional as F_, _native
+    M, Nn, D, Q = shape
+    g = torch.Generator().manual_seed(0)
+    store = torch.randn(M, Nn, D, generator=g).to(DEV)
+    cls = (torch.randn(Q, D, generator=g) * 0.3).to(DEV)
+    idx = torch.randperm(M, generator=g)[:M // 2].to(torch.int32).to(DEV)
+    scale = D ** -0.5
+    lib = _native.load()
+    for mode in (0, 1, 2, 3):
+        lib.ep_debug_force_generic_pool(mode)
+        try:
+            Pi, Si, MLi = F_.pool_forward(store, cls, scale, image_index=idx)
+            Pg, Sg, MLg = F_.pool_forward(store[idx.long()].contiguous(), cls, scale)
+            assert torch.equal(Pi, Pg) and torch.equal(Si, Sg) and torch.equal(MLi, MLg), mode
+            dP = torch.randn(Pi.shape, generator=g).to(DEV)
+            MLi[:, :, 2] = 0.1
+            di = F_.pool_backward(store, Si, MLi, dP, scale, image_index=idx)
+            dg = F_.pool_backward(store[idx.long()].contiguous(), Si, MLi, dP, scale)
+            assert torch.equal(di, dg), mode
+        finally:
+            lib.ep_debug_force_generic_pool(0)
+
+
+def test_resident_store_training_equals_gathered_batches(tmp_path):
+    from efficient_probing_amd import probe_heads, token_store as TS
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    rng = np.random.default_rng(3)
+    Nn, D, Q, C = 20, 256, 8, 12
+    w = TS.TokenStoreWriter(str(tmp_path), Nn, D, shard_images=40)
+    tok = rng.standard_normal((100, Nn, D), dtype=np.float32); lab = rng.integers(0, C, 100)
+    w.add(tok, lab); w.close()
+    store = TS.ResidentTokenStore(str(tmp_path), DEV, world=1, rank=0, seed=5)
+    assert store.num_images == 100 and store.tokens.shape == (100, Nn, D)
+    assert np.array_equal(store.tokens.cpu().numpy(), tok)
+
+    def make():
+        class Enc(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.head = torch.nn.Linear(D, C)
+        torch.manual_seed(0)
+        e = Enc()
+        probe_heads.build_probe_head(e, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=C))
+        return ProbeHeadEngine(e.head.to(DEV).train(), optimizer="lars", lr=0.3)
+    e1, e2 = make(), make()
+    n = 0
+    for tokens, idx, tgt in store.batches(32, epoch=0):
+        e1.train_step(tokens, tgt, image_index=idx)
+        e2.train_step(tokens[idx.long()].contiguous(), tgt)
+        n += 1
+    assert n == 3
+    for a, b in zip(e1.params_list, e2.params_list):
+        assert torch.equal(a, b)
+    assert e1.read_stats() == e2.read_stats()
+    # two ranks see disjoint shards that together cover the store
+    s0 = TS.ResidentTokenStore(str(tmp_path), DEV, world=2, rank=0)
+    s1 = TS.ResidentTokenStore(str(tmp_path), DEV, world=2, rank=1)
+    assert s0.num_images + s1.num_images == 100 and s0.num_images == 60
+
+
+def test_streaming_loader_delivers_the_store(tmp_path):
+    from efficient_probing_amd import token_store as TS
+    rng = np.random.default_rng(4)
+    w = TS.TokenStoreWriter(str(tmp_path), 6, 64, shard_images=25)
+    tok = rng.standard_normal((70, 6, 64), dtype=np.float32); lab = rng.integers(0, 5, 70)
+    w.add(tok, lab); w.close()
+    ld = TS.StreamingTokenLoader(str(tmp_path), DEV, batch_size=8)
+    seen_t, seen_l = [], []
+    for x, t in ld:
+        seen_t.append(x.cpu().numpy().copy()); seen_l.append(t.cpu().numpy())
+    assert len(seen_t) == len(ld) == 3 + 3 + 2          # per shard: 25//8, 25//8, 20//8
+    want = np.concatenate([tok[0:24], tok[25:49], tok[50:66]])
+    assert np.array_equal(np.concatenate(seen_t), want)
+    assert np.array_equal(np.concatenate(seen_l), np.concatenate([lab[0:24], lab[25:49], lab[50:66]]))
