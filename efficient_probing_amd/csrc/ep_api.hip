@@ -138,7 +138,7 @@ static int project_backward(const float* dy, const float* y, const float* P, con
     g.A = dy; g.lda = Dp; g.sAz = Dq; g.extA = Dq;
     g.B = P; g.ldb = (int64_t)Q * D; g.sBz = D; g.extB = D;
     g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
-    g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate;
+    g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
     EP_TRY(gemm(false, false, g, Q, st));
   }
   return 0;
@@ -163,7 +163,7 @@ static int linear_backward(const float* dl, int ldl, const float* z, const float
   if (dWc) {
     GemmParams g{};
     g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
-    g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate;
+    g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
     EP_TRY(gemm(false, false, g, 1, st));
   }
   if (dbc) EP_TRY(colsum(dl, B, C, ldl, accumulate, dbc, st));

@@ -32,6 +32,7 @@ struct GemmParams {
   int extA, extB;                   // readable extent of the contiguous dim of a T-layout operand
   float alpha;
   int accumulate;
+  int side;                         // 1: runs on the aux stream beside a token pass (kernel choice hint)
 };
 
 // element offset of image b of the batch inside the token buffer
