@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Print the kernel timeline of one steady-state step from a rocprofv3 kernel_trace csv directory."""
+import csv, glob, sys
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "pool_fwd" in r["Kernel_Name"] or "pool_mf_fwd" in r["Kernel_Name"] or "pool_mm_fwd" in r["Kernel_Name"]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+a, b = idx[k], idx[k + 1]
+t0 = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b + 1]:
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ep::", "")[:36]
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("%8.1f %8.1f %7.1f  q%s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), n))
