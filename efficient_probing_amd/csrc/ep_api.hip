@@ -121,6 +121,24 @@ static int project_forward(const float* P, const float* Wv, int B, int D, int Dp
   return gemm(true, true, g, Q, st);
 }
 
+// dWv[q*Dq + c, d] (+)= sum_b dy[b, q*Dq + c] * P[b, q, d]   (Q batched T/T contractions over the batch)
+static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp, int Q, float* dWv, int accumulate) {
+  const int Dq = Dp / Q;
+  GemmParams g{};
+  g.A = dy; g.lda = Dp; g.sAz = Dq; g.extA = Dq;
+  g.B = P; g.ldb = (int64_t)Q * D; g.sBz = D; g.extB = D;
+  g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
+  g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
+  return g;
+}
+// dWc[c, k] (+)= sum_b dlogits[b, c] * z[b, k]
+static GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int C, float* dWc, int accumulate) {
+  GemmParams g{};
+  g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
+  g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
+  return g;
+}
+
 static int project_backward(const float* dy, const float* y, const float* P, const float* Wv, int B, int D, int Dp,
                             int Q, float* dP, float* dWv, float* ML, int accumulate, hipStream_t st) {
   const int Dq = Dp / Q;
@@ -133,14 +151,7 @@ static int project_backward(const float* dy, const float* y, const float* P, con
     g.M = B; g.N = D; g.K = Dq; g.alpha = 1.f;
     EP_TRY(gemm(true, false, g, Q, st));
   }
-  if (dWv) {
-    GemmParams g{};
-    g.A = dy; g.lda = Dp; g.sAz = Dq; g.extA = Dq;
-    g.B = P; g.ldb = (int64_t)Q * D; g.sBz = D; g.extB = D;
-    g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
-    g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
-    EP_TRY(gemm(false, false, g, Q, st));
-  }
+  if (dWv) EP_TRY(gemm(false, false, dwv_gemm(dy, P, B, D, Dp, Q, dWv, accumulate), Q, st));
   return 0;
 }
 
@@ -160,12 +171,7 @@ static int linear_backward(const float* dl, int ldl, const float* z, const float
     g.M = B; g.N = Dp; g.K = C; g.alpha = 1.f;
     EP_TRY(gemm(true, false, g, 1, st));
   }
-  if (dWc) {
-    GemmParams g{};
-    g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
-    g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
-    EP_TRY(gemm(false, false, g, 1, st));
-  }
+  if (dWc) EP_TRY(gemm(false, false, dwc_gemm(dl, ldl, z, B, Dp, C, dWc, accumulate), 1, st));
   if (dbc) EP_TRY(colsum(dl, B, C, ldl, accumulate, dbc, st));
   return 0;
 }
@@ -339,33 +345,57 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
                             s->num_batches_tracked, w.bnpart, st));
     EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
     EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
-    // The weight gradients dWc / dbc / dWv and the statistics feed nothing before the optimizer:
-    // with an aux stream they run beside the critical path (dz -> BN backward -> dP -> second
-    // token pass), which is HBM/VALU-bound while these are MFMA-bound.
-    hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    if (side != st) {
-      EP_TRY(get_events(ev, 3));
-      EP_HIP(hipEventRecord(ev[0], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    }
-    EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
-    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
-                           s->accumulate, side));
-    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
-    EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[1], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
-    }
-    EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
-                            s->accumulate, side));
-    EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+    // The weight gradients dWc / dbc / dWv and the statistics feed nothing before the optimizer.
+    // Preferred: they ride in the launch of the second token pass as extra workgroups, which the
+    // dispatcher places as pooling workgroups retire (the tail of the pass) -- no second stream, no
+    // cross-queue events, no contention with the critical-path contractions.  Otherwise (kernel
+    // families without side support, unaligned shapes) they run on the aux stream beside it.
+    const GemmParams gWc = dwc_gemm(w.dlogits, w.ldl, w.z, d.B, Dp, d.C, s->grads + offs[2], s->accumulate);
+    const GemmParams gWv = dwv_gemm(w.dy, w.P, d.B, d.D, Dp, d.Q, s->grads + offs[1], s->accumulate);
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-    EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[2], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[2], 0));           // join: grads complete on `stream`
+    if (pool_backward_takes_side(p) && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
+      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
+      EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
+      EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+      SideTasks sd{};
+      auto add = [&](int i, const GemmParams& g, int batch) {
+        sd.g[i] = g;
+        sd.bm[i] = (g.M % 64 == 0 || g.M >= 256) ? 64 : 32;
+        sd.gx[i] = (g.N + 63) / 64; sd.gy[i] = (g.M + sd.bm[i] - 1) / sd.bm[i]; sd.gz[i] = batch;
+        sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
+      };
+      add(0, gWc, 1);
+      add(1, gWv, d.Q);
+      sd.cs_src = w.dlogits; sd.cs_out = s->grads + offs[3]; sd.cs_B = d.B; sd.cs_ncol = d.C; sd.cs_ld = w.ldl;
+      sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
+      sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;
+      sd.total += sd.n_colsum + sd.n_stats;
+      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, &sd));
+    } else {
+      hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
+      hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+      if (side != st) {
+        EP_TRY(get_events(ev, 3));
+        EP_HIP(hipEventRecord(ev[0], st));
+        EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
+      }
+      EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
+      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
+                             s->accumulate, side));
+      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
+      EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
+      if (side != st) {
+        EP_HIP(hipEventRecord(ev[1], st));
+        EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
+      }
+      EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
+                              s->accumulate, side));
+      EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st));
+      if (side != st) {
+        EP_HIP(hipEventRecord(ev[2], side));
+        EP_HIP(hipStreamWaitEvent(st, ev[2], 0));           // join: grads complete on `stream`
+      }
     }
   }
   if (s->phases & 2) {

@@ -35,13 +35,25 @@ struct GemmParams {
   int side;                         // 1: runs on the aux stream beside a token pass (kernel choice hint)
 };
 
+// Work appended to the launch of the second token pass (ep_side.h: run_side_task)
+struct SideTasks {
+  GemmParams g[2];                  // T/T-layout, 16-byte aligned operands
+  int gx[2], gy[2], gz[2], bm[2];   // tile grid and tile rows (32 / 64) of each; gx*gy*gz == 0 when unused
+  const float* cs_src; float* cs_out; int cs_B, cs_ncol, cs_ld, cs_accumulate, n_colsum;
+  const float* rowstat; float* stats; int rs_B, n_stats;
+  int total;                        // number of extra workgroups
+};
+
 // element offset of image b of the batch inside the token buffer
 #define EP_IMG_OFF(p, b) ((int64_t)((p).index ? (p).index[(b)] : (b)) * (p).x_bstride)
 
 size_t pool_workspace_bytes(int B, int N, int D, int Q);
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd);
 int pool_forward(const PoolParams& p, hipStream_t st);
-int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st);
+// `side` (optional): extra work to run inside the launch; honoured only when pool_backward_takes_side(p)
+int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st, const SideTasks* side = nullptr);
+bool pool_backward_takes_side(const PoolParams& p);
+bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
 int debug_force_generic(int on);
 int attention_from_scores(const float* S, const float* ML, int rows, int N, float* A, hipStream_t st);
 

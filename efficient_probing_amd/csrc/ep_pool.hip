@@ -172,6 +172,7 @@ StreamPlan stream_plan(int B, int N, int D, int Q) {
   int wg_per_cu = stream_waves_per_cu(c.qw, c.kp, c.nw) / c.nw;
   if (const char* e = getenv("EP_POOL_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }
   int grid = cu_count() * wg_per_cu;
+  if (const char* e = getenv("EP_POOL_GRID")) { int v = atoi(e); if (v >= 1) grid = v; }   // diagnostics
   if (grid > B) grid = B;
   c.grid = grid;
   c.ok = true;
@@ -240,10 +241,21 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
   return 0;
 }
 
-int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st) {
+// The vector-ALU streaming kernel with 4-wave workgroups can carry side work (256-thread tasks).
+bool pool_backward_takes_side(const PoolParams& p) {
+  static int allow = -1;
+  if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
+  if (!allow || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+  return c.ok && c.nw == 4;
+}
+
+int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side) {
   PoolParams p = p0;
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   int nparts;
+  EP_REQUIRE(!side || side->total == 0 || pool_backward_takes_side(p), EP_E_UNSUPPORTED,
+             "pool_backward: side tasks need the 4-wave streaming kernel");
   if (use_mm(p, true)) {
     nparts = mf_grid(p.B);
     EP_TRY(mm_launch(true, p, nparts, st));
@@ -252,7 +264,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));
   } else if (c.ok && !force_generic()) {
-    EP_TRY(stream_launch(true, c, p, st));
+    EP_TRY(stream_launch(true, c, p, st, side));
     nparts = c.grid;
   } else {
     const size_t lds = (size_t)(p.N + 8) * sizeof(float);

@@ -23,6 +23,7 @@
 #include "ep_common.h"
 #include "ep_internal.h"
 #include "ep_pool_stream.h"
+#include "ep_side.h"
 
 namespace ep {
 
@@ -304,10 +305,17 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 // header items fetch ML[b,q,0:4] of the wave's queries, token items fetch S[b,q,n0:n0+TT].
 // ---------------------------------------------------------------------------------------
 template <int QW, int KP, int NW, int DFIX>
-__global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_bwd_kernel(PoolParams p) {
+__global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_bwd_kernel(PoolParams p, SideTasks side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA, TT = Cfg::TT;
   extern __shared__ __attribute__((aligned(1024))) char ring[];
+  const int G = gridDim.x - side.total;             // pooling workgroups; the rest run side tasks
+  if constexpr (NW == 4) {
+    if ((int)blockIdx.x >= G) {
+      run_side_task(side, (int)blockIdx.x - G, ring);
+      return;
+    }
+  }
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = DFIX ? DFIX : p.D;
@@ -319,7 +327,6 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const int tiles_per_img = (N + TT - 1) / TT;
   const int H = (Q + TT - 1) / TT;
   const int items_per_img = H + tiles_per_img;
-  const int G = gridDim.x;
   const int wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * items_per_img;
@@ -449,24 +456,30 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 // launch
 // ---------------------------------------------------------------------------------------
 template <int QW, int KP, int NW, int DFIX>
-static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   const int D = p.D;
   const size_t slot = (size_t)Cfg::TT * D * 4;
-  const size_t lds = bwd ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
+  size_t lds = bwd ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
+  SideTasks sd{};
+  if (bwd && side && side->total > 0) {
+    if (NW != 4) { set_error("side tasks need 4-wave workgroups"); return EP_E_UNSUPPORTED; }
+    sd = *side;
+    if (lds < SIDE_LDS_BYTES) lds = SIDE_LDS_BYTES;
+  }
   auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX>;
   auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
-  if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(NW * 64), lds, st, p);
+  if (bwd) hipLaunchKernelGGL(kb, dim3(grid + sd.total), dim3(NW * 64), lds, st, p, sd);
   else hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, st, p);
   EP_LAUNCH_CHECK(bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel");
   return 0;
 }
 
 template <int QW, int KP, int NW>
-static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   if constexpr (!Cfg::VALID) {
     set_error("no streaming kernel for qw=%d kp=%d nw=%d", QW, KP, NW);
@@ -474,32 +487,32 @@ static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   } else {
     // compile-time D for the shapes the benchmark configs use (immediate LDS offsets)
     if constexpr ((QW == 2 && NW == 4 && (KP == 3 || KP == 4)) || (QW == 4 && NW == 8 && KP == 3)) {
-      if (p.D == 256 * KP) return launch_one<QW, KP, NW, 256 * KP>(bwd, p, grid, st);
+      if (p.D == 256 * KP) return launch_one<QW, KP, NW, 256 * KP>(bwd, p, grid, st, side);
     }
-    return launch_one<QW, KP, NW, 0>(bwd, p, grid, st);
+    return launch_one<QW, KP, NW, 0>(bwd, p, grid, st, side);
   }
 }
 
 template <int QW, int NW>
-static int dispatch_kp(bool bwd, int kp, const PoolParams& p, int grid, hipStream_t st) {
+static int dispatch_kp(bool bwd, int kp, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   switch (kp) {
-    case 1: return launch_cfg<QW, 1, NW>(bwd, p, grid, st);
-    case 2: return launch_cfg<QW, 2, NW>(bwd, p, grid, st);
-    case 3: return launch_cfg<QW, 3, NW>(bwd, p, grid, st);
-    case 4: return launch_cfg<QW, 4, NW>(bwd, p, grid, st);
-    case 5: return launch_cfg<QW, 5, NW>(bwd, p, grid, st);
-    case 6: return launch_cfg<QW, 6, NW>(bwd, p, grid, st);
+    case 1: return launch_cfg<QW, 1, NW>(bwd, p, grid, st, side);
+    case 2: return launch_cfg<QW, 2, NW>(bwd, p, grid, st, side);
+    case 3: return launch_cfg<QW, 3, NW>(bwd, p, grid, st, side);
+    case 4: return launch_cfg<QW, 4, NW>(bwd, p, grid, st, side);
+    case 5: return launch_cfg<QW, 5, NW>(bwd, p, grid, st, side);
+    case 6: return launch_cfg<QW, 6, NW>(bwd, p, grid, st, side);
   }
   set_error("no streaming kernel for kp=%d", kp);
   return EP_E_UNSUPPORTED;
 }
 
-int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st) {
-  if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st);
-  if (c.qw == 1 && c.nw == 8) return dispatch_kp<1, 8>(bwd, c.kp, p, c.grid, st);
-  if (c.qw == 2 && c.nw == 4) return dispatch_kp<2, 4>(bwd, c.kp, p, c.grid, st);
-  if (c.qw == 2 && c.nw == 8) return dispatch_kp<2, 8>(bwd, c.kp, p, c.grid, st);
-  if (c.qw == 4 && c.nw == 8) return dispatch_kp<4, 8>(bwd, c.kp, p, c.grid, st);
+int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side) {
+  if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st, side);
+  if (c.qw == 1 && c.nw == 8) return dispatch_kp<1, 8>(bwd, c.kp, p, c.grid, st, side);
+  if (c.qw == 2 && c.nw == 4) return dispatch_kp<2, 4>(bwd, c.kp, p, c.grid, st, side);
+  if (c.qw == 2 && c.nw == 8) return dispatch_kp<2, 8>(bwd, c.kp, p, c.grid, st, side);
+  if (c.qw == 4 && c.nw == 8) return dispatch_kp<4, 8>(bwd, c.kp, p, c.grid, st, side);
   set_error("no streaming kernel for qw=%d nw=%d", c.qw, c.nw);
   return EP_E_UNSUPPORTED;
 }

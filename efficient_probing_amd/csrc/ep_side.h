@@ -1,0 +1,282 @@
+// Device-side building blocks shared by the stand-alone kernels (ep_gemm.hip, ep_tail.hip) and by the
+// second token pass, which runs the weight-gradient contractions as extra workgroups of its own launch
+// (ep_pool_stream.hip): the exact-fp32 matrix-core tile, the column sum and the statistics fold.
+#pragma once
+#include "ep_common.h"
+#include "ep_internal.h"
+
+namespace ep {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDK = BK + 2;    // K-layout row stride (floats)
+constexpr int LDT = BM + 16;   // T-layout row stride (floats)
+
+
+// ---- global -> register tile loads ---------------------------------------------------------
+// K layout: 64 rows x 32 k ; thread handles float4 (row = idx/8, kq = idx%8), idx = tid + 256 r
+template <bool VEC, int RT>
+__device__ __forceinline__ void load_K(const float* __restrict__ base, int64_t ld, int rows, int K,
+                                       int r0, int k0, int tid, f4v (&reg)[2]) {
+#pragma unroll
+  for (int r = 0; r < RT / 32; ++r) {
+    const int idx = tid + 256 * r;
+    const int row = r0 + (idx >> 3), k = k0 + 4 * (idx & 7);
+    f4v v = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+      // branch-free: out-of-range lanes load a valid address and are zeroed afterwards, so the
+      // prefetch loads stay straight-line code and the compiler can count them exactly (vmcnt(N))
+      const int rowc = row < rows ? row : rows - 1;
+      v = *reinterpret_cast<const f4v*>(base + (int64_t)rowc * ld + (k < K ? k : 0));   // zeroed in store_K
+    } else if (row < rows) {
+      const float* ptr = base + (int64_t)row * ld + k;
+      if (k + 0 < K) v.x = ptr[0];
+      if (k + 1 < K) v.y = ptr[1];
+      if (k + 2 < K) v.z = ptr[2];
+      if (k + 3 < K) v.w = ptr[3];
+    }
+    reg[r] = v;
+  }
+}
+// T layout: 32 k-rows x 64 r ; thread handles float4 (krow = idx/16, rq = idx%16)
+template <bool VEC, int RT>
+__device__ __forceinline__ void load_T(const float* __restrict__ base, int64_t ld, int ext, int K,
+                                       int r0, int k0, int tid, f4v (&reg)[2]) {
+  constexpr int QPR = RT / 4;             // float4 per k-row (16 or 8)
+#pragma unroll
+  for (int r = 0; r < RT / 32; ++r) {
+    const int idx = tid + 256 * r;
+    const int k = k0 + idx / QPR, rr = r0 + 4 * (idx % QPR);
+    f4v v = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+      const int kc = k < K ? k : K - 1;
+      v = *reinterpret_cast<const f4v*>(base + (int64_t)kc * ld + (rr < ext ? rr : 0));  // zeroed in store_T
+    } else if (k < K) {
+      const float* ptr = base + (int64_t)k * ld + rr;
+      if (rr + 0 < ext) v.x = ptr[0];
+      if (rr + 1 < ext) v.y = ptr[1];
+      if (rr + 2 < ext) v.z = ptr[2];
+      if (rr + 3 < ext) v.w = ptr[3];
+    }
+    reg[r] = v;
+  }
+}
+// the out-of-range mask is applied here, at the point the loaded registers are consumed anyway
+// (a select right after the load would force the load to complete immediately)
+template <int RT>
+__device__ __forceinline__ void store_K(float* lds, int tid, const f4v (&reg)[2], int rows, int K, int r0, int k0) {
+#pragma unroll
+  for (int r = 0; r < RT / 32; ++r) {
+    const int idx = tid + 256 * r;
+    const bool ok = (r0 + (idx >> 3)) < rows && (k0 + 4 * (idx & 7)) < K;
+    const f4v v = ok ? reg[r] : f4v{0.f, 0.f, 0.f, 0.f};
+    float* d = lds + (idx >> 3) * LDK + 4 * (idx & 7);
+    *reinterpret_cast<f2*>(d) = f2{v.x, v.y};
+    *reinterpret_cast<f2*>(d + 2) = f2{v.z, v.w};
+  }
+}
+template <int RT>
+__device__ __forceinline__ void store_T(float* lds, int tid, const f4v (&reg)[2], int ext, int K, int r0, int k0) {
+  constexpr int QPR = RT / 4;
+#pragma unroll
+  for (int r = 0; r < RT / 32; ++r) {
+    const int idx = tid + 256 * r;
+    const bool ok = (k0 + idx / QPR) < K && (r0 + 4 * (idx % QPR)) < ext;
+    const f4v v = ok ? reg[r] : f4v{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4v*>(lds + (idx / QPR) * LDT + 4 * (idx % QPR)) = v;
+  }
+}
+
+constexpr int LDS_OPERAND = (64 * LDK > 32 * LDT) ? 64 * LDK : 32 * LDT;   // floats per operand image
+
+// BMT = rows of the output tile (64, or 32 when a 64-row tiling would leave CUs with a single
+// workgroup: two resident workgroups per CU hide each other's LDS / barrier latency)
+template <bool A_K, bool B_K, bool VEC, int BMT>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, int bz,
+                                          float (*lds)[2][LDS_OPERAND]) {   // lds[buffer][A|B][...]
+  constexpr int MI = BMT / 32;            // 16-row MFMA blocks per wave along M
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * BMT, n0 = bx * BN;
+  const int z = bz;
+  const float* A = p.A + (int64_t)z * p.sAz;
+  const float* B = p.B + (int64_t)z * p.sBz;
+  float* C = p.C + (int64_t)z * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+
+  f4v acc[MI][2];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  // Register ring of depth 3: the global loads of K-tile it+3 are issued while tile `it` is
+  // multiplied, so a load has ~2-3 iterations (2-3k cycles of MFMA) to land before it is copied
+  // into LDS one iteration ahead of its use.  R[j] indices are static (loop unrolled by 3).
+  f4v ra[3][2], rb[3][2];
+  auto gload = [&](int k0, f4v (&xa)[2], f4v (&xb)[2]) {
+    if (A_K) load_K<VEC, BMT>(A, p.lda, p.M, p.K, m0, k0, tid, xa);
+    else load_T<VEC, BMT>(A, p.lda, p.extA, p.K, m0, k0, tid, xa);
+    if (B_K) load_K<VEC, BN>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
+    else load_T<VEC, BN>(B, p.ldb, p.extB, p.K, n0, k0, tid, xb);
+  };
+  auto lstore = [&](int buf, const f4v (&xa)[2], const f4v (&xb)[2], int k0) {
+    if (A_K) store_K<BMT>(lds[buf][0], tid, xa, p.M, p.K, m0, k0); else store_T<BMT>(lds[buf][0], tid, xa, p.extA, p.K, m0, k0);
+    if (B_K) store_K<BN>(lds[buf][1], tid, xb, p.N, p.K, n0, k0); else store_T<BN>(lds[buf][1], tid, xb, p.extB, p.K, n0, k0);
+  };
+  auto compute = [&](int buf) {
+    const float* As = lds[buf][0];
+    const float* Bs = lds[buf][1];
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      float af[MI], bf[2];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (16 * MI) + mi * 16 + i16;
+        af[mi] = A_K ? As[row * LDK + 4 * s + kk] : As[(4 * s + kk) * LDT + row];
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = wn * 32 + ni * 16 + i16;
+        bf[ni] = B_K ? Bs[col * LDK + 4 * s + kk] : Bs[(4 * s + kk) * LDT + col];
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  auto tile_k0 = [&](int it) { return (it < nk ? it : nk - 1) * BK; };   // clamped: redundant, never out of range
+  gload(0, ra[0], rb[0]);
+  lstore(0, ra[0], rb[0], 0);
+  gload(tile_k0(1), ra[1], rb[1]);
+  gload(tile_k0(2), ra[2], rb[2]);
+  __syncthreads();
+  // One step = prefetch tile it+3 (unconditionally: straight-line code lets the compiler wait with an
+  // exact vmcnt(N) instead of draining), multiply tile it, stage tile it+1 into the other LDS buffer.
+#define EP_GEMM_STEP(IT, J)                                                 \
+  {                                                                         \
+    gload(tile_k0((IT) + 3), ra[J], rb[J]);                                 \
+    compute((IT) & 1);                                                      \
+    lstore(((IT) + 1) & 1, ra[((J) + 1) % 3], rb[((J) + 1) % 3], ((IT) + 1) * BK); \
+    __syncthreads();                                                        \
+  }
+  int it = 0;
+  for (; it + 2 < nk; it += 3) {
+    EP_GEMM_STEP(it, 0)
+    EP_GEMM_STEP(it + 1, 1)
+    EP_GEMM_STEP(it + 2, 2)
+  }
+  if (it < nk) {
+    EP_GEMM_STEP(it, 0)
+    if (it + 1 < nk) EP_GEMM_STEP(it + 1, 1)
+  }
+#undef EP_GEMM_STEP
+  // epilogue: D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 32 + ni * 16 + i16;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * (16 * MI) + mi * 16 + kk * 4 + r;
+        if (row < p.M) {
+          float* c = C + (int64_t)row * p.ldc + col;
+          float v = p.alpha * acc[mi][ni][r] + bv;
+          if (p.accumulate) v += *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+
+// ---- column sum / statistics fold (256 threads) -----------------------------------------------
+constexpr int CG = 16;   // columns per workgroup
+constexpr int RL = 16;   // row lanes per workgroup  (CG*RL = 256 threads)
+
+// sum over the RL row-lanes of a workgroup for each of its CG columns; result valid for ty == 0
+__device__ __forceinline__ float colreduce(float v, float (*sm)[CG], int tx, int ty) {
+  sm[ty][tx] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (ty == 0) {
+#pragma unroll
+    for (int r = 0; r < RL; ++r) s += sm[r][tx];
+  }
+  __syncthreads();
+  return s;
+}
+
+// out[col] (+)= sum_b src[b*ld + col] for the CG columns of block bx
+__device__ __forceinline__ void colsum_block(const float* __restrict__ src, int B, int ncol, int ld, int accumulate,
+                                             float* __restrict__ out, int bx, float (*sm)[CG]) {
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int col = bx * CG + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < ncol) {
+    int b = ty;
+    for (; b + 3 * RL < B; b += 4 * RL) {
+      s0 += src[(int64_t)b * ld + col];
+      s1 += src[(int64_t)(b + RL) * ld + col];
+      s2 += src[(int64_t)(b + 2 * RL) * ld + col];
+      s3 += src[(int64_t)(b + 3 * RL) * ld + col];
+    }
+    for (; b < B; b += RL) s0 += src[(int64_t)b * ld + col];
+  }
+  const float s = colreduce((s0 + s1) + (s2 + s3), sm, tx, ty);
+  if (ty == 0 && col < ncol) out[col] = accumulate ? out[col] + s : s;
+}
+
+// stats[0..3] += sum_b rowstat[b][0..3]   (one workgroup, fixed order: reproducible)
+__device__ __forceinline__ void ce_stats_block(const float* __restrict__ rowstat, int B, float* __restrict__ stats,
+                                               f4* sm) {
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < B; b += 256) s += *reinterpret_cast<const f4*>(rowstat + (int64_t)b * 4);
+  s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const f4 t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    stats[0] += t.x; stats[1] += t.y; stats[2] += t.z; stats[3] += t.w;
+  }
+}
+
+// ---- side tasks of the second token pass ---------------------------------------------------------
+// Workgroups with blockIdx.x >= (pooling workgroups) run these instead of streaming tokens.  They are
+// dispatched as pooling workgroups retire, i.e. into the tail of the pass where the chip would
+// otherwise drain; none of them feeds anything before the optimizer.  All T/T-layout vector GEMMs.
+constexpr size_t SIDE_LDS_BYTES = sizeof(float) * 2 * 2 * LDS_OPERAND;
+
+__device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* lds_raw) {
+  auto lds = reinterpret_cast<float (*)[2][LDS_OPERAND]>(lds_raw);
+  const int n0 = s.gx[0] * s.gy[0] * s.gz[0], n1 = s.gx[1] * s.gy[1] * s.gz[1];
+  if (t < n0 + n1) {
+    const int i = t < n0 ? 0 : 1;
+    if (i) t -= n0;
+    const int bx = t % s.gx[i], r = t / s.gx[i];
+    const int by = r % s.gy[i], bz = r / s.gy[i];
+    if (s.bm[i] == 64) gemm_tile<false, false, true, 64>(s.g[i], bx, by, bz, lds);
+    else gemm_tile<false, false, true, 32>(s.g[i], bx, by, bz, lds);
+    return;
+  }
+  t -= n0 + n1;
+  if (t < s.n_colsum) {
+    colsum_block(s.cs_src, s.cs_B, s.cs_ncol, s.cs_ld, s.cs_accumulate, s.cs_out, t,
+                 reinterpret_cast<float (*)[CG]>(lds_raw));
+    return;
+  }
+  t -= s.n_colsum;
+  if (t < s.n_stats) ce_stats_block(s.rowstat, s.rs_B, s.stats, reinterpret_cast<f4*>(lds_raw));
+}
+
+}  // namespace ep

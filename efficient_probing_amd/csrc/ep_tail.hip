@@ -3,26 +3,9 @@
 // (reference main_linprobe.py:589, engine_finetune.py:62-63), bias gradient, and the softmax
 // correction term delta of the pooling backward.  All fp32; batch reductions are done in a
 // fixed order (no atomics on values that feed the parameters), so a step is reproducible.
-#include "ep_common.h"
-#include "ep_internal.h"
+#include "ep_side.h"
 
 namespace ep {
-
-constexpr int CG = 16;   // columns per workgroup
-constexpr int RL = 16;   // row lanes per workgroup  (CG*RL = 256 threads)
-
-// sum over the RL row-lanes of a workgroup for each of its CG columns; result valid for ty == 0
-__device__ __forceinline__ float colreduce(float v, float (*sm)[CG], int tx, int ty) {
-  sm[ty][tx] = v;
-  __syncthreads();
-  float s = 0.f;
-  if (ty == 0) {
-#pragma unroll
-    for (int r = 0; r < RL; ++r) s += sm[r][tx];
-  }
-  __syncthreads();
-  return s;
-}
 
 // BatchNorm over the batch axis in two launches with whole-chip parallelism:
 //   stage 1: grid (Dp/CG, RS): per row-chunk, per column: (mean_chunk, M2_chunk) [train] or
@@ -169,21 +152,7 @@ __global__ __launch_bounds__(256) void ep_bn_bwd_apply_kernel(const float* __res
 __global__ __launch_bounds__(256) void ep_colsum_kernel(const float* __restrict__ src, int B, int ncol, int ld,
                                                       int accumulate, float* __restrict__ out) {
   __shared__ float sm[RL][CG];
-  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
-  const int col = blockIdx.x * CG + tx;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col < ncol) {
-    int b = ty;
-    for (; b + 3 * RL < B; b += 4 * RL) {
-      s0 += src[(int64_t)b * ld + col];
-      s1 += src[(int64_t)(b + RL) * ld + col];
-      s2 += src[(int64_t)(b + 2 * RL) * ld + col];
-      s3 += src[(int64_t)(b + 3 * RL) * ld + col];
-    }
-    for (; b < B; b += RL) s0 += src[(int64_t)b * ld + col];
-  }
-  float s = colreduce((s0 + s1) + (s2 + s3), sm, tx, ty);
-  if (ty == 0 && col < ncol) out[col] = accumulate ? out[col] + s : s;
+  colsum_block(src, B, ncol, ld, accumulate, out, blockIdx.x, sm);
 }
 
 // delta[b,q] = sum_c dy[b, q*Dq + c] * y[b, q*Dq + c]  ->  ML[b,q,2]   (one wave per (b,q))
@@ -283,15 +252,7 @@ __global__ __launch_bounds__(256) void ep_ce_kernel(const float* __restrict__ lo
 __global__ __launch_bounds__(256) void ep_ce_stats_kernel(const float* __restrict__ rowstat, int B,
                                                         float* __restrict__ stats) {
   __shared__ f4 sm[4];
-  f4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int b = threadIdx.x; b < B; b += 256) s += *reinterpret_cast<const f4*>(rowstat + (int64_t)b * 4);
-  s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const f4 t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-    stats[0] += t.x; stats[1] += t.y; stats[2] += t.z; stats[3] += t.w;
-  }
+  ce_stats_block(rowstat, B, stats, sm);
 }
 
 // ------------------------------------------------------------------------------------------
