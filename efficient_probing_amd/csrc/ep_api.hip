@@ -26,18 +26,9 @@ int cu_count() {
   return n;
 }
 
-#define EP_HIP(expr)                                                     \
-  do {                                                                   \
-    hipError_t e__ = (expr);                                             \
-    if (e__ != hipSuccess) {                                             \
-      ep::set_error("%s: %s", #expr, hipGetErrorString(e__));            \
-      return (int)e__;                                                   \
-    }                                                                    \
-  } while (0)
-
 // Fork/join events for the optional aux stream: a small per-thread pool created on first use and
 // reused (events carry no data; the library otherwise keeps no state).
-static int get_events(hipEvent_t* out, int n) {
+int get_events(hipEvent_t* out, int n) {
   static thread_local hipEvent_t pool[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < n; ++i) {
     if (!pool[i]) EP_HIP(hipEventCreateWithFlags(&pool[i], hipEventDisableTiming));
@@ -46,7 +37,7 @@ static int get_events(hipEvent_t* out, int n) {
   return 0;
 }
 
-static int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q) {
+int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q) {
   EP_REQUIRE(x != nullptr, EP_E_ARG, "x is null");
   EP_REQUIRE(B > 0 && N > 0 && D > 0 && Q > 0, EP_E_ARG, "B, N, D, Q must be positive (got %d %d %d %d)", B, N, D, Q);
   EP_REQUIRE(x_dtype == EP_DTYPE_F32, EP_E_UNSUPPORTED, "token dtype %d not implemented (fp32 only in this build)", x_dtype);
@@ -105,7 +96,7 @@ static int check_dims(const ep_head_dims& d) {
   return 0;
 }
 
-static PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale) {
+PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale) {
   PoolParams p{};
   p.x = static_cast<const float*>(x); p.x_bstride = x_bstride; p.B = B; p.N = N; p.D = D; p.Q = Q; p.scale = scale;
   return p;
@@ -132,7 +123,7 @@ static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp
   return g;
 }
 // dWc[c, k] (+)= sum_b dlogits[b, c] * z[b, k]
-static GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int C, float* dWc, int accumulate) {
+GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int C, float* dWc, int accumulate) {
   GemmParams g{};
   g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
   g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
@@ -155,7 +146,7 @@ static int project_backward(const float* dy, const float* y, const float* P, con
   return 0;
 }
 
-static int linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits,
+int linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits,
                           int ldl, hipStream_t st) {
   GemmParams g{};
   g.A = z; g.lda = Dp; g.B = Wc; g.ldb = Dp; g.C = logits; g.ldc = ldl; g.bias = bc;
@@ -163,7 +154,7 @@ static int linear_forward(const float* z, const float* Wc, const float* bc, int 
   return gemm(true, true, g, 1, st);
 }
 
-static int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, int B, int Dp, int C,
+int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, int B, int Dp, int C,
                            float* dz, float* dWc, float* dbc, int accumulate, hipStream_t st) {
   if (dz) {
     GemmParams g{};
@@ -173,6 +164,21 @@ static int linear_backward(const float* dl, int ldl, const float* z, const float
   }
   if (dWc) EP_TRY(gemm(false, false, dwc_gemm(dl, ldl, z, B, Dp, C, dWc, accumulate), 1, st));
   if (dbc) EP_TRY(colsum(dl, B, C, ldl, accumulate, dbc, st));
+  return 0;
+}
+
+void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch) {
+  const int i = sd.n_gemm++;
+  sd.g[i] = g;
+  sd.bm[i] = (g.M % 64 == 0 || g.M >= 256) ? 64 : 32;
+  sd.gx[i] = (g.N + 63) / 64; sd.gy[i] = (g.M + sd.bm[i] - 1) / sd.bm[i]; sd.gz[i] = batch;
+  sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
+}
+
+int side_run_standalone(const SideTasks& sd, hipStream_t st) {
+  for (int i = 0; i < sd.n_gemm; ++i) EP_TRY(gemm(false, false, sd.g[i], sd.gz[i], st));
+  if (sd.n_colsum) EP_TRY(colsum(sd.cs_src, sd.cs_B, sd.cs_ncol, sd.cs_ld, sd.cs_accumulate, sd.cs_out, st));
+  if (sd.n_stats) EP_TRY(ce_stats(sd.rowstat, sd.rs_B, sd.stats, st));
   return 0;
 }
 
@@ -358,14 +364,8 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
       SideTasks sd{};
-      auto add = [&](int i, const GemmParams& g, int batch) {
-        sd.g[i] = g;
-        sd.bm[i] = (g.M % 64 == 0 || g.M >= 256) ? 64 : 32;
-        sd.gx[i] = (g.N + 63) / 64; sd.gy[i] = (g.M + sd.bm[i] - 1) / sd.bm[i]; sd.gz[i] = batch;
-        sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
-      };
-      add(0, gWc, 1);
-      add(1, gWv, d.Q);
+      side_add_gemm(sd, gWc, 1);
+      side_add_gemm(sd, gWv, d.Q);
       sd.cs_src = w.dlogits; sd.cs_out = s->grads + offs[3]; sd.cs_B = d.B; sd.cs_ncol = d.C; sd.cs_ld = w.ldl;
       sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
       sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;

@@ -32,6 +32,15 @@ void set_error(const char* fmt, ...);
     if (rc__ != 0) return rc__; \
   } while (0)
 
+#define EP_HIP(expr)                                                     \
+  do {                                                                   \
+    hipError_t e__ = (expr);                                             \
+    if (e__ != hipSuccess) {                                             \
+      ep::set_error("%s: %s", #expr, hipGetErrorString(e__));            \
+      return (int)e__;                                                   \
+    }                                                                    \
+  } while (0)
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int cu_count();

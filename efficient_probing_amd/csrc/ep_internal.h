@@ -37,8 +37,9 @@ struct GemmParams {
 
 // Work appended to the launch of the second token pass (ep_side.h: run_side_task)
 struct SideTasks {
-  GemmParams g[2];                  // T/T-layout, 16-byte aligned operands
-  int gx[2], gy[2], gz[2], bm[2];   // tile grid and tile rows (32 / 64) of each; gx*gy*gz == 0 when unused
+  GemmParams g[3];                  // T/T-layout, 16-byte aligned operands
+  int gx[3], gy[3], gz[3], bm[3];   // tile grid and tile rows (32 / 64) of each; gx*gy*gz == 0 when unused
+  int n_gemm;
   const float* cs_src; float* cs_out; int cs_B, cs_ncol, cs_ld, cs_accumulate, n_colsum;
   const float* rowstat; float* stats; int rs_B, n_stats;
   int total;                        // number of extra workgroups
@@ -72,6 +73,21 @@ int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hip
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
                   float* loss_rows, float* dlogits, float* rowstat, hipStream_t st);
 int ce_stats(const float* rowstat, int B, float* stats, hipStream_t st);
+
+// shared host helpers (ep_api.hip)
+int get_events(hipEvent_t* out, int n);
+int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q);
+PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale);
+int linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits, int ldl,
+                   hipStream_t st);
+int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, int B, int Dp, int C, float* dz,
+                    float* dWc, float* dbc, int accumulate, hipStream_t st);
+GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int C, float* dWc, int accumulate);
+void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch);
+// run the side tasks as stand-alone launches on `st` (kernel families that cannot carry them)
+int side_run_standalone(const SideTasks& sd, hipStream_t st);
+int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
+                    hipStream_t st);
 
 size_t optim_workspace_bytes(int64_t total, int nseg);
 int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,

@@ -272,16 +272,19 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     EP_LAUNCH_CHECK("ep_pool_bwd_generic_kernel");
     nparts = p.B;
   }
-  // two deterministic stages: nparts -> 16 group sums (written behind the partials) -> dcls
-  const int n = p.Q * p.D;
+  return reduce_partials(p.Gpart, nparts, p.Q * p.D, p.scale, accumulate, dcls, p.Gpart + (int64_t)nparts * p.Q * p.D, st);
+}
+
+// out[n] (+)= scale * sum_i parts[i][n] in two deterministic stages for many parts:
+// nparts -> 16 group sums (`stage`, 16*n floats) -> out
+int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
+                    hipStream_t st) {
   const int gx = (n / 4 + 63) / 64;
   if (nparts > 32) {
-    float* stage = p.Gpart + (int64_t)nparts * n;
-    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 16), dim3(256), 0, st, p.Gpart, nparts, n, 1.0f, 0, stage);
-    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, stage, 16, n, p.scale, accumulate, dcls);
+    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 16), dim3(256), 0, st, parts, nparts, n, 1.0f, 0, stage);
+    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, stage, 16, n, scale, accumulate, out);
   } else {
-    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, p.Gpart, nparts, n, p.scale,
-                       accumulate, dcls);
+    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, parts, nparts, n, scale, accumulate, out);
   }
   EP_LAUNCH_CHECK("ep_reduce_partials_kernel");
   return 0;

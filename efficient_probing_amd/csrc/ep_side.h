@@ -259,17 +259,18 @@ constexpr size_t SIDE_LDS_BYTES = sizeof(float) * 2 * 2 * LDS_OPERAND;
 
 __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* lds_raw) {
   auto lds = reinterpret_cast<float (*)[2][LDS_OPERAND]>(lds_raw);
-  const int n0 = s.gx[0] * s.gy[0] * s.gz[0], n1 = s.gx[1] * s.gy[1] * s.gz[1];
-  if (t < n0 + n1) {
-    const int i = t < n0 ? 0 : 1;
-    if (i) t -= n0;
-    const int bx = t % s.gx[i], r = t / s.gx[i];
-    const int by = r % s.gy[i], bz = r / s.gy[i];
-    if (s.bm[i] == 64) gemm_tile<false, false, true, 64>(s.g[i], bx, by, bz, lds);
-    else gemm_tile<false, false, true, 32>(s.g[i], bx, by, bz, lds);
-    return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int n = s.gx[i] * s.gy[i] * s.gz[i];
+    if (t < n) {
+      const int bx = t % s.gx[i], r = t / s.gx[i];
+      const int by = r % s.gy[i], bz = r / s.gy[i];
+      if (s.bm[i] == 64) gemm_tile<false, false, true, 64>(s.g[i], bx, by, bz, lds);
+      else gemm_tile<false, false, true, 32>(s.g[i], bx, by, bz, lds);
+      return;
+    }
+    t -= n;
   }
-  t -= n0 + n1;
   if (t < s.n_colsum) {
     colsum_block(s.cs_src, s.cs_B, s.cs_ncol, s.cs_ld, s.cs_accumulate, s.cs_out, t,
                  reinterpret_cast<float (*)[CG]>(lds_raw));

@@ -29,13 +29,42 @@ OPTIMIZERS = {"lars": 0, "sgd": 1, "adamw": 2}
 
 
 class ProbeHeadEngine:
+    """Engine of Sequential(EfficientProbing, BatchNorm1d, Linear).  ``CocaHeadEngine`` below reuses everything
+    but the four ``_layout`` / ``_new_step`` / ``_ws_bytes`` / ``_call_*`` hooks."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_ep_head
+        if not is_native_ep_head(head):
+            raise TypeError("ProbeHeadEngine needs Sequential(EfficientProbing, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        """-> (dims struct, parameters in flat order, offsets, total elements)"""
+        D = self.pool.v.in_features
+        dims = N.EPHeadDims(B=0, N=0, D=D, Q=self.pool.num_queries, d_out=self.pool.d_out, C=self.fc.out_features)
+        offs = (C.c_int64 * 4)()
+        total = int(self.lib.ep_head_param_offsets(C.byref(dims), offs))
+        return dims, [self.pool.cls_token, self.pool.v.weight, self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        return N.EPHeadStep()
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_head_workspace_bytes(C.byref(self.dims))
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, iptr,
+                                             self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                             self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                             ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
     def __init__(self, head: nn.Sequential, optimizer: str = "lars", lr: float = 0.0, weight_decay: float = 0.0,
                  momentum: float = 0.9, trust_coefficient: float = 0.001, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                  process_group=None, loss_scale: float = 1.0, accum_iter: int = 1, broadcast_from_rank0: bool = True,
                  overlap: bool = True):
-        from .probe_heads import is_native_ep_head
-        if not is_native_ep_head(head):
-            raise TypeError("ProbeHeadEngine needs Sequential(EfficientProbing, BatchNorm1d, Linear)")
+        self._check_head(head)
         if optimizer not in OPTIMIZERS:
             raise ValueError(f"optimizer must be one of {sorted(OPTIMIZERS)}")
         self.head = head
@@ -55,13 +84,7 @@ class ProbeHeadEngine:
         self.opt_step = 0
         self._micro = 0
 
-        D = self.pool.v.in_features
-        self.dims = N.EPHeadDims(B=0, N=0, D=D, Q=self.pool.num_queries, d_out=self.pool.d_out,
-                                 C=self.fc.out_features)
-        offs = (C.c_int64 * 4)()
-        self.total = int(self.lib.ep_head_param_offsets(C.byref(self.dims), offs))
-        self.offsets = list(offs)
-        self.params_list = [self.pool.cls_token, self.pool.v.weight, self.fc.weight, self.fc.bias]
+        self.dims, self.params_list, self.offsets, self.total = self._layout()
         self.flat_p = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(self.total, device=dev, dtype=torch.float32)
         n_state = {"lars": 1, "sgd": 0, "adamw": 2}[optimizer]
@@ -96,15 +119,15 @@ class ProbeHeadEngine:
         key = (B, Nn)
         if self._ws_key != key:
             self.dims.B, self.dims.N = B, Nn
-            nbytes = self.lib.ep_head_workspace_bytes(C.byref(self.dims))
+            nbytes = self._ws_bytes()
             if nbytes == 0:
-                raise RuntimeError(f"ep_head_workspace_bytes: {N.last_error()}")
+                raise RuntimeError(f"head workspace query: {N.last_error()}")
             self._ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
             self._ws_key = key
         return self._ws
 
-    def _step_struct(self, x, bstride, targets, phases, accumulate, lr) -> N.EPHeadStep:
-        s = N.EPHeadStep()
+    def _step_struct(self, x, bstride, targets, phases, accumulate, lr):
+        s = self._new_step()
         s.dims = self.dims
         s.x = x.data_ptr() if x is not None else 0
         s.x_dtype = N.EP_DTYPE_F32
@@ -144,8 +167,7 @@ class ProbeHeadEngine:
         targets = targets.to(device=self.device, dtype=torch.int64)
         s = self._step_struct(xv, bstride, targets, 1, self._micro > 0, None)
         s.image_index = iptr
-        N.check(self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
-                                            N.current_stream_ptr(self.device)), "ep_head_train_step(fwd+bwd)")
+        N.check(self._call_train(s, ws), "head train step (fwd+bwd)")
         self._micro += 1
 
     def all_reduce_grads(self) -> None:
@@ -160,8 +182,7 @@ class ProbeHeadEngine:
         if ws is None:
             raise RuntimeError("optimizer_step before any forward_backward")
         s = self._step_struct(None, 0, None, 2, False, lr)
-        N.check(self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
-                                            N.current_stream_ptr(self.device)), "ep_head_train_step(optimizer)")
+        N.check(self._call_train(s, ws), "head train step (optimizer)")
         self._micro = 0
 
     def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None,
@@ -181,11 +202,7 @@ class ProbeHeadEngine:
         Cc = self.dims.C
         ldl = F_.padded_ld(Cc)
         out = torch.empty((B, ldl), device=self.device, dtype=torch.float32)
-        N.check(self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, iptr,
-                                              self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
-                                              self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
-                                              ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)),
-                "ep_head_eval_forward")
+        N.check(self._call_eval(xv, bstride, iptr, out, ldl, ws), "head eval forward")
         return out[:, :Cc]
 
     def read_stats(self, reset: bool = True):
@@ -195,3 +212,50 @@ class ProbeHeadEngine:
         if reset:
             self.stats.zero_()
         return vals
+
+
+class CocaHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(CrossAttention (CoCa pooler), BatchNorm1d, Linear): same flat-buffer
+    design, data parallelism and call surface as ProbeHeadEngine, through ``ep_coca_head_train_step``."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_coca_head
+        if not is_native_coca_head(head):
+            raise TypeError("CocaHeadEngine needs Sequential(poolings.coca.CrossAttention, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        D = p.to_q.in_features
+        dims = N.EPCocaDims(B=0, N=0, D=D, H=p.heads, dh=p.dim_head, M=p.img_queries.shape[0],
+                            C=self.fc.out_features)
+        offs = (C.c_int64 * 7)()
+        total = int(self.lib.ep_coca_head_param_offsets(C.byref(dims), offs))
+        plist = [p.norm.gamma, p.img_queries, p.to_q.weight, p.to_kv.weight, p.to_out.weight, self.fc.weight,
+                 self.fc.bias]
+        return dims, plist, list(offs), total
+
+    def _new_step(self):
+        s = N.EPCocaStep()
+        s.ln_beta = self.pool.norm.beta.data_ptr()
+        s.ln_eps = 1e-5                      # F.layer_norm default (coca_pytorch.py:77)
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_coca_head_workspace_bytes(C.byref(self.dims))
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_coca_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
+                                                N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_coca_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, iptr,
+                                                  self.flat_p.data_ptr(), self.pool.norm.beta.data_ptr(), 1e-5,
+                                                  self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr(),
+                                                  self.bn.eps, out.data_ptr(), ldl, ws.data_ptr(), ws.numel(),
+                                                  N.current_stream_ptr(self.device))
+
+
+def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
+    """The fused engine matching a native head (EP or CoCa)."""
+    from .probe_heads import is_native_coca_head
+    return CocaHeadEngine(head, **kw) if is_native_coca_head(head) else ProbeHeadEngine(head, **kw)

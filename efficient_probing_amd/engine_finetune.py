@@ -111,16 +111,16 @@ def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1, 5)):
 
 
 def _native_head(model):
-    from .probe_heads import is_native_ep_head
+    from .probe_heads import is_native_head
     m = model.module if hasattr(model, "module") else model
-    head = m if is_native_ep_head(m) else getattr(m, "head", None)
-    return head if (head is not None and is_native_ep_head(head)) else None
+    head = m if is_native_head(m) else getattr(m, "head", None)
+    return head if (head is not None and is_native_head(head)) else None
 
 
 def get_engine(model, optimizer=None, args=None):
     """The fused engine attached to ``model`` (created on first use from the optimizer's
     hyper-parameters; LARS / SGD / AdamW as selected by reference main_linprobe.py:403-408)."""
-    from .engine import ProbeHeadEngine
+    from .engine import make_engine
     m = model.module if hasattr(model, "module") else model
     eng = getattr(m, "_ep_engine", None)
     if eng is None:
@@ -138,7 +138,7 @@ def get_engine(model, optimizer=None, args=None):
             if name == "adamw":
                 kw.update(betas=g.get("betas", (0.9, 0.999)), adam_eps=g.get("eps", 1e-8))
         accum = getattr(args, "accum_iter", 1) if args is not None else 1
-        eng = ProbeHeadEngine(head, optimizer=name, accum_iter=accum, **kw)
+        eng = make_engine(head, optimizer=name, accum_iter=accum, **kw)
         if optimizer is not None and name == "lars":
             # keep optimizer.state_dict() interchangeable with the reference's (state[p]['mu']):
             # the optimizer's momentum entries become views of the engine's flat buffer

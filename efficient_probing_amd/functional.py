@@ -381,3 +381,83 @@ class _CrossEntropy(torch.autograd.Function):
 def cross_entropy_loss(logits, targets):
     """(loss, stats) with stats = [mean loss, #top1, #top5, #non-finite rows]."""
     return _CrossEntropy.apply(logits, targets)
+
+
+# --------------------------------------------------------------------------------------------
+# CoCa attentional pooler (reference poolings/coca_pytorch.py:250-343) on the EP token pass
+# --------------------------------------------------------------------------------------------
+def coca_dims(B, Nn, D, heads, dim_head, num_img_queries, C_=0):
+    return N.EPCocaDims(B=B, N=Nn, D=D, H=heads, dh=dim_head, M=num_img_queries, C=C_)
+
+
+def _coca_params_struct(gamma, beta, img_queries, to_q, to_kv, to_out):
+    return N.EPCocaParams(gamma=gamma.data_ptr(), beta=_ptr(beta), img_queries=img_queries.data_ptr(),
+                          to_q=to_q.data_ptr(), to_kv=to_kv.data_ptr(), to_out=to_out.data_ptr())
+
+
+class _CocaPool(torch.autograd.Function):
+    """out[:, 0] of the CoCa CrossAttention with gradients for its five parameter tensors (the tokens are
+    frozen in the probing protocol; no gradient w.r.t. x)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, img_queries, to_q, to_kv, to_out, heads, dim_head, ln_eps):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in ((gamma, "norm.gamma"), (img_queries, "img_queries"), (to_q, "to_q.weight"),
+                                          (to_kv, "to_kv.weight"), (to_out, "to_out.weight"))]
+        beta_c = _f32c(beta, "norm.beta") if beta is not None else None
+        dims = coca_dims(B, Nn, D, heads, dim_head, img_queries.shape[0])
+        nbytes = lib.ep_coca_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_coca_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        ps = _coca_params_struct(tens[0], beta_c, *tens[1:])
+        N.check(lib.ep_coca_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, 0, C.byref(ps),
+                                         float(ln_eps), y.data_ptr(), ws.data_ptr(), nbytes,
+                                         N.current_stream_ptr(xv.device)), "ep_coca_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.beta = beta_c
+        ctx.dims = dims
+        ctx.bstride = bstride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("CoCa pooler (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, gamma, imgq, to_q, to_kv, to_out = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in (gamma, imgq, to_q, to_kv, to_out)]
+        ps = _coca_params_struct(gamma, ctx.beta, imgq, to_q, to_kv, to_out)
+        gs = _coca_params_struct(grads[0], None, *grads[1:])
+        N.check(lib.ep_coca_pool_backward(C.byref(ctx.dims), xv.data_ptr(), N.EP_DTYPE_F32, ctx.bstride, 0,
+                                          C.byref(ps), dy.data_ptr(), C.byref(gs), 0, ws.data_ptr(), ws.numel(),
+                                          N.current_stream_ptr(xv.device)), "ep_coca_pool_backward")
+        return (None, grads[0], None, grads[1], grads[2], grads[3], grads[4], None, None, None)
+
+
+def coca_pool(x, gamma, beta, img_queries, to_q, to_kv, to_out, heads, dim_head, ln_eps=1e-5):
+    return _CocaPool.apply(x, gamma, beta, img_queries, to_q, to_kv, to_out, heads, dim_head, ln_eps)
+
+
+def coca_attention(x, gamma, beta, img_queries, to_q, to_kv, to_out, heads, dim_head, ln_eps=1e-5):
+    """softmax attention of image query 0 over the tokens, (B, heads, N)."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    B, Nn, D = xv.shape
+    dims = coca_dims(B, Nn, D, heads, dim_head, img_queries.shape[0])
+    nbytes = lib.ep_coca_pool_workspace_bytes(C.byref(dims))
+    ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+    y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    ps = _coca_params_struct(_f32c(gamma, "gamma"), beta, _f32c(img_queries, "img_queries"), _f32c(to_q, "to_q"),
+                             _f32c(to_kv, "to_kv"), _f32c(to_out, "to_out"))
+    st = N.current_stream_ptr(xv.device)
+    N.check(lib.ep_coca_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, 0, C.byref(ps),
+                                     float(ln_eps), y.data_ptr(), ws.data_ptr(), nbytes, st), "ep_coca_pool_forward")
+    A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_coca_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_coca_attention")
+    return A

@@ -14,8 +14,8 @@ Invariants kept from the reference (published numbers depend on them):
   * a ``_all`` suffix selects the same pooling over [CLS]+patch tokens (reference :95);
   * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
 
-Native on MI355X: ``ep`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of
-libep_hip.so).  The other thirteen names resolve to the reference's own PyTorch modules when the
+Native on MI355X: ``ep`` and ``coca`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of
+libep_hip.so).  The other twelve names resolve to the reference's own PyTorch modules when the
 reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
 ``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
 """
@@ -29,6 +29,7 @@ import torch.nn as nn
 
 from . import functional as F_
 from .poolings.ep import EfficientProbing
+from .poolings.coca import CrossAttention as CocaPooling
 from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
 
 BN_EPS = 1e-6
@@ -126,6 +127,7 @@ POOLINGS: Dict[str, Tuple[PoolingFactory, ClassifierFactory]] = {
     name: (_reference_pooling(name), None) for name in _REFERENCE_SPECS
 }
 POOLINGS["ep"] = (_make_ep, _make_ep_classifier)
+POOLINGS["coca"] = (lambda dim, args, model: CocaPooling(dim=dim), None)     # native (reference probe_heads.py:78)
 
 
 def register_pooling(name: str, make_pooling: PoolingFactory, make_classifier: ClassifierFactory = None) -> None:
@@ -155,6 +157,16 @@ def is_native_ep_head(head: nn.Module) -> bool:
     shape the fused train step (engine.ProbeHeadEngine) accelerates."""
     return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], EfficientProbing)
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
+def is_native_coca_head(head: nn.Module) -> bool:
+    """True for Sequential(poolings.coca.CrossAttention, BatchNorm1d, Linear) -- engine.CocaHeadEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], CocaPooling)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
+def is_native_head(head: nn.Module) -> bool:
+    return is_native_ep_head(head) or is_native_coca_head(head)
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 3
+#define EP_ABI_VERSION 4
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -225,6 +225,74 @@ int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, i
                          const int32_t* image_index, const float* params, const float* running_mean,
                          const float* running_var, float bn_eps, float* logits, int ldl,
                          void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CoCa attentional pooler head (reference poolings/coca_pytorch.py:250-343 CrossAttention with the
+ * registry's arguments probe_heads.py:78: dim_head 64, heads 8, 196 image queries, no context norm,
+ * no parallel feed-forward; `return out[:, 0]`).  Only query 0 reaches the output, the keys / values
+ * are one shared head, so the module is algebraically the EP token pass with H derived query rows
+ *     u[h] = scale * Wk^T (to_q(LayerNorm(img_queries[0])))[h]            (batch independent)
+ *     P[b,h] = softmax_n(u[h] . x[b,n]) x[b]      o[b,h] = P[b,h] Wv^T      y[b] = to_out(concat_h o[b,h])
+ * and runs on the same streaming kernels: two passes over the tokens per train step.
+ *
+ * Pooler parameters are five separate tensors:
+ *   gamma (D) | img_queries (M,D) | to_q.weight (H*dh, D) | to_kv.weight (2*dh, D) | to_out.weight (D, H*dh)
+ * `beta` is the LayerNorm buffer (zeros in the reference; NULL = zeros).  Rows 1..M-1 of img_queries
+ * receive zero gradient (they are still part of the LARS norm of the tensor).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_coca_dims {
+  int32_t B, N, D, H, dh, M, C;      /* C used only by the whole-head entry points */
+} ep_coca_dims;
+
+typedef struct ep_coca_params {
+  float* gamma; const float* beta; float* img_queries; float* to_q; float* to_kv; float* to_out;
+} ep_coca_params;
+
+size_t ep_coca_pool_workspace_bytes(const ep_coca_dims* dims);
+/* y (B, D) = pooler(x).  `ws` keeps what the backward needs (same ws must be passed to it). */
+int ep_coca_pool_forward(const ep_coca_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const ep_coca_params* params, float ln_eps,
+                         float* y, void* ws, size_t ws_bytes, ep_stream_t stream);
+/* grads (same five-tensor layout; beta ignored) (+)= d loss / d params for upstream dy (B, D). */
+int ep_coca_pool_backward(const ep_coca_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                          const int32_t* image_index, const ep_coca_params* params, const float* dy,
+                          const ep_coca_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                          ep_stream_t stream);
+/* attention of query 0: A (B, H, N) = softmax over tokens (for attention maps / tests) */
+int ep_coca_attention(const ep_coca_dims* dims, const void* ws, float* A, ep_stream_t stream);
+
+/* Whole train step of Sequential(CrossAttention, BN, Linear) + CE (+ optimizer), the counterpart of
+ * ep_head_train_step.  Flat parameter buffer, each tensor starting at a multiple of 4 elements:
+ *   gamma | img_queries | to_q.weight | to_kv.weight | to_out.weight | fc.weight (C,D) | fc.bias (C)
+ * (ep_coca_head_param_offsets fills the seven offsets and returns the total element count).        */
+typedef struct ep_coca_step {
+  ep_coca_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  const float* ln_beta; float ln_eps;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_coca_step;
+
+int64_t ep_coca_head_param_offsets(const ep_coca_dims* dims, int64_t offsets[7]);
+size_t ep_coca_head_workspace_bytes(const ep_coca_dims* dims);
+int ep_coca_head_train_step(const ep_coca_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_coca_head_eval_forward(const ep_coca_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                              const int32_t* image_index, const float* params, const float* ln_beta,
+                              float ln_eps, const float* running_mean, const float* running_var,
+                              float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
+                              ep_stream_t stream);
 
 #ifdef __cplusplus
 }

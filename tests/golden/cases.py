@@ -95,3 +95,59 @@ INIT_DIMS = [(384, 1, 1, 100), (768, 8, 1, 1000), (768, 32, 1, 1000), (1024, 8, 
 
 def case_dict(case: Case) -> dict:
     return asdict(case)
+
+
+# --------------------------------------------------------------------------------------------
+# CoCa attentional pooler head (reference poolings/coca_pytorch.py:250-343 behind probe_heads.py:78)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class CocaCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    M: int = 196                # num_img_queries (reference default)
+    heads: int = 8
+    dim_head: int = 64
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False         # large LayerNorm gain: attention far from uniform
+
+
+COCA_CASES = [
+    CocaCase("tiny", B=4, N=17, D=64, C=10, M=5, seed=0, weight_decay=1e-4),
+    CocaCase("tiny_sharp", B=4, N=33, D=64, C=10, M=196, seed=1, sharp=True, steps=1),
+    CocaCase("tiny_strided", B=3, N=16, D=128, C=7, M=7, seed=2, strided=True, steps=1),
+    CocaCase("vitb16", B=4, N=196, D=768, C=1000, seed=0, full=False, steps=1),
+    CocaCase("so400m", B=4, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),    # BASELINE config 4
+]
+COCA_BY_NAME = {c.name: c for c in COCA_CASES}
+COCA_INIT_DIMS = [(768, 1000), (1152, 1000)]      # (dim, nb_classes)
+
+
+def make_coca_inputs(case: CocaCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(5000 + case.seed)
+    D, inner = case.D, case.heads * case.dim_head
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    out = dict(
+        x_buf=rng.standard_normal((case.B, n_alloc, D), dtype=np.float32),
+        x_buf2=rng.standard_normal((case.B, n_alloc, D), dtype=np.float32),
+        gamma=((6.0 if case.sharp else 1.0) + 0.1 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32),
+        img_queries=rng.standard_normal((case.M, D), dtype=np.float32),
+        to_q=u(1.0 / np.sqrt(D), (inner, D)),
+        to_kv=u(1.0 / np.sqrt(D), (2 * case.dim_head, D)),
+        to_out=u(1.0 / np.sqrt(inner), (D, inner)),
+        fc_weight=u(1.0 / np.sqrt(D), (case.C, D)),
+        fc_bias=u(1.0 / np.sqrt(D), (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
+    return out
+
+
+COCA_PARAM_NAMES = ["gamma", "img_queries", "to_q", "to_kv", "to_out", "fc_weight", "fc_bias"]

@@ -27,7 +27,8 @@ sys.path.insert(0, HERE)
 REF = os.environ.get("EP_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 
-from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub)  # noqa: E402
+from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub,   # noqa: E402
+                   COCA_CASES, COCA_INIT_DIMS, COCA_PARAM_NAMES, make_coca_inputs)
 
 
 def _stub_missing_packages():
@@ -163,6 +164,100 @@ def run_case(case, optimizer_name="lars"):
     return out
 
 
+def coca_ref_params(head):
+    p = head[0]
+    return [p.norm.gamma, p.img_queries, p.to_q.weight, p.to_kv.weight, p.to_out.weight, head[2].weight, head[2].bias]
+
+
+def build_coca_ref_head(case_or_dim, C, M=196):
+    """Sequential(CrossAttention, BN, encoder.head) built by the reference registry for 'coca'
+    (probe_heads.py:78,102-106); ``M != 196`` swaps in a CrossAttention with that many image queries."""
+    dim = case_or_dim
+    head = build_ref_head(dim, 32, 1, C, cls_features="coca")
+    if M != 196:
+        from poolings.coca_pytorch import CrossAttention
+        head[0] = CrossAttention(dim=dim, num_img_queries=M)
+    return head
+
+
+def run_coca_case(case):
+    inp = make_coca_inputs(case)
+    out = {}
+    torch.manual_seed(0)
+    head = build_coca_ref_head(case.D, case.C, case.M)
+    plist = coca_ref_params(head)
+    with torch.no_grad():
+        for n, p in zip(COCA_PARAM_NAMES, plist):
+            p.copy_(torch.from_numpy(inp[n]))
+    head.train()
+    opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
+    crit = torch.nn.CrossEntropyLoss()
+    keep = (lambda a: a) if case.full else sub
+    small = ("gamma", "fc_bias")
+    for step in range(case.steps):
+        xb = inp["x_buf"] if step % 2 == 0 else inp["x_buf2"]
+        tg = inp["targets"] if step % 2 == 0 else inp["targets2"]
+        x = torch.from_numpy(xb[:, 1:] if case.strided else xb)
+        t = torch.from_numpy(tg)
+        for g in opt.param_groups:
+            g["lr"] = STEP_LRS[step % len(STEP_LRS)]
+        opt.zero_grad()
+        pooled = head[0](x)
+        z = head[1](pooled)
+        logits = head[2](z)
+        loss = crit(logits, t)
+        loss.backward()
+        if step == 0:
+            a1, a5 = topk_acc(logits, t)
+            # attention of image query 0, restated from coca_pytorch.py:307-330
+            pool = head[0]
+            with torch.no_grad():
+                q = pool.to_q(pool.norm(pool.img_queries[:1])).reshape(1, pool.heads, -1) * pool.scale   # (1,H,dh)
+                k = pool.to_kv(x)[..., :q.shape[-1]]                                                       # (B,N,dh)
+                attn0 = torch.einsum("hd,bnd->bhn", q[0], k).softmax(-1)
+            out.update(pooled=pooled.detach().numpy(), z=z.detach().numpy(), logits=logits.detach().numpy(),
+                       loss=np.float32(loss.item()), acc1=np.float32(a1), acc5=np.float32(a5), attn0=attn0.numpy())
+            for n, p in zip(COCA_PARAM_NAMES, plist):
+                g = p.grad.detach().numpy()
+                if n == "img_queries":
+                    out["grad_img_queries_row0"] = g[0].copy()
+                    out["grad_img_queries_rest_absmax"] = np.float32(np.abs(g[1:]).max() if g.shape[0] > 1 else 0.0)
+                else:
+                    out[f"grad_{n}"] = g if n in small else keep(g)
+                out[f"gradnorm_{n}"] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        tag = f"lars{step + 1}"
+        out[f"{tag}_loss"] = np.float32(loss.item())
+        for n, p in zip(COCA_PARAM_NAMES, plist):
+            a = p.detach().numpy().copy()
+            mu = opt.state[p]["mu"].numpy().copy()
+            out[f"{tag}_{n}"] = a if n in small else keep(a)
+            out[f"{tag}_mu_{n}"] = mu if n in small else keep(mu)
+        out[f"{tag}_running_mean"] = head[1].running_mean.numpy().copy()
+        out[f"{tag}_running_var"] = head[1].running_var.numpy().copy()
+    head.eval()
+    with torch.no_grad():
+        xb = inp["x_buf"]
+        out["eval_logits"] = head(torch.from_numpy(xb[:, 1:] if case.strided else xb)).numpy()
+    return out
+
+
+def coca_init_fixture():
+    rec = {}
+    for dim, C in COCA_INIT_DIMS:
+        torch.manual_seed(0)
+        head = build_coca_ref_head(dim, C)
+        sd = head.state_dict()
+        rec[f"d{dim}_c{C}"] = {
+            "repr_pool_class": type(head[0]).__name__,
+            "keys": {k: list(v.shape) for k, v in sd.items()},
+            "sha256": {k: sha(v) for k, v in sd.items()},
+            "head8": {k: v.flatten()[:8].double().tolist() for k, v in sd.items()},
+            "n_trainable": int(sum(p.numel() for p in head.parameters())),
+        }
+    return rec
+
+
 def init_fixture():
     """Initial weights of the head under torch.manual_seed(0), the way
     tools/inv_heads.py:102-120 fingerprints them."""
@@ -256,9 +351,15 @@ def main():
         path = os.path.join(HERE, f"ep_{case.name}.npz")
         np.savez_compressed(path, **out)
         print(f"{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
+    for case in COCA_CASES:
+        out = run_coca_case(case)
+        path = os.path.join(HERE, f"coca_{case.name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"coca_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
     np.savez_compressed(os.path.join(HERE, "lars_edges.npz"), **lars_edge_fixture())
     with open(os.path.join(HERE, "host_fixtures.json"), "w") as f:
-        json.dump(dict(meta=meta, init=init_fixture(), lr=lr_fixture(), scaler=scaler_fixture()),
+        json.dump(dict(meta=meta, init=init_fixture(), coca_init=coca_init_fixture(), lr=lr_fixture(),
+                       scaler=scaler_fixture()),
                   f, indent=1, sort_keys=True)
     print("wrote host_fixtures.json, lars_edges.npz")
 
