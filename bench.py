@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--head", default="ep", choices=["ep", "coca"],
+                    help="probe head: ep (the headline) or the CoCa attentional pooler on the same token pass")
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step (weak scaling)")
     ap.add_argument("--buffers", type=int, default=4, help="distinct token buffers rotated through (HBM, not cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +59,7 @@ def main():
     import torch.distributed as dist
     from argparse import Namespace
     from efficient_probing_amd import probe_heads, functional as F_
-    from efficient_probing_amd.engine import ProbeHeadEngine
+    from efficient_probing_amd.engine import make_engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -71,6 +73,9 @@ def main():
 
     Nn, D, Q, Cc, desc = WORKLOADS[args.workload]
     B = args.batch
+    if args.head == "coca":
+        Q = 8                                              # 8 query heads of image query 0 (coca_pytorch.py:259)
+        desc = desc.split(",")[0] + f", CoCa pooler (8 heads x 64, 196 image queries), {Cc} classes"
 
     class Enc(torch.nn.Module):
         def __init__(self):
@@ -78,10 +83,10 @@ def main():
             self.head = torch.nn.Linear(D, Cc)
     torch.manual_seed(0)                                   # same init on every rank (DDP broadcasts rank 0's)
     enc = Enc()
-    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc))
+    probe_heads.build_probe_head(enc, Namespace(cls_features=args.head, ep_queries=Q, d_out=1, nb_classes=Cc))
     head = enc.head.to(dev).train()
     lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
-    eng = ProbeHeadEngine(head, optimizer="lars", lr=lr, weight_decay=0.0)
+    eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     xs = [torch.randn(B, Nn, D, device=dev, generator=gen) for _ in range(args.buffers)]
@@ -119,8 +124,10 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / iters
 
-    cls = head[0].cls_token.detach()
-    scale = head[0].scale
+    if args.head == "coca":                                # the same kernel, fed with the H derived query rows
+        cls, scale = torch.randn(Q, D, device=dev) * 0.05, 1.0
+    else:
+        cls, scale = head[0].cls_token.detach(), head[0].scale
     keep = {}
 
     def run_fwd(i):
@@ -161,7 +168,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         out = {
-            "metric": "EP-head train images/sec", "value": round(value, 1), "unit": "images/s",
+            "metric": "EP-head train images/sec" if args.head == "ep" else "CoCa-head train images/sec", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B,
@@ -184,10 +191,14 @@ def main():
             # counts for ~2 s each and time the sample at the best one (that count is reported as `cores`)
             ncpu = os.cpu_count() or 8
             cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
-            probe = {c: torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=2.0, threads=c, min_steps=1)["value"]
-                     for c in cands}
+            mk = None
+            if args.head == "coca":
+                from oracle import coca_oracle
+                mk = lambda: coca_oracle.make_head(D, Cc)
+            probe = {c: torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=2.0, threads=c, min_steps=1,
+                                                    make=mk)["value"] for c in cands}
             best = max(probe, key=probe.get)
-            r = torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=args.cpu_seconds, threads=best)
+            r = torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=args.cpu_seconds, threads=best, make=mk)
             out["cpu_baseline"] = {"value": round(r["value"], 1), "unit": "images/s", "cores": r["threads"],
                                    "kind": "port", "host_cpus": ncpu,
                                    "sample": f"{r['steps']} train steps of batch {r['batch']} ({r['seconds']:.1f} s) "

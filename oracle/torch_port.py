@@ -65,13 +65,13 @@ def train_step(head, mus, x, targets, lr):
     return loss
 
 
-def time_train_steps(B, N, D, Q, C, budget_s=15.0, threads=None, min_steps=2):
+def time_train_steps(B, N, D, Q, C, budget_s=15.0, threads=None, min_steps=2, make=None):
     """Runs train steps for about ``budget_s`` seconds on the host cores; returns a dict with
-    images/s and what was run."""
+    images/s and what was run.  ``make``: factory of another head port (e.g. coca_oracle.make_head)."""
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(0)
-    head = make_head(D, Q, C).train()
+    head = (make() if make is not None else make_head(D, Q, C)).train()
     mus = [torch.zeros_like(p) for p in head.parameters()]
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, N, D, generator=g)
