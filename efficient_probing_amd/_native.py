@@ -87,6 +87,34 @@ class EPCocaStep(C.Structure):
     ]
 
 
+class EPAbmilpDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("C", C.c_int32)]
+
+
+class EPAbmilpParams(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("w1", C.c_void_p),
+                ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p)]
+
+
+class EPAbmilpStep(C.Structure):
+    _fields_ = [
+        ("dims", EPAbmilpDims),
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("targets", C.c_void_p),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("opt_state0", C.c_void_p), ("opt_state1", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("found_inf", C.c_void_p), ("grad_norm", C.c_void_p),
+        ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
+        ("grad_scale", C.c_float), ("inv_scale", C.c_float),
+        ("accumulate", C.c_int32), ("optimizer", C.c_int32),
+        ("lr", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float),
+        ("trust_coefficient", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("opt_step", C.c_int64),
+        ("phases", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -133,6 +161,16 @@ SIGNATURES = {
     "ep_coca_head_param_offsets": (c_i64, [C.POINTER(EPCocaDims), C.POINTER(c_i64)]),
     "ep_coca_head_workspace_bytes": (c_size, [C.POINTER(EPCocaDims)]),
     "ep_coca_head_train_step": (c_int, [C.POINTER(EPCocaStep), c_void, c_size, c_void]),
+    "ep_abmilp_pool_workspace_bytes": (c_size, [C.POINTER(EPAbmilpDims)]),
+    "ep_abmilp_pool_forward": (c_int, [C.POINTER(EPAbmilpDims), c_void, c_int, c_i64, C.POINTER(EPAbmilpParams),
+                                       c_f32p, c_f32p, c_void, c_size, c_void]),
+    "ep_abmilp_pool_backward": (c_int, [C.POINTER(EPAbmilpDims), c_void, c_int, c_i64, C.POINTER(EPAbmilpParams),
+                                        c_f32p, C.POINTER(EPAbmilpParams), c_int, c_void, c_size, c_void]),
+    "ep_abmilp_head_param_offsets": (c_i64, [C.POINTER(EPAbmilpDims), C.POINTER(c_i64)]),
+    "ep_abmilp_head_workspace_bytes": (c_size, [C.POINTER(EPAbmilpDims)]),
+    "ep_abmilp_head_train_step": (c_int, [C.POINTER(EPAbmilpStep), c_void, c_size, c_void]),
+    "ep_abmilp_head_eval_forward": (c_int, [C.POINTER(EPAbmilpDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p,
+                                            c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }

@@ -255,7 +255,57 @@ class CocaHeadEngine(ProbeHeadEngine):
                                                   N.current_stream_ptr(self.device))
 
 
+class AbmilpHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(ABMILPHead, BatchNorm1d, Linear) through ``ep_abmilp_head_train_step``.
+    Matrix-core bound (about 11 GFLOP per image per train step at 256 x 1152); tokens must be dense."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_abmilp_head
+        if not is_native_abmilp_head(head):
+            raise TypeError("AbmilpHeadEngine needs Sequential(poolings.abmilp.ABMILPHead, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        D = self.pool.self_attn.qkv.in_features
+        dims = N.EPAbmilpDims(B=0, N=0, D=D, C=self.fc.out_features)
+        offs = (C.c_int64 * 9)()
+        total = int(self.lib.ep_abmilp_head_param_offsets(C.byref(dims), offs))
+        return dims, list(self.pool._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        return N.EPAbmilpStep()
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_abmilp_head_workspace_bytes(C.byref(self.dims))
+
+    def _tokens(self, x, image_index):
+        if image_index is not None:
+            raise NotImplementedError("AbMILP: in-place indexed batches are not supported (gather the batch first)")
+        if self.pool.content == "patch":
+            x = x[:, 1:]
+        return F_._contiguous_tokens(x)
+
+    def forward_backward(self, x, targets, image_index=None):
+        super().forward_backward(self._tokens(x, image_index), targets, None)
+
+    def eval_logits(self, x, image_index=None):
+        return super().eval_logits(self._tokens(x, image_index), None)
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_abmilp_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
+                                                  N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_abmilp_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride,
+                                                    self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                    self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                                    ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
-    """The fused engine matching a native head (EP or CoCa)."""
-    from .probe_heads import is_native_coca_head
-    return CocaHeadEngine(head, **kw) if is_native_coca_head(head) else ProbeHeadEngine(head, **kw)
+    """The fused engine matching a native head (EP, CoCa or AbMILP)."""
+    from .probe_heads import is_native_abmilp_head, is_native_coca_head
+    if is_native_coca_head(head):
+        return CocaHeadEngine(head, **kw)
+    if is_native_abmilp_head(head):
+        return AbmilpHeadEngine(head, **kw)
+    return ProbeHeadEngine(head, **kw)

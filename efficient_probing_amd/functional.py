@@ -461,3 +461,66 @@ def coca_attention(x, gamma, beta, img_queries, to_q, to_kv, to_out, heads, dim_
     A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
     N.check(lib.ep_coca_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_coca_attention")
     return A
+
+
+# --------------------------------------------------------------------------------------------
+# AbMILP head (reference poolings/abmilp.py:11-75 + models_vit.py:43-97): matrix-core bound
+# --------------------------------------------------------------------------------------------
+def _abmilp_params_struct(ts):
+    return N.EPAbmilpParams(*[t.data_ptr() for t in ts])
+
+
+def _contiguous_tokens(x):
+    """AbMILP contracts over all B*N token rows at once, so the tokens must be one dense (B*N, D) matrix;
+    a strided view (e.g. ``feat[:, 1:]``) is compacted once -- noise next to ~4 GFLOP per image."""
+    N.require_gpu_tensor(x, "tokens")
+    if x.dim() != 3:
+        raise ValueError(f"tokens must be (B, N, D), got {tuple(x.shape)}")
+    x = x.float() if x.dtype != torch.float32 else x
+    return x if (x.is_contiguous() and x.data_ptr() % 16 == 0) else x.contiguous()
+
+
+class _AbmilpPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, qkv, proj_w, proj_b, w1, b1, w2, b2):
+        lib = N.load()
+        xv = _contiguous_tokens(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in ((qkv, "qkv"), (proj_w, "proj.weight"), (proj_b, "proj.bias"), (w1, "w1"),
+                                          (b1, "b1"), (w2, "w2"), (b2, "b2"))]
+        dims = N.EPAbmilpDims(B=B, N=Nn, D=D, C=0)
+        nbytes = lib.ep_abmilp_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_abmilp_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        amap = torch.empty((B, Nn), device=xv.device, dtype=torch.float32)
+        ps = _abmilp_params_struct(tens)
+        N.check(lib.ep_abmilp_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, Nn * D, C.byref(ps),
+                                           out.data_ptr(), amap.data_ptr(), ws.data_ptr(), nbytes,
+                                           N.current_stream_ptr(xv.device)), "ep_abmilp_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims = dims
+        ctx.mark_non_differentiable(amap)
+        return out, amap
+
+    @staticmethod
+    def backward(ctx, dout, _damap):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("AbMILP head (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        grads = [torch.empty_like(t) for t in tens]
+        d = ctx.dims
+        N.check(lib.ep_abmilp_pool_backward(C.byref(d), xv.data_ptr(), N.EP_DTYPE_F32, d.N * d.D,
+                                            C.byref(_abmilp_params_struct(tens)), dout.data_ptr(),
+                                            C.byref(_abmilp_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                            N.current_stream_ptr(xv.device)), "ep_abmilp_pool_backward")
+        return (None, *grads)
+
+
+def abmilp_pool(x, qkv, proj_w, proj_b, w1, b1, w2, b2):
+    """(out (B, D), attention map (B, N)) of the AbMILP head."""
+    return _AbmilpPool.apply(x, qkv, proj_w, proj_b, w1, b1, w2, b2)

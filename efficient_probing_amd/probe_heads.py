@@ -14,8 +14,8 @@ Invariants kept from the reference (published numbers depend on them):
   * a ``_all`` suffix selects the same pooling over [CLS]+patch tokens (reference :95);
   * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
 
-Native on MI355X: ``ep`` and ``coca`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of
-libep_hip.so).  The other twelve names resolve to the reference's own PyTorch modules when the
+Native on MI355X: ``ep``, ``coca`` and ``abmilp`` (pooling, BatchNorm1d and the classifier run in the HIP kernels
+of libep_hip.so).  The other eleven names resolve to the reference's own PyTorch modules when the
 reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
 ``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
 """
@@ -30,6 +30,7 @@ import torch.nn as nn
 from . import functional as F_
 from .poolings.ep import EfficientProbing
 from .poolings.coca import CrossAttention as CocaPooling
+from .poolings.abmilp import ABMILPHead
 from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
 
 BN_EPS = 1e-6
@@ -127,6 +128,9 @@ POOLINGS: Dict[str, Tuple[PoolingFactory, ClassifierFactory]] = {
     name: (_reference_pooling(name), None) for name in _REFERENCE_SPECS
 }
 POOLINGS["ep"] = (_make_ep, _make_ep_classifier)
+POOLINGS["abmilp"] = (lambda dim, args, model: ABMILPHead(       # native (reference probe_heads.py:42-51)
+    dim=dim, self_attention_apply_to=args.abmilp_sa, activation=args.abmilp_act, depth=args.abmilp_depth,
+    cond=args.abmilp_cond, content=args.abmilp_content, num_patches=model.patch_embed.num_patches), None)
 POOLINGS["coca"] = (lambda dim, args, model: CocaPooling(dim=dim), None)     # native (reference probe_heads.py:78)
 
 
@@ -165,8 +169,14 @@ def is_native_coca_head(head: nn.Module) -> bool:
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
 
 
+def is_native_abmilp_head(head: nn.Module) -> bool:
+    """True for Sequential(poolings.abmilp.ABMILPHead, BatchNorm1d, Linear) -- engine.AbmilpHeadEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], ABMILPHead)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
 def is_native_head(head: nn.Module) -> bool:
-    return is_native_ep_head(head) or is_native_coca_head(head)
+    return is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 4
+#define EP_ABI_VERSION 5
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -293,6 +293,70 @@ int ep_coca_head_eval_forward(const ep_coca_dims* dims, const void* x, int x_dty
                               float ln_eps, const float* running_mean, const float* running_var,
                               float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
                               ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AbMILP head (reference poolings/abmilp.py:11-75 with models_vit.Attention :43-97, num_heads = 1, no
+ * qkv bias; registry arguments probe_heads.py:42-51 at their defaults: self-attention applied to
+ * "both", tanh predictor of depth 2, no positional conditioning):
+ *     Xa = proj(softmax((x Wq^T * D^-1/2)(x Wk^T)^T)(x Wv^T)) + b_p                     (B,N,D)
+ *     a  = softmax_n(w2 . tanh(W1 Xa + b1) + b2)                                          (B,N)
+ *     out[b] = sum_n a[b,n] Xa[b,n,:]                                                     (B,D)
+ * Dense and matrix-core bound (about 3.7 GFLOP per image forward at N = 256, D = 1152): every
+ * contraction runs on the exact-fp32 MFMA kernel of this library, per image for the N x N attention
+ * and over all B*N token rows for the projections and their weight gradients.
+ * Tokens must be contiguous (x_bstride == N*D).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_abmilp_dims {
+  int32_t B, N, D, C;                 /* C used only by the whole-head entry points */
+} ep_abmilp_dims;
+
+typedef struct ep_abmilp_params {
+  float* qkv;      /* self_attn.qkv.weight (3D, D)            */
+  float* proj_w;   /* self_attn.proj.weight (D, D)            */
+  float* proj_b;   /* self_attn.proj.bias (D)                 */
+  float* w1;       /* attention_predictor.0.weight (D, D)     */
+  float* b1;       /* attention_predictor.0.bias (D)          */
+  float* w2;       /* attention_predictor.2.weight (1, D)     */
+  float* b2;       /* attention_predictor.2.bias (1)          */
+} ep_abmilp_params;
+
+size_t ep_abmilp_pool_workspace_bytes(const ep_abmilp_dims* dims);
+/* out (B, D); attn_map (B, N) optional (NULL to skip): the predictor's softmax weights
+ * (abmilp.py:56-66 forward_with_attn_map).  `ws` keeps what the backward needs. */
+int ep_abmilp_pool_forward(const ep_abmilp_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                           const ep_abmilp_params* params, float* out, float* attn_map, void* ws,
+                           size_t ws_bytes, ep_stream_t stream);
+int ep_abmilp_pool_backward(const ep_abmilp_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                            const ep_abmilp_params* params, const float* dout,
+                            const ep_abmilp_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                            ep_stream_t stream);
+
+/* Whole train step of Sequential(ABMILPHead, BN, Linear) + CE (+ optimizer).  Flat parameter buffer:
+ *   qkv | proj_w | proj_b | w1 | b1 | w2 | b2 | fc.weight (C,D) | fc.bias (C)      (nine offsets) */
+typedef struct ep_abmilp_step {
+  ep_abmilp_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+} ep_abmilp_step;
+
+int64_t ep_abmilp_head_param_offsets(const ep_abmilp_dims* dims, int64_t offsets[9]);
+size_t ep_abmilp_head_workspace_bytes(const ep_abmilp_dims* dims);
+int ep_abmilp_head_train_step(const ep_abmilp_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_abmilp_head_eval_forward(const ep_abmilp_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                                const float* params, const float* running_mean, const float* running_var,
+                                float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
+                                ep_stream_t stream);
 
 #ifdef __cplusplus
 }

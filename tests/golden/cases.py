@@ -151,3 +151,52 @@ def make_coca_inputs(case: CocaCase) -> Dict[str, np.ndarray]:
 
 
 COCA_PARAM_NAMES = ["gamma", "img_queries", "to_q", "to_kv", "to_out", "fc_weight", "fc_bias"]
+
+
+# --------------------------------------------------------------------------------------------
+# AbMILP head (reference poolings/abmilp.py:11-75 + models_vit.py:43-97 behind probe_heads.py:42-51,67)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class AbmilpCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    seed: int = 0
+    content: str = "all"        # "patch": the head drops token 0 itself (abmilp.py:56-57)
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False         # larger q/k and predictor weights: both softmaxes far from uniform
+
+
+ABMILP_CASES = [
+    AbmilpCase("tiny", B=4, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
+    AbmilpCase("tiny_sharp_patch", B=3, N=21, D=64, C=7, seed=1, content="patch", sharp=True, steps=1),
+    AbmilpCase("n197", B=5, N=197, D=128, C=10, seed=2, full=False, steps=1),
+    AbmilpCase("vitb14", B=6, N=256, D=768, C=1000, seed=0, full=False, steps=1, sharp=True),
+]
+ABMILP_BY_NAME = {c.name: c for c in ABMILP_CASES}
+ABMILP_INIT_DIMS = [(768, 1000), (1152, 1000)]
+ABMILP_PARAM_NAMES = ["qkv", "proj_w", "proj_b", "w1", "b1", "w2", "b2", "fc_weight", "fc_bias"]
+ABMILP_SMALL = ("proj_b", "b1", "w2", "b2", "fc_bias")
+
+
+def make_abmilp_inputs(case: AbmilpCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(9000 + case.seed)
+    D = case.D
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    g = 4.0 if case.sharp else 1.0
+    bd = 1.0 / np.sqrt(D)
+    qkv = u(bd, (3 * D, D))
+    qkv[:2 * D] *= g                                   # sharper token-token attention
+    return dict(
+        x_buf=rng.standard_normal((case.B, case.N, D), dtype=np.float32),
+        x_buf2=rng.standard_normal((case.B, case.N, D), dtype=np.float32),
+        qkv=qkv, proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)), w1=u(bd * g, (D, D)), b1=u(bd, (D,)),
+        w2=u(bd * g * 4, (1, D)), b2=u(bd, (1,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
