@@ -171,6 +171,10 @@ SIGNATURES = {
     "ep_abmilp_head_train_step": (c_int, [C.POINTER(EPAbmilpStep), c_void, c_size, c_void]),
     "ep_abmilp_head_eval_forward": (c_int, [C.POINTER(EPAbmilpDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p,
                                             c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_l2_normalize": (c_int, [c_f32p, c_i64, c_int, c_float, c_f32p, c_void]),
+    "ep_knn_workspace_bytes": (c_size, [c_int, c_int]),
+    "ep_knn_topk": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void, c_int, c_void, c_size, c_void]),
+    "ep_knn_vote": (c_int, [c_f32p, c_void, c_int, c_void, c_int, c_int, c_float, c_int, c_void, c_void, c_f32p, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 5
+#define EP_ABI_VERSION 6
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -357,6 +357,25 @@ int ep_abmilp_head_eval_forward(const ep_abmilp_dims* dims, const void* x, int x
                                 const float* params, const float* running_mean, const float* running_var,
                                 float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
                                 ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weighted k-NN classifier on frozen features (reference engine_finetune.py:224-266 knn_classifier;
+ * sweep over k and T in main_linprobe.py:411-465).  Features are row-major fp32, normally L2-normalised
+ * (ep_l2_normalize = torch.nn.functional.normalize, main_linprobe.py:441-442).
+ *   ep_knn_topk : sims (M, out_ld), idx (M, out_ld): the k largest test.train^T similarities of every
+ *                 test row, sorted descending (ties: lower train index first) -- `similarity.topk(k)`.
+ *                 Exact fp32; the similarity matrix is produced in row chunks inside `ws`.
+ *   ep_knn_vote : for a prefix k of those lists: probs[c] = sum exp(sim/T) over neighbours of label c,
+ *                 pred (M, 5) = the five best classes; with `targets`, counts[0] += #top-1 hits and
+ *                 counts[1] += #top-5 hits (float counters).
+ * ------------------------------------------------------------------------------------------ */
+int ep_l2_normalize(const float* x, int64_t rows, int D, float eps, float* out, ep_stream_t stream);
+size_t ep_knn_workspace_bytes(int M, int n_train);
+int ep_knn_topk(const float* test, const float* train, int M, int n_train, int D, int k, float* sims,
+                int32_t* idx, int out_ld, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_knn_vote(const float* sims, const int32_t* idx, int ld, const int64_t* train_labels, int M, int k,
+                float T, int num_classes, const int64_t* targets, int32_t* pred, float* counts,
+                ep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -200,3 +200,32 @@ def make_abmilp_inputs(case: AbmilpCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# weighted k-NN classifier (reference engine_finetune.py:224-266)
+# --------------------------------------------------------------------------------------------
+KNN_CASES = {
+    # name: (n_train, n_test, D, num_classes, seed, n_duplicates)
+    "small": (3000, 257, 64, 20, 0, 0),
+    "dups": (1200, 100, 32, 7, 1, 300),      # 300 train rows are copies of earlier rows with OTHER labels: exact ties
+    "wide": (5000, 128, 768, 1000, 2, 0),
+}
+KNN_GRID = [(5, 0.07), (20, 0.07), (200, 0.07), (20, 0.02), (50, 0.5)]
+
+
+def make_knn_inputs(name):
+    n_train, n_test, D, C, seed, ndup = KNN_CASES[name]
+    rng = np.random.default_rng(7000 + seed)
+    centers = rng.standard_normal((C, D), dtype=np.float32)
+    ltr = rng.integers(0, C, size=(n_train,), dtype=np.int64)
+    lte = rng.integers(0, C, size=(n_test,), dtype=np.int64)
+    tr = (centers[ltr] * 0.6 + rng.standard_normal((n_train, D), dtype=np.float32)).astype(np.float32)
+    te = (centers[lte] * 0.6 + rng.standard_normal((n_test, D), dtype=np.float32)).astype(np.float32)
+    if ndup:
+        src = rng.integers(0, n_train - ndup, size=(ndup,))
+        tr[n_train - ndup:] = tr[src]
+        ltr[n_train - ndup:] = (ltr[src] + 1 + rng.integers(0, C - 1, size=(ndup,))) % C
+    tr /= np.maximum(np.linalg.norm(tr, axis=1, keepdims=True), 1e-12)
+    te /= np.maximum(np.linalg.norm(te, axis=1, keepdims=True), 1e-12)
+    return dict(train=tr.astype(np.float32), train_labels=ltr, test=te.astype(np.float32), test_labels=lte, C=C)

@@ -29,7 +29,8 @@ sys.path.insert(0, REF)
 
 from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub,   # noqa: E402
                    COCA_CASES, COCA_INIT_DIMS, COCA_PARAM_NAMES, make_coca_inputs,
-                   ABMILP_CASES, ABMILP_INIT_DIMS, ABMILP_PARAM_NAMES, ABMILP_SMALL, make_abmilp_inputs)
+                   ABMILP_CASES, ABMILP_INIT_DIMS, ABMILP_PARAM_NAMES, ABMILP_SMALL, make_abmilp_inputs,
+                   KNN_CASES, KNN_GRID, make_knn_inputs)
 
 
 def _stub_missing_packages():
@@ -418,6 +419,35 @@ def scaler_fixture():
     return dict(scale=traj, stepped=stepped, inf_at=sorted(inf_at), growth_interval=4)
 
 
+def knn_fixture():
+    """(top1, top5) of the REAL reference knn_classifier (engine_finetune.py:224-266, CPU path) on seeded inputs.
+    engine_finetune imports the training stack (timm.data / timm.utils / backbones); none of that is used by the
+    function, so the absent packages are replaced by permissive name-only stubs for this import."""
+    class AnyNames(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (torch.nn.Module,), {})
+    for n in ["timm.data", "timm.data.mixup", "timm.utils", "wandb", "tensorboard", "timm.models.layers", "timm.layers",
+              "timm.models.registry", "timm.models.vision_transformer", "torch.utils.tensorboard", "timm.optim",
+              "timm.optim.optim_factory", "timm.loss", "timm.models.layers.helpers"]:
+        m = AnyNames(n); m.__path__ = []; sys.modules[n] = m
+    sys.modules["timm.models.layers"].to_2tuple = lambda x: (x, x)
+    sys.modules["timm.models.layers"].trunc_normal_ = torch.nn.init.trunc_normal_
+    import engine_finetune as EF                            # reference
+    out = {}
+    for name in KNN_CASES:
+        inp = make_knn_inputs(name)
+        tr, te = torch.from_numpy(inp["train"]), torch.from_numpy(inp["test"])
+        ltr, lte = torch.from_numpy(inp["train_labels"]), torch.from_numpy(inp["test_labels"])
+        rows = []
+        for k, T in KNN_GRID:
+            t1, t5 = EF.knn_classifier(tr, ltr, te, lte, k, T, use_cuda=False, num_classes=inp["C"], num_chunks=4)
+            rows.append(dict(k=k, T=T, top1=float(t1), top5=float(t5)))
+        out[name] = rows
+    return out
+
+
 def main():
     meta = {"torch": torch.__version__, "reference": REF, "cases": [c.name for c in CASES]}
     for case in CASES:
@@ -444,7 +474,9 @@ def main():
                        abmilp_init=abmilp_init_fixture(), lr=lr_fixture(),
                        scaler=scaler_fixture()),
                   f, indent=1, sort_keys=True)
-    print("wrote host_fixtures.json, lars_edges.npz")
+    with open(os.path.join(HERE, "knn_fixtures.json"), "w") as f:
+        json.dump(knn_fixture(), f, indent=1, sort_keys=True)
+    print("wrote host_fixtures.json, lars_edges.npz, knn_fixtures.json")
 
 
 if __name__ == "__main__":
