@@ -33,6 +33,7 @@ WORKLOADS = {
     "c1": (196, 384, 1, 100, "DINO ViT-S/16 tokens 196x384, EP q=1, 100 classes (BASELINE configs[0])"),
     "c3": (196, 1024, 8, 1000, "MAE ViT-L/16 tokens 196x1024, EP q=8 (BASELINE configs[2])"),
     "c4": (256, 1152, 8, 1000, "SigLIP2 SO400M/14 tokens 256x1152, EP q=8 (BASELINE configs[3])"),
+    "c5": (196, 4096, 8, 1000, "DINOv3 ViT-7B/16 tokens 196x4096, EP q=8 (BASELINE configs[4])"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 

@@ -210,9 +210,13 @@ static bool use_mm(const PoolParams& p, bool bwd) {
   return pool_mode() == 0 && bwd && p.D == 1152 && p.Q >= 5;
 }
 
+// wide rows (D = 2048 / 4096): the row is split across the waves of a workgroup
+static bool use_wide(const PoolParams& p) { return pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride); }
+
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd) {
   PoolParams p{};
   p.B = B; p.N = N; p.D = D; p.Q = Q;
+  if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
   if (stream_plan(B, N, D, Q).ok && !force_generic()) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
@@ -228,6 +232,7 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
+  if (use_wide(p)) return wide_launch(false, p, mf_grid(p.B), st);
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
@@ -245,7 +250,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
 bool pool_backward_takes_side(const PoolParams& p) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
-  if (!allow || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  if (!allow || use_wide(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   return c.ok && c.nw == 4;
 }
@@ -256,7 +261,10 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   int nparts;
   EP_REQUIRE(!side || side->total == 0 || pool_backward_takes_side(p), EP_E_UNSUPPORTED,
              "pool_backward: side tasks need the 4-wave streaming kernel");
-  if (use_mm(p, true)) {
+  if (use_wide(p)) {
+    nparts = mf_grid(p.B);
+    EP_TRY(wide_launch(true, p, nparts, st));
+  } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);
     EP_TRY(mm_launch(true, p, nparts, st));
   } else if (use_mf(p, true)) {

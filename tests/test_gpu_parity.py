@@ -182,11 +182,16 @@ def test_fused_engine_steps_golden(case, opt):
         np.testing.assert_allclose(ev2, ev, rtol=1e-6, atol=1e-6)
 
 
-def test_engine_matches_oracle_multi_step_random():
-    """Oracle (not golden) parity on a shape no fixture has, 4 LARS steps with weight decay."""
+ADHOC = [dict(B=16, N=50, D=256, Q=8, C=33), dict(B=6, N=37, D=2048, Q=8, C=20), dict(B=5, N=20, D=4096, Q=4, C=12)]
+
+
+@pytest.mark.parametrize("shape", ADHOC, ids=["d256", "wide2048", "wide4096"])
+def test_engine_matches_oracle_multi_step_random(shape):
+    """Oracle (not golden) parity on shapes no fixture has (incl. the wide-row kernels), 4 LARS steps with weight
+    decay."""
     from efficient_probing_amd.engine import ProbeHeadEngine
     from cases import Case
-    case = Case("adhoc", B=16, N=50, D=256, Q=8, C=33, seed=11, weight_decay=1e-3)
+    case = Case("adhoc", seed=11, weight_decay=1e-3, **shape)
     inp = make_inputs(case)
     head = build_head(case, inp)
     eng = ProbeHeadEngine(head, optimizer="lars", weight_decay=case.weight_decay)
@@ -251,11 +256,14 @@ def test_bad_arguments_fail_loudly():
 # full-size property tests (BASELINE.json config 2 and the north-star shape): the oracle is too slow
 # there, so parity is established through size-independent properties.
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(192, 256, 768, 8), (160, 197, 768, 8), (64, 196, 1024, 8), (48, 256, 1152, 8)],
-                         ids=["vitb14", "vitb16", "vitl16", "so400m"])
+@pytest.mark.parametrize("shape", [(192, 256, 768, 8), (160, 197, 768, 8), (64, 196, 1024, 8), (48, 256, 1152, 8),
+                                   (24, 196, 4096, 8), (20, 197, 2048, 5), (300, 31, 4096, 8)],
+                         ids=["vitb14", "vitb16", "vitl16", "so400m", "vit7b", "wide2048_odd", "vit7b_many_images"])
 def test_full_size_properties(shape):
     from efficient_probing_amd import functional as F_, _native
     B, Nn, D, Q = shape
+    if D >= 2048:
+        assert _native.load().ep_pool_kernel_name(B, Nn, D, Q, 0).decode() == "ep_pool_wide_fwd_kernel"
     gen = torch.Generator(device="cpu").manual_seed(3)
     x = torch.randn(B, Nn, D, generator=gen).to(DEV)
     cls = (torch.randn(Q, D, generator=gen) * 0.5).to(DEV)
@@ -290,3 +298,34 @@ def test_full_size_properties(shape):
     ML3 = ML2.clone(); ML3[:, :, 2] *= 2
     dcls2 = F_.pool_backward(x, S, ML3, 2 * dP, scale)
     assert torch.allclose(dcls2, 2 * dcls, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(7, 33, 2048, 8), (9, 40, 4096, 8), (5, 17, 4096, 3)], ids=["d2048", "d4096", "d4096_q3"])
+def test_wide_row_and_generic_kernels_agree(shape):
+    """The wide-row kernels (row split across the waves) against the generic kernel on the same inputs, including
+    an indexed (resident-store) batch."""
+    from efficient_probing_amd import functional as F_, _native
+    B, Nn, D, Q = shape
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    store = torch.randn(B + 3, Nn, D, generator=gen).to(DEV)
+    idx = torch.randperm(B + 3, generator=gen)[:B].to(torch.int32).to(DEV)
+    x = store[idx.long()].contiguous()
+    cls = (torch.randn(Q, D, generator=gen) * 0.3).to(DEV)
+    dP = torch.randn(B, Q, D, generator=gen).to(DEV)
+    scale = D ** -0.5
+    lib = _native.load()
+    outs = []
+    for mode in (1, 0):
+        lib.ep_debug_force_generic_pool(mode)
+        try:
+            P, S, ML = F_.pool_forward(x, cls, scale)
+            ML2 = ML.clone(); ML2[:, :, 2] = 0.25
+            dcls = F_.pool_backward(x, S, ML2, dP, scale)
+            lse = ML[:, :, 0] + torch.log(ML[:, :, 1])        # (running max, sum) is representation specific; their
+            outs.append([t.cpu().numpy() for t in (P, S, dcls, lse)])   # log-sum-exp is not
+        finally:
+            lib.ep_debug_force_generic_pool(0)
+    for a, b, name in zip(outs[1], outs[0], ("P", "S", "dcls", "logsumexp")):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(b).max())), err_msg=name)
+    Pi, Si, MLi = F_.pool_forward(store, cls, scale, image_index=idx)
+    assert torch.equal(Pi.cpu(), torch.from_numpy(outs[1][0])) and torch.equal(Si.cpu(), torch.from_numpy(outs[1][1]))
