@@ -232,7 +232,7 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
-  if (use_wide(p)) return wide_launch(false, p, mf_grid(p.B), st);
+  if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B), st);
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
@@ -262,7 +262,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   EP_REQUIRE(!side || side->total == 0 || pool_backward_takes_side(p), EP_E_UNSUPPORTED,
              "pool_backward: side tasks need the 4-wave streaming kernel");
   if (use_wide(p)) {
-    nparts = mf_grid(p.B);
+    nparts = wide_grid(p.D, p.B);
     EP_TRY(wide_launch(true, p, nparts, st));
   } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);

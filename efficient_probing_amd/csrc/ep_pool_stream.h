@@ -63,6 +63,7 @@ int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // wide-row variant (ep_pool_wide.hip): D = 2048 / 4096, Q <= 8, row split across the waves
 bool wide_supported(int D, int Q, int64_t cls_bstride);
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
+int wide_grid(int D, int B);
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side = nullptr);
 
 }  // namespace ep

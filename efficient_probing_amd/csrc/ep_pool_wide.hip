@@ -23,16 +23,17 @@ namespace ep {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
-constexpr int WNW = 8;                 // waves per workgroup = slices per row
+// waves per workgroup = slices per row: 8 (D = 2048, 4096) or 4 (D = 1024)
 constexpr int WQ = 8;                  // queries handled (Q <= 8)
 constexpr int WTB = 2;                 // tokens per ring item / mini-batch
 constexpr float W_LOG2E = 1.4426950408889634f;
 constexpr float W_LAZY = 12.0f;
 
-template <int KPW> struct WideCfg {
+template <int KPW, int WNW> struct WideCfg {
   static constexpr int ITEM_TOK_BYTES = WTB * KPW * 1024;                 // this wave's slice of two token rows
   static constexpr int ITEM_BYTES = ITEM_TOK_BYTES + 256;                 // + one 4-byte-per-lane piece (backward)
   static constexpr int NITEM = (KPW == 1) ? 8 : 4;                         // ring depth per wave
+  static constexpr int WG_PER_CU = (WNW == 4) ? 2 : 1;
   static constexpr int KD_F = WTB * KPW;                                  // DMA instructions per item, forward
   static constexpr int KD_B = WTB * KPW + 1;
   static constexpr size_t LDS_BYTES = (size_t)WNW * NITEM * ITEM_BYTES + 2 * WNW * WQ * WTB * 4;
@@ -58,6 +59,7 @@ __device__ __forceinline__ f2 wfma2(f2 a, f2 b, f2 c) { return __builtin_element
 // Stage 1 (inside the wave): fold across 32-lane halves, 16-lane rows, then inside rows; register i of the
 // folded set holds, in row r, the wave-sum of pin[i + 4*(r&1) + 8*(r>>1)].  Stage 2: 16 floats per wave
 // through LDS, one workgroup barrier, every wave adds the 8 contributions.
+template <int WNW>
 __device__ __forceinline__ float reduce_pairs(const float (&pin)[WQ * WTB], float* scratch_buf, int w, int lane) {
   float r8[8], r4[4];
 #pragma unroll
@@ -68,7 +70,8 @@ __device__ __forceinline__ float reduce_pairs(const float (&pin)[WQ * WTB], floa
   const float mine = li == 0 ? r4[0] : (li == 1 ? r4[1] : (li == 2 ? r4[2] : r4[3]));
   if (li < 4) scratch_buf[w * 16 + li + 4 * (row & 1) + 8 * (row >> 1)] = mine;
   wbarrier();
-  float s = scratch_buf[row * 16 + li] + scratch_buf[(row + 4) * 16 + li];     // waves row and row+4
+  float s = scratch_buf[row * 16 + li];                                          // wave `row` (+ wave row+4)
+  if (WNW == 8) s += scratch_buf[(row + 4) * 16 + li];
   s = fold16(s, s);
   s = fold32(s, s);
   return s;
@@ -91,9 +94,9 @@ __device__ __forceinline__ void wide_partials(const f4 (&w)[WQ][KPW], const f4 (
 }
 
 // ---------------------------------------------------------------------------------------
-template <int KPW>
+template <int KPW, int WNW>
 __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParams p) {
-  using Cfg = WideCfg<KPW>;
+  using Cfg = WideCfg<KPW, WNW>;
   constexpr int NITEM = Cfg::NITEM, KD = Cfg::KD_F;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int lane = lane_id();
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot's data is in registers: refill it
     cslot = (cslot + 1 == NITEM) ? 0 : cslot + 1;
     produce();
-    const float u = reduce_pairs(pin, scratch + (i & 1) * (WNW * 16), w, lane);     // score of pair (myq, myt)
+    const float u = reduce_pairs<WNW>(pin, scratch + (i & 1) * (WNW * 16), w, lane);     // score of pair (myq, myt)
     const bool valid = myt < nvalid;
     const float ue = valid ? u : -INFINITY;
     const float um = fmaxf(ue, dpp_f<0xB1>(ue));              // max over the two tokens of my query
@@ -223,9 +226,9 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
 }
 
 // ---------------------------------------------------------------------------------------
-template <int KPW>
+template <int KPW, int WNW>
 __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParams p) {
-  using Cfg = WideCfg<KPW>;
+  using Cfg = WideCfg<KPW, WNW>;
   constexpr int NITEM = Cfg::NITEM, KD = Cfg::KD_B;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int lane = lane_id();
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       cslot = (cslot + 1 == NITEM) ? 0 : cslot + 1;
       produce();
-      const float dA = reduce_pairs(pin, scratch + (i & 1) * (WNW * 16), w, lane);
+      const float dA = reduce_pairs<WNW>(pin, scratch + (i & 1) * (WNW * 16), w, lane);
       const float a = __builtin_amdgcn_exp2f(fmaf(sraw, W_LOG2E, -mLq)) * il;
       const float wgt = (myt < nvalid && myq < Q) ? a * (dA - dl) : 0.f;
 #pragma unroll
@@ -337,14 +340,21 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
 // ---------------------------------------------------------------------------------------
 bool wide_supported(int D, int Q, int64_t cls_bstride) {
   (void)cls_bstride;
-  return (D == 2048 || D == 4096) && Q >= 1 && Q <= WQ;
+  static int d1024 = -1;
+  if (d1024 < 0) { const char* e = getenv("EP_POOL_WIDE_1024"); d1024 = e ? atoi(e) : 0; }
+  return (D == 2048 || D == 4096 || (D == 1024 && d1024)) && Q >= 1 && Q <= WQ;
+}
+int wide_grid(int D, int B) {
+  int g = cu_count() * (D == 1024 ? 2 : 1);
+  if (const char* e = getenv("EP_POOL_GRID")) { int v = atoi(e); if (v >= 1) g = v; }
+  return g < B ? g : B;
 }
 
-template <int KPW>
+template <int KPW, int WNW>
 static int wide_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  using Cfg = WideCfg<KPW>;
-  auto kf = ep_pool_wide_fwd_kernel<KPW>;
-  auto kb = ep_pool_wide_bwd_kernel<KPW>;
+  using Cfg = WideCfg<KPW, WNW>;
+  auto kf = ep_pool_wide_fwd_kernel<KPW, WNW>;
+  auto kb = ep_pool_wide_bwd_kernel<KPW, WNW>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", Cfg::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
@@ -355,8 +365,9 @@ static int wide_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t 
 }
 
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  if (p.D == 2048) return wide_launch_one<1>(bwd, p, grid, st);
-  if (p.D == 4096) return wide_launch_one<2>(bwd, p, grid, st);
+  if (p.D == 1024) return wide_launch_one<1, 4>(bwd, p, grid, st);
+  if (p.D == 2048) return wide_launch_one<1, 8>(bwd, p, grid, st);
+  if (p.D == 4096) return wide_launch_one<2, 8>(bwd, p, grid, st);
   set_error("no wide-row kernel for D=%d", p.D);
   return EP_E_UNSUPPORTED;
 }

@@ -4,8 +4,8 @@ import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "pool_fwd" in r["Kernel_Name"] or "pool_mf_fwd" in r["Kernel_Name"] or "pool_mm_fwd" in r["Kernel_Name"]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+idx = [i for i, r in enumerate(rows) if "pool_" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else min(20, len(idx) - 6)
 a, b = idx[k], idx[k + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b + 1]:
