@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU per step (weak scaling); default 1024 (256 for --head abmilp)")
     ap.add_argument("--buffers", type=int, default=4, help="distinct token buffers rotated through (HBM, not cache)")
+    ap.add_argument("--tokens", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the tokens in HBM (arithmetic is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kernel-iters", type=int, default=20)
@@ -183,6 +185,9 @@ def main():
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     xs = [torch.randn(B, Nn, D, device=dev, generator=gen) for _ in range(args.buffers)]
+    if args.tokens == "bf16":
+        xs = [x.to(torch.bfloat16) for x in xs]
+    esize = 2 if args.tokens == "bf16" else 4
     ts = [torch.randint(0, Cc, (B,), device=dev, generator=gen) for _ in range(args.buffers)]
 
     def barrier():
@@ -237,18 +242,19 @@ def main():
 
     def run_bwd(i):
         x = xs[i % args.buffers]
-        N_.check(eng.lib.ep_pool_backward(x.data_ptr(), 0, Nn * D, 0, B, Nn, D, Q, float(scale), S.data_ptr(), ML.data_ptr(),
+        N_.check(eng.lib.ep_pool_backward(x.data_ptr(), 1 if args.tokens == "bf16" else 0, Nn * D, 0, B, Nn, D, Q, float(scale), S.data_ptr(), ML.data_ptr(),
                                           dP.data_ptr(), dcls.data_ptr(), 0, ws.data_ptr(), ws_bytes, stream), "bwd")
     t_bwd = time_kernel(run_bwd, args.kernel_iters)
 
-    algo_bytes = B * Nn * D * 4                               # one streaming read of the fp32 tokens
-    kname_f = eng.lib.ep_pool_kernel_name(B, Nn, D, Q, 0).decode()
-    kname_b = eng.lib.ep_pool_kernel_name(B, Nn, D, Q, 1).decode()
+    algo_bytes = B * Nn * D * esize                           # one streaming read of the stored tokens
+    dt = 1 if args.tokens == "bf16" else 0
+    kname_f = eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
+    kname_b = eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01", f"{args.workload}_hbm_traffic_pmc.json")
-    if os.path.exists(tpath) and B == 1024:
+    if os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
         try:
             pk = json.load(open(tpath))["per_kernel"]
             traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pk.items() if k.startswith(kname_f)), None)
@@ -264,7 +270,8 @@ def main():
             "metric": "EP-head train images/sec" if args.head == "ep" else "CoCa-head train images/sec", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B,
+            "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
+                       "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B, "token_storage": args.tokens,
                        "global_batch": B * world, "optimizer": "lars", "token_buffers": args.buffers,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": kname_f, "achieved": round(fwd_gbs, 1),
@@ -273,7 +280,7 @@ def main():
                          "bwd_kernel": {"kernel": kname_b, "achieved": round(bwd_gbs, 1),
                                         "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
                                         "us_per_launch": round(t_bwd * 1e6, 2)},
-                         "step_frac": round(value / world * 2 * Nn * D * 4 / 1e9 / HBM_PEAK_GBS, 4)},
+                         "step_frac": round(value / world * 2 * Nn * D * esize / 1e9 / HBM_PEAK_GBS, 4)},
             "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, args.steps), 5),
                       "nonfinite_rows": bad},
         }

@@ -40,8 +40,9 @@ int get_events(hipEvent_t* out, int n) {
 int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q) {
   EP_REQUIRE(x != nullptr, EP_E_ARG, "x is null");
   EP_REQUIRE(B > 0 && N > 0 && D > 0 && Q > 0, EP_E_ARG, "B, N, D, Q must be positive (got %d %d %d %d)", B, N, D, Q);
-  EP_REQUIRE(x_dtype == EP_DTYPE_F32, EP_E_UNSUPPORTED, "token dtype %d not implemented (fp32 only in this build)", x_dtype);
+  EP_REQUIRE(x_dtype == EP_DTYPE_F32 || x_dtype == EP_DTYPE_BF16, EP_E_UNSUPPORTED, "token dtype %d not implemented (fp32 / bf16)", x_dtype);
   EP_REQUIRE(D % 4 == 0, EP_E_SHAPE, "D = %d must be a multiple of 4", D);
+  EP_REQUIRE(x_dtype == EP_DTYPE_F32 || (D % 8 == 0 && x_bstride % 8 == 0), EP_E_SHAPE, "bf16 tokens: D and the batch stride must be multiples of 8");
   EP_REQUIRE(x_bstride >= (int64_t)N * D, EP_E_SHAPE, "batch stride %lld smaller than N*D", (long long)x_bstride);
   EP_REQUIRE(aligned16(x) && x_bstride % 4 == 0, EP_E_ALIGN, "token buffer / batch stride must be 16-byte aligned");
   return 0;
@@ -96,9 +97,9 @@ static int check_dims(const ep_head_dims& d) {
   return 0;
 }
 
-PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale) {
+PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale, int x_dtype) {
   PoolParams p{};
-  p.x = static_cast<const float*>(x); p.x_bstride = x_bstride; p.B = B; p.N = N; p.D = D; p.Q = Q; p.scale = scale;
+  p.x = static_cast<const float*>(x); p.x_bf16 = x_dtype == EP_DTYPE_BF16 ? 1 : 0; p.x_bstride = x_bstride; p.B = B; p.N = N; p.D = D; p.Q = Q; p.scale = scale;
   return p;
 }
 
@@ -195,6 +196,9 @@ int ep_debug_force_generic_pool(int on) { return debug_force_generic(on); }
 
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q) { return pool_workspace_bytes(B, N, D, Q); }
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward) { return pool_kernel_family(B, N, D, Q, backward); }
+const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype) {
+  return pool_kernel_family(B, N, D, Q, backward, x_dtype == EP_DTYPE_BF16);
+}
 
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
                     const float* cls_token, int64_t cls_bstride, int Q, float scale, float* P, float* S, float* ML,
@@ -204,7 +208,7 @@ int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t
   EP_REQUIRE(cls_token && P && S && ML, EP_E_ARG, "ep_pool_forward: null pointer");
   EP_REQUIRE(aligned16(cls_token) && aligned16(P) && aligned16(ML) && cls_bstride % 4 == 0, EP_E_ALIGN,
              "ep_pool_forward: cls_token / P / ML must be 16-byte aligned");
-  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale);
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale, x_dtype);
   p.cls = cls_token; p.cls_bstride = cls_bstride; p.P = P; p.S = S; p.ML = ML; p.index = image_index;
   return pool_forward(p, (hipStream_t)stream);
 }
@@ -218,7 +222,7 @@ int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_
              "ep_pool_backward: dP / dcls / ML / workspace must be 16-byte aligned");
   EP_REQUIRE(workspace_bytes >= pool_workspace_bytes(B, N, D, Q), EP_E_WORKSPACE,
              "ep_pool_backward: workspace %zu < %zu", workspace_bytes, pool_workspace_bytes(B, N, D, Q));
-  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale);
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale, x_dtype);
   p.S = const_cast<float*>(S); p.ML = const_cast<float*>(ML); p.dP = dP; p.Gpart = static_cast<float*>(workspace);
   p.index = image_index;
   return pool_backward(p, dcls, accumulate, (hipStream_t)stream);
@@ -343,7 +347,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   if (s->phases & 1) {
     EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
     EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.Q));
-    PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale);
+    PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale, s->x_dtype);
     p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
     EP_TRY(pool_forward(p, st));
     EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
@@ -427,7 +431,7 @@ int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, i
   int64_t offs[4];
   ep_head_param_offsets(&d, offs);
   const float scale = (float)pow((double)d.D, -0.5);
-  PoolParams p = pool_params(x, x_bstride, d.B, d.N, d.D, d.Q, scale);
+  PoolParams p = pool_params(x, x_bstride, d.B, d.N, d.D, d.Q, scale, x_dtype);
   p.cls = params + offs[0]; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = image_index;
   EP_TRY(pool_forward(p, st));
   EP_TRY(project_forward(w.P, params + offs[1], d.B, d.D, Dp, d.Q, w.y, st));

@@ -207,14 +207,14 @@ static int coca_params_ok(const ep_coca_params* p, const char* what) {
 }
 
 static PoolParams coca_pool_params(const ep_coca_dims& d, const void* x, int64_t bstride, const int32_t* index,
-                                   const CocaWs& w) {
-  PoolParams p = pool_params(x, bstride, d.B, d.N, d.D, d.H, 1.0f);     // the scale lives in u
+                                   const CocaWs& w, int x_dtype) {
+  PoolParams p = pool_params(x, bstride, d.B, d.N, d.D, d.H, 1.0f, x_dtype);     // the scale lives in u
   p.cls = w.u; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = index;
   return p;
 }
 
 // y (B,D) = to_out(concat_h(P[b,h] Wv^T))
-static int coca_forward_core(const ep_coca_dims& d, const void* x, int64_t bstride, const int32_t* index,
+static int coca_forward_core(const ep_coca_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
                              const ep_coca_params& pr, float ln_eps, const CocaWs& w, float* y, hipStream_t st) {
   const int D = d.D, HD = d.H * d.dh;
   const float scale = (float)pow((double)d.dh, -0.5);                   // coca_pytorch.py:266
@@ -222,7 +222,7 @@ static int coca_forward_core(const ep_coca_dims& d, const void* x, int64_t bstri
                      pr.beta, pr.to_q, D, HD, ln_eps, scale, w.xhat, w.qn, w.lnstat, w.qh);
   hipLaunchKernelGGL(ep_coca_u_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.qh, pr.to_kv, D, d.dh, w.u);
   EP_LAUNCH_CHECK("ep_coca_q/u kernels");
-  EP_TRY(pool_forward(coca_pool_params(d, x, bstride, index, w), st));
+  EP_TRY(pool_forward(coca_pool_params(d, x, bstride, index, w, x_dtype), st));
   const float* Wv = pr.to_kv + (int64_t)d.dh * D;
   GemmParams g{};                                                       // o[b, h*dh + c] = P[b,h,:] . Wv[c,:]
   g.A = w.P; g.lda = (int64_t)d.H * D; g.sAz = D; g.extA = D;
@@ -238,7 +238,7 @@ static int coca_forward_core(const ep_coca_dims& d, const void* x, int64_t bstri
 
 // gradients of the five pooler tensors from dy (B,D).  `extra`: more side work for the token pass
 // (the classifier's weight gradients when called from the whole-head step).
-static int coca_backward_core(const ep_coca_dims& d, const void* x, int64_t bstride, const int32_t* index,
+static int coca_backward_core(const ep_coca_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
                               const ep_coca_params& pr, const float* dy, const ep_coca_params& gr, int accumulate,
                               const CocaWs& w, SideTasks sd, hipStream_t st, hipStream_t aux) {
   const int D = d.D, HD = d.H * d.dh;
@@ -269,7 +269,7 @@ static int coca_backward_core(const ep_coca_dims& d, const void* x, int64_t bstr
   EP_REQUIRE(gemm_side_ok(gWo, false, false) && gemm_side_ok(gWv, false, false), EP_E_ALIGN, "coca: unaligned gradient contraction");
   side_add_gemm(sd, gWo, 1);
   side_add_gemm(sd, gWv, d.H);
-  PoolParams p = coca_pool_params(d, x, bstride, index, w);
+  PoolParams p = coca_pool_params(d, x, bstride, index, w, x_dtype);
   p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
   if (pool_backward_takes_side(p)) {
     EP_TRY(pool_backward(p, w.du, 0, st, &sd));
@@ -321,7 +321,7 @@ int ep_coca_pool_forward(const ep_coca_dims* dims, const void* x, int x_dtype, i
   EP_REQUIRE(aligned16(ws) && aligned16(y), EP_E_ALIGN, "ep_coca_pool_forward: y / ws must be 16-byte aligned");
   const CocaWs w = coca_carve(*dims, ws, false);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_coca_pool_forward: workspace %zu < %zu", ws_bytes, w.total);
-  return coca_forward_core(*dims, x, x_bstride, image_index, *params, ln_eps, w, y, (hipStream_t)stream);
+  return coca_forward_core(*dims, x, x_dtype, x_bstride, image_index, *params, ln_eps, w, y, (hipStream_t)stream);
 }
 
 int ep_coca_pool_backward(const ep_coca_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
@@ -335,7 +335,7 @@ int ep_coca_pool_backward(const ep_coca_dims* dims, const void* x, int x_dtype, 
   EP_REQUIRE(aligned16(ws) && aligned16(dy), EP_E_ALIGN, "ep_coca_pool_backward: dy / ws must be 16-byte aligned");
   const CocaWs w = coca_carve(*dims, ws, false);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_coca_pool_backward: workspace %zu < %zu", ws_bytes, w.total);
-  return coca_backward_core(*dims, x, x_bstride, image_index, *params, dy, *grads, accumulate, w, SideTasks{},
+  return coca_backward_core(*dims, x, x_dtype, x_bstride, image_index, *params, dy, *grads, accumulate, w, SideTasks{},
                             (hipStream_t)stream, nullptr);
 }
 
@@ -377,7 +377,7 @@ int ep_coca_head_train_step(const ep_coca_step* s, void* ws, size_t ws_bytes, ep
   if (s->phases & 1) {
     EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
     EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.H));
-    EP_TRY(coca_forward_core(d, s->x, s->x_bstride, s->image_index, pr, s->ln_eps, w, w.y, st));
+    EP_TRY(coca_forward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, pr, s->ln_eps, w, w.y, st));
     EP_TRY(bn_forward_train(w.y, d.B, d.D, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));
     EP_TRY(linear_forward(w.z, Wc, bc, d.B, d.D, d.C, w.logits, w.ldl, st));
@@ -393,7 +393,7 @@ int ep_coca_head_train_step(const ep_coca_step* s, void* ws, size_t ws_bytes, ep
     sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
     sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;
     sd.total += sd.n_colsum + sd.n_stats;
-    EP_TRY(coca_backward_core(d, s->x, s->x_bstride, s->image_index, pr, w.dy, gr, s->accumulate, w, sd, st,
+    EP_TRY(coca_backward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, pr, w.dy, gr, s->accumulate, w, sd, st,
                               (hipStream_t)s->aux_stream));
   }
   if (s->phases & 2) {
@@ -426,7 +426,7 @@ int ep_coca_head_eval_forward(const ep_coca_dims* dims, const void* x, int x_dty
   int64_t offs[7];
   coca_offsets(d, offs);
   const ep_coca_params pr = coca_views(const_cast<float*>(params), offs, ln_beta);
-  EP_TRY(coca_forward_core(d, x, x_bstride, image_index, pr, ln_eps, w, w.y, st));
+  EP_TRY(coca_forward_core(d, x, x_dtype, x_bstride, image_index, pr, ln_eps, w, w.y, st));
   EP_TRY(bn_forward_eval(w.y, d.B, d.D, bn_eps, running_mean, running_var, w.z, st));
   return linear_forward(w.z, params + offs[5], params + offs[6], d.B, d.D, d.C, logits, ldl, st);
 }

@@ -48,6 +48,20 @@ int cu_count();
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// ---- bf16 token storage: four consecutive bf16 values (8 bytes) widened to fp32 (exact) --------
+__device__ __forceinline__ f4 bf16x4_to_f4(uint2 v) {
+  f4 r;
+  r.x = __uint_as_float(v.x << 16); r.y = __uint_as_float(v.x & 0xffff0000u);
+  r.z = __uint_as_float(v.y << 16); r.w = __uint_as_float(v.y & 0xffff0000u);
+  return r;
+}
+// tokens are fp32 or bf16 in memory; all arithmetic is fp32.  `e`: element index (multiple of 4)
+template <bool BF16>
+__device__ __forceinline__ f4 load_tok4(const void* base, int64_t e) {
+  if (BF16) return bf16x4_to_f4(*reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + e));
+  return *reinterpret_cast<const f4*>(static_cast<const float*>(base) + e);
+}
+
 // ---- wave64 helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id_uniform() {

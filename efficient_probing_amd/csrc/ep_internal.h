@@ -5,7 +5,8 @@
 namespace ep {
 
 struct PoolParams {
-  const float* x;        // tokens
+  const float* x;        // tokens (fp32, or bf16 when x_bf16: then this pointer is only ever used as a byte address)
+  int x_bf16;            // 1: tokens are stored as bf16 (widened to fp32 on load; all arithmetic stays fp32)
   int64_t x_bstride;     // elements between images
   int B, N, D, Q;
   const float* cls;      // fwd: (Q,D) or (B,Q,D)
@@ -49,7 +50,7 @@ struct SideTasks {
 #define EP_IMG_OFF(p, b) ((int64_t)((p).index ? (p).index[(b)] : (b)) * (p).x_bstride)
 
 size_t pool_workspace_bytes(int B, int N, int D, int Q);
-const char* pool_kernel_family(int B, int N, int D, int Q, int bwd);
+const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16 = 0);
 int pool_forward(const PoolParams& p, hipStream_t st);
 // `side` (optional): extra work to run inside the launch; honoured only when pool_backward_takes_side(p)
 int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st, const SideTasks* side = nullptr);
@@ -77,7 +78,7 @@ int ce_stats(const float* rowstat, int B, float* stats, hipStream_t st);
 // shared host helpers (ep_api.hip)
 int get_events(hipEvent_t* out, int n);
 int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q);
-PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale);
+PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale, int x_dtype = 0);
 int linear_forward(const float* z, const float* Wc, const float* bc, int B, int Dp, int C, float* logits, int ldl,
                    hipStream_t st);
 int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, int B, int Dp, int C, float* dz,

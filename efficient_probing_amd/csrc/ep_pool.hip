@@ -60,20 +60,21 @@ __global__ __launch_bounds__(256) void ep_reduce_partials_kernel(const float* __
 // (the second one is served by L2 / Infinity Cache).  Used for shapes the streaming kernel
 // does not cover (D % 64 != 0, D > 1536, Q > 32) and as an in-library cross-check.
 // ---------------------------------------------------------------------------------------
+template <bool BF16>
 __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) {
   extern __shared__ float sm[];       // scores of one query row: N floats, then 8 scratch
   const int b = blockIdx.x;
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
-  const float* xb = p.x + EP_IMG_OFF(p, b);
+  const char* xb = reinterpret_cast<const char*>(p.x) + EP_IMG_OFF(p, b) * (BF16 ? 2 : 4);
   float* red = sm + N;
   for (int q = 0; q < Q; ++q) {
     const float* cq = p.cls + (int64_t)b * p.cls_bstride + (int64_t)q * D;
     for (int n = w; n < N; n += 4) {
       float s = 0.f;
       for (int d = lane * 4; d < D; d += 256) {
-        f4 xv = *reinterpret_cast<const f4*>(xb + (int64_t)n * D + d);
+        f4 xv = load_tok4<BF16>(xb, (int64_t)n * D + d);
         f4 cv = *reinterpret_cast<const f4*>(cq + d) * p.scale;
         s = fmaf(cv.x, xv.x, s); s = fmaf(cv.y, xv.y, s); s = fmaf(cv.z, xv.z, s); s = fmaf(cv.w, xv.w, s);
       }
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
     const float inv = 1.0f / l;
     for (int d = threadIdx.x * 4; d < D; d += 1024) {
       f4 a = {0, 0, 0, 0};
-      for (int n = 0; n < N; ++n) a += sm[n] * *reinterpret_cast<const f4*>(xb + (int64_t)n * D + d);
+      for (int n = 0; n < N; ++n) a += sm[n] * load_tok4<BF16>(xb, (int64_t)n * D + d);
       *reinterpret_cast<f4*>(p.P + ((int64_t)b * Q + q) * D + d) = a * inv;
     }
     if (threadIdx.x == 0) {
@@ -111,13 +112,14 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
   }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) {
   extern __shared__ float sm[];       // weights of one query row: N floats
   const int b = blockIdx.x;
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
-  const float* xb = p.x + EP_IMG_OFF(p, b);
+  const char* xb = reinterpret_cast<const char*>(p.x) + EP_IMG_OFF(p, b) * (BF16 ? 2 : 4);
   for (int q = 0; q < Q; ++q) {
     const float* g = p.dP + ((int64_t)b * Q + q) * D;
     const float* ml = p.ML + ((int64_t)b * Q + q) * 4;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) 
     for (int n = w; n < N; n += 4) {
       float s = 0.f;
       for (int d = lane * 4; d < D; d += 256) {
-        f4 xv = *reinterpret_cast<const f4*>(xb + (int64_t)n * D + d);
+        f4 xv = load_tok4<BF16>(xb, (int64_t)n * D + d);
         f4 gv = *reinterpret_cast<const f4*>(g + d);
         s = fmaf(gv.x, xv.x, s); s = fmaf(gv.y, xv.y, s); s = fmaf(gv.z, xv.z, s); s = fmaf(gv.w, xv.w, s);
       }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) 
     __syncthreads();
     for (int d = threadIdx.x * 4; d < D; d += 1024) {
       f4 a = {0, 0, 0, 0};
-      for (int n = 0; n < N; ++n) a += sm[n] * *reinterpret_cast<const f4*>(xb + (int64_t)n * D + d);
+      for (int n = 0; n < N; ++n) a += sm[n] * load_tok4<BF16>(xb, (int64_t)n * D + d);
       *reinterpret_cast<f4*>(p.Gpart + ((int64_t)b * Q + q) * D + d) = a;
     }
     __syncthreads();
@@ -196,7 +198,7 @@ static bool force_generic() { return pool_mode() == 1; }
 // Q = 1); the matrix-core kernel wins for wider rows and more queries.
 static bool use_mf(const PoolParams& p, bool bwd) {
   (void)bwd;
-  if (pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
+  if (p.x_bf16 || pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (c.ok && (p.Q <= 4 || stream_waves_per_cu(c.qw, c.kp, c.nw) == 12)) return false;   // vector-ALU kernel wins
   return true;
@@ -205,17 +207,19 @@ static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 // all-matrix-core kernel: forced with mode 3; chosen automatically only where it measured fastest
 // (backward at D = 1152, where the other two kernels run short of LDS / registers)
 static bool use_mm(const PoolParams& p, bool bwd) {
-  if (!mm_supported(p.D, p.Q, p.cls_bstride)) return false;
+  if (p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
   if (pool_mode() == 3) return true;
   return pool_mode() == 0 && bwd && p.D == 1152 && p.Q >= 5;
 }
 
 // wide rows (D = 2048 / 4096): the row is split across the waves of a workgroup
-static bool use_wide(const PoolParams& p) { return pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride); }
+static bool use_wide(const PoolParams& p) {
+  return pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
+}
 
-const char* pool_kernel_family(int B, int N, int D, int Q, int bwd) {
+const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) {
   PoolParams p{};
-  p.B = B; p.N = N; p.D = D; p.Q = Q;
+  p.B = B; p.N = N; p.D = D; p.Q = Q; p.x_bf16 = x_bf16;
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
@@ -232,7 +236,7 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
-  if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B), st);
+  if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B, p.x_bf16), st);
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
@@ -241,7 +245,8 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
     return stream_launch(false, c, p, st);
   }
   const size_t lds = (size_t)(p.N + 8) * sizeof(float);
-  hipLaunchKernelGGL(ep_pool_fwd_generic_kernel, dim3(p.B), dim3(256), lds, st, p);
+  if (p.x_bf16) hipLaunchKernelGGL(ep_pool_fwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(ep_pool_fwd_generic_kernel<false>, dim3(p.B), dim3(256), lds, st, p);
   EP_LAUNCH_CHECK("ep_pool_fwd_generic_kernel");
   return 0;
 }
@@ -262,7 +267,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   EP_REQUIRE(!side || side->total == 0 || pool_backward_takes_side(p), EP_E_UNSUPPORTED,
              "pool_backward: side tasks need the 4-wave streaming kernel");
   if (use_wide(p)) {
-    nparts = wide_grid(p.D, p.B);
+    nparts = wide_grid(p.D, p.B, p.x_bf16);
     EP_TRY(wide_launch(true, p, nparts, st));
   } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);
@@ -276,7 +281,8 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     nparts = c.grid;
   } else {
     const size_t lds = (size_t)(p.N + 8) * sizeof(float);
-    hipLaunchKernelGGL(ep_pool_bwd_generic_kernel, dim3(p.B), dim3(256), lds, st, p);
+    if (p.x_bf16) hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<false>, dim3(p.B), dim3(256), lds, st, p);
     EP_LAUNCH_CHECK("ep_pool_bwd_generic_kernel");
     nparts = p.B;
   }

@@ -20,7 +20,12 @@ namespace ep {
 //  * otherwise 8 waves per CU with 8-token tiles (fewer barriers per byte; with 1 query per wave the
 //    kernel is memory-bound and the longer DMA bursts win: 0.76 vs 0.62 of peak at Q = 1).
 constexpr int stream_waves_per_cu(int qw, int kp, int nw) { return (nw == 4 && qw == 2 && kp <= 3) ? 12 : 8; }
-constexpr int stream_tt(int qw, int kp, int nw) { return stream_waves_per_cu(qw, kp, nw) == 12 ? 4 : 8; }
+constexpr int stream_tt(int qw, int kp, int nw) {
+  if (stream_waves_per_cu(qw, kp, nw) == 12) return 4;
+  // 8-token tiles need a ring of >= 3 of them (backward: + the per-wave small pieces) in this workgroup's LDS share
+  const int budget = 160 * 1024 / (stream_waves_per_cu(qw, kp, nw) / nw);
+  return (3 * (8 * kp * 1024 + nw * 256) <= budget) ? 8 : 4;
+}
 
 constexpr int stream_kdma(int qw, int kp, int nw) { return (stream_tt(qw, kp, nw) * kp + nw - 1) / nw; }
 constexpr int stream_nslot(int qw, int kp, int nw, bool bwd) {
@@ -61,9 +66,9 @@ int mf_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 bool mm_supported(int D, int Q, int64_t cls_bstride);
 int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // wide-row variant (ep_pool_wide.hip): D = 2048 / 4096, Q <= 8, row split across the waves
-bool wide_supported(int D, int Q, int64_t cls_bstride);
+bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16 = 0);
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
-int wide_grid(int D, int B);
+int wide_grid(int D, int B, int x_bf16 = 0);
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side = nullptr);
 
 }  // namespace ep

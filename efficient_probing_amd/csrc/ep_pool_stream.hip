@@ -107,13 +107,15 @@ __device__ __forceinline__ void butterfly(const float (&part)[QW][TB], float (&u
   }
 }
 
-template <int QW, int KP>
+template <int QW, int KP, bool BF16>
 __device__ __forceinline__ void load_rows(const char* tile, int rowbytes, const int (&coff)[KP], f4 (&xv)[TB][KP]) {
 #pragma unroll
   for (int t = 0; t < TB; ++t)
 #pragma unroll
-    for (int k = 0; k < KP; ++k)
-      xv[t][k] = *reinterpret_cast<const f4*>(tile + t * rowbytes + coff[k]);
+    for (int k = 0; k < KP; ++k) {
+      if (BF16) xv[t][k] = bf16x4_to_f4(*reinterpret_cast<const uint2*>(tile + t * rowbytes + coff[k]));
+      else xv[t][k] = *reinterpret_cast<const f4*>(tile + t * rowbytes + coff[k]);
+    }
 }
 
 template <int QW, int KP>
@@ -131,17 +133,20 @@ __device__ __forceinline__ void accumulate_rows(const float (&wrow)[QW], const f
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int QW, int KP, int NW, int DFIX>
+// BF16: tokens are bf16 in memory; a ring tile then holds twice as many tokens in the same bytes and the rows are
+// widened to fp32 as they are read from LDS -- everything after that is the fp32 code path unchanged.
+template <int QW, int KP, int NW, int DFIX, bool BF16>
 __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_fwd_kernel(PoolParams p) {
   using Cfg = StreamCfgT<QW, KP, NW>;
-  constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA, TT = Cfg::TT;
+  constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA, TT = Cfg::TT * (BF16 ? 2 : 1);
+  constexpr int ES = BF16 ? 2 : 4;                 // bytes per stored token element
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = DFIX ? DFIX : p.D;
   const int N = p.N, Q = p.Q;
-  const int rowbytes = D * 4;
-  const int nchunk = D >> 2;                    // 16-byte chunks per row
+  const int rowbytes = D * ES;
+  const int nchunk = D >> 2;                    // 4-element chunks per row (16 bytes of fp32 / 8 bytes of bf16)
   const int slot_bytes = TT * rowbytes;
   const int npiece = slot_bytes >> 10;
   const int tiles_per_img = (N + TT - 1) / TT;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   // (last piece, D % 256 != 0) re-read chunk 0: finite data that meets a zero query weight.
   int coff[KP];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) coff[k] = ((lane + 64 * k) < nchunk ? (lane + 64 * k) : 0) * 16;
+  for (int k = 0; k < KP; ++k) coff[k] = ((lane + 64 * k) < nchunk ? (lane + 64 * k) : 0) * (4 * ES);
 
   // queries of this wave, pre-scaled like the reference (q = cls_token * scale, ep.py:39)
   f4 cq[QW][KP];
@@ -177,7 +182,8 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 
   // ---- producer: one ring item = one tile of TT token rows -------------------------------
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
-  const char* psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, wg));
+  const char* xbytes = reinterpret_cast<const char*>(p.x);
+  const char* psrc = xbytes + EP_IMG_OFF(p, wg) * ES;
   auto produce = [&]() {
     if (pi < n_items) {
       const int left = N - ptile * TT;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
       if (++ptile == tiles_per_img) {
         ptile = 0; ++pimg;
-        psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+        psrc = xbytes + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg) * ES;
       } else {
         psrc += slot_bytes;
       }
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       for (int t0 = 0; t0 < TT; t0 += TB) {
         if (t0 >= nvalid) break;
         f4 xv[TB][KP];
-        load_rows<QW, KP>(tile + t0 * rowbytes, rowbytes, coff, xv);
+        load_rows<QW, KP, BF16>(tile + t0 * rowbytes, rowbytes, coff, xv);
         float part[QW][TB];
         partial_scores<QW, KP>(cq, xv, part);
         float u[QW];
@@ -300,14 +306,16 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 
 // ---------------------------------------------------------------------------------------
 // backward (gradient of cls_token)
-// ring items per image: H = ceil(Q/TT) header items holding rows of dP[b], then the token tiles.
+// ring items per image: H = ceil(Q/HR) header items holding HR fp32 rows of dP[b] each, then the token tiles.
 // Every item additionally carries one 4-byte-per-lane DMA per wave into a private 256-byte area:
 // header items fetch ML[b,q,0:4] of the wave's queries, token items fetch S[b,q,n0:n0+TT].
 // ---------------------------------------------------------------------------------------
-template <int QW, int KP, int NW, int DFIX>
+template <int QW, int KP, int NW, int DFIX, bool BF16>
 __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_bwd_kernel(PoolParams p, SideTasks side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
-  constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA, TT = Cfg::TT;
+  constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA, TT = Cfg::TT * (BF16 ? 2 : 1);
+  constexpr int ES = BF16 ? 2 : 4;
+  constexpr int HR = Cfg::TT;                       // fp32 dP rows that fit one ring slot (header items)
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int G = gridDim.x - side.total;             // pooling workgroups; the rest run side tasks
   if constexpr (NW == 4) {
@@ -320,12 +328,13 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const int w = wave_id_uniform();
   const int D = DFIX ? DFIX : p.D;
   const int N = p.N, Q = p.Q;
-  const int rowbytes = D * 4;
+  const int rowbytes = D * ES;                      // token rows
+  const int hrowbytes = D * 4;                      // dP rows (always fp32)
   const int nchunk = D >> 2;
   const int slot_bytes = TT * rowbytes;
   const int npiece = slot_bytes >> 10;
   const int tiles_per_img = (N + TT - 1) / TT;
-  const int H = (Q + TT - 1) / TT;
+  const int H = (Q + HR - 1) / HR;
   const int items_per_img = H + tiles_per_img;
   const int wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
@@ -333,9 +342,13 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const int q0 = w * QW;
   const unsigned lane16 = (unsigned)lane * 16u;
   char* small_base = ring + NSLOT * slot_bytes;          // [NSLOT][NW][64 floats]
-  int coff[KP];
+  int coff[KP], hoff[KP];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) coff[k] = ((lane + 64 * k) < nchunk ? (lane + 64 * k) : 0) * 16;
+  for (int k = 0; k < KP; ++k) {
+    const int c = (lane + 64 * k) < nchunk ? (lane + 64 * k) : 0;
+    coff[k] = c * (4 * ES); hoff[k] = c * 16;
+  }
+  const char* xbytes = reinterpret_cast<const char*>(p.x);
 
   f4 gacc[QW][KP];
 #pragma unroll
@@ -355,16 +368,16 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         char* small = small_base + (pslot * NW + w) * 256;
         char* slot = ring + pslot * slot_bytes;
         if (pidx < H) {                                   // header: rows of dP[b]
-          const int r0 = pidx * TT;
-          const int rows = (Q - r0) < TT ? (Q - r0) : TT;
+          const int r0 = pidx * HR;
+          const int rows = (Q - r0) < HR ? (Q - r0) : HR;
           const char* src = reinterpret_cast<const char*>(p.dP + ((int64_t)b * Q + r0) * D);
-          dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
+          dma_rows<NW, KDMA>(src, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
           const float* ms = p.ML + ((int64_t)b * Q + hq) * 4 + (lane & 3);
           __builtin_amdgcn_global_load_lds((gptr_t)ms, (lds_ptr_t)small, 4, 0, 0);
         } else {
           const int n0 = (pidx - H) * TT;
           const int rows = (N - n0) < TT ? (N - n0) : TT;
-          const char* src = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, b) + (int64_t)n0 * D);
+          const char* src = xbytes + (EP_IMG_OFF(p, b) + (int64_t)n0 * D) * ES;
           dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
           int nn = n0 + st; nn = nn < N ? nn : N - 1;
           const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;
@@ -396,11 +409,11 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
           const int q = q0 + j;
-          if (q < Q && q / TT == cidx) {
-            const int r = q % TT;
+          if (q < Q && q / HR == cidx) {
+            const int r = q % HR;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-              f4 v = *reinterpret_cast<const f4*>(tile + r * rowbytes + coff[k]);
+              f4 v = *reinterpret_cast<const f4*>(tile + r * hrowbytes + hoff[k]);
               if (lane + 64 * k >= nchunk) v = f4{0.f, 0.f, 0.f, 0.f};
               gq[j][k] = v;
             }
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         for (int t0 = 0; t0 < TT; t0 += TB) {
           if (t0 >= nvalid) break;
           f4 xv[TB][KP];
-          load_rows<QW, KP>(tile + t0 * rowbytes, rowbytes, coff, xv);
+          load_rows<QW, KP, BF16>(tile + t0 * rowbytes, rowbytes, coff, xv);
           float part[QW][TB];
           partial_scores<QW, KP>(gq, xv, part);
           float u[QW];
@@ -455,11 +468,11 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 // ---------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------
-template <int QW, int KP, int NW, int DFIX>
+template <int QW, int KP, int NW, int DFIX, bool BF16>
 static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   const int D = p.D;
-  const size_t slot = (size_t)Cfg::TT * D * 4;
+  const size_t slot = (size_t)Cfg::TT * D * 4;          // bf16: twice the tokens, half the bytes each
   size_t lds = bwd ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
   SideTasks sd{};
   if (bwd && side && side->total > 0) {
@@ -467,8 +480,8 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
     sd = *side;
     if (lds < SIDE_LDS_BYTES) lds = SIDE_LDS_BYTES;
   }
-  auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX>;
-  auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX>;
+  auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX, BF16>;
+  auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX, BF16>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
@@ -487,9 +500,11 @@ static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   } else {
     // compile-time D for the shapes the benchmark configs use (immediate LDS offsets)
     if constexpr ((QW == 2 && NW == 4 && (KP == 3 || KP == 4)) || (QW == 4 && NW == 8 && KP == 3)) {
-      if (p.D == 256 * KP) return launch_one<QW, KP, NW, 256 * KP>(bwd, p, grid, st, side);
+      if (p.D == 256 * KP && !p.x_bf16) return launch_one<QW, KP, NW, 256 * KP, false>(bwd, p, grid, st, side);
+      if (p.D == 256 * KP) return launch_one<QW, KP, NW, 256 * KP, true>(bwd, p, grid, st, side);
     }
-    return launch_one<QW, KP, NW, 0>(bwd, p, grid, st, side);
+    if (p.x_bf16) return launch_one<QW, KP, NW, 0, true>(bwd, p, grid, st, side);
+    return launch_one<QW, KP, NW, 0, false>(bwd, p, grid, st, side);
   }
 }
 

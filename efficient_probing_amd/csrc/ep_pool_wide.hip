@@ -29,13 +29,43 @@ constexpr int WTB = 2;                 // tokens per ring item / mini-batch
 constexpr float W_LOG2E = 1.4426950408889634f;
 constexpr float W_LAZY = 12.0f;
 
-template <int KPW, int WNW> struct WideCfg {
-  static constexpr int ITEM_TOK_BYTES = WTB * KPW * 1024;                 // this wave's slice of two token rows
+// BF16: tokens stored as bf16.  A lane then owns 8 CONSECUTIVE elements of the slice per 16-byte DMA piece (two
+// 4-element register chunks), so the fp32 side arrays (queries, pooled state, dP, gradient partials) are addressed
+// with the matching element map `eoff`; KPW must be even.
+template <int KPW, int WNW, bool BF16> struct WideCfg {
+  static constexpr int DPT = BF16 ? KPW / 2 : KPW;                        // 1 KiB DMA pieces per token per wave
+  static constexpr int ITEM_TOK_BYTES = WTB * DPT * 1024;                 // this wave's slice of two token rows
   static constexpr int ITEM_BYTES = ITEM_TOK_BYTES + 256;                 // + one 4-byte-per-lane piece (backward)
-  static constexpr int NITEM = (KPW == 1) ? 8 : 4;                         // ring depth per wave
+  static constexpr int NITEM = (DPT == 1) ? 8 : 4;                         // ring depth per wave
   static constexpr int WG_PER_CU = (WNW == 4) ? 2 : 1;
-  static constexpr int KD_F = WTB * KPW;                                  // DMA instructions per item, forward
-  static constexpr int KD_B = WTB * KPW + 1;
+  static constexpr int KD_F = WTB * DPT;                                  // DMA instructions per item, forward
+  static constexpr int KD_B = WTB * DPT + 1;
+  static_assert(!BF16 || KPW % 2 == 0, "bf16 wide rows: KPW must be even");
+  // element offset (inside the wave's slice) of register chunk k of lane `lane`
+  static __device__ __forceinline__ int eoff(int k, int lane) {
+    return BF16 ? (k >> 1) * 512 + lane * 8 + (k & 1) * 4 : k * 256 + lane * 4;
+  }
+  // read this lane's data of token t of an item into KPW fp32 chunks
+  static __device__ __forceinline__ void read_tok(const char* item, int t, int lane, f4 (&x)[KPW]) {
+    if (BF16) {
+#pragma unroll
+      for (int j = 0; j < KPW / 2; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4*>(item + (t * DPT + j) * 1024 + lane * 16);
+        x[2 * j] = bf16x4_to_f4(uint2{v.x, v.y});
+        x[2 * j + 1] = bf16x4_to_f4(uint2{v.z, v.w});
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KPW; ++k) x[k] = *reinterpret_cast<const f4*>(item + (t * KPW + k) * 1024 + lane * 16);
+    }
+  }
+  // issue the DMA pieces of token row `row` (element pointer semantics: byte address of the slice start)
+  static __device__ __forceinline__ void dma_tok(const char* slice_row, char* slot, int t, int lane) {
+#pragma unroll
+    for (int j = 0; j < DPT; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(slice_row + j * 1024 + lane * 16), (lds_ptr_t)(slot + (t * DPT + j) * 1024), 16, 0,
+                                       EP_DMA_AUX);
+  }
   static constexpr size_t LDS_BYTES = (size_t)WNW * NITEM * ITEM_BYTES + 2 * WNW * WQ * WTB * 4;
 };
 
@@ -94,16 +124,17 @@ __device__ __forceinline__ void wide_partials(const f4 (&w)[WQ][KPW], const f4 (
 }
 
 // ---------------------------------------------------------------------------------------
-template <int KPW, int WNW>
+template <int KPW, int WNW, bool BF16>
 __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParams p) {
-  using Cfg = WideCfg<KPW, WNW>;
+  using Cfg = WideCfg<KPW, WNW, BF16>;
+  constexpr int ES = BF16 ? 2 : 4;
   constexpr int NITEM = Cfg::NITEM, KD = Cfg::KD_F;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
   const int Ds = KPW * 256;
-  const int soff = w * Ds + lane * 4;                         // this lane's first float inside a row (chunk 0)
+  const int sbase = w * Ds;                                   // first element of this wave's slice inside a row
   char* ring = lds + (size_t)w * NITEM * Cfg::ITEM_BYTES;
   float* scratch = reinterpret_cast<float*>(lds + (size_t)WNW * NITEM * Cfg::ITEM_BYTES);
   const int G = gridDim.x, wg = blockIdx.x;
@@ -119,7 +150,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
 #pragma unroll
       for (int k = 0; k < KPW; ++k) {
         f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q < Q) v = *reinterpret_cast<const f4*>(p.cls + (int64_t)b * p.cls_bstride + (int64_t)q * D + soff + k * 256);
+        if (q < Q) v = *reinterpret_cast<const f4*>(p.cls + (int64_t)b * p.cls_bstride + (int64_t)q * D + sbase + Cfg::eoff(k, lane));
         cq[q][k] = v * p.scale;
       }
   };
@@ -130,15 +161,12 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
   auto produce = [&]() {
     if (pi < n_items) {
       const int b = wg + pimg * G;
-      const float* src = p.x + EP_IMG_OFF(p, b) + soff;
+      const char* src = reinterpret_cast<const char*>(p.x) + (EP_IMG_OFF(p, b) + sbase) * ES;
       char* slot = ring + pslot * Cfg::ITEM_BYTES;         // wave-uniform; lane l's 16 bytes land at +16*l
 #pragma unroll
       for (int t = 0; t < WTB; ++t) {
         int n = pit * WTB + t; n = n < N ? n : N - 1;          // odd N: the surplus row re-reads the last token
-#pragma unroll
-        for (int k = 0; k < KPW; ++k)
-          __builtin_amdgcn_global_load_lds((gptr_t)(src + (int64_t)n * D + k * 256),
-                                           (lds_ptr_t)(slot + (t * KPW + k) * 1024), 16, 0, EP_DMA_AUX);
+        Cfg::dma_tok(src + (int64_t)n * D * ES, slot, t, lane);
       }
       ++pi;
       pslot = (pslot + 1 == NITEM) ? 0 : pslot + 1;
@@ -166,12 +194,10 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
 #pragma unroll
         for (int k = 0; k < KPW; ++k) acc[q][k] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    const char* item = ring + cslot * Cfg::ITEM_BYTES + lane * 16;
+    const char* item = ring + cslot * Cfg::ITEM_BYTES;
     f4 xv[WTB][KPW];
 #pragma unroll
-    for (int t = 0; t < WTB; ++t)
-#pragma unroll
-      for (int k = 0; k < KPW; ++k) xv[t][k] = *reinterpret_cast<const f4*>(item + (t * KPW + k) * 1024);
+    for (int t = 0; t < WTB; ++t) Cfg::read_tok(item, t, lane, xv[t]);
     float pin[WQ * WTB];
     wide_partials<KPW>(cq, xv, pin);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot's data is in registers: refill it
@@ -210,9 +236,9 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
       for (int q = 0; q < WQ; ++q)
         if (q < Q) {
           const float iq = readlane_f(inv, 2 * q);
-          float* Pq = p.P + ((int64_t)b * Q + q) * D + soff;
+          float* Pq = p.P + ((int64_t)b * Q + q) * D + sbase;
 #pragma unroll
-          for (int k = 0; k < KPW; ++k) *reinterpret_cast<f4*>(Pq + k * 256) = acc[q][k] * iq;
+          for (int k = 0; k < KPW; ++k) *reinterpret_cast<f4*>(Pq + Cfg::eoff(k, lane)) = acc[q][k] * iq;
         }
       if (w == 0 && lane < 16 && myt == 0 && myq < Q) {
         const f4 rec = {m, l, 0.f, 0.f};
@@ -226,16 +252,17 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
 }
 
 // ---------------------------------------------------------------------------------------
-template <int KPW, int WNW>
+template <int KPW, int WNW, bool BF16>
 __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParams p) {
-  using Cfg = WideCfg<KPW, WNW>;
+  using Cfg = WideCfg<KPW, WNW, BF16>;
+  constexpr int ES = BF16 ? 2 : 4;
   constexpr int NITEM = Cfg::NITEM, KD = Cfg::KD_B;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
   const int Ds = KPW * 256;
-  const int soff = w * Ds + lane * 4;
+  const int sbase = w * Ds;
   char* ring = lds + (size_t)w * NITEM * Cfg::ITEM_BYTES;
   float* scratch = reinterpret_cast<float*>(lds + (size_t)WNW * NITEM * Cfg::ITEM_BYTES);
   const int G = gridDim.x, wg = blockIdx.x;
@@ -256,15 +283,12 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
     auto produce = [&]() {
       if (pi < n_items) {
         const int b = wg + pimg * G;
-        const float* src = p.x + EP_IMG_OFF(p, b) + soff;
+        const char* src = reinterpret_cast<const char*>(p.x) + (EP_IMG_OFF(p, b) + sbase) * ES;
         char* slot = ring + pslot * Cfg::ITEM_BYTES;
 #pragma unroll
         for (int t = 0; t < WTB; ++t) {
           int n = pit * WTB + t; n = n < N ? n : N - 1;
-#pragma unroll
-          for (int k = 0; k < KPW; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (int64_t)n * D + k * 256),
-                                             (lds_ptr_t)(slot + (t * KPW + k) * 1024), 16, 0, EP_DMA_AUX);
+          Cfg::dma_tok(src + (int64_t)n * D * ES, slot, t, lane);
         }
         int nn = pit * WTB + myt; nn = nn < N ? nn : N - 1;   // raw score of my (query, token) pair
         __builtin_amdgcn_global_load_lds((gptr_t)(p.S + ((int64_t)b * Q + sq) * N + nn),
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
 #pragma unroll
           for (int k = 0; k < KPW; ++k) {
             f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < Q) v = *reinterpret_cast<const f4*>(p.dP + ((int64_t)b * Q + q) * D + soff + k * 256);
+            if (q < Q) v = *reinterpret_cast<const f4*>(p.dP + ((int64_t)b * Q + q) * D + sbase + Cfg::eoff(k, lane));
             gq[q][k] = v;
           }
         const f4 ml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + sq) * 4);
@@ -305,9 +329,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
       const char* item = ring + cslot * Cfg::ITEM_BYTES;
       f4 xv[WTB][KPW];
 #pragma unroll
-      for (int t = 0; t < WTB; ++t)
-#pragma unroll
-        for (int k = 0; k < KPW; ++k) xv[t][k] = *reinterpret_cast<const f4*>(item + (t * KPW + k) * 1024 + lane * 16);
+      for (int t = 0; t < WTB; ++t) Cfg::read_tok(item, t, lane, xv[t]);
       const float sraw = *reinterpret_cast<const float*>(item + Cfg::ITEM_TOK_BYTES + lane * 4);
       float pin[WQ * WTB];
       wide_partials<KPW>(gq, xv, pin);
@@ -331,30 +353,30 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
 #pragma unroll
   for (int q = 0; q < WQ; ++q)
     if (q < Q) {
-      float* Gq = p.Gpart + ((int64_t)wg * Q + q) * D + soff;
+      float* Gq = p.Gpart + ((int64_t)wg * Q + q) * D + sbase;
 #pragma unroll
-      for (int k = 0; k < KPW; ++k) *reinterpret_cast<f4*>(Gq + k * 256) = gacc[q][k];
+      for (int k = 0; k < KPW; ++k) *reinterpret_cast<f4*>(Gq + Cfg::eoff(k, lane)) = gacc[q][k];
     }
 }
 
 // ---------------------------------------------------------------------------------------
-bool wide_supported(int D, int Q, int64_t cls_bstride) {
+bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16) {
   (void)cls_bstride;
   static int d1024 = -1;
   if (d1024 < 0) { const char* e = getenv("EP_POOL_WIDE_1024"); d1024 = e ? atoi(e) : 0; }
-  return (D == 2048 || D == 4096 || (D == 1024 && d1024)) && Q >= 1 && Q <= WQ;
+  return (D == 2048 || D == 4096 || (D == 1024 && d1024 && !x_bf16)) && Q >= 1 && Q <= WQ;
 }
-int wide_grid(int D, int B) {
-  int g = cu_count() * (D == 1024 ? 2 : 1);
+int wide_grid(int D, int B, int x_bf16) {
+  int g = cu_count() * ((D == 1024 || (D == 2048 && x_bf16)) ? 2 : 1);        // 4-wave variants: two workgroups per CU
   if (const char* e = getenv("EP_POOL_GRID")) { int v = atoi(e); if (v >= 1) g = v; }
   return g < B ? g : B;
 }
 
-template <int KPW, int WNW>
+template <int KPW, int WNW, bool BF16>
 static int wide_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  using Cfg = WideCfg<KPW, WNW>;
-  auto kf = ep_pool_wide_fwd_kernel<KPW, WNW>;
-  auto kb = ep_pool_wide_bwd_kernel<KPW, WNW>;
+  using Cfg = WideCfg<KPW, WNW, BF16>;
+  auto kf = ep_pool_wide_fwd_kernel<KPW, WNW, BF16>;
+  auto kb = ep_pool_wide_bwd_kernel<KPW, WNW, BF16>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", Cfg::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
@@ -365,9 +387,14 @@ static int wide_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t 
 }
 
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  if (p.D == 1024) return wide_launch_one<1, 4>(bwd, p, grid, st);
-  if (p.D == 2048) return wide_launch_one<1, 8>(bwd, p, grid, st);
-  if (p.D == 4096) return wide_launch_one<2, 8>(bwd, p, grid, st);
+  if (p.x_bf16) {
+    if (p.D == 2048) return wide_launch_one<2, 4, true>(bwd, p, grid, st);      // 4 waves x 512-element slices
+    if (p.D == 4096) return wide_launch_one<2, 8, true>(bwd, p, grid, st);
+  } else {
+    if (p.D == 1024) return wide_launch_one<1, 4, false>(bwd, p, grid, st);
+    if (p.D == 2048) return wide_launch_one<1, 8, false>(bwd, p, grid, st);
+    if (p.D == 4096) return wide_launch_one<2, 8, false>(bwd, p, grid, st);
+  }
   set_error("no wide-row kernel for D=%d", p.D);
   return EP_E_UNSUPPORTED;
 }

@@ -55,7 +55,7 @@ class ProbeHeadEngine:
         return self.lib.ep_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
-        return self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, iptr,
+        return self.lib.ep_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
                                              self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                              self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
                                              ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
@@ -130,7 +130,7 @@ class ProbeHeadEngine:
         s = self._new_step()
         s.dims = self.dims
         s.x = x.data_ptr() if x is not None else 0
-        s.x_dtype = N.EP_DTYPE_F32
+        s.x_dtype = F_.token_dtype_code(x) if x is not None else N.EP_DTYPE_F32
         s.x_bstride = bstride
         s.targets = targets.data_ptr() if targets is not None else 0
         s.params = self.flat_p.data_ptr(); s.grads = self.flat_g.data_ptr()
@@ -248,7 +248,7 @@ class CocaHeadEngine(ProbeHeadEngine):
                                                 N.current_stream_ptr(self.device))
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
-        return self.lib.ep_coca_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, iptr,
+        return self.lib.ep_coca_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
                                                   self.flat_p.data_ptr(), self.pool.norm.beta.data_ptr(), 1e-5,
                                                   self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr(),
                                                   self.bn.eps, out.data_ptr(), ldl, ws.data_ptr(), ws.numel(),

@@ -28,19 +28,28 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def as_token_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
-    """Return (x', batch_stride) with x' fp32, inner two dims contiguous.  A view such as
-    ``feat[:, 1:]`` (reference models_more.py:24) is passed through without a copy."""
+    """Return (x', batch_stride) with x' fp32 or bf16, inner two dims contiguous.  A view such as
+    ``feat[:, 1:]`` (reference models_more.py:24) is passed through without a copy.  bf16 tokens (a bf16
+    backbone's output, or a bf16 token store) are read as they are -- the token passes widen them to fp32 on the
+    fly and compute in fp32; fp16 is widened once here."""
     N.require_gpu_tensor(x, "tokens")
     if x.dim() != 3:
         raise ValueError(f"tokens must be (B, N, D), got {tuple(x.shape)}")
-    if x.dtype != torch.float32:
-        x = x.float()          # bf16/fp16 autocast outputs: widened once (native bf16 path: later round)
     B, Nn, D = x.shape
+    if x.dtype == torch.bfloat16 and D % 8 != 0:
+        x = x.float()
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    al = 8 if x.dtype == torch.bfloat16 else 4
     ok = x.stride(2) == 1 and x.stride(1) == D and (B == 1 or x.stride(0) >= Nn * D) \
-        and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+        and x.stride(0) % al == 0 and x.data_ptr() % 16 == 0
     if not ok:
         x = x.contiguous()
     return x, (x.stride(0) if B > 1 else Nn * D)
+
+
+def token_dtype_code(x: torch.Tensor) -> int:
+    return N.EP_DTYPE_BF16 if x.dtype == torch.bfloat16 else N.EP_DTYPE_F32
 
 
 def _index_arg(image_index, x):
@@ -68,7 +77,7 @@ def pool_forward(x: torch.Tensor, cls_token: torch.Tensor, scale: float,
     P = torch.empty((B, Q, D), device=x.device, dtype=torch.float32)
     S = torch.empty((B, Q, Nn), device=x.device, dtype=torch.float32)
     ML = torch.empty((B, Q, 4), device=x.device, dtype=torch.float32)
-    rc = lib.ep_pool_forward(x.data_ptr(), N.EP_DTYPE_F32, bstride, iptr, B, Nn, D, cls.data_ptr(), cls_bstride, Q,
+    rc = lib.ep_pool_forward(x.data_ptr(), token_dtype_code(x), bstride, iptr, B, Nn, D, cls.data_ptr(), cls_bstride, Q,
                              float(scale), P.data_ptr(), S.data_ptr(), ML.data_ptr(), 0, 0,
                              N.current_stream_ptr(x.device))
     N.check(rc, "ep_pool_forward")
@@ -89,7 +98,7 @@ def pool_backward(x: torch.Tensor, S: torch.Tensor, ML: torch.Tensor, dP: torch.
         accumulate = False
     nbytes = lib.ep_pool_workspace_bytes(B, Nn, D, Q)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    rc = lib.ep_pool_backward(x.data_ptr(), N.EP_DTYPE_F32, bstride, iptr, B, Nn, D, Q, float(scale), S.data_ptr(),
+    rc = lib.ep_pool_backward(x.data_ptr(), token_dtype_code(x), bstride, iptr, B, Nn, D, Q, float(scale), S.data_ptr(),
                               ML.data_ptr(), dP.data_ptr(), dcls.data_ptr(), int(accumulate), ws.data_ptr(), nbytes,
                               N.current_stream_ptr(x.device))
     N.check(rc, "ep_pool_backward")
@@ -414,7 +423,7 @@ class _CocaPool(torch.autograd.Function):
         ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
         y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
         ps = _coca_params_struct(tens[0], beta_c, *tens[1:])
-        N.check(lib.ep_coca_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, 0, C.byref(ps),
+        N.check(lib.ep_coca_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, C.byref(ps),
                                          float(ln_eps), y.data_ptr(), ws.data_ptr(), nbytes,
                                          N.current_stream_ptr(xv.device)), "ep_coca_pool_forward")
         ctx.save_for_backward(xv, ws, *tens)
@@ -434,7 +443,7 @@ class _CocaPool(torch.autograd.Function):
         grads = [torch.empty_like(t) for t in (gamma, imgq, to_q, to_kv, to_out)]
         ps = _coca_params_struct(gamma, ctx.beta, imgq, to_q, to_kv, to_out)
         gs = _coca_params_struct(grads[0], None, *grads[1:])
-        N.check(lib.ep_coca_pool_backward(C.byref(ctx.dims), xv.data_ptr(), N.EP_DTYPE_F32, ctx.bstride, 0,
+        N.check(lib.ep_coca_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0,
                                           C.byref(ps), dy.data_ptr(), C.byref(gs), 0, ws.data_ptr(), ws.numel(),
                                           N.current_stream_ptr(xv.device)), "ep_coca_pool_backward")
         return (None, grads[0], None, grads[1], grads[2], grads[3], grads[4], None, None, None)
@@ -456,7 +465,7 @@ def coca_attention(x, gamma, beta, img_queries, to_q, to_kv, to_out, heads, dim_
     ps = _coca_params_struct(_f32c(gamma, "gamma"), beta, _f32c(img_queries, "img_queries"), _f32c(to_q, "to_q"),
                              _f32c(to_kv, "to_kv"), _f32c(to_out, "to_out"))
     st = N.current_stream_ptr(xv.device)
-    N.check(lib.ep_coca_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride, 0, C.byref(ps),
+    N.check(lib.ep_coca_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, C.byref(ps),
                                      float(ln_eps), y.data_ptr(), ws.data_ptr(), nbytes, st), "ep_coca_pool_forward")
     A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
     N.check(lib.ep_coca_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_coca_attention")

@@ -5,8 +5,10 @@ The reference can dump frozen-backbone tokens only as one small ``.npz`` (``toke
 encoder (BASELINE config 5) needs the whole dataset's tokens on disk once and then a reader that
 keeps the head kernels fed.  This module provides
 
-  * a sharded on-disk format: ``meta.json`` + ``tokens-XXXXX.bin`` (raw row-major ``(n_i, N, D)`` fp32)
-    + ``labels-XXXXX.npy``; shards are independent, so ranks partition them with no communication;
+  * a sharded on-disk format: ``meta.json`` + ``tokens-XXXXX.bin`` (raw row-major ``(n_i, N, D)`` fp32 or bf16)
+    + ``labels-XXXXX.npy``; shards are independent, so ranks partition them with no communication.  bf16 storage
+    halves disk / HBM footprint (the 1.28 M x 196 x 4096 tokens of a ViT-7B fit 8 GPUs only in bf16); the token
+    passes widen bf16 to fp32 on the fly and compute in fp32;
   * ``TokenStoreWriter`` / ``read_reference_npz`` (imports the reference's ``.npz`` dump);
   * ``ResidentTokenStore``: a rank's shard loaded ONCE into HBM (288 GB per MI355X: 163 k images of
     256x768 fp32 tokens per GPU, the whole 1.28 M-image ImageNet train set on 8 GPUs) and batches
@@ -29,10 +31,12 @@ META = "meta.json"
 
 class TokenStoreWriter:
     def __init__(self, out_dir: str, num_tokens: int, dim: int, shard_images: int = 8192, dtype: str = "float32"):
-        if dtype != "float32":
-            raise NotImplementedError("token store dtype: float32 only in this build")
+        if dtype not in ("float32", "bfloat16"):
+            raise NotImplementedError("token store dtype: float32 or bfloat16")
+        if dtype == "bfloat16" and dim % 8 != 0:
+            raise ValueError("bfloat16 token store: dim must be a multiple of 8")
         os.makedirs(out_dir, exist_ok=True)
-        self.out_dir, self.N, self.D, self.shard_images = out_dir, num_tokens, dim, shard_images
+        self.out_dir, self.N, self.D, self.shard_images, self.dtype = out_dir, num_tokens, dim, shard_images, dtype
         self.shards: List[dict] = []
         self._tok: List[np.ndarray] = []
         self._lab: List[np.ndarray] = []
@@ -49,7 +53,7 @@ class TokenStoreWriter:
     def _flush(self, n: int) -> None:
         tok = np.concatenate(self._tok); lab = np.concatenate(self._lab)
         idx = len(self.shards)
-        tok[:n].tofile(os.path.join(self.out_dir, f"tokens-{idx:05d}.bin"))
+        _encode(tok[:n], self.dtype).tofile(os.path.join(self.out_dir, f"tokens-{idx:05d}.bin"))
         np.save(os.path.join(self.out_dir, f"labels-{idx:05d}.npy"), lab[:n])
         self.shards.append({"index": idx, "images": int(n)})
         self._tok, self._lab, self._n = ([tok[n:]] if len(tok) > n else []), ([lab[n:]] if len(lab) > n else []), len(tok) - n
@@ -57,11 +61,23 @@ class TokenStoreWriter:
     def close(self) -> dict:
         if self._n:
             self._flush(self._n)
-        meta = {"format": "ep-token-store-v1", "num_tokens": self.N, "dim": self.D, "dtype": "float32",
+        meta = {"format": "ep-token-store-v1", "num_tokens": self.N, "dim": self.D, "dtype": self.dtype,
                 "shards": self.shards, "total_images": int(sum(s["images"] for s in self.shards))}
         with open(os.path.join(self.out_dir, META), "w") as f:
             json.dump(meta, f, indent=1)
         return meta
+
+
+def _encode(tok: np.ndarray, dtype: str) -> np.ndarray:
+    """fp32 -> stored element type; bf16 (round to nearest even) travels as its raw 16-bit pattern."""
+    if dtype == "float32":
+        return tok
+    return torch.from_numpy(np.ascontiguousarray(tok)).to(torch.bfloat16).view(torch.int16).numpy()
+
+
+def _to_torch(arr: np.ndarray, dtype: str) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    return t.view(torch.bfloat16) if dtype == "bfloat16" else t
 
 
 def read_reference_npz(path: str) -> Tuple[np.ndarray, List[str]]:
@@ -84,7 +100,8 @@ def shards_of_rank(meta: dict, world: int, rank: int) -> List[dict]:
 
 
 def open_shard(store_dir: str, meta: dict, shard: dict) -> Tuple[np.memmap, np.ndarray]:
-    tok = np.memmap(os.path.join(store_dir, f"tokens-{shard['index']:05d}.bin"), dtype=np.float32, mode="r",
+    tok = np.memmap(os.path.join(store_dir, f"tokens-{shard['index']:05d}.bin"),
+                    dtype=np.float32 if meta.get("dtype", "float32") == "float32" else np.int16, mode="r",
                     shape=(shard["images"], meta["num_tokens"], meta["dim"]))
     lab = np.load(os.path.join(store_dir, f"labels-{shard['index']:05d}.npy"))
     return tok, lab
@@ -100,12 +117,14 @@ class ResidentTokenStore:
         mine = shards_of_rank(meta, world, rank)
         n = sum(s["images"] for s in mine)
         self.N, self.D, self.seed, self.rank = meta["num_tokens"], meta["dim"], seed, rank
-        self.tokens = torch.empty((max(n, 1), self.N, self.D), device=device, dtype=torch.float32)
+        self.dtype = meta.get("dtype", "float32")
+        tdt = torch.float32 if self.dtype == "float32" else torch.bfloat16
+        self.tokens = torch.empty((max(n, 1), self.N, self.D), device=device, dtype=tdt)
         labels = []
         off = 0
         for s in mine:
             tok, lab = open_shard(store_dir, meta, s)
-            self.tokens[off:off + s["images"]].copy_(torch.from_numpy(np.ascontiguousarray(tok)))
+            self.tokens[off:off + s["images"]].copy_(_to_torch(tok, self.dtype))
             labels.append(lab); off += s["images"]
         self.num_images = n
         self.labels = torch.from_numpy(np.concatenate(labels) if labels else np.zeros(0, np.int64)).to(device)
@@ -129,8 +148,10 @@ class StreamingTokenLoader:
         self.shards = shards_of_rank(self.meta, world, rank)
         self.stream = torch.cuda.Stream(device=device)
         N, D = self.meta["num_tokens"], self.meta["dim"]
-        self.stage = [torch.empty((batch_size, N, D), dtype=torch.float32).pin_memory() for _ in range(2)]
-        self.dev = [torch.empty((batch_size, N, D), dtype=torch.float32, device=device) for _ in range(2)]
+        self.dtype = self.meta.get("dtype", "float32")
+        tdt = torch.float32 if self.dtype == "float32" else torch.bfloat16
+        self.stage = [torch.empty((batch_size, N, D), dtype=tdt).pin_memory() for _ in range(2)]
+        self.dev = [torch.empty((batch_size, N, D), dtype=tdt, device=device) for _ in range(2)]
 
     def __len__(self):
         return sum(s["images"] // self.B for s in self.shards)
@@ -147,7 +168,7 @@ class StreamingTokenLoader:
                 buf = k & 1
                 if copied[buf] is not None:
                     copied[buf].synchronize()                     # previous H2D out of this staging buffer is done
-                self.stage[buf].copy_(torch.from_numpy(np.ascontiguousarray(tok[lo:lo + self.B])))
+                self.stage[buf].copy_(_to_torch(tok[lo:lo + self.B], self.dtype))
                 with torch.cuda.stream(self.stream):
                     if consumed[buf] is not None:
                         self.stream.wait_event(consumed[buf])     # consumer finished with this device buffer

@@ -75,6 +75,8 @@ size_t ep_pool_workspace_bytes(int B, int N, int D, int Q);
 /* name of the device kernel ep_pool_forward / ep_pool_backward will launch for this shape (for
  * matching profiler output; static string) */
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward);
+/* same, for a given token storage type (EP_DTYPE_F32 / EP_DTYPE_BF16) */
+const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype);
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
                     int B, int N, int D,
                     const float* cls_token, int64_t cls_bstride, int Q, float scale,

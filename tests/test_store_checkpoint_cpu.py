@@ -108,3 +108,24 @@ def test_export_format(tmp_path):
     enc3 = make_head(q=4)
     CK.load_model(Namespace(resume=os.path.join(dst, "ep_head.pth"), start_epoch=0), enc3, None, None)
     assert torch.equal(enc3.head[2].weight, enc.head[2].weight)
+
+
+def test_bf16_token_store_roundtrip(tmp_path):
+    """bf16 storage: values are the round-to-nearest-even bf16 of the fp32 tokens, shards hold raw 16-bit patterns."""
+    import torch
+    from efficient_probing_amd import token_store as TS
+    rng = np.random.default_rng(3)
+    w = TS.TokenStoreWriter(str(tmp_path), num_tokens=3, dim=16, shard_images=4, dtype="bfloat16")
+    t = rng.standard_normal((6, 3, 16), dtype=np.float32)
+    w.add(t, np.arange(6))
+    meta = w.close()
+    assert meta["dtype"] == "bfloat16" and [s["images"] for s in meta["shards"]] == [4, 2]
+    tok, lab = TS.open_shard(str(tmp_path), meta, meta["shards"][0])
+    assert tok.dtype == np.int16 and os.path.getsize(tmp_path / "tokens-00000.bin") == 4 * 3 * 16 * 2
+    back = TS._to_torch(np.asarray(tok), "bfloat16").float().numpy()
+    want = torch.from_numpy(t[:4]).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(back, want) and np.abs(back - t[:4]).max() < 2 ** -7 * np.abs(t).max()
+    with pytest.raises(ValueError):
+        TS.TokenStoreWriter(str(tmp_path / "x"), num_tokens=3, dim=12, dtype="bfloat16")
+    with pytest.raises(NotImplementedError):
+        TS.TokenStoreWriter(str(tmp_path / "y"), num_tokens=3, dim=16, dtype="float16")
