@@ -197,11 +197,13 @@ def main():
 
     for i in range(args.warmup):
         eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+    eng.flush()                                             # (data parallel: the deferred half of a pipelined step)
     eng.read_stats()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+    eng.flush()                                             # all K steps complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -52,6 +52,7 @@ class EPHeadStep(C.Structure):
         ("opt_step", C.c_int64),
         ("phases", C.c_int32),
         ("aux_stream", C.c_void_p),
+        ("opt_first_segment", C.c_int32), ("opt_num_segments", C.c_int32),
     ]
 
 

@@ -344,12 +344,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   float* cls = s->params + offs[0]; float* Wv = s->params + offs[1];
   float* Wc = s->params + offs[2]; float* bc = s->params + offs[3];
   const float scale = (float)pow((double)d.D, -0.5);   // head_dim ** -0.5 with num_heads = 1 (ep.py:19-20)
-  if (s->phases & 1) {
+  if (s->phases & (1 | 4 | 8)) {
     EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
     EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.Q));
-    PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale, s->x_dtype);
-    p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
-    EP_TRY(pool_forward(p, st));
+  }
+  PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale, s->x_dtype);
+  p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
+  if (s->phases & (1 | 4)) EP_TRY(pool_forward(p, st));      // first token pass: depends on cls_token only
+  if (s->phases & (1 | 8)) {
     EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));
@@ -407,8 +409,13 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     ep_segment segs[4];
     const int64_t sizes[4] = {(int64_t)d.Q * d.D, (int64_t)Dp * d.D, (int64_t)d.C * Dp, (int64_t)d.C};
     for (int i = 0; i < 4; ++i) segs[i] = ep_segment{offs[i], sizes[i], i < 3 ? 1 : 0, 0};   // bias: ndim 1
+    const bool sub = s->opt_num_segments > 0;
+    EP_REQUIRE(!sub || (s->opt_first_segment >= 0 && s->opt_first_segment + s->opt_num_segments <= 4), EP_E_ARG,
+               "optimizer segment range [%d, +%d) outside the four tensors", s->opt_first_segment, s->opt_num_segments);
+    const ep_segment* use = (s->optimizer == 0 || sub) ? segs + (sub ? s->opt_first_segment : 0) : nullptr;
+    const int nuse = (s->optimizer == 0 || sub) ? (sub ? s->opt_num_segments : 4) : 0;
     EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
-                      s->optimizer == 0 ? segs : nullptr, s->optimizer == 0 ? 4 : 0, s->lr, s->weight_decay,
+                      use, nuse, s->lr, s->weight_decay,
                       s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,
                       s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st));
   }

@@ -63,7 +63,7 @@ class ProbeHeadEngine:
     def __init__(self, head: nn.Sequential, optimizer: str = "lars", lr: float = 0.0, weight_decay: float = 0.0,
                  momentum: float = 0.9, trust_coefficient: float = 0.001, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                  process_group=None, loss_scale: float = 1.0, accum_iter: int = 1, broadcast_from_rank0: bool = True,
-                 overlap: bool = True):
+                 overlap: bool = True, overlap_comm=None):
         self._check_head(head)
         if optimizer not in OPTIMIZERS:
             raise ValueError(f"optimizer must be one of {sorted(OPTIMIZERS)}")
@@ -101,9 +101,22 @@ class ProbeHeadEngine:
         self._ws = None
         self._ws_key = None
         self.aux_stream = torch.cuda.Stream(device=dev) if overlap else None
+        # Communication overlap (EP head, data parallel): the next step's first token pass needs the updated
+        # cls_token only, so the step all-reduces + updates cls_token first and lets the large all-reduce of the
+        # other gradients (and their update) run beside the next first token pass.  Same arithmetic, same order.
+        # None: on when world > 1, no gradient accumulation and no loss scaling (the inf-skip of a GradScaler
+        # needs all gradients before any update); "force": also with one rank (tests); env EP_OVERLAP_COMM=0: off.
+        import os
+        want = overlap_comm if overlap_comm is not None else (os.environ.get("EP_OVERLAP_COMM", "1") != "0")
+        self._pipelined = bool(want) and self._supports_comm_overlap() and self.accum_iter == 1 \
+            and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force")
+        self._pending = None
         if broadcast_from_rank0 and self.world > 1:
             dist.broadcast(self.flat_p, src=0, group=self.group)     # what DDP does at wrap time
             self.sync_buffers()
+
+    def _supports_comm_overlap(self) -> bool:
+        return type(self) is ProbeHeadEngine           # the split phases exist for the EP head only
 
     # ------------------------------------------------------------------------------------
     def mu_views(self):
@@ -111,6 +124,7 @@ class ProbeHeadEngine:
         return [self.state[0][o:o + p.numel()].view(p.shape) for p, o in zip(self.params_list, self.offsets)]
 
     def sync_buffers(self):
+        self.flush()
         if self.world > 1:
             for b in (self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked):
                 dist.broadcast(b, src=0, group=self.group)
@@ -160,6 +174,7 @@ class ProbeHeadEngine:
         """Phase 1: forward + CE + backward into the flat gradient buffer (accumulating across
         micro-steps when accum_iter > 1).  Adds to ``self.stats``.  With ``image_index`` (int32 (B,)),
         ``x`` is a token store resident in HBM and the batch is read from it in place."""
+        self.flush()
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
@@ -174,20 +189,64 @@ class ProbeHeadEngine:
         """THE collective of a data-parallel step: one sum all-reduce of the flat gradients
         (parallel.all_reduce_flat_grads); the 1/world factor rides on the optimizer's inv_scale."""
         from .parallel import all_reduce_flat_grads
+        self.flush()
         all_reduce_flat_grads(self.flat_g, self.group)
 
-    def optimizer_step(self, lr: Optional[float] = None) -> None:
-        self.opt_step += 1
+    def _optimizer_call(self, lr, first_seg=0, num_segs=0, opt_step=None) -> None:
         ws = self._ws
         if ws is None:
             raise RuntimeError("optimizer_step before any forward_backward")
         s = self._step_struct(None, 0, None, 2, False, lr)
+        if opt_step is not None:
+            s.opt_step = opt_step
+        if num_segs:
+            s.opt_first_segment, s.opt_num_segments = first_seg, num_segs
         N.check(self._call_train(s, ws), "head train step (optimizer)")
+
+    def optimizer_step(self, lr: Optional[float] = None) -> None:
+        self.flush()
+        self.opt_step += 1
+        self._optimizer_call(lr)
         self._micro = 0
+
+    def flush(self) -> None:
+        """Complete the deferred half of a pipelined step: wait for the large gradient all-reduce and update the
+        tensors it covers.  Called automatically before anything that reads those parameters."""
+        if self._pending is not None:
+            work, lr, step = self._pending
+            self._pending = None
+            if work is not None:
+                work.wait()                                   # the current stream waits; the host does not
+            self._optimizer_call(lr, 1, len(self.params_list) - 1, opt_step=step)
+
+    def _train_step_pipelined(self, x, targets, lr, image_index) -> None:
+        xv, bstride = F_.as_token_view(x)
+        _, Nn, D = xv.shape
+        iptr, B = F_._index_arg(image_index, xv)
+        ws = self._workspace(B, Nn)
+        targets = targets.to(device=self.device, dtype=torch.int64)
+        s = self._step_struct(xv, bstride, targets, 4, False, None)          # first token pass (needs cls_token only)
+        s.image_index = iptr
+        N.check(self._call_train(s, ws), "head train step (first token pass)")
+        self.flush()                                                         # previous step's large bucket lands here
+        s = self._step_struct(xv, bstride, targets, 8, False, None)
+        s.image_index = iptr
+        N.check(self._call_train(s, ws), "head train step (rest of fwd+bwd)")
+        cut = self.offsets[1]
+        w1 = w2 = None
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+            w1 = dist.all_reduce(self.flat_g[:cut], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w2 = dist.all_reduce(self.flat_g[cut:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w1.wait()
+        self.opt_step += 1
+        self._optimizer_call(lr, 0, 1)                                       # cls_token: the next step can start
+        self._pending = (w2, lr, self.opt_step)
 
     def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None,
                    image_index: Optional[torch.Tensor] = None) -> None:
         """One full iteration (accum_iter == 1): forward/backward, gradient all-reduce, update."""
+        if self._pipelined:
+            return self._train_step_pipelined(x, targets, lr, image_index)
         self.forward_backward(x, targets, image_index)
         if self._micro >= self.accum_iter:
             self.all_reduce_grads()
@@ -195,6 +254,7 @@ class ProbeHeadEngine:
 
     @torch.no_grad()
     def eval_logits(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self.flush()
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)

@@ -218,6 +218,9 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             epoch_1000x = int((step / n_iter + epoch) * 1000)
             log_writer.add_scalar("loss", misc.all_reduce_mean(metric_logger.meters["loss"].value), epoch_1000x)
             log_writer.add_scalar("lr", metric_logger.meters["lr"].value, epoch_1000x)
+    eng = getattr(model.module if hasattr(model, "module") else model, "_ep_engine", None)
+    if eng is not None:
+        eng.flush()                       # a pipelined data-parallel step defers its large update by half a step
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     return {k: m.global_avg for k, m in metric_logger.meters.items()}

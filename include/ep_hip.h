@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 6
+#define EP_ABI_VERSION 7
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -216,6 +216,14 @@ typedef struct ep_head_step {
   ep_stream_t aux_stream; /* optional second caller-owned stream: the weight-gradient contractions
                              (dWc, dWv, dbc) that nothing else in the step depends on run there,
                              concurrently with the second token pass; NULL = everything on `stream` */
+  /* Split phases for communication overlap (ABI v7).  phases bit 2 (4): only the first token pass
+   * (needs nothing but cls_token); bit 3 (8): everything of phase 1 after it.  1 == 4|8.
+   * The optimizer phase updates parameter tensors [opt_first_segment, opt_first_segment +
+   * opt_num_segments) of the flat layout (0, 0 = all four): a data-parallel caller all-reduces the
+   * cls_token gradient first, updates it, starts the next step's first token pass and lets the large
+   * all-reduce of the remaining gradients run beside it (see engine.ProbeHeadEngine).  found_inf /
+   * grad_norm then cover the updated tensors only. */
+  int32_t opt_first_segment, opt_num_segments;
 } ep_head_step;
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);

@@ -1,0 +1,84 @@
+"""Communication overlap of the data-parallel EP step (engine.ProbeHeadEngine, split phases of ep_head_train_step):
+the pipelined schedule -- all-reduce + update cls_token, start the next first token pass, let the large all-reduce
+and its update land beside it -- must produce exactly the parameters of the plain schedule.  One rank, so the
+collectives are identities, but every stream dependency and every deferred update is exercised.
+Needs an MI355X (pytest -m gpu)."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from cases import Case, make_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(case, inp, **kw):
+    from efficient_probing_amd import probe_heads
+    from efficient_probing_amd.engine import ProbeHeadEngine
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(case.D, case.C)
+    enc = Enc()
+    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=case.Q, d_out=1, nb_classes=case.C))
+    head = enc.head
+    with torch.no_grad():
+        head[0].cls_token.copy_(torch.from_numpy(inp["cls_token"])); head[0].v.weight.copy_(torch.from_numpy(inp["v_weight"]))
+        head[2].weight.copy_(torch.from_numpy(inp["fc_weight"])); head[2].bias.copy_(torch.from_numpy(inp["fc_bias"]))
+    return ProbeHeadEngine(head.to(DEV).train(), **kw)
+
+
+@pytest.fixture
+def one_rank_group():
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            created = True
+        except Exception as e:           # no RCCL in this process: still test the schedule without collectives
+            print("no process group:", e)
+    yield dist.is_initialized()
+    if created:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("opt", ["lars", "sgd", "adamw"])
+def test_pipelined_step_equals_plain_step(one_rank_group, opt):
+    case = Case("ov", B=32, N=50, D=256, Q=8, C=40, seed=21, weight_decay=1e-3)
+    inp = make_inputs(case)
+    plain = build(case, inp, optimizer=opt, weight_decay=case.weight_decay, overlap_comm=False)
+    piped = build(case, inp, optimizer=opt, weight_decay=case.weight_decay, overlap_comm="force")
+    assert piped._pipelined and not plain._pipelined
+    xs = [torch.from_numpy(inp["x_buf"]).to(DEV), torch.from_numpy(inp["x_buf2"]).to(DEV)]
+    ts = [torch.from_numpy(inp["targets"]).to(DEV), torch.from_numpy(inp["targets2"]).to(DEV)]
+    for step in range(5):
+        lr = [0.05, 0.3, 0.2, 0.1, 0.02][step] * (0.02 if opt == "adamw" else 1.0)
+        plain.train_step(xs[step % 2], ts[step % 2], lr=lr)
+        piped.train_step(xs[step % 2], ts[step % 2], lr=lr)
+        # cls_token is current after every step; the other tensors trail by the deferred update until flush()
+        assert torch.equal(plain.params_list[0], piped.params_list[0])
+    assert piped._pending is not None
+    logits = piped.eval_logits(xs[0])                     # flushes
+    assert piped._pending is None
+    assert torch.equal(plain.flat_p, piped.flat_p)
+    for a, b in zip(plain.state, piped.state):
+        assert torch.equal(a, b)
+    assert torch.equal(logits, plain.eval_logits(xs[0]))
+    assert plain.read_stats() == piped.read_stats()
+    assert plain.opt_step == piped.opt_step == 5
+
+
+def test_overlap_is_off_when_it_must_be():
+    case = Case("ov2", B=8, N=17, D=64, Q=4, C=10, seed=2)
+    inp = make_inputs(case)
+    assert not build(case, inp, overlap_comm="force", accum_iter=2)._pipelined       # gradient accumulation
+    assert not build(case, inp, overlap_comm="force", loss_scale=1024.0)._pipelined  # GradScaler inf-skip needs all grads
+    assert not build(case, inp)._pipelined                                           # one rank: nothing to overlap
