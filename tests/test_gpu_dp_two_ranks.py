@@ -1,0 +1,81 @@
+"""Two data-parallel ranks on ONE GPU (gloo backend moving CUDA tensors): the real kernels, the real two-bucket
+all-reduce and the pipelined schedule of engine.ProbeHeadEngine, against an in-process simulation of the same two ranks
+(plain schedule, gradients summed by hand).  Every rank must end with the same parameters, bit for bit equal to the
+simulation.  Needs an MI355X (pytest -m gpu)."""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPE = dict(B=24, N=40, D=256, Q=8, C=30)
+STEPS, LRS = 4, [0.05, 0.3, 0.2, 0.1]
+
+
+def _build(overlap_comm, world_aware=True):
+    from efficient_probing_amd import probe_heads
+    from efficient_probing_amd.engine import ProbeHeadEngine
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(SHAPE["D"], SHAPE["C"])
+    torch.manual_seed(0)
+    enc = Enc()
+    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=SHAPE["Q"], d_out=1, nb_classes=SHAPE["C"]))
+    return ProbeHeadEngine(enc.head.to("cuda:0").train(), optimizer="lars", weight_decay=1e-3, overlap_comm=overlap_comm)
+
+
+def _data(rank, step):
+    g = torch.Generator().manual_seed(1000 * rank + step)
+    x = torch.randn(SHAPE["B"], SHAPE["N"], SHAPE["D"], generator=g)
+    t = torch.randint(0, SHAPE["C"], (SHAPE["B"],), generator=g)
+    return x.to("cuda:0"), t.to("cuda:0")
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    eng = _build(overlap_comm=True)
+    assert eng.world == world and eng._pipelined
+    for step in range(STEPS):
+        x, t = _data(rank, step)
+        eng.train_step(x, t, lr=LRS[step])
+    eng.flush()
+    eng.sync_buffers()
+    torch.cuda.synchronize()
+    torch.save({"p": eng.flat_p.cpu(), "mu": eng.state[0].cpu(), "rm": eng.bn.running_mean.cpu()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_pipelined_equals_simulation(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 29650 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert torch.equal(got[0]["p"], got[1]["p"]) and torch.equal(got[0]["mu"], got[1]["mu"])
+    assert torch.equal(got[0]["rm"], got[1]["rm"])                       # sync_buffers: rank 0's running statistics
+    # in-process simulation: two replicas, plain schedule, gradients summed by hand, 1/world in the optimizer
+    reps = [_build(overlap_comm=False) for _ in range(world)]
+    for e in reps:
+        e.world = world                                                  # inv_scale = 1 / (loss_scale * world)
+    for step in range(STEPS):
+        for r, e in enumerate(reps):
+            x, t = _data(r, step)
+            e.forward_backward(x, t)
+        total = reps[0].flat_g + reps[1].flat_g
+        for e in reps:
+            e.flat_g.copy_(total)
+            e.optimizer_step(LRS[step])
+    assert torch.equal(reps[0].flat_p, reps[1].flat_p)
+    assert torch.equal(got[0]["p"], reps[0].flat_p.cpu())
+    assert torch.equal(got[0]["mu"], reps[0].state[0].cpu())
+    assert torch.equal(got[0]["rm"], reps[0].bn.running_mean.cpu())
