@@ -44,6 +44,7 @@ struct SideTasks {
   const float* cs_src; float* cs_out; int cs_B, cs_ncol, cs_ld, cs_accumulate, n_colsum;
   const float* rowstat; float* stats; int rs_B, n_stats;
   int total;                        // number of extra workgroups
+  int first_block;                  // set by the launcher: side workgroups occupy blocks [first_block, first_block + total)
 };
 
 // element offset of image b of the batch inside the token buffer

@@ -317,11 +317,19 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   constexpr int ES = BF16 ? 2 : 4;
   constexpr int HR = Cfg::TT;                       // fp32 dP rows that fit one ring slot (header items)
   extern __shared__ __attribute__((aligned(1024))) char ring[];
-  const int G = gridDim.x - side.total;             // pooling workgroups; the rest run side tasks
+  // Block order = dispatch order: pooling workgroups [0, first_block), then the side tasks, then the remaining
+  // pooling workgroups.  Default first_block = G: the side tasks fill the tail of the pass.  Starting them earlier
+  // (EP_SIDE_EARLY=<first_block>, diagnostics) measured slower at every position (0.495-0.520 vs 0.489 ms per step at
+  // 256x768): dispatch is in order, so pooling workgroups queued behind the side tasks start late.
+  const int G = gridDim.x - side.total;             // pooling workgroups
+  int wg = blockIdx.x;
   if constexpr (NW == 4) {
-    if ((int)blockIdx.x >= G) {
-      run_side_task(side, (int)blockIdx.x - G, ring);
-      return;
+    if (wg >= side.first_block) {
+      if (wg < side.first_block + side.total) {
+        run_side_task(side, wg - side.first_block, ring);
+        return;
+      }
+      wg -= side.total;
     }
   }
   const int lane = lane_id();
@@ -336,7 +344,6 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const int tiles_per_img = (N + TT - 1) / TT;
   const int H = (Q + HR - 1) / HR;
   const int items_per_img = H + tiles_per_img;
-  const int wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * items_per_img;
   const int q0 = w * QW;
@@ -479,6 +486,11 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
     if (NW != 4) { set_error("side tasks need 4-wave workgroups"); return EP_E_UNSUPPORTED; }
     sd = *side;
     if (lds < SIDE_LDS_BYTES) lds = SIDE_LDS_BYTES;
+    static int early = -1;
+    if (early < 0) { const char* e = getenv("EP_SIDE_EARLY"); early = e ? atoi(e) : 0; }
+    sd.first_block = (early > 0 && early < grid) ? early : grid;
+  } else {
+    sd.first_block = grid;
   }
   auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX, BF16>;
   auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX, BF16>;
