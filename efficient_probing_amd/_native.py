@@ -154,6 +154,11 @@ SIGNATURES = {
     "ep_head_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),
     "ep_head_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p,
                                      c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_lp_param_offsets": (c_i64, [C.POINTER(EPHeadDims), C.POINTER(c_i64)]),
+    "ep_lp_workspace_bytes": (c_size, [C.POINTER(EPHeadDims)]),
+    "ep_lp_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),
+    "ep_lp_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void,
+                                   c_size, c_void]),
     "ep_coca_pool_workspace_bytes": (c_size, [C.POINTER(EPCocaDims)]),
     "ep_coca_pool_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, C.POINTER(EPCocaParams),
                                      c_float, c_f32p, c_void, c_size, c_void]),

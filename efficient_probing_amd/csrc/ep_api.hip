@@ -447,4 +447,92 @@ int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, i
   return 0;
 }
 
+
+/* ---- plain linear probing: BatchNorm1d + Linear on (B, D) features ---------------------------------- */
+struct LpWs { float *z, *rstd, *logits, *dlogits, *rowstat, *bnpart; void* opt_ws; size_t opt_ws_bytes; int ldl; size_t total; };
+
+static LpWs lp_carve(const ep_head_dims& d, void* base) {
+  LpWs w{};
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += round_up(nfloat * sizeof(float), 256);
+    return p;
+  };
+  w.ldl = (d.C + 3) / 4 * 4;
+  const size_t B = d.B;
+  w.z = take(B * d.D); w.rstd = take(d.D); w.logits = take(B * w.ldl); w.dlogits = take(B * w.ldl);
+  w.rowstat = take(B * 4); w.bnpart = take(bn_workspace_bytes(d.B, d.D) / sizeof(float));
+  int64_t offs[2];
+  w.opt_ws_bytes = optim_workspace_bytes(ep_lp_param_offsets(&d, offs), 2);
+  w.opt_ws = take(w.opt_ws_bytes / sizeof(float));
+  w.total = off;
+  return w;
+}
+
+int64_t ep_lp_param_offsets(const ep_head_dims* d, int64_t offsets[2]) {
+  offsets[0] = 0;
+  offsets[1] = ((int64_t)d->C * d->D + 3) / 4 * 4;
+  return offsets[1] + ((int64_t)d->C + 3) / 4 * 4;
+}
+
+size_t ep_lp_workspace_bytes(const ep_head_dims* dims) {
+  if (!dims || dims->B <= 0 || dims->D <= 0 || dims->C <= 0 || dims->D % 4 != 0) {
+    set_error("linear probe dims: B, D, C must be positive and D a multiple of 4");
+    return 0;
+  }
+  return lp_carve(*dims, nullptr).total;
+}
+
+int ep_lp_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(s && ws, EP_E_ARG, "ep_lp_train_step: null pointer");
+  const ep_head_dims& d = s->dims;
+  EP_REQUIRE(d.B > 0 && d.D > 0 && d.C > 0 && d.D % 4 == 0, EP_E_SHAPE, "linear probe dims: B, D, C must be positive and D a multiple of 4");
+  EP_REQUIRE(aligned16(ws), EP_E_ALIGN, "workspace must be 16-byte aligned");
+  const LpWs w = lp_carve(d, ws);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_lp_train_step: workspace %zu < %zu", ws_bytes, w.total);
+  EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t offs[2];
+  const int64_t total = ep_lp_param_offsets(&d, offs);
+  float* Wc = s->params + offs[0]; float* bc = s->params + offs[1];
+  if (s->phases & 1) {
+    EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
+    EP_REQUIRE(s->x_dtype == EP_DTYPE_F32 && s->x_bstride == d.D && aligned16(s->x), EP_E_SHAPE,
+               "linear probe: features must be a dense 16-byte aligned (B, D) fp32 matrix");
+    const float* x = static_cast<const float*>(s->x);
+    EP_TRY(bn_forward_train(x, d.B, d.D, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
+                            s->num_batches_tracked, w.bnpart, st));
+    EP_TRY(linear_forward(w.z, Wc, bc, d.B, d.D, d.C, w.logits, w.ldl, st));
+    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
+    EP_TRY(ce_stats(w.rowstat, d.B, s->stats, st));
+    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, nullptr, s->grads + offs[0], s->grads + offs[1],
+                           s->accumulate, st));
+  }
+  if (s->phases & 2) {
+    EP_REQUIRE(s->found_inf, EP_E_ARG, "optimizer phase needs found_inf");
+    ep_segment segs[2] = {{offs[0], (int64_t)d.C * d.D, 1, 0}, {offs[1], (int64_t)d.C, 0, 0}};
+    EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
+                      s->optimizer == 0 ? segs : nullptr, s->optimizer == 0 ? 2 : 0, s->lr, s->weight_decay, s->momentum,
+                      s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step, s->found_inf,
+                      s->grad_norm, w.opt_ws, w.opt_ws_bytes, st));
+  }
+  return 0;
+}
+
+int ep_lp_eval_forward(const ep_head_dims* dims, const float* x, const float* params, const float* running_mean,
+                       const float* running_var, float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
+                       ep_stream_t stream) {
+  EP_REQUIRE(dims && x && params && running_mean && running_var && logits && ws, EP_E_ARG, "ep_lp_eval_forward: null pointer");
+  const ep_head_dims& d = *dims;
+  EP_REQUIRE(d.B > 0 && d.D > 0 && d.C > 0 && d.D % 4 == 0 && ldl >= d.C, EP_E_SHAPE, "ep_lp_eval_forward: bad dims");
+  const LpWs w = lp_carve(d, ws);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_lp_eval_forward: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t offs[2];
+  ep_lp_param_offsets(&d, offs);
+  EP_TRY(bn_forward_eval(x, d.B, d.D, bn_eps, running_mean, running_var, w.z, st));
+  return linear_forward(w.z, params + offs[0], params + offs[1], d.B, d.D, d.C, logits, ldl, st);
+}
+
 }  // extern "C"

@@ -37,6 +37,7 @@ class ProbeHeadEngine:
         if not is_native_ep_head(head):
             raise TypeError("ProbeHeadEngine needs Sequential(EfficientProbing, BatchNorm1d, Linear)")
 
+
     def _layout(self):
         """-> (dims struct, parameters in flat order, offsets, total elements)"""
         D = self.pool.v.in_features
@@ -361,9 +362,74 @@ class AbmilpHeadEngine(ProbeHeadEngine):
                                                     ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class LinearProbeEngine(ProbeHeadEngine):
+    """Fused train / eval step of plain linear probing, Sequential(BatchNorm1d, Linear) on one feature vector per
+    image (what the registry builds for --cls_features cls / gap / pos ..., reference probe_heads.py:96-99).
+    ``x`` is a (B, D) feature matrix; a (B, N, D) token tensor is mean-pooled first by the token pass."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_lp_head
+        if not is_native_lp_head(self._lp_head):
+            raise TypeError("LinearProbeEngine needs Sequential(BatchNorm1d(affine=False), Linear)")
+
+    def __init__(self, head, **kw):
+        self._lp_head = head
+        super().__init__(_LPView(head), **kw)
+        self.head = head
+
+    def _layout(self):
+        dims = N.EPHeadDims(B=0, N=1, D=self.fc.in_features, Q=1, d_out=1, C=self.fc.out_features)
+        offs = (C.c_int64 * 2)()
+        total = int(self.lib.ep_lp_param_offsets(C.byref(dims), offs))
+        return dims, [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_lp_workspace_bytes(C.byref(self.dims))
+
+    def _features(self, x, image_index):
+        if image_index is not None:
+            x = x[image_index.long()]
+        if x.dim() == 3:
+            from .knn import mean_tokens
+            x = mean_tokens(x)
+        return F_._f32c(x, "features")
+
+    def _workspace(self, B, Nn):
+        return super()._workspace(B, 1)
+
+    def forward_backward(self, x, targets, image_index=None):
+        f = self._features(x, image_index)
+        super().forward_backward(f.view(f.shape[0], 1, f.shape[1]), targets, None)
+
+    def eval_logits(self, x, image_index=None):
+        f = self._features(x, image_index)
+        return super().eval_logits(f.view(f.shape[0], 1, f.shape[1]), None)
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_lp_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_lp_eval_forward(C.byref(self.dims), xv.data_ptr(), self.flat_p.data_ptr(),
+                                           self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr(), self.bn.eps,
+                                           out.data_ptr(), ldl, ws.data_ptr(), ws.numel(),
+                                           N.current_stream_ptr(self.device))
+
+
+class _LPView:
+    """Presents Sequential(BN, Linear) with the (pooling, bn, fc) indexing the base engine expects."""
+
+    def __init__(self, head):
+        self._h = head
+
+    def __getitem__(self, i):
+        return (None, self._h[0], self._h[1])[i]
+
+
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
-    """The fused engine matching a native head (EP, CoCa or AbMILP)."""
-    from .probe_heads import is_native_abmilp_head, is_native_coca_head
+    """The fused engine matching a native head (EP, CoCa, AbMILP or plain linear probing)."""
+    from .probe_heads import is_native_abmilp_head, is_native_coca_head, is_native_lp_head
+    if is_native_lp_head(head):
+        return LinearProbeEngine(head, **kw)
     if is_native_coca_head(head):
         return CocaHeadEngine(head, **kw)
     if is_native_abmilp_head(head):

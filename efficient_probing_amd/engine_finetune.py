@@ -187,10 +187,13 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         fused = engine is not None and (samples.dim() == 3 or token_fn is not None)
         if fused:
             tokens = samples if samples.dim() == 3 else token_fn(samples)
-            engine.forward_backward(tokens.detach(), targets)
-            if (step + 1) % accum_iter == 0:
-                engine.all_reduce_grads()
-                engine.optimizer_step(lr=max(g["lr"] for g in optimizer.param_groups))
+            if accum_iter == 1:        # one call: lets a data-parallel EP step overlap its large all-reduce
+                engine.train_step(tokens.detach(), targets, lr=max(g["lr"] for g in optimizer.param_groups))
+            else:
+                engine.forward_backward(tokens.detach(), targets)
+                if (step + 1) % accum_iter == 0:
+                    engine.all_reduce_grads()
+                    engine.optimizer_step(lr=max(g["lr"] for g in optimizer.param_groups))
             pending += 1
             if pending == print_freq or step == n_iter - 1:
                 flush_stats(pending)

@@ -175,8 +175,16 @@ def is_native_abmilp_head(head: nn.Module) -> bool:
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
 
 
+def is_native_lp_head(head: nn.Module) -> bool:
+    """True for Sequential(BatchNorm1d(affine=False), Linear): plain linear probing (build_probe_head for names
+    without a pooling entry, reference probe_heads.py:96-99) -- engine.LinearProbeEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 2 and isinstance(head[0], nn.BatchNorm1d)
+            and not head[0].affine and isinstance(head[1], nn.Linear))
+
+
 def is_native_head(head: nn.Module) -> bool:
-    return is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
+    return (is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
+            or is_native_lp_head(head))
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

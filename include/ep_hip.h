@@ -387,6 +387,19 @@ int ep_knn_vote(const float* sims, const int32_t* idx, int ld, const int64_t* tr
                 float T, int num_classes, const int64_t* targets, int32_t* pred, float* counts,
                 ep_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Plain linear probing: Sequential(BatchNorm1d(affine=False, eps=1e-6), Linear) on one feature vector
+ * per image -- what reference probe_heads.py:96-99 builds for --cls_features cls / gap / pos / ... (no
+ * attentive pooling).  Flat parameter buffer: fc.weight (C, D) | fc.bias (C).  Same step struct as the EP
+ * head (dims.N, dims.Q, dims.d_out are ignored; x is the (B, D) fp32 feature matrix, x_bstride = D).
+ * ------------------------------------------------------------------------------------------ */
+int64_t ep_lp_param_offsets(const ep_head_dims* dims, int64_t offsets[2]);
+size_t ep_lp_workspace_bytes(const ep_head_dims* dims);
+int ep_lp_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_lp_eval_forward(const ep_head_dims* dims, const float* x, const float* params, const float* running_mean,
+                       const float* running_var, float bn_eps, float* logits, int ldl, void* ws,
+                       size_t ws_bytes, ep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
