@@ -329,3 +329,46 @@ def test_wide_row_and_generic_kernels_agree(shape):
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(b).max())), err_msg=name)
     Pi, Si, MLi = F_.pool_forward(store, cls, scale, image_index=idx)
     assert torch.equal(Pi.cpu(), torch.from_numpy(outs[1][0])) and torch.equal(Si.cpu(), torch.from_numpy(outs[1][1]))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 64, 1), (2, 3, 64, 4), (1, 5, 768, 8), (3, 1, 4096, 8), (1, 2, 2048, 8), (2, 7, 1152, 8),
+                                   (1, 9, 1024, 16), (5, 4, 200, 5)], ids=lambda s: "x".join(map(str, s)))
+def test_degenerate_shapes(shape):
+    """One image, one token, fewer tokens than a ring tile, a single query: every kernel family against the numpy
+    oracle (forward) and against the generic kernel (backward)."""
+    from efficient_probing_amd import functional as F_, _native
+    B, Nn, D, Q = shape
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((B, Nn, D), dtype=np.float32)
+    cls = (0.3 * rng.standard_normal((1, Q, D), dtype=np.float32)).astype(np.float32)
+    scale = D ** -0.5
+    xd, cd = torch.from_numpy(x).to(DEV), torch.from_numpy(cls).to(DEV)
+    P, S, ML = F_.pool_forward(xd, cd, scale)
+    A = F_.attention_from_scores(S, ML).cpu().numpy()
+    want_A = O.ep_attention(x, cls)
+    np.testing.assert_allclose(A, want_A, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(P.cpu().numpy(), np.einsum("bqn,bnd->bqd", want_A, x), rtol=2e-5, atol=2e-6)
+    dP = torch.from_numpy(rng.standard_normal((B, Q, D), dtype=np.float32)).to(DEV)
+    ML2 = ML.clone(); ML2[:, :, 2] = (dP * P).sum(-1)
+    got = F_.pool_backward(xd, S, ML2, dP, scale).cpu().numpy()
+    lib = _native.load()
+    lib.ep_debug_force_generic_pool(1)
+    try:
+        ref = F_.pool_backward(xd, S, ML2, dP, scale).cpu().numpy()
+    finally:
+        lib.ep_debug_force_generic_pool(0)
+    if Nn == 1:        # one token: A = 1, so dS = dA - dP.P = 0 exactly; both sides hold rounding noise of the two terms
+        assert float(np.abs(got).max()) < 2e-5 and float(np.abs(ref).max()) < 2e-5
+    else:
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(ref).max())))
+
+
+def test_empty_batch_and_bad_token_arguments_fail_loudly():
+    from efficient_probing_amd import functional as F_
+    cls = torch.zeros(1, 4, 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        F_.pool_forward(torch.zeros(0, 5, 64, device=DEV), cls, 0.125)          # B = 0
+    with pytest.raises(RuntimeError):
+        F_.pool_forward(torch.zeros(2, 5, 62, device=DEV), torch.zeros(1, 4, 62, device=DEV), 0.125)   # D % 4 != 0
+    with pytest.raises(ValueError):
+        F_.pool_forward(torch.zeros(2, 64, device=DEV), cls, 0.125)             # not (B, N, D)
