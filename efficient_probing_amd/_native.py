@@ -116,6 +116,37 @@ class EPAbmilpStep(C.Structure):
     ]
 
 
+class EPSiglipDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("hidden", C.c_int32),
+                ("C", C.c_int32)]
+
+
+class EPSiglipParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("latent", "q_w", "q_b", "kv_w", "kv_b", "proj_w", "proj_b", "fc1_w", "fc1_b",
+                                          "fc2_w", "fc2_b")]
+
+
+class EPSiglipStep(C.Structure):
+    _fields_ = [
+        ("dims", EPSiglipDims),
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("image_index", C.c_void_p),
+        ("targets", C.c_void_p),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("opt_state0", C.c_void_p), ("opt_state1", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("found_inf", C.c_void_p), ("grad_norm", C.c_void_p),
+        ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
+        ("grad_scale", C.c_float), ("inv_scale", C.c_float),
+        ("accumulate", C.c_int32), ("optimizer", C.c_int32),
+        ("lr", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float),
+        ("trust_coefficient", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("opt_step", C.c_int64),
+        ("phases", C.c_int32),
+        ("aux_stream", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -182,6 +213,17 @@ SIGNATURES = {
     "ep_knn_workspace_bytes": (c_size, [c_int, c_int]),
     "ep_knn_topk": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void, c_int, c_void, c_size, c_void]),
     "ep_knn_vote": (c_int, [c_f32p, c_void, c_int, c_void, c_int, c_int, c_float, c_int, c_void, c_void, c_f32p, c_void]),
+    "ep_siglip_pool_workspace_bytes": (c_size, [C.POINTER(EPSiglipDims)]),
+    "ep_siglip_pool_forward": (c_int, [C.POINTER(EPSiglipDims), c_void, c_int, c_i64, c_void, C.POINTER(EPSiglipParams),
+                                       c_f32p, c_void, c_size, c_void]),
+    "ep_siglip_pool_backward": (c_int, [C.POINTER(EPSiglipDims), c_void, c_int, c_i64, c_void, C.POINTER(EPSiglipParams),
+                                        c_f32p, C.POINTER(EPSiglipParams), c_int, c_void, c_size, c_void]),
+    "ep_siglip_attention": (c_int, [C.POINTER(EPSiglipDims), c_void, c_f32p, c_void]),
+    "ep_siglip_head_param_offsets": (c_i64, [C.POINTER(EPSiglipDims), C.POINTER(c_i64)]),
+    "ep_siglip_head_workspace_bytes": (c_size, [C.POINTER(EPSiglipDims)]),
+    "ep_siglip_head_train_step": (c_int, [C.POINTER(EPSiglipStep), c_void, c_size, c_void]),
+    "ep_siglip_head_eval_forward": (c_int, [C.POINTER(EPSiglipDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p,
+                                            c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void ep_gemm_ws_kernel(GemmParams p) {
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + wn * 32 + ni * 16 + i16;
       if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 32 + mi * 16 + kk * 4 + r;

@@ -30,6 +30,7 @@ struct GemmParams {
   int M, N, K;
   int64_t lda, ldb, ldc;            // leading dimensions (elements)
   int64_t sAz, sBz, sCz;            // batch strides (elements)
+  int64_t sBiasz;                   // batch stride of the bias vector (0: shared)
   int extA, extB;                   // readable extent of the contiguous dim of a T-layout operand
   float alpha;
   int accumulate;
@@ -38,8 +39,8 @@ struct GemmParams {
 
 // Work appended to the launch of the second token pass (ep_side.h: run_side_task)
 struct SideTasks {
-  GemmParams g[3];                  // T/T-layout, 16-byte aligned operands
-  int gx[3], gy[3], gz[3], bm[3];   // tile grid and tile rows (32 / 64) of each; gx*gy*gz == 0 when unused
+  GemmParams g[6];                  // T/T-layout, 16-byte aligned operands
+  int gx[6], gy[6], gz[6], bm[6];   // tile grid and tile rows (32 / 64) of each; gx*gy*gz == 0 when unused
   int n_gemm;
   const float* cs_src; float* cs_out; int cs_B, cs_ncol, cs_ld, cs_accumulate, n_colsum;
   const float* rowstat; float* stats; int rs_B, n_stats;
@@ -71,7 +72,9 @@ int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean
 int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, float* partial,
                 hipStream_t st);
 int colsum(const float* src, int B, int ncol, int ld, int accumulate, float* out, hipStream_t st);
-int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st);
+// delta[r] = sum_c dy[r,c] * (y[r,c] - bias[(r % Q)*Dq + c]) -> ML[r,2]   (bias may be null; rows = B*Q)
+int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st,
+               const float* bias = nullptr, int Q = 1);
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
                   float* loss_rows, float* dlogits, float* rowstat, hipStream_t st);
 int ce_stats(const float* rowstat, int B, float* stats, hipStream_t st);

@@ -185,7 +185,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, i
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + wn * 32 + ni * 16 + i16;
       if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * (16 * MI) + mi * 16 + kk * 4 + r;
@@ -260,7 +260,7 @@ constexpr size_t SIDE_LDS_BYTES = sizeof(float) * 2 * 2 * LDS_OPERAND;
 __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* lds_raw) {
   auto lds = reinterpret_cast<float (*)[2][LDS_OPERAND]>(lds_raw);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 6; ++i) {
     const int n = s.gx[i] * s.gy[i] * s.gz[i];
     if (t < n) {
       const int bx = t % s.gx[i], r = t / s.gx[i];

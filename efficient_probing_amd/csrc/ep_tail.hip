@@ -157,11 +157,16 @@ __global__ __launch_bounds__(256) void ep_colsum_kernel(const float* __restrict_
 
 // delta[b,q] = sum_c dy[b, q*Dq + c] * y[b, q*Dq + c]  ->  ML[b,q,2]   (one wave per (b,q))
 __global__ __launch_bounds__(256) void ep_delta_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                     int rows, int Dq, float* __restrict__ ML) {
+                                                     int rows, int Dq, float* __restrict__ ML,
+                                                     const float* __restrict__ bias, int Q) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
   float s = 0.f;
+  if (bias) {
+    const float* bq = bias + (int64_t)(r % Q) * Dq;
+    for (int c = lane; c < Dq; c += 64) s = fmaf(dy[(int64_t)r * Dq + c], y[(int64_t)r * Dq + c] - bq[c], s);
+  } else
   for (int c = lane; c < Dq; c += 64) s = fmaf(dy[(int64_t)r * Dq + c], y[(int64_t)r * Dq + c], s);
   s = wave_sum(s);
   if (lane == 0) ML[(int64_t)r * 4 + 2] = s;
@@ -295,8 +300,8 @@ int colsum(const float* src, int B, int ncol, int ld, int accumulate, float* out
   EP_LAUNCH_CHECK("ep_colsum_kernel");
   return 0;
 }
-int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st) {
-  hipLaunchKernelGGL(ep_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, y, rows, Dq, ML);
+int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st, const float* bias, int Q) {
+  hipLaunchKernelGGL(ep_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, y, rows, Dq, ML, bias, Q);
   EP_LAUNCH_CHECK("ep_delta_kernel");
   return 0;
 }

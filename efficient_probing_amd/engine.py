@@ -362,6 +362,40 @@ class AbmilpHeadEngine(ProbeHeadEngine):
                                                     ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class SiglipHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(AttentionPoolLatent (SigLIP head), BatchNorm1d, Linear) through
+    ``ep_siglip_head_train_step``: the EP token passes with derived queries + proj + residual MLP per image."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_siglip_head
+        if not is_native_siglip_head(head):
+            raise TypeError("SiglipHeadEngine needs Sequential(poolings.siglip.AttentionPoolLatent, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        dims = N.EPSiglipDims(B=0, N=0, D=p.q.in_features, H=p.num_heads, hidden=p.mlp.fc1.out_features,
+                              C=self.fc.out_features)
+        offs = (C.c_int64 * 13)()
+        total = int(self.lib.ep_siglip_head_param_offsets(C.byref(dims), offs))
+        return dims, list(p._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        return N.EPSiglipStep()
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_siglip_head_workspace_bytes(C.byref(self.dims))
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_siglip_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
+                                                  N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_siglip_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride,
+                                                    iptr, self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                    self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                                    ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+
 class LinearProbeEngine(ProbeHeadEngine):
     """Fused train / eval step of plain linear probing, Sequential(BatchNorm1d, Linear) on one feature vector per
     image (what the registry builds for --cls_features cls / gap / pos ..., reference probe_heads.py:96-99).
@@ -427,9 +461,11 @@ class _LPView:
 
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
     """The fused engine matching a native head (EP, CoCa, AbMILP or plain linear probing)."""
-    from .probe_heads import is_native_abmilp_head, is_native_coca_head, is_native_lp_head
+    from .probe_heads import is_native_abmilp_head, is_native_coca_head, is_native_lp_head, is_native_siglip_head
     if is_native_lp_head(head):
         return LinearProbeEngine(head, **kw)
+    if is_native_siglip_head(head):
+        return SiglipHeadEngine(head, **kw)
     if is_native_coca_head(head):
         return CocaHeadEngine(head, **kw)
     if is_native_abmilp_head(head):

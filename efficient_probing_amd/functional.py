@@ -533,3 +533,75 @@ class _AbmilpPool(torch.autograd.Function):
 def abmilp_pool(x, qkv, proj_w, proj_b, w1, b1, w2, b2):
     """(out (B, D), attention map (B, N)) of the AbMILP head."""
     return _AbmilpPool.apply(x, qkv, proj_w, proj_b, w1, b1, w2, b2)
+
+
+# --------------------------------------------------------------------------------------------
+# SigLIP attention-pool head (reference poolings/clip/attention_pool.py:13-140) on the EP token pass
+# --------------------------------------------------------------------------------------------
+SIGLIP_TENSORS = ("latent", "q.weight", "q.bias", "kv.weight", "kv.bias", "proj.weight", "proj.bias",
+                  "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+def _siglip_params_struct(ts):
+    return N.EPSiglipParams(*[t.data_ptr() for t in ts])
+
+
+class _SiglipPool(torch.autograd.Function):
+    """AttentionPoolLatent(x) with gradients for its eleven parameter tensors (no gradient w.r.t. the tokens)."""
+
+    @staticmethod
+    def forward(ctx, x, heads, hidden, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, SIGLIP_TENSORS)]
+        dims = N.EPSiglipDims(B=B, N=Nn, D=D, H=heads, hidden=hidden, C=0)
+        nbytes = lib.ep_siglip_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_siglip_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_siglip_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0,
+                                           C.byref(_siglip_params_struct(tens)), out.data_ptr(), ws.data_ptr(), nbytes,
+                                           N.current_stream_ptr(xv.device)), "ep_siglip_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("SigLIP attention pool (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_siglip_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0,
+                                            C.byref(_siglip_params_struct(tens)), dout.data_ptr(),
+                                            C.byref(_siglip_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                            N.current_stream_ptr(xv.device)), "ep_siglip_pool_backward")
+        return (None, None, None, *grads)
+
+
+def siglip_pool(x, heads, hidden, *tens):
+    return _SiglipPool.apply(x, heads, hidden, *tens)
+
+
+def siglip_attention(x, heads, hidden, *tens):
+    """softmax attention of the latent query over the tokens, (B, heads, N)."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    B, Nn, D = xv.shape
+    tens = [_f32c(t, n) for t, n in zip(tens, SIGLIP_TENSORS)]
+    dims = N.EPSiglipDims(B=B, N=Nn, D=D, H=heads, hidden=hidden, C=0)
+    nbytes = lib.ep_siglip_pool_workspace_bytes(C.byref(dims))
+    ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+    out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    st = N.current_stream_ptr(xv.device)
+    N.check(lib.ep_siglip_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0,
+                                       C.byref(_siglip_params_struct(tens)), out.data_ptr(), ws.data_ptr(), nbytes, st),
+            "ep_siglip_pool_forward")
+    A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_siglip_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_siglip_attention")
+    return A

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 7
+#define EP_ABI_VERSION 8
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -399,6 +399,65 @@ int ep_lp_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_str
 int ep_lp_eval_forward(const ep_head_dims* dims, const float* x, const float* params, const float* running_mean,
                        const float* running_var, float bn_eps, float* logits, int ldl, void* ws,
                        size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SigLIP attention-pool head (reference poolings/clip/attention_pool.py:13-140 AttentionPoolLatent as the
+ * registry builds it, probe_heads.py:72: AttentionPoolLatent(in_features=dim) -> 8 heads, one latent query,
+ * qkv bias, mlp_ratio 4, no norms, pool 'token').  With u_h = scale Wk_h^T q_h (q = q(latent)):
+ *     o[b,h] = softmax_n(u_h . x[b,n]) x[b] Wv_h^T + bv_h      z1 = proj(o)      out = z1 + mlp(z1)
+ * -- the EP token passes with H derived query rows and the EP per-query value projection, then two small
+ * dense layers per image.  Eleven pooler tensors (nn.Module state-dict names):
+ *   latent (1,1,D) | q.weight q.bias | kv.weight (2D,D) kv.bias (2D) | proj.weight proj.bias |
+ *   mlp.fc1.weight (hidden,D) mlp.fc1.bias | mlp.fc2.weight (D,hidden) mlp.fc2.bias
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_siglip_dims {
+  int32_t B, N, D, H, hidden, C;     /* C used only by the whole-head entry points */
+} ep_siglip_dims;
+
+typedef struct ep_siglip_params {
+  float *latent, *q_w, *q_b, *kv_w, *kv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} ep_siglip_params;
+
+size_t ep_siglip_pool_workspace_bytes(const ep_siglip_dims* dims);
+int ep_siglip_pool_forward(const ep_siglip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                           const int32_t* image_index, const ep_siglip_params* params, float* out, void* ws,
+                           size_t ws_bytes, ep_stream_t stream);
+int ep_siglip_pool_backward(const ep_siglip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                            const int32_t* image_index, const ep_siglip_params* params, const float* dout,
+                            const ep_siglip_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                            ep_stream_t stream);
+/* attention of the latent query: A (B, H, N) */
+int ep_siglip_attention(const ep_siglip_dims* dims, const void* ws, float* A, ep_stream_t stream);
+
+/* Whole train step of Sequential(AttentionPoolLatent, BN, Linear) + CE (+ optimizer).  Flat parameter buffer:
+ * the eleven pooler tensors in the order above | fc.weight (C,D) | fc.bias (C)   (thirteen offsets).
+ * Same fields as ep_coca_step without the LayerNorm ones. */
+typedef struct ep_siglip_step {
+  ep_siglip_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_siglip_step;
+
+int64_t ep_siglip_head_param_offsets(const ep_siglip_dims* dims, int64_t offsets[13]);
+size_t ep_siglip_head_workspace_bytes(const ep_siglip_dims* dims);
+int ep_siglip_head_train_step(const ep_siglip_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_siglip_head_eval_forward(const ep_siglip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                                const int32_t* image_index, const float* params, const float* running_mean,
+                                const float* running_var, float bn_eps, float* logits, int ldl, void* ws,
+                                size_t ws_bytes, ep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -229,3 +229,58 @@ def make_knn_inputs(name):
     tr /= np.maximum(np.linalg.norm(tr, axis=1, keepdims=True), 1e-12)
     te /= np.maximum(np.linalg.norm(te, axis=1, keepdims=True), 1e-12)
     return dict(train=tr.astype(np.float32), train_labels=ltr, test=te.astype(np.float32), test_labels=lte, C=C)
+
+
+# --------------------------------------------------------------------------------------------
+# SigLIP attention-pool head (reference poolings/clip/attention_pool.py:13-140 behind probe_heads.py:72)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class SiglipCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+SIGLIP_CASES = [
+    SiglipCase("tiny", B=6, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
+    SiglipCase("tiny_sharp_strided", B=5, N=16, D=128, C=7, seed=1, strided=True, sharp=True, steps=1),
+    SiglipCase("vitb16", B=6, N=197, D=768, C=1000, seed=0, full=False, steps=1),
+    SiglipCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),     # BASELINE config 4
+]
+SIGLIP_BY_NAME = {c.name: c for c in SIGLIP_CASES}
+SIGLIP_INIT_DIMS = [(768, 1000), (1152, 1000)]
+SIGLIP_PARAM_NAMES = ["latent", "q_w", "q_b", "kv_w", "kv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                      "fc_weight", "fc_bias"]
+SIGLIP_SMALL = ("latent", "q_b", "kv_b", "proj_b", "fc1_b", "fc2_b", "fc_bias")
+
+
+def siglip_sub(a: np.ndarray) -> np.ndarray:
+    """Row subsample (every 64th row) for the large tensors of the big SigLIP cases."""
+    return np.ascontiguousarray(a.reshape(-1, a.shape[-1])[::64])
+
+
+def make_siglip_inputs(case: SiglipCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(11000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (6.0 if case.sharp else 1.0)
+    return dict(
+        x_buf=rng.standard_normal((case.B, n_alloc, D), dtype=np.float32),
+        x_buf2=rng.standard_normal((case.B, n_alloc, D), dtype=np.float32),
+        latent=(g * rng.standard_normal((1, 1, D), dtype=np.float32)).astype(np.float32),
+        q_w=u(bd, (D, D)), q_b=u(bd, (D,)), kv_w=u(bd * g, (2 * D, D)), kv_b=u(0.5, (2 * D,)),
+        proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)), fc1_w=u(bd, (4 * D, D)), fc1_b=u(bd, (4 * D,)),
+        fc2_w=u(0.5 * bd, (D, 4 * D)), fc2_b=u(0.5 * bd, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
