@@ -7,7 +7,8 @@ from argparse import Namespace
 from efficient_probing_amd import probe_heads
 from efficient_probing_amd.engine import ProbeHeadEngine
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
-dist.init_process_group("nccl", rank=0, world_size=1)
+if "--no-dist" not in sys.argv:
+    dist.init_process_group("nccl", rank=0, world_size=1)
 dev = torch.device("cuda:0")
 B, Nn, D, Q, C = 1024, 256, 768, 8, 1000
 res = {}
@@ -27,5 +28,7 @@ for mode in (False, "force"):
     eng.flush(); torch.cuda.synchronize()
     tot = time.perf_counter() - t0
     res[str(mode)] = {"ms_per_step": round(tot / 200 * 1e3, 4), "host_enqueue_ms_per_step": round(host / 200 * 1e3, 4)}
+res["dist"] = dist.is_initialized()
 print(json.dumps(res))
-dist.destroy_process_group()
+if dist.is_initialized():
+    dist.destroy_process_group()
