@@ -203,12 +203,17 @@ def main():
     eng.flush()                                             # (data parallel: the deferred half of a pipelined step)
     eng.read_stats()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread (no host sync)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+        marks[i + 1].record()
     eng.flush()                                             # all K steps complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 4)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,7 +293,8 @@ def main():
                                         "us_per_launch": round(t_bwd * 1e6, 2)},
                          "step_frac": round(value / world * 2 * Nn * D * esize / 1e9 / HBM_PEAK_GBS, 4)},
             "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, args.steps), 5),
-                      "nonfinite_rows": bad},
+                      "nonfinite_rows": bad,
+                      "step_ms_device": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port
