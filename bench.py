@@ -220,6 +220,15 @@ def main():
         elapsed = float(t.item())
     loss_sum, top1, _, bad = eng.read_stats()
 
+    # ---- eval forward (reference engine_finetune.py:106-166 inner forward), outside the timed training region ----
+    n_eval = max(10, args.steps // 2)
+    eng.eval_logits(xs[0]); torch.cuda.synchronize()
+    te0 = time.perf_counter()
+    for i in range(n_eval):
+        eng.eval_logits(xs[i % args.buffers])
+    torch.cuda.synchronize()
+    eval_s = (time.perf_counter() - te0) / n_eval
+
     # ---- dominant kernel: EP pooling passes, timed alone with HIP events on the launch stream ----
     def time_kernel(fn, iters):
         fn(0)
@@ -295,6 +304,7 @@ def main():
             "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, args.steps), 5),
                       "nonfinite_rows": bad,
                       "step_ms_device": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}},
+            "eval_forward": {"value": round(B / eval_s, 1), "unit": "images/s per GPU", "ms_per_batch": round(eval_s * 1e3, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port

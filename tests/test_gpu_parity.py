@@ -372,3 +372,36 @@ def test_empty_batch_and_bad_token_arguments_fail_loudly():
         F_.pool_forward(torch.zeros(2, 5, 62, device=DEV), torch.zeros(1, 4, 62, device=DEV), 0.125)   # D % 4 != 0
     with pytest.raises(ValueError):
         F_.pool_forward(torch.zeros(2, 64, device=DEV), cls, 0.125)             # not (B, N, D)
+
+
+@pytest.mark.parametrize("shape", [(6, 200, 768, 8), (5, 197, 384, 1), (4, 196, 1024, 8), (4, 256, 1152, 8), (3, 100, 4096, 8),
+                                   (3, 64, 2048, 4), (4, 90, 256, 16)], ids=lambda s: "x".join(map(str, s)))
+def test_online_softmax_under_adversarial_score_order(shape):
+    """Scores that keep growing along the token axis (every tile raises the running maximum, so the lazy-max rescale
+    path runs all the time) and span +-60 (exp would overflow without the running maximum): every kernel family must
+    match an fp64 softmax, forward and backward, with no non-finite value."""
+    from efficient_probing_amd import functional as F_
+    B, Nn, D, Q = shape
+    gen = torch.Generator(device="cpu").manual_seed(13)
+    cls = torch.randn(Q, D, generator=gen)
+    cls = cls / cls.norm(dim=1, keepdim=True)
+    x = torch.randn(B, Nn, D, generator=gen) * 0.05
+    ramp = torch.linspace(-60.0, 60.0, Nn)                                    # target score of token n for query 0
+    x = x + ramp[None, :, None] * cls[0][None, None, :]                        # along cls[0]: score_0(n) ~ ramp[n]
+    xd, cd = x.to(DEV), cls.to(DEV)
+    P, S, ML = F_.pool_forward(xd, cd, 1.0)
+    assert torch.isfinite(P).all() and torch.isfinite(S).all() and torch.isfinite(ML[:, :, :2]).all()
+    Sref = torch.matmul(cls.double(), x.double().transpose(1, 2))
+    Aref = torch.softmax(Sref, dim=-1)
+    Pref = torch.matmul(Aref, x.double())
+    np.testing.assert_allclose(S.cpu().double().numpy(), Sref.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(P.cpu().double().numpy(), Pref.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(F_.attention_from_scores(S, ML).cpu().double().numpy(), Aref.numpy(), rtol=2e-4, atol=1e-7)
+    dP = torch.randn(B, Q, D, generator=gen)
+    delta = (dP.double() * Pref).sum(-1)
+    ML2 = ML.clone(); ML2[:, :, 2] = delta.float().to(DEV)
+    dcls = F_.pool_backward(xd, S, ML2, dP.to(DEV), 1.0)
+    dA = torch.matmul(dP.double(), x.double().transpose(1, 2))
+    ref = torch.matmul(Aref * (dA - delta[..., None]), x.double()).sum(0)
+    assert torch.isfinite(dcls).all()
+    np.testing.assert_allclose(dcls.cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=5e-5 * float(ref.abs().max()))
