@@ -155,6 +155,11 @@ SIGNATURES = {
     "ep_debug_force_generic_pool": (c_int, [c_int]),
     "ep_pool_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "ep_pool_kernel_name": (C.c_char_p, [c_int, c_int, c_int, c_int, c_int]),
+    "ep_token_stats": (c_int, [c_void, c_int, c_i64, c_int, c_int, c_int, c_float, c_f32p, c_void]),
+    "ep_pool_forward_ln": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_i64, c_int, c_float, c_f32p,
+                                   c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),
+    "ep_pool_backward_ln": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p,
+                                    c_f32p, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_pool_kernel_name_ex": (C.c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ep_pool_forward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_i64, c_int, c_float,
                                 c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),

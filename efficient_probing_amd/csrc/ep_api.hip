@@ -228,6 +228,41 @@ int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_
   return pool_backward(p, dcls, accumulate, (hipStream_t)stream);
 }
 
+int ep_token_stats(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, float eps, float* stats,
+                   ep_stream_t stream) {
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, 1));
+  EP_REQUIRE(stats, EP_E_ARG, "ep_token_stats: null output");
+  return token_stats(x, x_dtype == EP_DTYPE_BF16, x_bstride, B, N, D, eps, stats, (hipStream_t)stream);
+}
+
+int ep_pool_forward_ln(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                       const float* cls_token, int64_t cls_bstride, int Q, float scale, const float* token_stats_,
+                       float* P, float* S, float* ML, void* workspace, size_t workspace_bytes, ep_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  EP_REQUIRE(cls_token && P && S && ML && token_stats_, EP_E_ARG, "ep_pool_forward_ln: null pointer");
+  EP_REQUIRE(aligned16(cls_token) && aligned16(P) && aligned16(ML) && cls_bstride % 4 == 0, EP_E_ALIGN,
+             "ep_pool_forward_ln: cls_token / P / ML must be 16-byte aligned");
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale, x_dtype);
+  p.cls = cls_token; p.cls_bstride = cls_bstride; p.P = P; p.S = S; p.ML = ML; p.index = image_index; p.tokstat = token_stats_;
+  return pool_forward(p, (hipStream_t)stream);
+}
+
+int ep_pool_backward_ln(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                        int Q, float scale, const float* token_stats_, const float* S, const float* ML, const float* dP,
+                        float* dcls, int accumulate, void* workspace, size_t workspace_bytes, ep_stream_t stream) {
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  EP_REQUIRE(S && ML && dP && dcls && workspace && token_stats_, EP_E_ARG, "ep_pool_backward_ln: null pointer");
+  EP_REQUIRE(aligned16(dP) && aligned16(dcls) && aligned16(ML) && aligned16(workspace), EP_E_ALIGN,
+             "ep_pool_backward_ln: dP / dcls / ML / workspace must be 16-byte aligned");
+  EP_REQUIRE(workspace_bytes >= pool_workspace_bytes(B, N, D, Q), EP_E_WORKSPACE,
+             "ep_pool_backward_ln: workspace %zu < %zu", workspace_bytes, pool_workspace_bytes(B, N, D, Q));
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale, x_dtype);
+  p.S = const_cast<float*>(S); p.ML = const_cast<float*>(ML); p.dP = dP; p.Gpart = static_cast<float*>(workspace);
+  p.index = image_index; p.tokstat = token_stats_;
+  return pool_backward(p, dcls, accumulate, (hipStream_t)stream);
+}
+
 int ep_attention_from_scores(const float* S, const float* ML, int B, int Q, int N, float* A, ep_stream_t stream) {
   EP_REQUIRE(S && ML && A && B > 0 && Q > 0 && N > 0, EP_E_ARG, "ep_attention_from_scores: bad argument");
   return attention_from_scores(S, ML, B * Q, N, A, (hipStream_t)stream);

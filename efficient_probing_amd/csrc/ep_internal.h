@@ -18,6 +18,9 @@ struct PoolParams {
   const float* dP;       // bwd in (B,Q,D)
   float* Gpart;          // bwd out (n_workgroups, Q, D)
   const int* index;      // optional (B,) image indices into x: image b is x[index[b]] (resident token store)
+  const float* tokstat;  // optional (M or B, N, 2) per-token {mean, rstd} of a LayerNorm over D (indexed like x): the
+                         // pass then pools the NORMALISED tokens xhat = (x - mean) * rstd without materialising them:
+                         // scores q.xhat, pooled sum_n A xhat; backward accumulates sum dS xhat
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
   int kdma;              // 16-byte DMA instructions per wave per ring item
@@ -59,6 +62,7 @@ int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t 
 bool pool_backward_takes_side(const PoolParams& p);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
 int debug_force_generic(int on);
+int token_stats(const void* x, int x_bf16, int64_t bstride, int B, int N, int D, float eps, float* stats, hipStream_t st);
 int attention_from_scores(const float* S, const float* ML, int rows, int N, float* A, hipStream_t st);
 
 // a_k / b_k: operand contiguous along K (true) or along its free dimension (false)

@@ -69,8 +69,20 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
   const int D = p.D, N = p.N, Q = p.Q;
   const char* xb = reinterpret_cast<const char*>(p.x) + EP_IMG_OFF(p, b) * (BF16 ? 2 : 4);
   float* red = sm + N;
+  // LayerNorm-of-tokens mode: per-token {mean, rstd}; scores q.xhat = rstd (q.x - mean sum(q))
+  const float* ts = p.tokstat ? p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2 : nullptr;
   for (int q = 0; q < Q; ++q) {
     const float* cq = p.cls + (int64_t)b * p.cls_bstride + (int64_t)q * D;
+    float wsum = 0.f;
+    if (ts) {
+      float t = 0.f;
+      for (int d = threadIdx.x; d < D; d += 256) t += cq[d] * p.scale;
+      t = wave_sum(t);
+      if (lane == 0) red[w] = t;
+      __syncthreads();
+      wsum = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
+    }
     for (int n = w; n < N; n += 4) {
       float s = 0.f;
       for (int d = lane * 4; d < D; d += 256) {
@@ -79,6 +91,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
         s = fmaf(cv.x, xv.x, s); s = fmaf(cv.y, xv.y, s); s = fmaf(cv.z, xv.z, s); s = fmaf(cv.w, xv.w, s);
       }
       s = wave_sum(s);
+      if (ts) s = ts[2 * n + 1] * (s - ts[2 * n] * wsum);
       if (lane == 0) { sm[n] = s; p.S[((int64_t)b * Q + q) * N + n] = s; }
     }
     __syncthreads();
@@ -99,10 +112,20 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
     __syncthreads();
     l = (red[0] + red[1]) + (red[2] + red[3]);
     const float inv = 1.0f / l;
+    float shift = 0.f;                                 // sum_n e_n rstd_n mean_n (LayerNorm mode)
+    if (ts) {
+      __syncthreads();
+      float c = 0.f;
+      for (int n = threadIdx.x; n < N; n += 256) { const float er = sm[n] * ts[2 * n + 1]; c = fmaf(er, ts[2 * n], c); sm[n] = er; }
+      c = wave_sum(c);
+      if (lane == 0) red[w] = c;
+      __syncthreads();
+      shift = (red[0] + red[1]) + (red[2] + red[3]);
+    }
     for (int d = threadIdx.x * 4; d < D; d += 1024) {
       f4 a = {0, 0, 0, 0};
       for (int n = 0; n < N; ++n) a += sm[n] * load_tok4<BF16>(xb, (int64_t)n * D + d);
-      *reinterpret_cast<f4*>(p.P + ((int64_t)b * Q + q) * D + d) = a * inv;
+      *reinterpret_cast<f4*>(p.P + ((int64_t)b * Q + q) * D + d) = (a - shift) * inv;
     }
     if (threadIdx.x == 0) {
       f4 rec = {mx, l, 0.f, 0.f};
@@ -120,10 +143,22 @@ __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) 
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
   const char* xb = reinterpret_cast<const char*>(p.x) + EP_IMG_OFF(p, b) * (BF16 ? 2 : 4);
+  const float* ts = p.tokstat ? p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2 : nullptr;
+  float* red = sm + N;
   for (int q = 0; q < Q; ++q) {
     const float* g = p.dP + ((int64_t)b * Q + q) * D;
     const float* ml = p.ML + ((int64_t)b * Q + q) * 4;
     const float mx = ml[0], inv = 1.0f / ml[1], delta = ml[2];
+    float gsum = 0.f;
+    if (ts) {
+      float t = 0.f;
+      for (int d = threadIdx.x; d < D; d += 256) t += g[d];
+      t = wave_sum(t);
+      if (lane == 0) red[w] = t;
+      __syncthreads();
+      gsum = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
+    }
     for (int n = w; n < N; n += 4) {
       float s = 0.f;
       for (int d = lane * 4; d < D; d += 256) {
@@ -132,19 +167,59 @@ __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) 
         s = fmaf(gv.x, xv.x, s); s = fmaf(gv.y, xv.y, s); s = fmaf(gv.z, xv.z, s); s = fmaf(gv.w, xv.w, s);
       }
       s = wave_sum(s);
+      if (ts) s = ts[2 * n + 1] * (s - ts[2 * n] * gsum);                 // dA = dP . xhat_n
       if (lane == 0) {
         const float a = __builtin_amdgcn_exp2f((p.S[((int64_t)b * Q + q) * N + n] - mx) * LOG2E) * inv;
         sm[n] = a * (s - delta);
       }
     }
     __syncthreads();
+    float shift = 0.f;
+    if (ts) {
+      float c = 0.f;
+      for (int n = threadIdx.x; n < N; n += 256) { const float er = sm[n] * ts[2 * n + 1]; c = fmaf(er, ts[2 * n], c); sm[n] = er; }
+      c = wave_sum(c);
+      if (lane == 0) red[w] = c;
+      __syncthreads();
+      shift = (red[0] + red[1]) + (red[2] + red[3]);
+    }
     for (int d = threadIdx.x * 4; d < D; d += 1024) {
       f4 a = {0, 0, 0, 0};
       for (int n = 0; n < N; ++n) a += sm[n] * load_tok4<BF16>(xb, (int64_t)n * D + d);
-      *reinterpret_cast<f4*>(p.Gpart + ((int64_t)b * Q + q) * D + d) = a;
+      *reinterpret_cast<f4*>(p.Gpart + ((int64_t)b * Q + q) * D + d) = a - shift;
     }
     __syncthreads();
   }
+}
+
+// per-token LayerNorm statistics {mean, rstd} over D (biased variance, eps inside the root: torch.nn.LayerNorm);
+// one wave per token, two passes over the row (the second one hits L2)
+template <bool BF16>
+__global__ __launch_bounds__(256) void ep_token_stats_kernel(const void* __restrict__ x, int64_t bstride, int N, int64_t rows,
+                                                           int D, float eps, float* __restrict__ stats) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = (r / N) * bstride + (r % N) * (int64_t)D;          // first element of token r
+  float s = 0.f;
+  for (int d = lane * 4; d < D; d += 256) { const f4 v = load_tok4<BF16>(x, e0 + d); s += (v.x + v.y) + (v.z + v.w); }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const f4 v = load_tok4<BF16>(x, e0 + d) - mean;
+    q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { stats[r * 2] = mean; stats[r * 2 + 1] = rstd; }
+}
+
+int token_stats(const void* x, int x_bf16, int64_t bstride, int B, int N, int D, float eps, float* stats, hipStream_t st) {
+  const int64_t rows = (int64_t)B * N;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (x_bf16) hipLaunchKernelGGL(ep_token_stats_kernel<true>, dim3(grid), dim3(256), 0, st, x, bstride, N, rows, D, eps, stats);
+  else hipLaunchKernelGGL(ep_token_stats_kernel<false>, dim3(grid), dim3(256), 0, st, x, bstride, N, rows, D, eps, stats);
+  EP_LAUNCH_CHECK("ep_token_stats_kernel");
+  return 0;
 }
 
 __global__ void ep_attention_kernel(const float* __restrict__ S, const float* __restrict__ ML,
@@ -198,7 +273,7 @@ static bool force_generic() { return pool_mode() == 1; }
 // Q = 1); the matrix-core kernel wins for wider rows and more queries.
 static bool use_mf(const PoolParams& p, bool bwd) {
   (void)bwd;
-  if (p.x_bf16 || pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
+  if (p.tokstat || p.x_bf16 || pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (c.ok && (p.Q <= 4 || stream_waves_per_cu(c.qw, c.kp, c.nw) == 12)) return false;   // vector-ALU kernel wins
   return true;
@@ -207,14 +282,21 @@ static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 // all-matrix-core kernel: forced with mode 3; chosen automatically only where it measured fastest
 // (backward at D = 1152, where the other two kernels run short of LDS / registers)
 static bool use_mm(const PoolParams& p, bool bwd) {
-  if (p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
+  if (p.tokstat || p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
   if (pool_mode() == 3) return true;
   return pool_mode() == 0 && bwd && p.D == 1152 && p.Q >= 5;
 }
 
+// what the vector-ALU streaming kernels can take: LayerNorm-of-tokens mode needs fp32 tokens
+static bool stream_takes(const PoolParams& p) {
+  static int ln = -1;
+  if (ln < 0) { const char* e = getenv("EP_POOL_LN_STREAM"); ln = e ? atoi(e) : 1; }
+  return !p.tokstat || (ln && !p.x_bf16 && stream_ln_supported(p.D, p.Q));
+}
+
 // wide rows (D = 2048 / 4096): the row is split across the waves of a workgroup
 static bool use_wide(const PoolParams& p) {
-  return pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
+  return !p.tokstat && pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
 }
 
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) {
@@ -223,7 +305,7 @@ const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) 
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
-  if (stream_plan(B, N, D, Q).ok && !force_generic()) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
+  if (stream_plan(B, N, D, Q).ok && !force_generic() && stream_takes(p)) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
   return bwd ? "ep_pool_bwd_generic_kernel" : "ep_pool_fwd_generic_kernel";
 }
 
@@ -240,7 +322,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
-  if (c.ok && !force_generic()) {
+  if (c.ok && !force_generic() && stream_takes(p)) {
     if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
     return stream_launch(false, c, p, st);
   }
@@ -255,7 +337,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
 bool pool_backward_takes_side(const PoolParams& p) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
-  if (!allow || use_wide(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  if (!allow || p.tokstat || use_wide(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   return c.ok && c.nw == 4;
 }
@@ -276,7 +358,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     const int grid = mf_grid(p.B);
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));
-  } else if (c.ok && !force_generic()) {
+  } else if (c.ok && !force_generic() && stream_takes(p)) {
     EP_TRY(stream_launch(true, c, p, st, side));
     nparts = c.grid;
   } else {

@@ -135,10 +135,14 @@ __device__ __forceinline__ void accumulate_rows(const float (&wrow)[QW], const f
 // ---------------------------------------------------------------------------------------
 // BF16: tokens are bf16 in memory; a ring tile then holds twice as many tokens in the same bytes and the rows are
 // widened to fp32 as they are read from LDS -- everything after that is the fp32 code path unchanged.
-template <int QW, int KP, int NW, int DFIX, bool BF16>
+// LN: LayerNorm-of-tokens mode (PoolParams.tokstat): every ring item carries one extra 4-byte-per-lane DMA with the
+// {mean, rstd} pairs of its tokens; scores become rstd (q.x - mean sum(q)), the pooling weights a * rstd, and the
+// mean term sum a rstd mean is carried as one scalar per query and subtracted at the end of the image.
+template <int QW, int KP, int NW, int DFIX, bool BF16, bool LN>
 __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_fwd_kernel(PoolParams p) {
   using Cfg = StreamCfgT<QW, KP, NW>;
-  constexpr int NSLOT = Cfg::NSLOT_F, KDMA = Cfg::KDMA, TT = Cfg::TT * (BF16 ? 2 : 1);
+  constexpr int NSLOT = LN ? Cfg::NSLOT_B : Cfg::NSLOT_F, KDMA = Cfg::KDMA, TT = Cfg::TT * (BF16 ? 2 : 1);
+  constexpr int KD = KDMA + (LN ? 1 : 0);          // VMEM operations per ring item
   constexpr int ES = BF16 ? 2 : 4;                 // bytes per stored token element
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int lane = lane_id();
@@ -179,6 +183,18 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   };
   load_cls(wg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight before the ring starts
+  float wsum[QW];                                    // LN: sum over D of the scaled query
+  auto sum_cls = [&]() {
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) t += (cq[j][k].x + cq[j][k].y) + (cq[j][k].z + cq[j][k].w);
+      wsum[j] = LN ? wave_sum(t) : 0.f;
+    }
+  };
+  sum_cls();
+  char* small_base = ring + NSLOT * slot_bytes;      // LN: [NSLOT][NW][64 floats] of {mean, rstd} pairs
 
   // ---- producer: one ring item = one tile of TT token rows -------------------------------
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
@@ -189,6 +205,12 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       const int left = N - ptile * TT;
       const unsigned limit = (unsigned)((left < TT ? left : TT) * rowbytes - 16);
       dma_rows<NW, KDMA>(psrc, limit, ring + pslot * slot_bytes, npiece, w, lane16);
+      if (LN) {
+        const int bb = (wg + pimg * G) < p.B ? (wg + pimg * G) : wg;
+        int e = ptile * TT * 2 + lane; e = e < 2 * N ? e : 2 * N - 1;
+        const float* ts = p.tokstat + (int64_t)(p.index ? p.index[bb] : bb) * N * 2 + e;
+        __builtin_amdgcn_global_load_lds((gptr_t)ts, (lds_ptr_t)(small_base + (pslot * NW + w) * 256), 4, 0, 0);
+      }
       ++pi;
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
       if (++ptile == tiles_per_img) {
@@ -203,28 +225,29 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   for (int s = 0; s < NSLOT - 1; ++s) produce();
 
   f4 acc[QW][KP];
-  float m[QW], mL[QW], lsum[QW];
+  float m[QW], mL[QW], lsum[QW], c2[QW];
   int cimg = 0, ctile = 0, cslot = 0;
   for (int i = 0; i < n_items; ++i) {
     // ---- wait for item i, free the slot of item i-1, refill it ---------------------------
-    // Outstanding VMEM ops of this wave, oldest first: DMA of items i..pi-1 (KDMA each), then the
-    // S / P stores of the previous iteration.  Requiring <= (pi-1-i)*KDMA outstanding retires
+    // Outstanding VMEM ops of this wave, oldest first: DMA of items i..pi-1 (KD each), then the
+    // S / P stores of the previous iteration.  Requiring <= (pi-1-i)*KD outstanding retires
     // item i (and, harmlessly early, a few ops of item i+1 in place of the stores).
     const int ahead = pi - 1 - i;
-    if (ahead == NSLOT - 2) wait_vmcnt_imm<(NSLOT - 2) * KDMA>();
-    else wait_vmcnt(ahead * KDMA);
+    if (ahead == NSLOT - 2) wait_vmcnt_imm<(NSLOT - 2) * KD>();
+    else wait_vmcnt(ahead * KD);
     ring_barrier();
     produce();
     const int b = wg + cimg * G;
     const int n0 = ctile * TT;
     const int nvalid = (N - n0) < TT ? (N - n0) : TT;
     const char* tile = ring + cslot * slot_bytes;
+    const float* small = reinterpret_cast<const float*>(small_base + (cslot * NW + w) * 256);
     cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
     if (ctile == 0) {
-      if (p.cls_bstride != 0 && cimg != 0) load_cls(b);   // per-image query override (rare path)
+      if (p.cls_bstride != 0 && cimg != 0) { load_cls(b); sum_cls(); }   // per-image query override (rare path)
 #pragma unroll
       for (int j = 0; j < QW; ++j) {
-        m[j] = -INFINITY; mL[j] = -INFINITY; lsum[j] = 0.f;
+        m[j] = -INFINITY; mL[j] = -INFINITY; lsum[j] = 0.f; c2[j] = 0.f;
 #pragma unroll
         for (int k = 0; k < KP; ++k) acc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
       }
@@ -242,6 +265,12 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         butterfly<QW>(part, u);
         const int row = lane >> 4;
         const bool rowvalid = (t0 + row) < nvalid;
+        float tmean = 0.f, trstd = 1.f;
+        if (LN) {
+          tmean = small[2 * (t0 + row)]; trstd = small[2 * (t0 + row) + 1];
+#pragma unroll
+          for (int j = 0; j < QW; ++j) u[j] = trstd * (u[j] - tmean * wsum[j]);     // q . xhat
+        }
         float ue[QW];
         bool need = false;
 #pragma unroll
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
             const float mn = fmaxf(m[j], mx);
             const float f = __builtin_amdgcn_exp2f((m[j] - mn) * LOG2E);   // m = -inf -> 0
             m[j] = mn; mL[j] = mn * LOG2E;
-            lsum[j] *= f;
+            lsum[j] *= f; c2[j] *= f;
 #pragma unroll
             for (int k = 0; k < KP; ++k) acc[j][k] *= f;
           }
@@ -274,6 +303,10 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           for (int j = 0; j < QW; ++j)
             if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + t0 + row)] = u[j];
         }
+        if (LN) {
+#pragma unroll
+          for (int j = 0; j < QW; ++j) { pr[j] *= trstd; c2[j] = fmaf(pr[j], tmean, c2[j]); }   // weights a * rstd
+        }
         if (p.ablate != 3) accumulate_rows<QW, KP>(pr, xv, acc);
       }
     }
@@ -284,12 +317,14 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         const float l = readlane_f(lsum[j], 0) + readlane_f(lsum[j], 16) +
                         readlane_f(lsum[j], 32) + readlane_f(lsum[j], 48);
         const float inv = 1.0f / l;
+        const float shift = LN ? (readlane_f(c2[j], 0) + readlane_f(c2[j], 16) + readlane_f(c2[j], 32) +
+                                  readlane_f(c2[j], 48)) * inv : 0.f;
         if (q0 + j < Q) {
           float* Pq = p.P + ((int64_t)b * Q + q0 + j) * D;
 #pragma unroll
           for (int k = 0; k < KP; ++k) {
             const int c = lane + 64 * k;
-            if (c < nchunk) *reinterpret_cast<f4*>(Pq + 4 * c) = acc[j][k] * inv;
+            if (c < nchunk) *reinterpret_cast<f4*>(Pq + 4 * c) = acc[j][k] * inv - shift;
           }
           if (lane == 0) {
             const f4 rec = {m[j], l, 0.f, 0.f};
@@ -310,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 // Every item additionally carries one 4-byte-per-lane DMA per wave into a private 256-byte area:
 // header items fetch ML[b,q,0:4] of the wave's queries, token items fetch S[b,q,n0:n0+TT].
 // ---------------------------------------------------------------------------------------
-template <int QW, int KP, int NW, int DFIX, bool BF16>
+template <int QW, int KP, int NW, int DFIX, bool BF16, bool LN>
 __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) void ep_pool_bwd_kernel(PoolParams p, SideTasks side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   constexpr int NSLOT = Cfg::NSLOT_B, KDMA = Cfg::KDMA, TT = Cfg::TT * (BF16 ? 2 : 1);
@@ -358,10 +393,14 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const char* xbytes = reinterpret_cast<const char*>(p.x);
 
   f4 gacc[QW][KP];
+  float c3[QW];                      // LN: sum dS rstd mean (the mean term of sum dS xhat)
 #pragma unroll
-  for (int j = 0; j < QW; ++j)
+  for (int j = 0; j < QW; ++j) {
+    c3[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < KP; ++k) gacc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  static_assert(!LN || QW * TT + 2 * TT <= 64, "LN: scores and token statistics share one 64-lane small piece");
 
   if (n_items > 0) {
     // lane -> element of the per-item small DMA
@@ -388,6 +427,10 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
           int nn = n0 + st; nn = nn < N ? nn : N - 1;
           const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;
+          if (LN && lane >= QW * TT) {              // lanes behind the scores fetch the {mean, rstd} pairs of the tile
+            int e = n0 * 2 + (lane - QW * TT); e = e < 2 * N ? e : 2 * N - 1;
+            ss = p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2 + e;
+          }
           __builtin_amdgcn_global_load_lds((gptr_t)ss, (lds_ptr_t)small, 4, 0, 0);
         }
         ++pi;
@@ -400,6 +443,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 
     f4 gq[QW][KP];                  // dP rows of this wave's queries for the current image
     float mLq[QW], il[QW], dl[QW];  // row max * log2e, 1/l, delta of this wave's queries
+    float gsum[QW];                 // LN: sum over D of the dP row
     int cidx = 0, cslot = 0;
     constexpr int KD = KDMA + 1;
     for (int i = 0; i < n_items; ++i) {
@@ -432,6 +476,15 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           il[j] = 1.0f / small[4 * j + 1];
           dl[j] = small[4 * j + 2];
         }
+        if (LN && cidx == H - 1) {
+#pragma unroll
+          for (int j = 0; j < QW; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) t += (gq[j][k].x + gq[j][k].y) + (gq[j][k].z + gq[j][k].w);
+            gsum[j] = wave_sum(t);
+          }
+        }
       } else {
         const int n0 = (cidx - H) * TT;
         const int nvalid = q0 < Q ? ((N - n0) < TT ? (N - n0) : TT) : 0;   // waves without a query skip
@@ -446,12 +499,19 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           butterfly<QW>(part, u);                       // dA[q][t] in row t
           const int row = lane >> 4;
           const bool rowvalid = (t0 + row) < nvalid;
+          float tmean = 0.f, trstd = 1.f;
+          if (LN) {
+            tmean = small[QW * TT + 2 * (t0 + row)]; trstd = small[QW * TT + 2 * (t0 + row) + 1];
+#pragma unroll
+            for (int j = 0; j < QW; ++j) u[j] = trstd * (u[j] - tmean * gsum[j]);     // dA = dP . xhat
+          }
           float wgt[QW];
 #pragma unroll
           for (int j = 0; j < QW; ++j) {
             const float s = small[j * TT + t0 + row];
             const float a = __builtin_amdgcn_exp2f(fmaf(s, LOG2E, -mLq[j])) * il[j];
             wgt[j] = rowvalid ? a * (u[j] - dl[j]) : 0.f;
+            if (LN) { wgt[j] *= trstd; c3[j] = fmaf(wgt[j], tmean, c3[j]); }
           }
           accumulate_rows<QW, KP>(wgt, xv, gacc);
         }
@@ -464,10 +524,11 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   for (int j = 0; j < QW; ++j)
     if (q0 + j < Q) {
       float* Gq = p.Gpart + ((int64_t)wg * Q + q0 + j) * D;
+      const float shift = LN ? (readlane_f(c3[j], 0) + readlane_f(c3[j], 16)) + (readlane_f(c3[j], 32) + readlane_f(c3[j], 48)) : 0.f;
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
         const int c = lane + 64 * k;
-        if (c < nchunk) *reinterpret_cast<f4*>(Gq + 4 * c) = gacc[j][k];
+        if (c < nchunk) *reinterpret_cast<f4*>(Gq + 4 * c) = gacc[j][k] - shift;
       }
     }
 }
@@ -475,12 +536,12 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 // ---------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------
-template <int QW, int KP, int NW, int DFIX, bool BF16>
+template <int QW, int KP, int NW, int DFIX, bool BF16, bool LN>
 static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
   const int D = p.D;
   const size_t slot = (size_t)Cfg::TT * D * 4;          // bf16: twice the tokens, half the bytes each
-  size_t lds = bwd ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
+  size_t lds = (bwd || LN) ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
   SideTasks sd{};
   if (bwd && side && side->total > 0) {
     if (NW != 4) { set_error("side tasks need 4-wave workgroups"); return EP_E_UNSUPPORTED; }
@@ -492,8 +553,8 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   } else {
     sd.first_block = grid;
   }
-  auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX, BF16>;
-  auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX, BF16>;
+  auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX, BF16, LN>;
+  auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX, BF16, LN>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
@@ -512,11 +573,15 @@ static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   } else {
     // compile-time D for the shapes the benchmark configs use (immediate LDS offsets)
     if constexpr ((QW == 2 && NW == 4 && (KP == 3 || KP == 4)) || (QW == 4 && NW == 8 && KP == 3)) {
-      if (p.D == 256 * KP && !p.x_bf16) return launch_one<QW, KP, NW, 256 * KP, false>(bwd, p, grid, st, side);
-      if (p.D == 256 * KP) return launch_one<QW, KP, NW, 256 * KP, true>(bwd, p, grid, st, side);
+      if (p.D == 256 * KP && !p.x_bf16 && !p.tokstat) return launch_one<QW, KP, NW, 256 * KP, false, false>(bwd, p, grid, st, side);
+      if (p.D == 256 * KP && !p.tokstat) return launch_one<QW, KP, NW, 256 * KP, true, false>(bwd, p, grid, st, side);
     }
-    if (p.x_bf16) return launch_one<QW, KP, NW, 0, true>(bwd, p, grid, st, side);
-    return launch_one<QW, KP, NW, 0, false>(bwd, p, grid, st, side);
+    if (p.tokstat) {
+      if (p.x_bf16) { set_error("LayerNorm-of-tokens mode takes fp32 tokens"); return EP_E_UNSUPPORTED; }
+      return launch_one<QW, KP, NW, 0, false, true>(bwd, p, grid, st, side);
+    }
+    if (p.x_bf16) return launch_one<QW, KP, NW, 0, true, false>(bwd, p, grid, st, side);
+    return launch_one<QW, KP, NW, 0, false, false>(bwd, p, grid, st, side);
   }
 }
 
@@ -533,6 +598,8 @@ static int dispatch_kp(bool bwd, int kp, const PoolParams& p, int grid, hipStrea
   set_error("no streaming kernel for kp=%d", kp);
   return EP_E_UNSUPPORTED;
 }
+
+bool stream_ln_supported(int D, int Q) { return stream_plan(1 << 20, 1, D, Q).ok; }
 
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side) {
   if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st, side);

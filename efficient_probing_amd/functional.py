@@ -605,3 +605,53 @@ def siglip_attention(x, heads, hidden, *tens):
     A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
     N.check(lib.ep_siglip_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_siglip_attention")
     return A
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm-of-tokens mode of the token passes (heads that layer-norm every token before k / v)
+# --------------------------------------------------------------------------------------------
+def token_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """(B, N, 2) per-token {mean, rstd} of a LayerNorm over D (biased variance, eps inside the root)."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    B, Nn, D = xv.shape
+    out = torch.empty((B, Nn, 2), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_token_stats(xv.data_ptr(), token_dtype_code(xv), bstride, B, Nn, D, float(eps), out.data_ptr(),
+                               N.current_stream_ptr(xv.device)), "ep_token_stats")
+    return out
+
+
+def pool_forward_ln(x, cls_token, scale, stats, image_index=None):
+    """EP pooling of the NORMALISED tokens xhat = (x - mean) * rstd without materialising them.
+    Returns P (B,Q,D) = softmax_n(S) xhat, S (B,Q,N) = (cls*scale) . xhat, ML (B,Q,4)."""
+    lib = N.load()
+    x, bstride = as_token_view(x)
+    _, Nn, D = x.shape
+    iptr, B = _index_arg(image_index, x)
+    cls = _f32c(cls_token, "cls_token")
+    stats = _f32c(stats, "token_stats")
+    Q = cls.shape[-2]
+    P = torch.empty((B, Q, D), device=x.device, dtype=torch.float32)
+    S = torch.empty((B, Q, Nn), device=x.device, dtype=torch.float32)
+    ML = torch.empty((B, Q, 4), device=x.device, dtype=torch.float32)
+    N.check(lib.ep_pool_forward_ln(x.data_ptr(), token_dtype_code(x), bstride, iptr, B, Nn, D, cls.data_ptr(), 0, Q,
+                                   float(scale), stats.data_ptr(), P.data_ptr(), S.data_ptr(), ML.data_ptr(), 0, 0,
+                                   N.current_stream_ptr(x.device)), "ep_pool_forward_ln")
+    return P, S, ML
+
+
+def pool_backward_ln(x, S, ML, dP, scale, stats, image_index=None):
+    lib = N.load()
+    x, bstride = as_token_view(x)
+    _, Nn, D = x.shape
+    iptr, B = _index_arg(image_index, x)
+    Q = S.shape[1]
+    dP = _f32c(dP, "dP")
+    stats = _f32c(stats, "token_stats")
+    dcls = torch.empty((Q, D), device=x.device, dtype=torch.float32)
+    nbytes = lib.ep_pool_workspace_bytes(B, Nn, D, Q)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    N.check(lib.ep_pool_backward_ln(x.data_ptr(), token_dtype_code(x), bstride, iptr, B, Nn, D, Q, float(scale),
+                                    stats.data_ptr(), S.data_ptr(), ML.data_ptr(), dP.data_ptr(), dcls.data_ptr(), 0,
+                                    ws.data_ptr(), nbytes, N.current_stream_ptr(x.device)), "ep_pool_backward_ln")
+    return dcls

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 8
+#define EP_ABI_VERSION 9
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -75,6 +75,23 @@ size_t ep_pool_workspace_bytes(int B, int N, int D, int Q);
 /* name of the device kernel ep_pool_forward / ep_pool_backward will launch for this shape (for
  * matching profiler output; static string) */
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward);
+/* LayerNorm-of-tokens variants.  Several attentive poolers layer-norm every token before their key / value
+ * projections (reference poolings/cae_att.py:103-104, poolings/jepa/modules.py:180, poolings/simpool.py:52).  With
+ * xhat[b,n] = (x[b,n] - mean) * rstd the passes compute S = (cls*scale) . xhat, P = softmax_n(S) xhat and, backward,
+ * dcls = scale * sum dS xhat WITHOUT materialising xhat: per-token {mean, rstd} come from ep_token_stats (one extra
+ * streaming read; they depend on the frozen tokens only, so a resident token store computes them once) and enter the
+ * passes as two scalars per token.  The LayerNorm's affine part stays outside (it folds into the queries / values).
+ * token_stats: (B, N, 2) fp32, or (M, N, 2) indexed by image_index like x. */
+int ep_token_stats(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, float eps, float* stats,
+                   ep_stream_t stream);
+int ep_pool_forward_ln(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N,
+                       int D, const float* cls_token, int64_t cls_bstride, int Q, float scale,
+                       const float* token_stats, float* P, float* S, float* ML, void* workspace,
+                       size_t workspace_bytes, ep_stream_t stream);
+int ep_pool_backward_ln(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N,
+                        int D, int Q, float scale, const float* token_stats, const float* S, const float* ML,
+                        const float* dP, float* dcls, int accumulate, void* workspace, size_t workspace_bytes,
+                        ep_stream_t stream);
 /* same, for a given token storage type (EP_DTYPE_F32 / EP_DTYPE_BF16) */
 const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype);
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
