@@ -147,6 +147,37 @@ class EPSiglipStep(C.Structure):
     ]
 
 
+class EPCaeDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("C", C.c_int32)]
+
+
+class EPCaeParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("query", "nq_w", "nq_b", "nk_w", "nk_b", "nv_w", "nv_b", "n2_w", "n2_b", "q_w",
+                                          "k_w", "v_w", "proj_w", "proj_b")]
+
+
+class EPCaeStep(C.Structure):
+    _fields_ = [
+        ("dims", EPCaeDims),
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("image_index", C.c_void_p),
+        ("token_stats", C.c_void_p), ("ln_eps", C.c_float),
+        ("targets", C.c_void_p),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("opt_state0", C.c_void_p), ("opt_state1", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("found_inf", C.c_void_p), ("grad_norm", C.c_void_p),
+        ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
+        ("grad_scale", C.c_float), ("inv_scale", C.c_float),
+        ("accumulate", C.c_int32), ("optimizer", C.c_int32),
+        ("lr", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float),
+        ("trust_coefficient", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("opt_step", C.c_int64),
+        ("phases", C.c_int32),
+        ("aux_stream", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -229,6 +260,16 @@ SIGNATURES = {
     "ep_siglip_head_train_step": (c_int, [C.POINTER(EPSiglipStep), c_void, c_size, c_void]),
     "ep_siglip_head_eval_forward": (c_int, [C.POINTER(EPSiglipDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p,
                                             c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_cae_pool_workspace_bytes": (c_size, [C.POINTER(EPCaeDims)]),
+    "ep_cae_pool_forward": (c_int, [C.POINTER(EPCaeDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, C.POINTER(EPCaeParams),
+                                    c_f32p, c_void, c_size, c_void]),
+    "ep_cae_pool_backward": (c_int, [C.POINTER(EPCaeDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, C.POINTER(EPCaeParams),
+                                     c_f32p, C.POINTER(EPCaeParams), c_int, c_void, c_size, c_void]),
+    "ep_cae_head_param_offsets": (c_i64, [C.POINTER(EPCaeDims), C.POINTER(c_i64)]),
+    "ep_cae_head_workspace_bytes": (c_size, [C.POINTER(EPCaeDims)]),
+    "ep_cae_head_train_step": (c_int, [C.POINTER(EPCaeStep), c_void, c_size, c_void]),
+    "ep_cae_head_eval_forward": (c_int, [C.POINTER(EPCaeDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, c_f32p, c_f32p,
+                                         c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }

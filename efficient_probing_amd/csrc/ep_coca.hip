@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void ep_coca_qgrad_kernel(const float* __restr
 __global__ __launch_bounds__(256) void ep_coca_lnbwd_kernel(const float* __restrict__ dqn, const float* __restrict__ xhat,
                                                           const float* __restrict__ gamma, const float* __restrict__ lnstat,
                                                           int D, int accumulate, float* __restrict__ dgamma,
-                                                          float* __restrict__ dimgq0) {
+                                                          float* __restrict__ dimgq0, float* __restrict__ dbeta) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
   float a = 0.f, b = 0.f;
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void ep_coca_lnbwd_kernel(const float* __restr
     const float dg = dqn[d] * xhat[d];
     dgamma[d] = accumulate ? dgamma[d] + dg : dg;
     dimgq0[d] = accumulate ? dimgq0[d] + dx : dx;
+    if (dbeta) dbeta[d] = accumulate ? dbeta[d] + dqn[d] : dqn[d];
   }
 }
 
@@ -295,7 +296,7 @@ static int coca_backward_core(const ep_coca_dims& d, const void* x, int x_dtype,
                      w.du, w.qn, pr.to_q, D, d.H, d.dh, d.M, scale, accumulate, gr.to_kv, gr.to_q, w.dqn,
                      gr.img_queries);
   hipLaunchKernelGGL(ep_coca_lnbwd_kernel, dim3(1), dim3(256), 0, st, w.dqn, w.xhat, pr.gamma, w.lnstat, D, accumulate,
-                     gr.gamma, gr.img_queries);
+                     gr.gamma, gr.img_queries, (float*)nullptr);
   EP_LAUNCH_CHECK("ep_coca backward kernels");
   return 0;
 }
@@ -429,6 +430,422 @@ int ep_coca_head_eval_forward(const ep_coca_dims* dims, const void* x, int x_dty
   EP_TRY(coca_forward_core(d, x, x_dtype, x_bstride, image_index, pr, ln_eps, w, w.y, st));
   EP_TRY(bn_forward_eval(w.y, d.B, d.D, bn_eps, running_mean, running_var, w.z, st));
   return linear_forward(w.z, params + offs[5], params + offs[6], d.B, d.D, d.C, logits, ldl, st);
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// CAE attentive block (reference poolings/cae_att.py:79-108 CAEAttentiveBlock with its CrossAttention :19-77; registry
+// entry probe_heads.py:83: CAEAttentiveBlock(dim=dim) -> 8 heads, no qkv bias).  One learned query token; the keys
+// are LN_k(x) Wk^T and the values LN_v(x) Wv^T -- two LayerNorms of the SAME token, i.e. the same normalised token
+// xhat with two affine maps.  With qh = scale Wq LN_q(query) and u_h = Wk_h^T qh_h:
+//     score[b,h,n] = u_h . (gk * xhat[b,n] + bk) = (gk * u_h) . xhat[b,n] + const
+//     o[b,h]       = Wv_h (gv * Phat[b,h] + bv),      Phat[b,h] = sum_n A[b,h,n] xhat[b,n]
+// so the token-dependent part is the LayerNorm-of-tokens mode of the EP passes (PoolParams.tokstat) with the H query
+// rows w_h = gk * u_h, followed by the per-head projection with Wv' = Wv diag(gv) and bias Wv bv, then proj.
+// =============================================================================================
+namespace ep {
+
+// w[h,d] = gk[d] * u[h,d],  u[h,d] = sum_c qh[h*dh + c] Wk[h*dh + c, d]
+__global__ __launch_bounds__(256) void ep_cae_w_kernel(const float* __restrict__ qh, const float* __restrict__ Wk,
+                                                     const float* __restrict__ gk, int D, int dh, float* __restrict__ u,
+                                                     float* __restrict__ wq) {
+  const int d = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  if (d >= D) return;
+  float acc = 0.f;
+  for (int c = 0; c < dh; ++c) acc = fmaf(qh[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
+  u[(int64_t)h * D + d] = acc;
+  wq[(int64_t)h * D + d] = acc * gk[d];
+}
+
+// Wv'[r,d] = Wv[r,d] gv[d];  bo[r] = Wv[r,:] . bv      (one wave per row)
+__global__ __launch_bounds__(256) void ep_cae_wv_kernel(const float* __restrict__ Wv, const float* __restrict__ gv,
+                                                      const float* __restrict__ bv, int D, float* __restrict__ Wvs,
+                                                      float* __restrict__ bo) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= D) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float wv = Wv[(int64_t)r * D + d];
+    Wvs[(int64_t)r * D + d] = wv * gv[d];
+    acc = fmaf(wv, bv[d], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) bo[r] = acc;
+}
+
+// du[h,d] = gk[d] dw[h,d];  d gk[d] (+)= sum_h u[h,d] dw[h,d];  d bk[d] <- 0 (the key-side shift cancels in the softmax)
+__global__ __launch_bounds__(256) void ep_cae_du_kernel(const float* __restrict__ dw, const float* __restrict__ u,
+                                                      const float* __restrict__ gk, int D, int H, int accumulate,
+                                                      float* __restrict__ du, float* __restrict__ dgk, float* __restrict__ dbk) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float g = 0.f;
+  for (int h = 0; h < H; ++h) {
+    const float v = dw[(int64_t)h * D + d];
+    du[(int64_t)h * D + d] = gk[d] * v;
+    g = fmaf(u[(int64_t)h * D + d], v, g);
+  }
+  dgk[d] = accumulate ? dgk[d] + g : g;
+  if (!accumulate) dbk[d] = 0.f;
+}
+
+// dqh[j] = Wk[j,:] . du[h(j),:]
+__global__ __launch_bounds__(256) void ep_cae_dqh_kernel(const float* __restrict__ du, const float* __restrict__ Wk, int D,
+                                                       int dh, float* __restrict__ dqh) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= D) return;
+  const int h = j / dh, lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) acc = fmaf(Wk[(int64_t)j * D + d], du[(int64_t)h * D + d], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) dqh[j] = acc;
+}
+
+// per 64-column block of d:  dWk[j,d] (+)= qh[j] du[h(j),d];  dWq[j,d] (+)= scale dqh[j] qn[d];
+// dqn[d] = scale sum_j Wq[j,d] dqh[j]
+__global__ __launch_bounds__(256) void ep_cae_qgrad_kernel(const float* __restrict__ qh, const float* __restrict__ dqh,
+                                                         const float* __restrict__ du, const float* __restrict__ qn,
+                                                         const float* __restrict__ Wq, int D, int dh, float scale,
+                                                         int accumulate, float* __restrict__ dWk, float* __restrict__ dWq,
+                                                         float* __restrict__ dqn) {
+  extern __shared__ float sh[];          // qh[D] | dqh[D] | partial[4][64]
+  float* s_qh = sh; float* s_dqh = sh + D; float* part = sh + 2 * D;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  for (int i = tid; i < D; i += 256) { s_qh[i] = qh[i]; s_dqh[i] = dqh[i]; }
+  __syncthreads();
+  const int d = blockIdx.x * 64 + tx;
+  const bool ok = d < D;
+  float acc = 0.f;
+  if (ok) {
+    const float qd = qn[d] * scale;
+    for (int j = ty; j < D; j += 4) {
+      const float gk_ = s_qh[j] * du[(int64_t)(j / dh) * D + d];
+      float* o1 = dWk + (int64_t)j * D + d;
+      *o1 = accumulate ? *o1 + gk_ : gk_;
+      const float gq = s_dqh[j] * qd;
+      float* o2 = dWq + (int64_t)j * D + d;
+      *o2 = accumulate ? *o2 + gq : gq;
+      acc = fmaf(Wq[(int64_t)j * D + d], s_dqh[j], acc);
+    }
+  }
+  part[ty * 64 + tx] = acc;
+  __syncthreads();
+  if (ty == 0 && ok) dqn[d] = ((part[tx] + part[64 + tx]) + (part[128 + tx] + part[192 + tx])) * scale;
+}
+
+// value side, per 64-column block of d: dWv[r,d] (+)= dWvs[r,d] gv[d] + dbo[r] bv[d];
+// d gv[d] (+)= sum_r dWvs[r,d] Wv[r,d];  d bv[d] (+)= sum_r dbo[r] Wv[r,d];  unused norm2_cross gradients <- 0
+__global__ __launch_bounds__(256) void ep_cae_dwv_kernel(const float* __restrict__ dWvs, const float* __restrict__ dbo,
+                                                       const float* __restrict__ Wv, const float* __restrict__ gv,
+                                                       const float* __restrict__ bv, int D, int accumulate,
+                                                       float* __restrict__ dWv, float* __restrict__ dgv, float* __restrict__ dbv,
+                                                       float* __restrict__ dn2w, float* __restrict__ dn2b) {
+  __shared__ float pg[4][64], pb[4][64];
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int d = blockIdx.x * 64 + tx;
+  const bool ok = d < D;
+  float ag = 0.f, ab = 0.f;
+  if (ok) {
+    const float g = gv[d], b = bv[d];
+    for (int r = ty; r < D; r += 4) {
+      const float ds = dWvs[(int64_t)r * D + d], wv = Wv[(int64_t)r * D + d], db = dbo[r];
+      const float v = fmaf(ds, g, db * b);
+      float* o = dWv + (int64_t)r * D + d;
+      *o = accumulate ? *o + v : v;
+      ag = fmaf(ds, wv, ag); ab = fmaf(db, wv, ab);
+    }
+  }
+  pg[ty][tx] = ag; pb[ty][tx] = ab;
+  __syncthreads();
+  if (ty == 0 && ok) {
+    const float sg = (pg[0][tx] + pg[1][tx]) + (pg[2][tx] + pg[3][tx]);
+    const float sb = (pb[0][tx] + pb[1][tx]) + (pb[2][tx] + pb[3][tx]);
+    dgv[d] = accumulate ? dgv[d] + sg : sg;
+    dbv[d] = accumulate ? dbv[d] + sb : sb;
+    if (!accumulate) { dn2w[d] = 0.f; dn2b[d] = 0.f; }
+  }
+}
+
+constexpr int CAE_NT = 16;
+struct CaeWs {
+  float *P, *S, *ML, *o, *dO, *dP, *stats, *xhat, *qn, *qh, *u, *wq, *lnstat, *dw, *du, *dqh, *dqn, *Wvs, *bo, *dWvs, *dbo;
+  void* pool_ws; size_t pool_ws_bytes;
+  size_t pool_total;
+  float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
+  void* opt_ws; size_t opt_ws_bytes;
+  int ldl;
+  size_t total;
+};
+
+static int64_t cae_offsets(const ep_cae_dims& d, int64_t offs[CAE_NT]) {
+  const int64_t D = d.D;
+  const int64_t sizes[CAE_NT] = {D, D, D, D, D, D, D, D, D, D * D, D * D, D * D, D * D, D, (int64_t)d.C * D, d.C};
+  int64_t off = 0;
+  for (int i = 0; i < CAE_NT; ++i) { offs[i] = off; off += (sizes[i] + 3) / 4 * 4; }
+  return off;
+}
+
+static CaeWs cae_carve(const ep_cae_dims& d, void* base, bool head) {
+  CaeWs w{};
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += round_up(nfloat * sizeof(float), 256);
+    return p;
+  };
+  const size_t B = d.B, D = d.D;
+  w.P = take(B * d.H * D); w.S = take(B * d.H * d.N); w.ML = take(B * d.H * 4);
+  w.o = take(B * D); w.dO = take(B * D); w.dP = take(B * d.H * D); w.stats = take(B * d.N * 2);
+  w.xhat = take(D); w.qn = take(D); w.qh = take(D); w.u = take((size_t)d.H * D); w.wq = take((size_t)d.H * D);
+  w.lnstat = take(4); w.dw = take((size_t)d.H * D); w.du = take((size_t)d.H * D); w.dqh = take(D); w.dqn = take(D);
+  w.Wvs = take(D * D); w.bo = take(D); w.dWvs = take(D * D); w.dbo = take(D);
+  w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.H);
+  w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
+  w.pool_total = off;
+  if (head) {
+    w.ldl = (d.C + 3) / 4 * 4;
+    w.y = take(B * D); w.z = take(B * D); w.rstd = take(D);
+    w.logits = take(B * w.ldl); w.dlogits = take(B * w.ldl); w.rowstat = take(B * 4);
+    w.bnpart = take(bn_workspace_bytes(d.B, d.D) / sizeof(float));
+    w.dz = take(B * D); w.dy = take(B * D);
+    int64_t offs[CAE_NT];
+    w.opt_ws_bytes = optim_workspace_bytes(cae_offsets(d, offs), CAE_NT);
+    w.opt_ws = take(w.opt_ws_bytes / sizeof(float));
+  }
+  w.total = off;
+  return w;
+}
+
+static int cae_check(const ep_cae_dims& d, bool head) {
+  EP_REQUIRE(d.B > 0 && d.N > 0 && d.D > 0 && d.H > 0, EP_E_ARG, "cae dims must be positive");
+  EP_REQUIRE(d.D % d.H == 0 && (d.D / d.H) % 4 == 0 && d.D % 4 == 0, EP_E_SHAPE, "cae: D %% H == 0 and D/H, D multiples of 4");
+  EP_REQUIRE(d.H <= 32 && (size_t)(2 * d.D + 256) * 4 <= 60000, EP_E_UNSUPPORTED, "cae: heads > 32 or D too large");
+  EP_REQUIRE(!head || d.C > 0, EP_E_ARG, "cae head: C must be positive");
+  return 0;
+}
+
+static int cae_params_ok(const ep_cae_params* p, const char* what) {
+  EP_REQUIRE(p && p->query && p->nq_w && p->nq_b && p->nk_w && p->nk_b && p->nv_w && p->nv_b && p->n2_w && p->n2_b && p->q_w &&
+             p->k_w && p->v_w && p->proj_w && p->proj_b, EP_E_ARG, "%s: null tensor", what);
+  const float* ts[] = {p->query, p->nq_w, p->nq_b, p->nk_w, p->nk_b, p->nv_w, p->nv_b, p->n2_w, p->n2_b, p->q_w, p->k_w, p->v_w,
+                       p->proj_w, p->proj_b};
+  for (const float* t : ts) EP_REQUIRE(aligned16(t), EP_E_ALIGN, "%s: tensors must be 16-byte aligned", what);
+  return 0;
+}
+
+static PoolParams cae_pool_params(const ep_cae_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
+                                  const float* tokstat, const CaeWs& w) {
+  PoolParams p = pool_params(x, bstride, d.B, d.N, d.D, d.H, 1.0f, x_dtype);
+  p.cls = w.wq; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = index; p.tokstat = tokstat;
+  return p;
+}
+
+static GemmParams cg(const float* A, int64_t lda, const float* Bm, int64_t ldb, float* C, int64_t ldc, int M, int N, int K) {
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.f;
+  g.extA = (int)lda; g.extB = (int)ldb;
+  return g;
+}
+
+// tokstat: per-token {mean, rstd} of the caller (a resident store computes them once), or nullptr: computed here
+static int cae_forward_core(const ep_cae_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
+                            const float* tokstat, float ln_eps, const ep_cae_params& pr, const CaeWs& w, float* y,
+                            hipStream_t st) {
+  const int D = d.D, dh = D / d.H;
+  const float scale = (float)pow((double)dh, -0.5);                        // cae_att.py:29
+  if (!tokstat) {
+    EP_REQUIRE(!index, EP_E_ARG, "cae: an indexed token store needs precomputed token statistics");
+    EP_TRY(token_stats(x, x_dtype == EP_DTYPE_BF16, bstride, d.B, d.N, D, ln_eps, w.stats, st));
+    tokstat = w.stats;
+  }
+  hipLaunchKernelGGL(ep_coca_q_kernel, dim3((D + 3) / 4), dim3(256), (size_t)D * 4, st, pr.query, pr.nq_w, pr.nq_b, pr.q_w, D, D,
+                     ln_eps, scale, w.xhat, w.qn, w.lnstat, w.qh);
+  hipLaunchKernelGGL(ep_cae_w_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.qh, pr.k_w, pr.nk_w, D, dh, w.u, w.wq);
+  hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.v_w, pr.nv_w, pr.nv_b, D, w.Wvs, w.bo);
+  EP_LAUNCH_CHECK("ep_cae query kernels");
+  EP_TRY(pool_forward(cae_pool_params(d, x, x_dtype, bstride, index, tokstat, w), st));
+  {
+    GemmParams g = cg(w.P, (int64_t)d.H * D, w.Wvs, D, w.o, D, d.B, dh, D);          // o = Phat (Wv gv)_h^T + (Wv bv)_h
+    g.sAz = D; g.sBz = (int64_t)dh * D; g.sCz = dh; g.bias = w.bo; g.sBiasz = dh;
+    EP_TRY(gemm(true, true, g, d.H, st));
+  }
+  GemmParams g = cg(w.o, D, pr.proj_w, D, y, D, d.B, D, D); g.bias = pr.proj_b;
+  return gemm(true, true, g, 1, st);
+}
+
+static int cae_backward_core(const ep_cae_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
+                             const float* tokstat, float ln_eps, const ep_cae_params& pr, const float* dy,
+                             const ep_cae_params& gr, int acc, const CaeWs& w, SideTasks sd, hipStream_t st, hipStream_t aux) {
+  const int D = d.D, dh = D / d.H, B = d.B;
+  const float scale = (float)pow((double)dh, -0.5);
+  if (!tokstat) tokstat = w.stats;                                                     // left there by the forward
+  EP_TRY(gemm(true, false, cg(dy, D, pr.proj_w, D, w.dO, D, B, D, D), 1, st));         // dO = dy Wp
+  EP_TRY(colsum(dy, B, D, D, acc, gr.proj_b, st));
+  EP_TRY(colsum(w.dO, B, D, D, 0, w.dbo, st));                                          // d(Wv bv)
+  EP_TRY(delta_rows(w.dO, w.o, B * d.H, dh, w.ML, st, w.bo, d.H));                      // dPhat . Phat (bias taken out)
+  {
+    GemmParams g = cg(w.dO, D, w.Wvs, D, w.dP, (int64_t)d.H * D, B, D, dh);             // dPhat[b,h] = dO[b,h] (Wv gv)_h
+    g.sAz = dh; g.sBz = (int64_t)dh * D; g.sCz = D; g.extB = D;
+    EP_TRY(gemm(true, false, g, d.H, st));
+  }
+  GemmParams gWp = cg(dy, D, w.o, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;          // dWp = dy^T o
+  GemmParams gWv = cg(w.dO, D, w.P, (int64_t)d.H * D, w.dWvs, D, dh, D, B);                               // d(Wv gv)_h = dO_h^T Phat_h
+  gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.side = 1;
+  EP_REQUIRE(gemm_side_ok(gWp, false, false) && gemm_side_ok(gWv, false, false), EP_E_ALIGN, "cae: unaligned gradient contraction");
+  side_add_gemm(sd, gWp, 1); side_add_gemm(sd, gWv, d.H);
+  PoolParams p = cae_pool_params(d, x, x_dtype, bstride, index, tokstat, w);
+  p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
+  {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t side = aux ? aux : st;
+    if (side != st) {
+      EP_TRY(get_events(ev, 2));
+      EP_HIP(hipEventRecord(ev[0], st));
+      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    }
+    EP_TRY(side_run_standalone(sd, side));
+    EP_TRY(pool_backward(p, w.dw, 0, st));
+    if (side != st) {
+      EP_HIP(hipEventRecord(ev[1], side));
+      EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
+    }
+  }
+  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dWvs, w.dbo, pr.v_w, pr.nv_w, pr.nv_b, D, acc,
+                     gr.v_w, gr.nv_w, gr.nv_b, gr.n2_w, gr.n2_b);
+  hipLaunchKernelGGL(ep_cae_du_kernel, dim3((D + 255) / 256), dim3(256), 0, st, w.dw, w.u, pr.nk_w, D, d.H, acc, w.du, gr.nk_w,
+                     gr.nk_b);
+  hipLaunchKernelGGL(ep_cae_dqh_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.du, pr.k_w, D, dh, w.dqh);
+  hipLaunchKernelGGL(ep_cae_qgrad_kernel, dim3((D + 63) / 64), dim3(256), (size_t)(2 * D + 256) * 4, st, w.qh, w.dqh, w.du, w.qn,
+                     pr.q_w, D, dh, scale, acc, gr.k_w, gr.q_w, w.dqn);
+  hipLaunchKernelGGL(ep_coca_lnbwd_kernel, dim3(1), dim3(256), 0, st, w.dqn, w.xhat, pr.nq_w, w.lnstat, D, acc, gr.nq_w,
+                     gr.query, gr.nq_b);
+  EP_LAUNCH_CHECK("ep_cae backward kernels");
+  (void)ln_eps;
+  return 0;
+}
+
+static ep_cae_params cae_views(float* base, const int64_t o[CAE_NT]) {
+  ep_cae_params p;
+  p.query = base + o[0]; p.nq_w = base + o[1]; p.nq_b = base + o[2]; p.nk_w = base + o[3]; p.nk_b = base + o[4];
+  p.nv_w = base + o[5]; p.nv_b = base + o[6]; p.n2_w = base + o[7]; p.n2_b = base + o[8]; p.q_w = base + o[9];
+  p.k_w = base + o[10]; p.v_w = base + o[11]; p.proj_w = base + o[12]; p.proj_b = base + o[13];
+  return p;
+}
+
+}  // namespace ep
+
+extern "C" {
+
+size_t ep_cae_pool_workspace_bytes(const ep_cae_dims* dims) {
+  if (!dims || cae_check(*dims, false) != 0) return 0;
+  return cae_carve(*dims, nullptr, false).total;
+}
+
+int ep_cae_pool_forward(const ep_cae_dims* dims, const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
+                        const float* token_stats_, float ln_eps, const ep_cae_params* params, float* y, void* ws,
+                        size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(dims && y && ws, EP_E_ARG, "ep_cae_pool_forward: null pointer");
+  EP_TRY(cae_check(*dims, false));
+  EP_TRY(cae_params_ok(params, "ep_cae_pool_forward"));
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, dims->B, dims->N, dims->D, dims->H));
+  EP_REQUIRE(aligned16(ws) && aligned16(y), EP_E_ALIGN, "ep_cae_pool_forward: y / ws must be 16-byte aligned");
+  const CaeWs w = cae_carve(*dims, ws, false);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_cae_pool_forward: workspace %zu < %zu", ws_bytes, w.total);
+  return cae_forward_core(*dims, x, x_dtype, x_bstride, image_index, token_stats_, ln_eps, *params, w, y, (hipStream_t)stream);
+}
+
+int ep_cae_pool_backward(const ep_cae_dims* dims, const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
+                         const float* token_stats_, float ln_eps, const ep_cae_params* params, const float* dy,
+                         const ep_cae_params* grads, int accumulate, void* ws, size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(dims && dy && ws, EP_E_ARG, "ep_cae_pool_backward: null pointer");
+  EP_TRY(cae_check(*dims, false));
+  EP_TRY(cae_params_ok(params, "ep_cae_pool_backward(params)"));
+  EP_TRY(cae_params_ok(grads, "ep_cae_pool_backward(grads)"));
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, dims->B, dims->N, dims->D, dims->H));
+  EP_REQUIRE(aligned16(ws) && aligned16(dy), EP_E_ALIGN, "ep_cae_pool_backward: dy / ws must be 16-byte aligned");
+  const CaeWs w = cae_carve(*dims, ws, false);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_cae_pool_backward: workspace %zu < %zu", ws_bytes, w.total);
+  return cae_backward_core(*dims, x, x_dtype, x_bstride, image_index, token_stats_, ln_eps, *params, dy, *grads, accumulate, w,
+                           SideTasks{}, (hipStream_t)stream, nullptr);
+}
+
+int64_t ep_cae_head_param_offsets(const ep_cae_dims* dims, int64_t offsets[16]) { return cae_offsets(*dims, offsets); }
+
+size_t ep_cae_head_workspace_bytes(const ep_cae_dims* dims) {
+  if (!dims || cae_check(*dims, true) != 0) return 0;
+  return cae_carve(*dims, nullptr, true).total;
+}
+
+int ep_cae_head_train_step(const ep_cae_step* s, void* ws, size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(s && ws, EP_E_ARG, "ep_cae_head_train_step: null pointer");
+  const ep_cae_dims& d = s->dims;
+  EP_TRY(cae_check(d, true));
+  EP_REQUIRE(aligned16(ws), EP_E_ALIGN, "workspace must be 16-byte aligned");
+  const CaeWs w = cae_carve(d, ws, true);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_cae_head_train_step: workspace %zu < %zu", ws_bytes, w.total);
+  EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t offs[CAE_NT];
+  const int64_t total = cae_offsets(d, offs);
+  const ep_cae_params pr = cae_views(s->params, offs), gr = cae_views(s->grads, offs);
+  float* Wc = s->params + offs[14]; float* bc = s->params + offs[15];
+  if (s->phases & 1) {
+    EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
+    EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.H));
+    EP_TRY(cae_forward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, s->token_stats, s->ln_eps, pr, w, w.y, st));
+    EP_TRY(bn_forward_train(w.y, d.B, d.D, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
+                            s->num_batches_tracked, w.bnpart, st));
+    EP_TRY(linear_forward(w.z, Wc, bc, d.B, d.D, d.C, w.logits, w.ldl, st));
+    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
+    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, nullptr, nullptr, 0, st));
+    EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, d.D, w.dy, w.bnpart, st));
+    SideTasks sd{};
+    const GemmParams gWc = dwc_gemm(w.dlogits, w.ldl, w.z, d.B, d.D, d.C, s->grads + offs[14], s->accumulate);
+    EP_REQUIRE(gemm_side_ok(gWc, false, false), EP_E_ALIGN, "cae head: unaligned classifier gradient");
+    side_add_gemm(sd, gWc, 1);
+    sd.cs_src = w.dlogits; sd.cs_out = s->grads + offs[15]; sd.cs_B = d.B; sd.cs_ncol = d.C; sd.cs_ld = w.ldl;
+    sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
+    sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;
+    sd.total += sd.n_colsum + sd.n_stats;
+    EP_TRY(cae_backward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, s->token_stats, s->ln_eps, pr, w.dy, gr,
+                             s->accumulate, w, sd, st, (hipStream_t)s->aux_stream));
+  }
+  if (s->phases & 2) {
+    EP_REQUIRE(s->found_inf, EP_E_ARG, "optimizer phase needs found_inf");
+    const int64_t D = d.D;
+    const int64_t sizes[CAE_NT] = {D, D, D, D, D, D, D, D, D, D * D, D * D, D * D, D * D, D, (int64_t)d.C * D, d.C};
+    // util/lars.py:22: trust ratio + weight decay for ndim > 1: the query token is (1, 1, D); LayerNorm vectors and biases are not
+    const int trust[CAE_NT] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0};
+    ep_segment segs[CAE_NT];
+    for (int i = 0; i < CAE_NT; ++i) segs[i] = ep_segment{offs[i], sizes[i], trust[i], 0};
+    EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
+                      s->optimizer == 0 ? segs : nullptr, s->optimizer == 0 ? CAE_NT : 0, s->lr, s->weight_decay, s->momentum,
+                      s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step, s->found_inf,
+                      s->grad_norm, w.opt_ws, w.opt_ws_bytes, st));
+  }
+  return 0;
+}
+
+int ep_cae_head_eval_forward(const ep_cae_dims* dims, const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
+                             const float* token_stats_, float ln_eps, const float* params, const float* running_mean,
+                             const float* running_var, float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
+                             ep_stream_t stream) {
+  EP_REQUIRE(dims && x && params && running_mean && running_var && logits && ws, EP_E_ARG, "ep_cae_head_eval_forward: null pointer");
+  const ep_cae_dims& d = *dims;
+  EP_TRY(cae_check(d, true));
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, d.B, d.N, d.D, d.H));
+  const CaeWs w = cae_carve(d, ws, true);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_cae_head_eval_forward: workspace %zu < %zu", ws_bytes, w.total);
+  EP_REQUIRE(ldl >= d.C, EP_E_ARG, "ldl < C");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t offs[CAE_NT];
+  cae_offsets(d, offs);
+  const ep_cae_params pr = cae_views(const_cast<float*>(params), offs);
+  EP_TRY(cae_forward_core(d, x, x_dtype, x_bstride, image_index, token_stats_, ln_eps, pr, w, w.y, st));
+  EP_TRY(bn_forward_eval(w.y, d.B, d.D, bn_eps, running_mean, running_var, w.z, st));
+  return linear_forward(w.z, params + offs[14], params + offs[15], d.B, d.D, d.C, logits, ldl, st);
 }
 
 }  // extern "C"

@@ -655,3 +655,56 @@ def pool_backward_ln(x, S, ML, dP, scale, stats, image_index=None):
                                     stats.data_ptr(), S.data_ptr(), ML.data_ptr(), dP.data_ptr(), dcls.data_ptr(), 0,
                                     ws.data_ptr(), nbytes, N.current_stream_ptr(x.device)), "ep_pool_backward_ln")
     return dcls
+
+
+# --------------------------------------------------------------------------------------------
+# CAE attentive block (reference poolings/cae_att.py:79-108) on the LayerNorm-of-tokens token passes
+# --------------------------------------------------------------------------------------------
+CAE_TENSORS = ("query_token", "norm1_q.weight", "norm1_q.bias", "norm1_k.weight", "norm1_k.bias", "norm1_v.weight",
+               "norm1_v.bias", "norm2_cross.weight", "norm2_cross.bias", "cross_attn.q.weight", "cross_attn.k.weight",
+               "cross_attn.v.weight", "cross_attn.proj.weight", "cross_attn.proj.bias")
+CAE_LN_EPS = 1e-5          # nn.LayerNorm default (cae_att.py:82 norm_layer=nn.LayerNorm)
+
+
+def _cae_params_struct(ts):
+    return N.EPCaeParams(*[t.data_ptr() for t in ts])
+
+
+class _CaePool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, CAE_TENSORS)]
+        dims = N.EPCaeDims(B=B, N=Nn, D=D, H=heads, C=0)
+        nbytes = lib.ep_cae_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_cae_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_cae_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, CAE_LN_EPS,
+                                        C.byref(_cae_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes,
+                                        N.current_stream_ptr(xv.device)), "ep_cae_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("CAE attentive block (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_cae_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0, 0, CAE_LN_EPS,
+                                         C.byref(_cae_params_struct(tens)), dy.data_ptr(), C.byref(_cae_params_struct(grads)),
+                                         0, ws.data_ptr(), ws.numel(), N.current_stream_ptr(xv.device)),
+                "ep_cae_pool_backward")
+        return (None, None, *grads)
+
+
+def cae_pool(x, heads, *tens):
+    return _CaePool.apply(x, heads, *tens)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 9
+#define EP_ABI_VERSION 10
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -475,6 +475,61 @@ int ep_siglip_head_eval_forward(const ep_siglip_dims* dims, const void* x, int x
                                 const int32_t* image_index, const float* params, const float* running_mean,
                                 const float* running_var, float bn_eps, float* logits, int ldl, void* ws,
                                 size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CAE attentive block (reference poolings/cae_att.py:79-108 CAEAttentiveBlock with CrossAttention :19-77 as the
+ * registry builds it, probe_heads.py:83: CAEAttentiveBlock(dim=dim) -> 8 heads, no qkv bias).  One learned query
+ * token; keys LN_k(x) Wk^T, values LN_v(x) Wv^T: two LayerNorms of the same token, i.e. one normalised token xhat with
+ * two affine maps -- the LayerNorm-of-tokens mode of the EP passes (ep_pool_forward_ln) with derived query rows
+ * gk * (Wk_h^T qh_h), then the per-head projection with Wv diag(gv) and bias Wv bv, then proj.
+ * Fourteen tensors: query_token (1,1,D) | norm1_q.weight .bias | norm1_k.weight .bias | norm1_v.weight .bias |
+ * norm2_cross.weight .bias (unused by the forward: zero gradient) | cross_attn.q.weight k.weight v.weight (D,D) |
+ * cross_attn.proj.weight (D,D) .bias.  token_stats: optional (B|M, N, 2) from ep_token_stats (NULL: computed here).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_cae_dims {
+  int32_t B, N, D, H, C;
+} ep_cae_dims;
+
+typedef struct ep_cae_params {
+  float *query, *nq_w, *nq_b, *nk_w, *nk_b, *nv_w, *nv_b, *n2_w, *n2_b, *q_w, *k_w, *v_w, *proj_w, *proj_b;
+} ep_cae_params;
+
+size_t ep_cae_pool_workspace_bytes(const ep_cae_dims* dims);
+int ep_cae_pool_forward(const ep_cae_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                        const int32_t* image_index, const float* token_stats, float ln_eps,
+                        const ep_cae_params* params, float* y, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_cae_pool_backward(const ep_cae_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* token_stats, float ln_eps,
+                         const ep_cae_params* params, const float* dy, const ep_cae_params* grads, int accumulate,
+                         void* ws, size_t ws_bytes, ep_stream_t stream);
+
+typedef struct ep_cae_step {
+  ep_cae_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* token_stats; float ln_eps;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_cae_step;
+
+int64_t ep_cae_head_param_offsets(const ep_cae_dims* dims, int64_t offsets[16]);
+size_t ep_cae_head_workspace_bytes(const ep_cae_dims* dims);
+int ep_cae_head_train_step(const ep_cae_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_cae_head_eval_forward(const ep_cae_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                             const int32_t* image_index, const float* token_stats, float ln_eps, const float* params,
+                             const float* running_mean, const float* running_var, float bn_eps, float* logits,
+                             int ldl, void* ws, size_t ws_bytes, ep_stream_t stream);
 
 #ifdef __cplusplus
 }

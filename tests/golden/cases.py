@@ -284,3 +284,57 @@ def make_siglip_inputs(case: SiglipCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# CAE attentive block (reference poolings/cae_att.py:79-108 behind probe_heads.py:83)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class CaeCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+CAE_CASES = [
+    CaeCase("tiny", B=6, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
+    CaeCase("tiny_sharp_strided", B=5, N=16, D=128, C=7, seed=1, strided=True, sharp=True, steps=1),
+    CaeCase("vitb16", B=6, N=197, D=768, C=1000, seed=0, full=False, steps=1),
+    CaeCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+CAE_BY_NAME = {c.name: c for c in CAE_CASES}
+CAE_INIT_DIMS = [(768, 1000)]
+CAE_PARAM_NAMES = ["query", "nq_w", "nq_b", "nk_w", "nk_b", "nv_w", "nv_b", "n2_w", "n2_b", "q_w", "k_w", "v_w", "proj_w",
+                   "proj_b", "fc_weight", "fc_bias"]
+CAE_SMALL = ("query", "nq_w", "nq_b", "nk_w", "nk_b", "nv_w", "nv_b", "n2_w", "n2_b", "proj_b", "fc_bias")
+
+
+def make_cae_inputs(case: CaeCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(13000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    ln = lambda: (1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (5.0 if case.sharp else 1.0)
+    # tokens with a per-token offset and scale (what a LayerNorm is for)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, n_alloc, 1), dtype=np.float32)).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        query=(g * rng.standard_normal((1, 1, D), dtype=np.float32)).astype(np.float32),
+        nq_w=ln(), nq_b=u(0.2, (D,)), nk_w=ln(), nk_b=u(0.2, (D,)), nv_w=ln(), nv_b=u(0.2, (D,)),
+        n2_w=ln(), n2_b=u(0.2, (D,)),
+        q_w=u(bd, (D, D)), k_w=u(bd * g, (D, D)), v_w=u(bd, (D, D)), proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
