@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
@@ -171,6 +171,9 @@ def main():
     if args.head == "coca":
         Q = 8                                              # 8 query heads of image query 0 (coca_pytorch.py:259)
         desc = desc.split(",")[0] + f", CoCa pooler (8 heads x 64, 196 image queries), {Cc} classes"
+    if args.head == "cae":
+        Q = 8                                              # 8 heads of the query token (cae_att.py:81)
+        desc = desc.split(",")[0] + f", CAE attentive block (8 heads, LayerNorm-ed keys / values), {Cc} classes"
     if args.head == "siglip":
         Q = 8                                              # 8 heads of the latent query (attention_pool.py:24)
         desc = desc.split(",")[0] + f", SigLIP attention pool (8 heads, latent query, MLP x4), {Cc} classes"
@@ -241,7 +244,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / iters
 
-    if args.head in ("coca", "siglip"):                    # the same kernel, fed with the H derived query rows
+    if args.head in ("coca", "siglip", "cae"):             # the same kernel, fed with the H derived query rows
         cls, scale = torch.randn(Q, D, device=dev) * 0.05, 1.0
     else:
         cls, scale = head[0].cls_token.detach(), head[0].scale
@@ -287,7 +290,7 @@ def main():
         value = B * world * args.steps / elapsed
         out = {
             "metric": {"ep": "EP-head train images/sec", "coca": "CoCa-head train images/sec",
-                       "siglip": "SigLIP-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
+                       "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
@@ -320,6 +323,9 @@ def main():
             if args.head == "siglip":
                 from oracle import siglip_oracle
                 mk = lambda: siglip_oracle.make_head(D, Cc)
+            if args.head == "cae":
+                from oracle import cae_oracle
+                mk = lambda: cae_oracle.make_head(D, Cc)
             probe = {c: torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=2.0, threads=c, min_steps=1,
                                                     make=mk)["value"] for c in cands}
             best = max(probe, key=probe.get)

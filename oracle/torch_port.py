@@ -46,6 +46,8 @@ def make_head(dim, num_queries, nb_classes, d_out=1):
 def lars_update(params, mus, lr, weight_decay=0.0, momentum=0.9, tc=0.001):
     for p, mu in zip(params, mus):
         dp = p.grad
+        if dp is None:                       # util/lars.py:18-19: parameters without a gradient are skipped
+            continue
         if p.ndim > 1:
             dp = dp.add(p, alpha=weight_decay)
             pn, un = torch.norm(p), torch.norm(dp)
