@@ -178,6 +178,20 @@ class EPCaeStep(C.Structure):
     ]
 
 
+class EPJepaDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("hidden", C.c_int32),
+                ("C", C.c_int32)]
+
+
+class EPJepaParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("query", "n1_w", "n1_b", "q_w", "q_b", "kv_w", "kv_b", "proj_w", "proj_b", "n2_w",
+                                          "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class EPJepaStep(C.Structure):
+    _fields_ = [("dims", EPJepaDims)] + list(EPCaeStep._fields_[1:])
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -270,6 +284,16 @@ SIGNATURES = {
     "ep_cae_head_train_step": (c_int, [C.POINTER(EPCaeStep), c_void, c_size, c_void]),
     "ep_cae_head_eval_forward": (c_int, [C.POINTER(EPCaeDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, c_f32p, c_f32p,
                                          c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_jepa_pool_workspace_bytes": (c_size, [C.POINTER(EPJepaDims)]),
+    "ep_jepa_pool_forward": (c_int, [C.POINTER(EPJepaDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, C.POINTER(EPJepaParams),
+                                     c_f32p, c_void, c_size, c_void]),
+    "ep_jepa_pool_backward": (c_int, [C.POINTER(EPJepaDims), c_void, c_int, c_i64, c_void, c_f32p, C.POINTER(EPJepaParams),
+                                      c_f32p, C.POINTER(EPJepaParams), c_int, c_void, c_size, c_void]),
+    "ep_jepa_head_param_offsets": (c_i64, [C.POINTER(EPJepaDims), C.POINTER(c_i64)]),
+    "ep_jepa_head_workspace_bytes": (c_size, [C.POINTER(EPJepaDims)]),
+    "ep_jepa_head_train_step": (c_int, [C.POINTER(EPJepaStep), c_void, c_size, c_void]),
+    "ep_jepa_head_eval_forward": (c_int, [C.POINTER(EPJepaDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, c_f32p, c_f32p,
+                                          c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }

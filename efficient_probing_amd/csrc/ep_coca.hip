@@ -12,6 +12,7 @@
 #include <math.h>
 #include "ep_common.h"
 #include "ep_internal.h"
+#include "ep_lnaffine.h"
 
 namespace ep {
 
@@ -458,39 +459,6 @@ __global__ __launch_bounds__(256) void ep_cae_w_kernel(const float* __restrict__
   wq[(int64_t)h * D + d] = acc * gk[d];
 }
 
-// Wv'[r,d] = Wv[r,d] gv[d];  bo[r] = Wv[r,:] . bv      (one wave per row)
-__global__ __launch_bounds__(256) void ep_cae_wv_kernel(const float* __restrict__ Wv, const float* __restrict__ gv,
-                                                      const float* __restrict__ bv, int D, float* __restrict__ Wvs,
-                                                      float* __restrict__ bo) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= D) return;
-  const int lane = threadIdx.x & 63;
-  float acc = 0.f;
-  for (int d = lane; d < D; d += 64) {
-    const float wv = Wv[(int64_t)r * D + d];
-    Wvs[(int64_t)r * D + d] = wv * gv[d];
-    acc = fmaf(wv, bv[d], acc);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) bo[r] = acc;
-}
-
-// du[h,d] = gk[d] dw[h,d];  d gk[d] (+)= sum_h u[h,d] dw[h,d];  d bk[d] <- 0 (the key-side shift cancels in the softmax)
-__global__ __launch_bounds__(256) void ep_cae_du_kernel(const float* __restrict__ dw, const float* __restrict__ u,
-                                                      const float* __restrict__ gk, int D, int H, int accumulate,
-                                                      float* __restrict__ du, float* __restrict__ dgk, float* __restrict__ dbk) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float g = 0.f;
-  for (int h = 0; h < H; ++h) {
-    const float v = dw[(int64_t)h * D + d];
-    du[(int64_t)h * D + d] = gk[d] * v;
-    g = fmaf(u[(int64_t)h * D + d], v, g);
-  }
-  dgk[d] = accumulate ? dgk[d] + g : g;
-  if (!accumulate) dbk[d] = 0.f;
-}
-
 // dqh[j] = Wk[j,:] . du[h(j),:]
 __global__ __launch_bounds__(256) void ep_cae_dqh_kernel(const float* __restrict__ du, const float* __restrict__ Wk, int D,
                                                        int dh, float* __restrict__ dqh) {
@@ -533,39 +501,6 @@ __global__ __launch_bounds__(256) void ep_cae_qgrad_kernel(const float* __restri
   part[ty * 64 + tx] = acc;
   __syncthreads();
   if (ty == 0 && ok) dqn[d] = ((part[tx] + part[64 + tx]) + (part[128 + tx] + part[192 + tx])) * scale;
-}
-
-// value side, per 64-column block of d: dWv[r,d] (+)= dWvs[r,d] gv[d] + dbo[r] bv[d];
-// d gv[d] (+)= sum_r dWvs[r,d] Wv[r,d];  d bv[d] (+)= sum_r dbo[r] Wv[r,d];  unused norm2_cross gradients <- 0
-__global__ __launch_bounds__(256) void ep_cae_dwv_kernel(const float* __restrict__ dWvs, const float* __restrict__ dbo,
-                                                       const float* __restrict__ Wv, const float* __restrict__ gv,
-                                                       const float* __restrict__ bv, int D, int accumulate,
-                                                       float* __restrict__ dWv, float* __restrict__ dgv, float* __restrict__ dbv,
-                                                       float* __restrict__ dn2w, float* __restrict__ dn2b) {
-  __shared__ float pg[4][64], pb[4][64];
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const int d = blockIdx.x * 64 + tx;
-  const bool ok = d < D;
-  float ag = 0.f, ab = 0.f;
-  if (ok) {
-    const float g = gv[d], b = bv[d];
-    for (int r = ty; r < D; r += 4) {
-      const float ds = dWvs[(int64_t)r * D + d], wv = Wv[(int64_t)r * D + d], db = dbo[r];
-      const float v = fmaf(ds, g, db * b);
-      float* o = dWv + (int64_t)r * D + d;
-      *o = accumulate ? *o + v : v;
-      ag = fmaf(ds, wv, ag); ab = fmaf(db, wv, ab);
-    }
-  }
-  pg[ty][tx] = ag; pb[ty][tx] = ab;
-  __syncthreads();
-  if (ty == 0 && ok) {
-    const float sg = (pg[0][tx] + pg[1][tx]) + (pg[2][tx] + pg[3][tx]);
-    const float sb = (pb[0][tx] + pb[1][tx]) + (pb[2][tx] + pb[3][tx]);
-    dgv[d] = accumulate ? dgv[d] + sg : sg;
-    dbv[d] = accumulate ? dbv[d] + sb : sb;
-    if (!accumulate) { dn2w[d] = 0.f; dn2b[d] = 0.f; }
-  }
 }
 
 constexpr int CAE_NT = 16;
@@ -663,7 +598,8 @@ static int cae_forward_core(const ep_cae_dims& d, const void* x, int x_dtype, in
   hipLaunchKernelGGL(ep_coca_q_kernel, dim3((D + 3) / 4), dim3(256), (size_t)D * 4, st, pr.query, pr.nq_w, pr.nq_b, pr.q_w, D, D,
                      ln_eps, scale, w.xhat, w.qn, w.lnstat, w.qh);
   hipLaunchKernelGGL(ep_cae_w_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.qh, pr.k_w, pr.nk_w, D, dh, w.u, w.wq);
-  hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.v_w, pr.nv_w, pr.nv_b, D, w.Wvs, w.bo);
+  hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.v_w, pr.nv_w, pr.nv_b, D, w.Wvs, w.bo,
+                     (const float*)nullptr);
   EP_LAUNCH_CHECK("ep_cae query kernels");
   EP_TRY(pool_forward(cae_pool_params(d, x, x_dtype, bstride, index, tokstat, w), st));
   {

@@ -439,6 +439,42 @@ class CaeHeadEngine(ProbeHeadEngine):
                                                  ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class JepaHeadEngine(CaeHeadEngine):
+    """Fused train / eval step of Sequential(AttentivePooler (V-JEPA), BatchNorm1d, Linear) through
+    ``ep_jepa_head_train_step`` (LayerNorm-of-tokens mode of the token passes)."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_jepa_head
+        if not is_native_jepa_head(head):
+            raise TypeError("JepaHeadEngine needs Sequential(poolings.jepa.AttentivePooler, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        b = self.pool.cross_attention_block
+        dims = N.EPJepaDims(B=0, N=0, D=b.xattn.q.in_features, H=b.xattn.num_heads, hidden=b.mlp.fc1.out_features,
+                            C=self.fc.out_features)
+        offs = (C.c_int64 * 17)()
+        total = int(self.lib.ep_jepa_head_param_offsets(C.byref(dims), offs))
+        return dims, list(self.pool._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        s = N.EPJepaStep()
+        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.ln_eps = F_.JEPA_LN_EPS
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_jepa_head_workspace_bytes(C.byref(self.dims))
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_jepa_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_jepa_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+                                                  F_.JEPA_LN_EPS, self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                  self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                                  ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+
 class LinearProbeEngine(ProbeHeadEngine):
     """Fused train / eval step of plain linear probing, Sequential(BatchNorm1d, Linear) on one feature vector per
     image (what the registry builds for --cls_features cls / gap / pos ..., reference probe_heads.py:96-99).
@@ -504,10 +540,12 @@ class _LPView:
 
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
     """The fused engine matching a native head (EP, CoCa, AbMILP or plain linear probing)."""
-    from .probe_heads import (is_native_abmilp_head, is_native_cae_head, is_native_coca_head, is_native_lp_head,
-                              is_native_siglip_head)
+    from .probe_heads import (is_native_abmilp_head, is_native_cae_head, is_native_coca_head, is_native_jepa_head,
+                              is_native_lp_head, is_native_siglip_head)
     if is_native_lp_head(head):
         return LinearProbeEngine(head, **kw)
+    if is_native_jepa_head(head):
+        return JepaHeadEngine(head, **kw)
     if is_native_cae_head(head):
         return CaeHeadEngine(head, **kw)
     if is_native_siglip_head(head):

@@ -708,3 +708,56 @@ class _CaePool(torch.autograd.Function):
 
 def cae_pool(x, heads, *tens):
     return _CaePool.apply(x, heads, *tens)
+
+
+# --------------------------------------------------------------------------------------------
+# V-JEPA attentive pooler (reference poolings/jepa/attentive_pooler.py:21-104) on the LayerNorm-of-tokens passes
+# --------------------------------------------------------------------------------------------
+JEPA_TENSORS = ("query_tokens", "norm1.weight", "norm1.bias", "xattn.q.weight", "xattn.q.bias", "xattn.kv.weight",
+                "xattn.kv.bias", "xattn.proj.weight", "xattn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight",
+                "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+JEPA_LN_EPS = 1e-5
+
+
+def _jepa_params_struct(ts):
+    return N.EPJepaParams(*[t.data_ptr() for t in ts])
+
+
+class _JepaPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, hidden, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, JEPA_TENSORS)]
+        dims = N.EPJepaDims(B=B, N=Nn, D=D, H=heads, hidden=hidden, C=0)
+        nbytes = lib.ep_jepa_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_jepa_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_jepa_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, JEPA_LN_EPS,
+                                         C.byref(_jepa_params_struct(tens)), out.data_ptr(), ws.data_ptr(), nbytes,
+                                         N.current_stream_ptr(xv.device)), "ep_jepa_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("JEPA attentive pooler (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_jepa_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0, 0,
+                                          C.byref(_jepa_params_struct(tens)), dout.data_ptr(),
+                                          C.byref(_jepa_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                          N.current_stream_ptr(xv.device)), "ep_jepa_pool_backward")
+        return (None, None, None, *grads)
+
+
+def jepa_pool(x, heads, hidden, *tens):
+    return _JepaPool.apply(x, heads, hidden, *tens)

@@ -14,8 +14,8 @@ Invariants kept from the reference (published numbers depend on them):
   * a ``_all`` suffix selects the same pooling over [CLS]+patch tokens (reference :95);
   * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
 
-Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip`` and ``cae`` (pooling, BatchNorm1d and the classifier run in
-the HIP kernels of libep_hip.so).  The other nine names resolve to the reference's own PyTorch modules when the
+Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae`` and ``jepa`` (pooling, BatchNorm1d and the classifier
+run in the HIP kernels of libep_hip.so).  The other eight names resolve to the reference's own PyTorch modules when the
 reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
 ``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
 """
@@ -33,6 +33,7 @@ from .poolings.coca import CrossAttention as CocaPooling
 from .poolings.abmilp import ABMILPHead
 from .poolings.siglip import AttentionPoolLatent
 from .poolings.cae import CAEAttentiveBlock
+from .poolings.jepa import AttentivePooler
 from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
 
 BN_EPS = 1e-6
@@ -135,6 +136,7 @@ POOLINGS["abmilp"] = (lambda dim, args, model: ABMILPHead(       # native (refer
     cond=args.abmilp_cond, content=args.abmilp_content, num_patches=model.patch_embed.num_patches), None)
 POOLINGS["siglip"] = (lambda dim, args, model: AttentionPoolLatent(in_features=dim), None)   # native (:72)
 POOLINGS["cae"] = (lambda dim, args, model: CAEAttentiveBlock(dim=dim), None)               # native (:83)
+POOLINGS["jepa"] = (lambda dim, args, model: AttentivePooler(embed_dim=dim, num_heads=args.num_heads), None)   # native (:81)
 POOLINGS["coca"] = (lambda dim, args, model: CocaPooling(dim=dim), None)     # native (reference probe_heads.py:78)
 
 
@@ -191,6 +193,12 @@ def is_native_cae_head(head: nn.Module) -> bool:
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
 
 
+def is_native_jepa_head(head: nn.Module) -> bool:
+    """True for Sequential(poolings.jepa.AttentivePooler, BatchNorm1d, Linear) -- engine.JepaHeadEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], AttentivePooler)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
 def is_native_lp_head(head: nn.Module) -> bool:
     """True for Sequential(BatchNorm1d(affine=False), Linear): plain linear probing (build_probe_head for names
     without a pooling entry, reference probe_heads.py:96-99) -- engine.LinearProbeEngine."""
@@ -200,7 +208,8 @@ def is_native_lp_head(head: nn.Module) -> bool:
 
 def is_native_head(head: nn.Module) -> bool:
     return (is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
-            or is_native_siglip_head(head) or is_native_cae_head(head) or is_native_lp_head(head))
+            or is_native_siglip_head(head) or is_native_cae_head(head) or is_native_jepa_head(head)
+            or is_native_lp_head(head))
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 10
+#define EP_ABI_VERSION 11
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -530,6 +530,61 @@ int ep_cae_head_eval_forward(const ep_cae_dims* dims, const void* x, int x_dtype
                              const int32_t* image_index, const float* token_stats, float ln_eps, const float* params,
                              const float* running_mean, const float* running_var, float bn_eps, float* logits,
                              int ldl, void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * V-JEPA attentive pooler (reference poolings/jepa/attentive_pooler.py:21-104 with CrossAttentionBlock / CrossAttention /
+ * MLP of poolings/jepa/modules.py:13-183 as the registry builds it, probe_heads.py:81: AttentivePooler(embed_dim=dim,
+ * num_heads=args.num_heads): one query token, depth 1, complete block, qkv bias):
+ *     y = xattn(q0, LN1(x));  q1 = q0 + y;  out = q1 + mlp(LN2(q1))
+ * = the SigLIP head with LayerNorm-ed keys / values (LayerNorm-of-tokens mode of the passes), the residual with the
+ * query token and a LayerNorm in front of the MLP.  Fifteen tensors: query_tokens (1,1,D) | norm1.weight .bias |
+ * xattn.q.weight .bias | xattn.kv.weight (2D,D) .bias | xattn.proj.weight .bias | norm2.weight .bias |
+ * mlp.fc1.weight (hidden,D) .bias | mlp.fc2.weight (D,hidden) .bias.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_jepa_dims {
+  int32_t B, N, D, H, hidden, C;
+} ep_jepa_dims;
+
+typedef struct ep_jepa_params {
+  float *query, *n1_w, *n1_b, *q_w, *q_b, *kv_w, *kv_b, *proj_w, *proj_b, *n2_w, *n2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} ep_jepa_params;
+
+size_t ep_jepa_pool_workspace_bytes(const ep_jepa_dims* dims);
+int ep_jepa_pool_forward(const ep_jepa_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* token_stats, float ln_eps,
+                         const ep_jepa_params* params, float* out, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_jepa_pool_backward(const ep_jepa_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                          const int32_t* image_index, const float* token_stats, const ep_jepa_params* params,
+                          const float* dout, const ep_jepa_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                          ep_stream_t stream);
+
+typedef struct ep_jepa_step {
+  ep_jepa_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* token_stats; float ln_eps;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_jepa_step;
+
+int64_t ep_jepa_head_param_offsets(const ep_jepa_dims* dims, int64_t offsets[17]);
+size_t ep_jepa_head_workspace_bytes(const ep_jepa_dims* dims);
+int ep_jepa_head_train_step(const ep_jepa_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_jepa_head_eval_forward(const ep_jepa_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                              const int32_t* image_index, const float* token_stats, float ln_eps, const float* params,
+                              const float* running_mean, const float* running_var, float bn_eps, float* logits,
+                              int ldl, void* ws, size_t ws_bytes, ep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -338,3 +338,57 @@ def make_cae_inputs(case: CaeCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# V-JEPA attentive pooler (reference poolings/jepa/attentive_pooler.py:21-104 behind probe_heads.py:81)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class JepaCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    heads: int = 16
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+JEPA_CASES = [
+    JepaCase("tiny", B=6, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
+    JepaCase("tiny_sharp_strided", B=5, N=16, D=128, C=7, heads=8, seed=1, strided=True, sharp=True, steps=1),
+    JepaCase("vitb16", B=6, N=197, D=768, C=1000, seed=0, full=False, steps=1),
+    JepaCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+JEPA_BY_NAME = {c.name: c for c in JEPA_CASES}
+JEPA_INIT_DIMS = [(768, 1000, 16), (384, 100, 12)]
+JEPA_PARAM_NAMES = ["query", "n1_w", "n1_b", "q_w", "q_b", "kv_w", "kv_b", "proj_w", "proj_b", "n2_w", "n2_b", "fc1_w",
+                    "fc1_b", "fc2_w", "fc2_b", "fc_weight", "fc_bias"]
+JEPA_SMALL = ("query", "n1_w", "n1_b", "q_b", "kv_b", "proj_b", "n2_w", "n2_b", "fc1_b", "fc2_b", "fc_bias")
+
+
+def make_jepa_inputs(case: JepaCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(15000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    ln = lambda: (1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (5.0 if case.sharp else 1.0)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, n_alloc, 1), dtype=np.float32)).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        query=(g * rng.standard_normal((1, 1, D), dtype=np.float32)).astype(np.float32),
+        n1_w=ln(), n1_b=u(0.2, (D,)), q_w=u(bd, (D, D)), q_b=u(0.2, (D,)), kv_w=u(bd * g, (2 * D, D)), kv_b=u(0.3, (2 * D,)),
+        proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)), n2_w=ln(), n2_b=u(0.2, (D,)),
+        fc1_w=u(bd, (4 * D, D)), fc1_b=u(bd, (4 * D,)), fc2_w=u(0.5 * bd, (D, 4 * D)), fc2_b=u(0.5 * bd, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )

@@ -32,7 +32,8 @@ from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_toke
                    ABMILP_CASES, ABMILP_INIT_DIMS, ABMILP_PARAM_NAMES, ABMILP_SMALL, make_abmilp_inputs,
                    KNN_CASES, KNN_GRID, make_knn_inputs,
                    SIGLIP_CASES, SIGLIP_INIT_DIMS, SIGLIP_PARAM_NAMES, SIGLIP_SMALL, make_siglip_inputs, siglip_sub,
-                   CAE_CASES, CAE_INIT_DIMS, CAE_PARAM_NAMES, CAE_SMALL, make_cae_inputs)
+                   CAE_CASES, CAE_INIT_DIMS, CAE_PARAM_NAMES, CAE_SMALL, make_cae_inputs,
+                   JEPA_CASES, JEPA_INIT_DIMS, JEPA_PARAM_NAMES, JEPA_SMALL, make_jepa_inputs)
 
 
 def _stub_missing_packages():
@@ -244,6 +245,80 @@ def run_coca_case(case):
         xb = inp["x_buf"]
         out["eval_logits"] = head(torch.from_numpy(xb[:, 1:] if case.strided else xb)).numpy()
     return out
+
+
+def jepa_ref_params(head):
+    p = head[0]
+    b = p.cross_attention_block
+    return [p.query_tokens, b.norm1.weight, b.norm1.bias, b.xattn.q.weight, b.xattn.q.bias, b.xattn.kv.weight, b.xattn.kv.bias,
+            b.xattn.proj.weight, b.xattn.proj.bias, b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias,
+            b.mlp.fc2.weight, b.mlp.fc2.bias, head[2].weight, head[2].bias]
+
+
+def build_jepa_ref_head(dim, C, heads):
+    enc = StubEncoder(dim, C)
+    probe_heads.build_probe_head(enc, ref_args(cls_features="jepa", nb_classes=C, num_heads=heads))
+    return enc.head
+
+
+def run_jepa_case(case):
+    inp = make_jepa_inputs(case)
+    out = {}
+    torch.manual_seed(0)
+    head = build_jepa_ref_head(case.D, case.C, case.heads)
+    plist = jepa_ref_params(head)
+    with torch.no_grad():
+        for n, p in zip(JEPA_PARAM_NAMES, plist):
+            p.copy_(torch.from_numpy(inp[n]))
+    head.train()
+    opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
+    crit = torch.nn.CrossEntropyLoss()
+    keep = (lambda a: a) if case.full else siglip_sub
+    for step in range(case.steps):
+        xb = inp["x_buf"] if step % 2 == 0 else inp["x_buf2"]
+        x = torch.from_numpy(xb[:, 1:] if case.strided else xb)
+        t = torch.from_numpy(inp["targets"] if step % 2 == 0 else inp["targets2"])
+        for g in opt.param_groups:
+            g["lr"] = STEP_LRS[step % len(STEP_LRS)]
+        opt.zero_grad()
+        pooled = head[0](x)
+        z = head[1](pooled)
+        logits = head[2](z)
+        loss = crit(logits, t)
+        loss.backward()
+        if step == 0:
+            a1, a5 = topk_acc(logits, t)
+            out.update(pooled=pooled.detach().numpy(), z=z.detach().numpy(), logits=logits.detach().numpy(),
+                       loss=np.float32(loss.item()), acc1=np.float32(a1), acc5=np.float32(a5))
+            for n, p in zip(JEPA_PARAM_NAMES, plist):
+                g = p.grad.detach().numpy()
+                out[f"grad_{n}"] = g if n in JEPA_SMALL else keep(g)
+                out[f"gradnorm_{n}"] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        tag = f"lars{step + 1}"
+        out[f"{tag}_loss"] = np.float32(loss.item())
+        for n, p in zip(JEPA_PARAM_NAMES, plist):
+            a = p.detach().numpy().copy()
+            out[f"{tag}_{n}"] = a if n in JEPA_SMALL else keep(a)
+        out[f"{tag}_running_mean"] = head[1].running_mean.numpy().copy()
+        out[f"{tag}_running_var"] = head[1].running_var.numpy().copy()
+    head.eval()
+    with torch.no_grad():
+        xb = inp["x_buf"]
+        out["eval_logits"] = head(torch.from_numpy(xb[:, 1:] if case.strided else xb)).numpy()
+    return out
+
+
+def jepa_init_fixture():
+    rec = {}
+    for dim, C, heads in JEPA_INIT_DIMS:
+        torch.manual_seed(0)
+        head = build_jepa_ref_head(dim, C, heads)
+        sd = head.state_dict()
+        rec[f"d{dim}_c{C}_h{heads}"] = {"keys": {k: list(v.shape) for k, v in sd.items()},
+                                        "sha256": {k: sha(v) for k, v in sd.items()},
+                                        "n_trainable": int(sum(p.numel() for p in head.parameters()))}
+    return rec
 
 
 def cae_ref_params(head):
@@ -608,6 +683,11 @@ def main():
         path = os.path.join(HERE, f"coca_{case.name}.npz")
         np.savez_compressed(path, **out)
         print(f"coca_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
+    for case in JEPA_CASES:
+        out = run_jepa_case(case)
+        path = os.path.join(HERE, f"jepa_{case.name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"jepa_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
     for case in CAE_CASES:
         out = run_cae_case(case)
         path = os.path.join(HERE, f"cae_{case.name}.npz")
@@ -626,7 +706,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "lars_edges.npz"), **lars_edge_fixture())
     with open(os.path.join(HERE, "host_fixtures.json"), "w") as f:
         json.dump(dict(meta=meta, init=init_fixture(), coca_init=coca_init_fixture(),
-                       abmilp_init=abmilp_init_fixture(), siglip_init=siglip_init_fixture(), cae_init=cae_init_fixture(), lr=lr_fixture(),
+                       abmilp_init=abmilp_init_fixture(), siglip_init=siglip_init_fixture(), cae_init=cae_init_fixture(), jepa_init=jepa_init_fixture(), lr=lr_fixture(),
                        scaler=scaler_fixture()),
                   f, indent=1, sort_keys=True)
     with open(os.path.join(HERE, "knn_fixtures.json"), "w") as f:
