@@ -137,6 +137,261 @@ __global__ __launch_bounds__(512) void ep_gemm_ws_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (the default for 16-byte aligned operands).  The stand-alone contractions of the head run one
+// 64x64 tile per CU, so nothing hides a workgroup's own latencies: with register staging the K loop ran at ~2x its
+// MFMA time, waiting on global loads two K-tiles deep.  Here the operand tiles go from L2 straight into a ring of
+// NST LDS stages (global_load_lds_dwordx4, 1 KiB per wave-instruction, NST-1 K-tiles in flight, exact counted
+// vmcnt waits), no staging registers.  WS = wave-specialised (8 waves): waves 4-7 only issue the DMA (an LDS-DMA
+// instruction costs its issuing wave ~100 cycles, which a matrix wave would spend not issuing MFMAs), waves 0-3
+// only read fragments and multiply; !WS = 4 symmetric waves doing both.
+//   * LDS images are unpadded and XOR-swizzled -- the swizzle is applied for free on the DMA source address:
+//       K layout (64 rows x 8 chunks of 16 B): chunk c of row r sits in slot c ^ ((r >> 1) & 7); a lane reads its
+//         four k-values with ONE ds_read_b128, conflict-free for the 4 x 16 lane groups of that instruction;
+//       T layout (32 k-rows x 16 chunks): chunk c of k-row k sits in slot c ^ (4 * ((k >> 2) & 1)); ds_read_b32,
+//         conflict-free for its 2 x 32 lane groups.
+//   * k-mapping inside a K-tile: MFMA step (g, j) (g = 0..1, j = 0..3) feeds lane group kk with k = 16 g + 4 kk + j,
+//     the same for both operands (any bijection is valid for the contraction).
+//   * fragments of tile it+1 are read into a second register set while tile it is multiplied (a whole K-tile of
+//     MFMAs hides the LDS latency); one s_barrier per K-tile.
+//   * K tail (K % 32 != 0): sources are clamped to valid addresses and the out-of-range k fragments are zeroed in
+//     registers on the last tile.  Rows / columns beyond M / N are clamped on load and masked at the store.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+template <int N>
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool A_K, bool B_K, int NST, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams p) {
+  constexpr int OPB = 64 * BK * 4;                   // bytes per operand image (8 KiB)
+  constexpr int STB = 2 * OPB;                       // bytes per ring stage
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = WS && wall >= 4;               // WS: waves 4-7 only move data, waves 0-3 only multiply
+  const int w = wall & 3;
+  const int wm = w >> 1, wn = w & 1;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const float* A = p.A + (int64_t)z * p.sAz;
+  const float* B = p.B + (int64_t)z * p.sBz;
+  float* C = p.C + (int64_t)z * p.sCz;
+  const int nk = (p.K + BK - 1) / BK;
+
+  // ---- DMA source offsets (elements) of this lane's two pieces per operand, for a full K-tile at k0 = 0 ----
+  // piece pc = w + 4 jj covers LDS positions pc*64 + lane
+  int64_t srcA[2], srcB[2];
+  int64_t kstepA, kstepB;
+  auto src_off = [&](bool klay, int64_t ld, int lim, int ext, int r0, int pos, int k0) -> int64_t {
+    // lim: number of rows (K layout) ; ext: readable extent along the contiguous dim (T layout)
+    if (klay) {
+      const int r = pos >> 3, q = pos & 7;
+      const int kq = q ^ ((r >> 1) & 7);
+      int row = r0 + r; row = row < lim ? row : lim - 1;
+      int k = k0 + 4 * kq; k = k < p.K ? k : 0;
+      return (int64_t)row * ld + k;
+    } else {
+      const int k = pos >> 4, q = pos & 15;
+      const int c = q ^ (4 * ((k >> 2) & 1));
+      int kr = k0 + k; kr = kr < p.K ? kr : p.K - 1;
+      int col = r0 + 4 * c; col = col < ext ? col : r0;
+      return (int64_t)kr * ld + col;
+    }
+  };
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int pos = (w + 4 * jj) * 64 + lane;
+    srcA[jj] = src_off(A_K, p.lda, p.M, p.extA, m0, pos, 0);
+    srcB[jj] = src_off(B_K, p.ldb, p.N, p.extB, n0, pos, 0);
+  }
+  kstepA = A_K ? BK : (int64_t)BK * p.lda;
+  kstepB = B_K ? BK : (int64_t)BK * p.ldb;
+  const bool ktail = (p.K % BK) != 0;
+  auto issue = [&](int t) {                          // DMA K-tile t (clamped to the last one) into stage t % NST
+    const int tt = t < nk ? t : nk - 1;
+    char* st = lds + (t % NST) * STB;
+    if (ktail && tt == nk - 1) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int pos = (w + 4 * jj) * 64 + lane;
+        const int64_t oa = src_off(A_K, p.lda, p.M, p.extA, m0, pos, tt * BK);
+        const int64_t ob = src_off(B_K, p.ldb, p.N, p.extB, n0, pos, tt * BK);
+        __builtin_amdgcn_global_load_lds((gptr_t)(A + oa), (lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(B + ob), (lds_ptr_t)(st + OPB + (w + 4 * jj) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(A + srcA[jj] + tt * kstepA), (lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(B + srcB[jj] + tt * kstepB), (lds_ptr_t)(st + OPB + (w + 4 * jj) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  if (WS && loader) {
+    // loader waves: tiles 0 .. NST-2 in flight, then one K-tile per step behind the same barriers as the matrix waves
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t);
+    dma_wait<4 * (NST - 2)>();
+    ws_barrier();                                    // tile 0 landed
+    for (int it = 0; it < nk; ++it) {
+      dma_wait<4 * (NST - 3 >= 0 ? NST - 3 : 0)>();  // tile it+1 landed (this wave's pieces)
+      ws_barrier();                                  // ... everyone's; the matrix waves hold tile `it` in registers
+      issue(it + NST - 1);                           // refill the stage tile it-1 lived in
+    }
+    dma_wait<0>();
+    return;
+  }
+
+  // ---- fragment addressing (bytes inside an operand image) ----
+  // K layout: block mi, group g : row r = base + 16 mi + i16 ; chunk 4g + kk -> r*128 + 16*((4g+kk) ^ ((r>>1)&7))
+  // T layout: value (g, j)      : k = 16g + 4kk + j ; col = base + 16 mi + i16
+  //           -> (16g + j)*256 + [4kk*256 + 16*((col>>2) ^ 4(kk&1)) + 4(col&3)]
+  int fragA[2][2], fragB[2][2];                      // [block][g] (K layout) or [block][0] (T layout: lane base)
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi) {
+    {
+      const int r = wm * 32 + bi * 16 + i16;
+      if (A_K) {
+        fragA[bi][0] = r * 128 + 16 * ((0 + kk) ^ ((r >> 1) & 7));
+        fragA[bi][1] = r * 128 + 16 * ((4 + kk) ^ ((r >> 1) & 7));
+      } else {
+        fragA[bi][0] = 4 * kk * 256 + 16 * ((r >> 2) ^ (4 * (kk & 1))) + 4 * (r & 3);
+        fragA[bi][1] = 0;
+      }
+    }
+    {
+      const int r = wn * 32 + bi * 16 + i16;
+      if (B_K) {
+        fragB[bi][0] = r * 128 + 16 * ((0 + kk) ^ ((r >> 1) & 7));
+        fragB[bi][1] = r * 128 + 16 * ((4 + kk) ^ ((r >> 1) & 7));
+      } else {
+        fragB[bi][0] = 4 * kk * 256 + 16 * ((r >> 2) ^ (4 * (kk & 1))) + 4 * (r & 3);
+        fragB[bi][1] = 0;
+      }
+    }
+  }
+  // fragment registers: [set][block][g] as f4 (elements j = 0..3)
+  f4v fa[2][2][2], fb[2][2][2];
+  auto read_frags = [&](int stage, f4v (&xa)[2][2], f4v (&xb)[2][2]) {
+    const char* sa = lds + stage * STB;
+    const char* sb = sa + OPB;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (A_K) xa[bi][g] = *reinterpret_cast<const f4v*>(sa + fragA[bi][g]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xa[bi][g][j] = *reinterpret_cast<const float*>(sa + fragA[bi][0] + (16 * g + j) * 256);
+        }
+        if (B_K) xb[bi][g] = *reinterpret_cast<const f4v*>(sb + fragB[bi][g]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xb[bi][g][j] = *reinterpret_cast<const float*>(sb + fragB[bi][0] + (16 * g + j) * 256);
+        }
+      }
+  };
+  f4v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const f4v (&xa)[2][2], const f4v (&xb)[2][2]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mi][g][j], xb[ni][g][j], acc[mi][ni], 0, 0, 0);
+  };
+  auto zero_tail = [&](int k0, f4v (&xa)[2][2], f4v (&xb)[2][2]) {   // last tile only: k >= K contributes nothing
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool out = k0 + 16 * g + 4 * kk + j >= p.K;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+          xa[bi][g][j] = out ? 0.f : xa[bi][g][j];
+          xb[bi][g][j] = out ? 0.f : xb[bi][g][j];
+        }
+      }
+  };
+
+  // ---- pipeline ----
+  // prologue: tiles 0 .. NST-2 in flight; tile 0 landed -> fragments of tile 0 in set 0
+  if (!WS) {
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t);
+    dma_wait<4 * (NST - 2)>();                       // this wave's pieces of tile 0 (4 DMA instructions per tile)
+  }
+  ws_barrier();                                      // ... and every other wave's
+  read_frags(0, fa[0], fb[0]);
+  if (ktail && nk == 1) { __builtin_amdgcn_s_waitcnt(0xc07f); zero_tail(0, fa[0], fb[0]); }
+  // step it (set F = it % 2): tile it+1 landed (vmcnt + barrier; the barrier also says every wave has tile `it` in
+  // registers, so its stage can be refilled) -> DMA tile it+NST-1 into that stage, read the fragments of tile it+1
+  // into the other set, multiply tile it.
+#define EP_DMA_STEP(IT, F)                                                         \
+  {                                                                                \
+    if (!WS) dma_wait<4 * (NST - 3 >= 0 ? NST - 3 : 0)>();                         \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                            \
+    ws_barrier();                                                                  \
+    if (!WS) issue((IT) + NST - 1);                                                \
+    read_frags(((IT) + 1) % NST, fa[(F) ^ 1], fb[(F) ^ 1]);                        \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    multiply(fa[F], fb[F]);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    if (ktail && (IT) + 1 == nk - 1) { __builtin_amdgcn_s_waitcnt(0xc07f); zero_tail(((IT) + 1) * BK, fa[(F) ^ 1], fb[(F) ^ 1]); } \
+  }
+  int it = 0;
+  for (; it + 1 < nk; it += 2) {
+    EP_DMA_STEP(it, 0)
+    EP_DMA_STEP(it + 1, 1)
+  }
+  if (it < nk) EP_DMA_STEP(it, 0)
+#undef EP_DMA_STEP
+  if (!WS) dma_wait<0>();                            // redundant prefetches past the last tile: drain before exit
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 32 + ni * 16 + i16;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + kk * 4 + r;
+        if (row < p.M) {
+          float* c = C + (int64_t)row * p.ldc + col;
+          float v = p.alpha * acc[mi][ni][r] + bv;
+          if (p.accumulate) v += *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+static void gemm_launch_dma(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + 63) / 64, batch);
+  // 4 ring stages (64 KiB: two workgroups per CU on large grids), wave-specialised: measured fastest of
+  // {3, 4, 5 stages} x {specialised, symmetric} on both the 256-tile head contractions and the 65536-row AbMILP ones
+#define EP_GEMM_LAUNCH(AK, BK_) hipLaunchKernelGGL((ep_gemm_dma_kernel<AK, BK_, 4, true>), grid, dim3(512), 0, st, p)
+  if (a_k && b_k) EP_GEMM_LAUNCH(true, true);
+  else if (a_k && !b_k) EP_GEMM_LAUNCH(true, false);
+  else if (!a_k && b_k) EP_GEMM_LAUNCH(false, true);
+  else EP_GEMM_LAUNCH(false, false);
+#undef EP_GEMM_LAUNCH
+}
+
 static void gemm_launch_ws(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   dim3 grid((p.N + BN - 1) / BN, (p.M + 63) / 64, batch);
 #define EP_GEMM_LAUNCH(AK, BK_) hipLaunchKernelGGL((ep_gemm_ws_kernel<AK, BK_, true>), grid, dim3(512), 0, st, p)
@@ -188,7 +443,10 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   // wave-specialised kernel: pays off for long K on the critical path; bit 1 of EP_GEMM_WS also enables it
   // for the weight-gradient contractions that run beside the second token pass
   const bool ws_ok = use_ws && vec && !force_bm && p.K >= 256 && (!p.side || (use_ws & 2));
-  if (ws_ok) gemm_launch_ws(a_k, b_k, p, batch, st);
+  static int use_dma = -1;
+  if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
+  if (use_dma && vec && !force_bm) gemm_launch_dma(a_k, b_k, p, batch, st);
+  else if (ws_ok) gemm_launch_ws(a_k, b_k, p, batch, st);
   else if (small) gemm_launch<32>(a_k, b_k, vec, p, batch, st);
   else gemm_launch<64>(a_k, b_k, vec, p, batch, st);
   EP_LAUNCH_CHECK("ep_gemm_kernel");
