@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
@@ -174,6 +174,9 @@ def main():
     if args.head == "jepa":
         Q = 16                                             # --num_heads default (main_linprobe.py:116)
         desc = desc.split(",")[0] + f", V-JEPA attentive pooler (16 heads, LayerNorm-ed keys / values, MLP x4), {Cc} classes"
+    if args.head == "aim":
+        Q = 16                                             # --num_heads default (main_linprobe.py:116)
+        desc = desc.split(",")[0] + f", AIM attention pooling (16 heads, batch-normalised tokens), {Cc} classes"
     if args.head == "cae":
         Q = 8                                              # 8 heads of the query token (cae_att.py:81)
         desc = desc.split(",")[0] + f", CAE attentive block (8 heads, LayerNorm-ed keys / values), {Cc} classes"
@@ -247,7 +250,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / iters
 
-    if args.head in ("coca", "siglip", "cae", "jepa"):     # the same kernel, fed with the H derived query rows
+    if args.head in ("coca", "siglip", "cae", "jepa", "aim"):   # the same kernel, fed with the H derived query rows
         cls, scale = torch.randn(Q, D, device=dev) * 0.05, 1.0
     else:
         cls, scale = head[0].cls_token.detach(), head[0].scale
@@ -294,7 +297,7 @@ def main():
         out = {
             "metric": {"ep": "EP-head train images/sec", "coca": "CoCa-head train images/sec",
                        "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec",
-                       "jepa": "JEPA-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
+                       "jepa": "JEPA-head train images/sec", "aim": "AIM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
@@ -333,6 +336,9 @@ def main():
             if args.head == "jepa":
                 from oracle import jepa_oracle
                 mk = lambda: jepa_oracle.make_head(D, Cc)
+            if args.head == "aim":
+                from oracle import aim_oracle
+                mk = lambda: aim_oracle.make_head(D, Cc)
             probe = {c: torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=2.0, threads=c, min_steps=1,
                                                     make=mk)["value"] for c in cands}
             best = max(probe, key=probe.get)

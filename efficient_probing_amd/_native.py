@@ -192,6 +192,25 @@ class EPJepaStep(C.Structure):
     _fields_ = [("dims", EPJepaDims)] + list(EPCaeStep._fields_[1:])
 
 
+class EPAimDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("C", C.c_int32)]
+
+
+class EPAimParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cls_token", "k_w", "v_w")]
+
+
+class EPAimStep(C.Structure):
+    _fields_ = [
+        ("dims", EPAimDims),
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("image_index", C.c_void_p),
+        ("image_stats", C.c_void_p),
+        ("tok_running_mean", C.c_void_p), ("tok_running_var", C.c_void_p), ("tok_num_batches_tracked", C.c_void_p),
+        ("tok_bn_eps", C.c_float), ("tok_bn_momentum", C.c_float),
+    ] + list(EPCaeStep._fields_[7:])                 # targets ... aux_stream, as in every head step
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -296,6 +315,18 @@ SIGNATURES = {
                                           c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
+    "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
+    "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,
+                                    c_f32p, c_void, C.POINTER(EPAimParams), c_f32p, c_void, c_size, c_void]),
+    "ep_aim_pool_backward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, C.POINTER(EPAimParams), c_f32p, c_f32p,
+                                     C.POINTER(EPAimParams), c_int, c_void, c_size, c_void]),
+    "ep_aim_attention": (c_int, [C.POINTER(EPAimDims), c_void, c_f32p, c_void]),
+    "ep_aim_head_param_offsets": (c_i64, [C.POINTER(EPAimDims), C.POINTER(c_i64)]),
+    "ep_aim_head_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
+    "ep_aim_head_train_step": (c_int, [C.POINTER(EPAimStep), c_void, c_size, c_void]),
+    "ep_aim_head_eval_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_float, c_f32p, c_f32p, c_f32p,
+                                         c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -577,6 +577,10 @@ static int mf_dispatch_ng(bool bwd, int ng, const PoolParams& p, int grid, hipSt
 }
 
 bool mf_supported(int D, int Q, int64_t cls_bstride) {
+  // The forward's image epilogue merges the two token halves through the idle tile slot: 4 * QP * KP KiB of the slot's
+  // 64 * D bytes.  With QP = 4 (Q > 8) that only fits when D / 128 is even (KP = ceil(D / 256)): odd widths such as
+  // 1152 overran the slot into the next tile, so they take another kernel family.
+  if (Q > 8 && (D / 128) % 2 != 0) return false;
   return D % 128 == 0 && D >= 256 && D <= 1152 && Q >= 1 && Q <= 16 && cls_bstride == 0;
 }
 int mf_partials_per_wg() { return 2; }

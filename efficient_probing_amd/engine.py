@@ -475,6 +475,61 @@ class JepaHeadEngine(CaeHeadEngine):
                                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class AimHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(AttentionPoolingClassifier (AIM), BatchNorm1d, Linear) through
+    ``ep_aim_head_train_step``.  ``image_stats`` (functional.channel_stats of a resident store, (M, 2, D)) can be passed per
+    call: the token BatchNorm's batch statistics are then combined from the cached rows instead of re-reading the tokens."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_aim_head
+        if not is_native_aim_head(head):
+            raise TypeError("AimHeadEngine needs Sequential(poolings.aim.AttentionPoolingClassifier, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        dims = N.EPAimDims(B=0, N=0, D=p.k.in_features, H=p.num_heads, C=self.fc.out_features)
+        offs = (C.c_int64 * 5)()
+        total = int(self.lib.ep_aim_head_param_offsets(C.byref(dims), offs))
+        return dims, list(p._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        s = N.EPAimStep()
+        tb = self.pool.bn
+        s.image_stats = self._imgstat.data_ptr() if getattr(self, "_imgstat", None) is not None else 0
+        s.tok_running_mean = tb.running_mean.data_ptr(); s.tok_running_var = tb.running_var.data_ptr()
+        s.tok_num_batches_tracked = tb.num_batches_tracked.data_ptr()
+        s.tok_bn_eps = tb.eps; s.tok_bn_momentum = tb.momentum
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_aim_head_workspace_bytes(C.byref(self.dims))
+
+    def train_step(self, x, targets, lr=None, image_index=None, image_stats=None):
+        self._imgstat = image_stats
+        try:
+            super().train_step(x, targets, lr, image_index)
+        finally:
+            self._imgstat = None
+
+    def sync_buffers(self):
+        super().sync_buffers()
+        if self.world > 1:
+            tb = self.pool.bn
+            for b in (tb.running_mean, tb.running_var, tb.num_batches_tracked):
+                dist.broadcast(b, src=0, group=self.group)
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_aim_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        tb = self.pool.bn
+        return self.lib.ep_aim_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                 tb.eps, tb.running_mean.data_ptr(), tb.running_var.data_ptr(),
+                                                 self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                 self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                                 ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+
 class LinearProbeEngine(ProbeHeadEngine):
     """Fused train / eval step of plain linear probing, Sequential(BatchNorm1d, Linear) on one feature vector per
     image (what the registry builds for --cls_features cls / gap / pos ..., reference probe_heads.py:96-99).
@@ -540,10 +595,12 @@ class _LPView:
 
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
     """The fused engine matching a native head (EP, CoCa, AbMILP or plain linear probing)."""
-    from .probe_heads import (is_native_abmilp_head, is_native_cae_head, is_native_coca_head, is_native_jepa_head,
-                              is_native_lp_head, is_native_siglip_head)
+    from .probe_heads import (is_native_abmilp_head, is_native_aim_head, is_native_cae_head, is_native_coca_head,
+                              is_native_jepa_head, is_native_lp_head, is_native_siglip_head)
     if is_native_lp_head(head):
         return LinearProbeEngine(head, **kw)
+    if is_native_aim_head(head):
+        return AimHeadEngine(head, **kw)
     if is_native_jepa_head(head):
         return JepaHeadEngine(head, **kw)
     if is_native_cae_head(head):

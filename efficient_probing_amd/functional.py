@@ -761,3 +761,92 @@ class _JepaPool(torch.autograd.Function):
 
 def jepa_pool(x, heads, hidden, *tens):
     return _JepaPool.apply(x, heads, hidden, *tens)
+
+
+# --------------------------------------------------------------------------------------------
+# AIM attention-pooling head (reference poolings/aim.py:337-392) on the plain EP token passes
+# --------------------------------------------------------------------------------------------
+AIM_TENSORS = ("cls_token", "k.weight", "v.weight")
+AIM_BN_EPS = 1e-6          # aim.py:357 BatchNorm1d(dim, affine=False, eps=1e-6)
+
+
+def _aim_params_struct(ts):
+    return N.EPAimParams(*[t.data_ptr() for t in ts])
+
+
+def channel_stats(x: torch.Tensor, image_index=None) -> torch.Tensor:
+    """Per-image column statistics {mean over the N tokens, sum of squared deviations} -> (B, 2, D) fp32.
+    They depend on the frozen tokens only: compute them once for a resident token store and hand the table to
+    ``AimHeadEngine.train_step(..., image_stats=...)``."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    out = torch.empty((B, 2, D), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_channel_stats(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, B, Nn, D, out.data_ptr(),
+                                 N.current_stream_ptr(xv.device)), "ep_channel_stats")
+    return out
+
+
+class _AimPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, training, eps, momentum, running_mean, running_var, nbt, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, AIM_TENSORS)]
+        dims = N.EPAimDims(B=B, N=Nn, D=D, H=heads, C=0)
+        nbytes = lib.ep_aim_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_aim_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_aim_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, int(training),
+                                        float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                        C.byref(_aim_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes,
+                                        N.current_stream_ptr(xv.device)), "ep_aim_pool_forward")
+        ctx.save_for_backward(xv, ws, y, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("AIM attention pooling (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, y, *tens = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_aim_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0,
+                                         C.byref(_aim_params_struct(tens)), y.data_ptr(), dy.data_ptr(),
+                                         C.byref(_aim_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                         N.current_stream_ptr(xv.device)), "ep_aim_pool_backward")
+        return (None,) * 8 + tuple(grads)
+
+
+def aim_pool(x, heads, training, eps, momentum, running_mean, running_var, nbt, *tens):
+    return _AimPool.apply(x, heads, training, eps, momentum, running_mean, running_var, nbt, *tens)
+
+
+def aim_attention(x, heads, training, eps, running_mean, running_var, *tens):
+    """Attention weights (B, H, N) of the AIM head (no statistics update)."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    B, Nn, D = xv.shape
+    tens = [_f32c(t.detach(), n) for t, n in zip(tens, AIM_TENSORS)]
+    dims = N.EPAimDims(B=B, N=Nn, D=D, H=heads, C=0)
+    nbytes = lib.ep_aim_pool_workspace_bytes(C.byref(dims))
+    ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+    y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    rm = running_mean.clone() if running_mean is not None else None      # batch statistics without side effects
+    rv = running_var.clone() if running_var is not None else None
+    N.check(lib.ep_aim_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, int(training),
+                                    float(eps), 0.0, _ptr(rm), _ptr(rv), 0, C.byref(_aim_params_struct(tens)),
+                                    y.data_ptr(), ws.data_ptr(), nbytes, N.current_stream_ptr(xv.device)),
+            "ep_aim_pool_forward")
+    A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_aim_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), N.current_stream_ptr(xv.device)),
+            "ep_aim_attention")
+    return A

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 11
+#define EP_ABI_VERSION 12
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -585,6 +585,76 @@ int ep_jepa_head_eval_forward(const ep_jepa_dims* dims, const void* x, int x_dty
                               const int32_t* image_index, const float* token_stats, float ln_eps, const float* params,
                               const float* running_mean, const float* running_var, float bn_eps, float* logits,
                               int ldl, void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AIM attention-pooling head (reference poolings/aim.py:337-392 AttentionPoolingClassifier as the registry builds it,
+ * probe_heads.py:73: AttentionPoolingClassifier(dim=dim, num_heads=args.num_heads); one learned query token split into
+ * H heads, keys / values = Linear(dim, dim, bias=False) of the per-channel batch-normalised tokens, aim.py:364-391).
+ * The token BatchNorm1d(dim, affine=False, eps=1e-6) has no parameters and the tokens are frozen, so its statistics
+ * mu, r are constants of the step: the head is the plain EP token pass with derived query rows r * (scale Wk_h^T q_h),
+ * followed by the per-head projection with Wv diag(r) and bias -Wv (mu r).  Three tensors: cls_token (1,1,D) |
+ * k.weight (D,D) | v.weight (D,D); the BatchNorm's running_mean / running_var / num_batches_tracked are buffers.
+ *
+ * ep_channel_stats: per-image column statistics image_stats[b] = {mean_n x[b,n,:], sum_n (x[b,n,:] - mean)^2}
+ * ((B, 2, D) floats).  They depend on the frozen tokens only: a resident token store computes them ONCE for all its
+ * images and passes the (M, 2, D) table as `image_stats` (rows are then addressed through image_index like the
+ * tokens); with image_stats == NULL the step computes them for the batch (one more streaming read of the tokens).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_aim_dims {
+  int32_t B, N, D, H, C;
+} ep_aim_dims;
+
+typedef struct ep_aim_params {
+  float *cls_token, *k_w, *v_w;
+} ep_aim_params;
+
+int ep_channel_stats(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                     float* image_stats, ep_stream_t stream);
+size_t ep_aim_pool_workspace_bytes(const ep_aim_dims* dims);
+/* training != 0: batch statistics (running_* updated with `bn_momentum`, unbiased variance, num_batches_tracked += 1;
+ * running pointers may be NULL); training == 0: the running statistics normalise. */
+int ep_aim_pool_forward(const ep_aim_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                        const int32_t* image_index, const float* image_stats, int training, float bn_eps,
+                        float bn_momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        const ep_aim_params* params, float* y, void* ws, size_t ws_bytes, ep_stream_t stream);
+/* `y`: the output of the matching ep_aim_pool_forward call on the same workspace */
+int ep_aim_pool_backward(const ep_aim_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const ep_aim_params* params, const float* y, const float* dy,
+                         const ep_aim_params* grads, int accumulate, void* ws, size_t ws_bytes, ep_stream_t stream);
+/* attention weights (B, H, N) of the last forward on this workspace (tools/ep_attention_maps.py counterpart) */
+int ep_aim_attention(const ep_aim_dims* dims, const void* ws, float* A, ep_stream_t stream);
+
+typedef struct ep_aim_step {
+  ep_aim_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* image_stats;                          /* optional cached (M, 2, D) table of ep_channel_stats */
+  float* tok_running_mean; float* tok_running_var; int64_t* tok_num_batches_tracked;   /* 0.bn.* buffers */
+  float tok_bn_eps, tok_bn_momentum;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_aim_step;
+
+/* flat layout: cls_token | k.weight | v.weight | fc.weight | fc.bias */
+int64_t ep_aim_head_param_offsets(const ep_aim_dims* dims, int64_t offsets[5]);
+size_t ep_aim_head_workspace_bytes(const ep_aim_dims* dims);
+int ep_aim_head_train_step(const ep_aim_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_aim_head_eval_forward(const ep_aim_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                             const int32_t* image_index, float tok_bn_eps, const float* tok_running_mean,
+                             const float* tok_running_var, const float* params, const float* running_mean,
+                             const float* running_var, float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
+                             ep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -392,3 +392,55 @@ def make_jepa_inputs(case: JepaCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# AIM attention-pooling head (reference poolings/aim.py:337-392 behind probe_heads.py:73)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class AimCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    heads: int = 16
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+AIM_CASES = [
+    AimCase("tiny", B=6, N=17, D=64, C=10, heads=4, seed=0, weight_decay=1e-4),
+    AimCase("tiny_sharp_strided", B=5, N=16, D=128, C=7, heads=8, seed=1, strided=True, sharp=True, steps=2),
+    AimCase("vitb16", B=6, N=197, D=768, C=1000, heads=16, seed=0, full=False, steps=1),
+    AimCase("so400m", B=5, N=256, D=1152, C=1000, heads=16, seed=1, full=False, steps=1, sharp=True),
+]
+AIM_BY_NAME = {c.name: c for c in AIM_CASES}
+AIM_INIT_DIMS = [(768, 1000)]
+AIM_PARAM_NAMES = ["cls_token", "k_w", "v_w", "fc_weight", "fc_bias"]
+AIM_SMALL = ("cls_token", "fc_bias")
+
+
+def make_aim_inputs(case: AimCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(17000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (6.0 if case.sharp else 1.0)
+    # tokens with a per-channel offset and scale (what the token BatchNorm is for)
+    ch_scale = (0.5 + 2.0 * rng.random((1, 1, D), dtype=np.float32)).astype(np.float32)
+    ch_off = (0.7 * rng.standard_normal((1, 1, D), dtype=np.float32)).astype(np.float32)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32) * ch_scale + ch_off).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        cls_token=(g * rng.standard_normal((1, 1, D), dtype=np.float32)).astype(np.float32),
+        k_w=u(bd * g, (D, D)), v_w=u(bd, (D, D)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        tok_running_mean=u(0.3, (D,)), tok_running_var=(0.5 + rng.random((D,), dtype=np.float32)).astype(np.float32),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )

@@ -33,7 +33,8 @@ from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_toke
                    KNN_CASES, KNN_GRID, make_knn_inputs,
                    SIGLIP_CASES, SIGLIP_INIT_DIMS, SIGLIP_PARAM_NAMES, SIGLIP_SMALL, make_siglip_inputs, siglip_sub,
                    CAE_CASES, CAE_INIT_DIMS, CAE_PARAM_NAMES, CAE_SMALL, make_cae_inputs,
-                   JEPA_CASES, JEPA_INIT_DIMS, JEPA_PARAM_NAMES, JEPA_SMALL, make_jepa_inputs)
+                   JEPA_CASES, JEPA_INIT_DIMS, JEPA_PARAM_NAMES, JEPA_SMALL, make_jepa_inputs,
+                   AIM_CASES, AIM_INIT_DIMS, AIM_PARAM_NAMES, AIM_SMALL, make_aim_inputs)
 
 
 def _stub_missing_packages():
@@ -81,10 +82,10 @@ def ref_args(case_or=None, **kw):
     return a
 
 
-def build_ref_head(dim, Q, d_out, C, cls_features="ep"):
+def build_ref_head(dim, Q, d_out, C, cls_features="ep", **kw):
     enc = StubEncoder(dim, C)
     probe_heads.build_probe_head(enc, ref_args(cls_features=cls_features, ep_queries=Q,
-                                               d_out=d_out, nb_classes=C))
+                                               d_out=d_out, nb_classes=C, **kw))
     return enc.head
 
 
@@ -394,6 +395,90 @@ def cae_init_fixture():
     return rec
 
 
+def aim_ref_params(head):
+    p = head[0]
+    return [p.cls_token, p.k.weight, p.v.weight, head[2].weight, head[2].bias]
+
+
+def run_aim_case(case):
+    """--cls_features aim: the REAL AttentionPoolingClassifier (poolings/aim.py:337-392) behind BatchNorm1d + Linear."""
+    inp = make_aim_inputs(case)
+    out = {}
+    torch.manual_seed(0)
+    head = build_ref_head(case.D, 32, 1, case.C, cls_features="aim", num_heads=case.heads)
+    assert head[0].num_heads == case.heads
+    plist = aim_ref_params(head)
+    with torch.no_grad():
+        for n, p in zip(AIM_PARAM_NAMES, plist):
+            p.copy_(torch.from_numpy(inp[n]))
+        head[0].bn.running_mean.copy_(torch.from_numpy(inp["tok_running_mean"]))
+        head[0].bn.running_var.copy_(torch.from_numpy(inp["tok_running_var"]))
+    head.train()
+    opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
+    crit = torch.nn.CrossEntropyLoss()
+    keep = (lambda a: a) if case.full else siglip_sub
+    view = lambda xb: torch.from_numpy(xb[:, 1:] if case.strided else xb)
+    for step in range(case.steps):
+        x = view(inp["x_buf"] if step % 2 == 0 else inp["x_buf2"])
+        t = torch.from_numpy(inp["targets"] if step % 2 == 0 else inp["targets2"])
+        for g in opt.param_groups:
+            g["lr"] = STEP_LRS[step % len(STEP_LRS)]
+        opt.zero_grad()
+        pooled = head[0](x)
+        z = head[1](pooled)
+        logits = head[2](z)
+        loss = crit(logits, t)
+        loss.backward()
+        if step == 0:
+            a1, a5 = topk_acc(logits, t)
+            # attention of the query token: recomputed with the batch statistics this forward used
+            with torch.no_grad():
+                xb = x.transpose(-2, -1)
+                mu = xb.mean(dim=(0, 2), keepdim=True); var = xb.var(dim=(0, 2), unbiased=False, keepdim=True)
+                xn = ((xb - mu) / torch.sqrt(var + 1e-6)).transpose(-2, -1)
+                B, N, C = xn.shape
+                H = case.heads
+                q = head[0].cls_token.expand(B, -1, -1).reshape(B, 1, H, C // H).permute(0, 2, 1, 3) * head[0].scale
+                k = head[0].k(xn).reshape(B, N, H, C // H).permute(0, 2, 1, 3)
+                attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)[:, :, 0]
+            out.update(pooled=pooled.detach().numpy(), attn=attn.numpy(), z=z.detach().numpy(), logits=logits.detach().numpy(),
+                       loss=np.float32(loss.item()), acc1=np.float32(a1), acc5=np.float32(a5))
+            for n, p in zip(AIM_PARAM_NAMES, plist):
+                g = p.grad.detach().numpy()
+                out[f"grad_{n}"] = g if n in AIM_SMALL else keep(g)
+                out[f"gradnorm_{n}"] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        tag = f"lars{step + 1}"
+        out[f"{tag}_loss"] = np.float32(loss.item())
+        for n, p in zip(AIM_PARAM_NAMES, plist):
+            a = p.detach().numpy().copy()
+            out[f"{tag}_{n}"] = a if n in AIM_SMALL else keep(a)
+            if "mu" in opt.state[p]:
+                mu_ = opt.state[p]["mu"].numpy().copy()
+                out[f"{tag}_mu_{n}"] = mu_ if n in AIM_SMALL else keep(mu_)
+        out[f"{tag}_running_mean"] = head[1].running_mean.numpy().copy()
+        out[f"{tag}_running_var"] = head[1].running_var.numpy().copy()
+        out[f"{tag}_tok_running_mean"] = head[0].bn.running_mean.numpy().copy()
+        out[f"{tag}_tok_running_var"] = head[0].bn.running_var.numpy().copy()
+        out[f"{tag}_tok_nbt"] = np.int64(head[0].bn.num_batches_tracked.item())
+    head.eval()
+    with torch.no_grad():
+        out["eval_logits"] = head(view(inp["x_buf"])).numpy()
+    return out
+
+
+def aim_init_fixture():
+    rec = {}
+    for dim, C in AIM_INIT_DIMS:
+        torch.manual_seed(0)
+        head = build_ref_head(dim, 32, 1, C, cls_features="aim")
+        sd = head.state_dict()
+        rec[f"d{dim}_c{C}"] = {"keys": {k: list(v.shape) for k, v in sd.items()}, "sha256": {k: sha(v) for k, v in sd.items()},
+                               "n_trainable": int(sum(p.numel() for p in head.parameters())),
+                               "num_heads": int(head[0].num_heads)}
+    return rec
+
+
 def siglip_ref_params(head):
     p = head[0]
     return [p.latent, p.q.weight, p.q.bias, p.kv.weight, p.kv.bias, p.proj.weight, p.proj.bias, p.mlp.fc1.weight,
@@ -669,49 +754,49 @@ def knn_fixture():
 
 
 def main():
+    """``python make_golden.py`` regenerates everything; ``python make_golden.py aim [jepa ...]`` only the named families
+    (their .npz files and their entry of host_fixtures.json)."""
+    only = set(sys.argv[1:])
+    want = lambda fam: not only or fam in only
     meta = {"torch": torch.__version__, "reference": REF, "cases": [c.name for c in CASES]}
-    for case in CASES:
-        out = run_case(case, "lars")
-        if case.full:
-            sgd = run_case(case, "sgd")
-            out.update({k: v for k, v in sgd.items() if k.startswith("sgd")})
-        path = os.path.join(HERE, f"ep_{case.name}.npz")
+
+    def dump(prefix, case, out):
+        path = os.path.join(HERE, f"{prefix}_{case.name}.npz")
         np.savez_compressed(path, **out)
-        print(f"{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
-    for case in COCA_CASES:
-        out = run_coca_case(case)
-        path = os.path.join(HERE, f"coca_{case.name}.npz")
-        np.savez_compressed(path, **out)
-        print(f"coca_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
-    for case in JEPA_CASES:
-        out = run_jepa_case(case)
-        path = os.path.join(HERE, f"jepa_{case.name}.npz")
-        np.savez_compressed(path, **out)
-        print(f"jepa_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
-    for case in CAE_CASES:
-        out = run_cae_case(case)
-        path = os.path.join(HERE, f"cae_{case.name}.npz")
-        np.savez_compressed(path, **out)
-        print(f"cae_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
-    for case in SIGLIP_CASES:
-        out = run_siglip_case(case)
-        path = os.path.join(HERE, f"siglip_{case.name}.npz")
-        np.savez_compressed(path, **out)
-        print(f"siglip_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
-    for case in ABMILP_CASES:
-        out = run_abmilp_case(case)
-        path = os.path.join(HERE, f"abmilp_{case.name}.npz")
-        np.savez_compressed(path, **out)
-        print(f"abmilp_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
-    np.savez_compressed(os.path.join(HERE, "lars_edges.npz"), **lars_edge_fixture())
-    with open(os.path.join(HERE, "host_fixtures.json"), "w") as f:
-        json.dump(dict(meta=meta, init=init_fixture(), coca_init=coca_init_fixture(),
-                       abmilp_init=abmilp_init_fixture(), siglip_init=siglip_init_fixture(), cae_init=cae_init_fixture(), jepa_init=jepa_init_fixture(), lr=lr_fixture(),
-                       scaler=scaler_fixture()),
-                  f, indent=1, sort_keys=True)
-    with open(os.path.join(HERE, "knn_fixtures.json"), "w") as f:
-        json.dump(knn_fixture(), f, indent=1, sort_keys=True)
-    print("wrote host_fixtures.json, lars_edges.npz, knn_fixtures.json")
+        print(f"{prefix}_{case.name}: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+    if want("ep"):
+        for case in CASES:
+            out = run_case(case, "lars")
+            if case.full:
+                sgd = run_case(case, "sgd")
+                out.update({k: v for k, v in sgd.items() if k.startswith("sgd")})
+            dump("ep", case, out)
+    for fam, cases, run in (("coca", COCA_CASES, run_coca_case), ("aim", AIM_CASES, run_aim_case),
+                            ("jepa", JEPA_CASES, run_jepa_case), ("cae", CAE_CASES, run_cae_case),
+                            ("siglip", SIGLIP_CASES, run_siglip_case), ("abmilp", ABMILP_CASES, run_abmilp_case)):
+        if want(fam):
+            for case in cases:
+                dump(fam, case, run(case))
+    hp = os.path.join(HERE, "host_fixtures.json")
+    if only:
+        with open(hp) as f:
+            host = json.load(f)
+    else:
+        np.savez_compressed(os.path.join(HERE, "lars_edges.npz"), **lars_edge_fixture())
+        host = dict(meta=meta, lr=lr_fixture(), scaler=scaler_fixture())
+    for fam, key, fn in (("ep", "init", init_fixture), ("coca", "coca_init", coca_init_fixture),
+                         ("abmilp", "abmilp_init", abmilp_init_fixture), ("siglip", "siglip_init", siglip_init_fixture),
+                         ("cae", "cae_init", cae_init_fixture), ("jepa", "jepa_init", jepa_init_fixture),
+                         ("aim", "aim_init", aim_init_fixture)):
+        if want(fam):
+            host[key] = fn()
+    with open(hp, "w") as f:
+        json.dump(host, f, indent=1, sort_keys=True)
+    if want("knn"):
+        with open(os.path.join(HERE, "knn_fixtures.json"), "w") as f:
+            json.dump(knn_fixture(), f, indent=1, sort_keys=True)
+    print("wrote host_fixtures.json" + ("" if only else ", lars_edges.npz") + (", knn_fixtures.json" if want("knn") else ""))
 
 
 if __name__ == "__main__":
