@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
@@ -174,6 +174,11 @@ def main():
     if args.head == "jepa":
         Q = 16                                             # --num_heads default (main_linprobe.py:116)
         desc = desc.split(",")[0] + f", V-JEPA attentive pooler (16 heads, LayerNorm-ed keys / values, MLP x4), {Cc} classes"
+    if args.head in ("simpool", "esimpool"):
+        Q = 1 if args.head == "simpool" else 12            # probe_heads.py:66-69
+        desc = desc.split(",")[0] + (f", SimPool (mean-token query, LayerNorm-ed keys / values, wq / wk), {Cc} classes"
+                                     if args.head == "simpool" else
+                                     f", SimPool without linear maps (12 channel-slice heads), {Cc} classes")
     if args.head == "aim":
         Q = 16                                             # --num_heads default (main_linprobe.py:116)
         desc = desc.split(",")[0] + f", AIM attention pooling (16 heads, batch-normalised tokens), {Cc} classes"
@@ -250,18 +255,29 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / iters
 
-    if args.head in ("coca", "siglip", "cae", "jepa", "aim"):   # the same kernel, fed with the H derived query rows
+    imgq = args.head in ("simpool", "esimpool")            # per-image-query passes (csrc/ep_pool_imgq.hip)
+    if imgq:
+        cls, scale = torch.randn(B, D, device=dev) * 0.05, 1.0
+        tstat = F_.token_stats(xs[0] if args.tokens == "f32" else xs[0].float(), 1e-6)
+    elif args.head in ("coca", "siglip", "cae", "jepa", "aim"):   # the same kernel, fed with the H derived query rows
         cls, scale = torch.randn(Q, D, device=dev) * 0.05, 1.0
     else:
         cls, scale = head[0].cls_token.detach(), head[0].scale
     keep = {}
 
     def run_fwd(i):
-        keep["out"] = F_.pool_forward(xs[i % args.buffers], cls, scale)
+        if imgq:
+            keep["out"] = F_.imgq_pool_forward(xs[i % args.buffers], cls, Q, tstat, args.head == "simpool")
+        else:
+            keep["out"] = F_.pool_forward(xs[i % args.buffers], cls, scale)
     t_fwd = time_kernel(run_fwd, args.kernel_iters)
-    P, S, ML = keep["out"]
+    if imgq:
+        P, ML = keep["out"]
+        S = None
+    else:
+        P, S, ML = keep["out"]
+        ML[:, :, 2] = 0.0
     dP = torch.randn_like(P)
-    ML[:, :, 2] = 0.0
     ws_bytes = eng.lib.ep_pool_workspace_bytes(B, Nn, D, Q)
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     dcls = torch.empty(Q, D, device=dev)
@@ -270,14 +286,17 @@ def main():
 
     def run_bwd(i):
         x = xs[i % args.buffers]
+        if imgq:
+            F_.imgq_pool_backward(x, cls, Q, P, ML, dP, tstat, args.head == "simpool")
+            return
         N_.check(eng.lib.ep_pool_backward(x.data_ptr(), 1 if args.tokens == "bf16" else 0, Nn * D, 0, B, Nn, D, Q, float(scale), S.data_ptr(), ML.data_ptr(),
                                           dP.data_ptr(), dcls.data_ptr(), 0, ws.data_ptr(), ws_bytes, stream), "bwd")
     t_bwd = time_kernel(run_bwd, args.kernel_iters)
 
     algo_bytes = B * Nn * D * esize                           # one streaming read of the stored tokens
     dt = 1 if args.tokens == "bf16" else 0
-    kname_f = eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
-    kname_b = eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
+    kname_f = "ep_imgq_kernel (forward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
+    kname_b = "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic = None
@@ -297,7 +316,8 @@ def main():
         out = {
             "metric": {"ep": "EP-head train images/sec", "coca": "CoCa-head train images/sec",
                        "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec",
-                       "jepa": "JEPA-head train images/sec", "aim": "AIM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
+                       "jepa": "JEPA-head train images/sec", "aim": "AIM-head train images/sec",
+                       "simpool": "SimPool-head train images/sec", "esimpool": "eSimPool-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
@@ -339,6 +359,9 @@ def main():
             if args.head == "aim":
                 from oracle import aim_oracle
                 mk = lambda: aim_oracle.make_head(D, Cc)
+            if args.head in ("simpool", "esimpool"):
+                from oracle import simpool_oracle
+                mk = lambda: simpool_oracle.make_head(D, Cc, args.head == "simpool")
             probe = {c: torch_port.time_train_steps(cb, Nn, D, Q, Cc, budget_s=2.0, threads=c, min_steps=1,
                                                     make=mk)["value"] for c in cands}
             best = max(probe, key=probe.get)

@@ -211,6 +211,24 @@ class EPAimStep(C.Structure):
     ] + list(EPCaeStep._fields_[7:])                 # targets ... aux_stream, as in every head step
 
 
+class EPSimpoolDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("C", C.c_int32),
+                ("linears", C.c_int32)]
+
+
+class EPSimpoolParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "wq", "wk")]
+
+
+class EPSimpoolStep(C.Structure):
+    _fields_ = [
+        ("dims", EPSimpoolDims),
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("x_bstride", C.c_int64),
+        ("image_index", C.c_void_p),
+        ("token_stats", C.c_void_p), ("image_stats", C.c_void_p), ("ln_eps", C.c_float),
+    ] + list(EPCaeStep._fields_[7:])                 # targets ... aux_stream, as in every head step
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -315,6 +333,22 @@ SIGNATURES = {
                                           c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_coca_head_eval_forward": (c_int, [C.POINTER(EPCocaDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p,
                                           c_float, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_imgq_pool_forward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_int, c_f32p,
+                                     c_f32p, c_void]),
+    "ep_imgq_pool_backward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_int, c_f32p,
+                                      c_f32p, c_f32p, c_f32p, c_void]),
+    "ep_simpool_pool_workspace_bytes": (c_size, [C.POINTER(EPSimpoolDims)]),
+    "ep_simpool_pool_forward": (c_int, [C.POINTER(EPSimpoolDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_float,
+                                        C.POINTER(EPSimpoolParams), c_f32p, c_void, c_size, c_void]),
+    "ep_simpool_pool_backward": (c_int, [C.POINTER(EPSimpoolDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_float,
+                                         C.POINTER(EPSimpoolParams), c_f32p, c_f32p, C.POINTER(EPSimpoolParams), c_int, c_void,
+                                         c_size, c_void]),
+    "ep_simpool_attention": (c_int, [C.POINTER(EPSimpoolDims), c_void, c_int, c_i64, c_void, c_f32p, c_void, c_f32p, c_void]),
+    "ep_simpool_head_param_offsets": (c_i64, [C.POINTER(EPSimpoolDims), C.POINTER(c_i64)]),
+    "ep_simpool_head_workspace_bytes": (c_size, [C.POINTER(EPSimpoolDims)]),
+    "ep_simpool_head_train_step": (c_int, [C.POINTER(EPSimpoolStep), c_void, c_size, c_void]),
+    "ep_simpool_head_eval_forward": (c_int, [C.POINTER(EPSimpoolDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_float,
+                                             c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
     "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,

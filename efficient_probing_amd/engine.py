@@ -530,6 +530,56 @@ class AimHeadEngine(ProbeHeadEngine):
                                                  ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class SimpoolHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(SimPool | SimPool_nolinears, BatchNorm1d, Linear) through
+    ``ep_simpool_head_train_step`` (per-image-query token passes).  ``token_stats`` (functional.token_stats(store, 1e-6)) and
+    ``image_stats`` (functional.channel_stats(store)) of a resident store can be passed per call; ``token_stats`` is required
+    with ``image_index``."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_simpool_head
+        if not is_native_simpool_head(head):
+            raise TypeError("SimpoolHeadEngine needs Sequential(poolings.simpool.SimPool | SimPool_nolinears, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        dims = N.EPSimpoolDims(B=0, N=0, D=p.norm_patches.normalized_shape[0], H=p.num_heads, C=self.fc.out_features,
+                               linears=int(p.linears))
+        offs = (C.c_int64 * 6)()
+        total = int(self.lib.ep_simpool_head_param_offsets(C.byref(dims), offs))
+        offs = list(offs)
+        if not p.linears:
+            offs = offs[:2] + offs[4:]
+        return dims, list(p._tensors()) + [self.fc.weight, self.fc.bias], offs, total
+
+    def _new_step(self):
+        s = N.EPSimpoolStep()
+        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.image_stats = self._imgstat.data_ptr() if getattr(self, "_imgstat", None) is not None else 0
+        s.ln_eps = F_.SIMPOOL_LN_EPS
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_simpool_head_workspace_bytes(C.byref(self.dims))
+
+    def train_step(self, x, targets, lr=None, image_index=None, token_stats=None, image_stats=None):
+        self._tokstat, self._imgstat = token_stats, image_stats
+        try:
+            super().train_step(x, targets, lr, image_index)
+        finally:
+            self._tokstat = self._imgstat = None
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_simpool_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_simpool_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                     0, 0, F_.SIMPOOL_LN_EPS, self.flat_p.data_ptr(),
+                                                     self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr(),
+                                                     self.bn.eps, out.data_ptr(), ldl, ws.data_ptr(), ws.numel(),
+                                                     N.current_stream_ptr(self.device))
+
+
 class LinearProbeEngine(ProbeHeadEngine):
     """Fused train / eval step of plain linear probing, Sequential(BatchNorm1d, Linear) on one feature vector per
     image (what the registry builds for --cls_features cls / gap / pos ..., reference probe_heads.py:96-99).
@@ -596,9 +646,11 @@ class _LPView:
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
     """The fused engine matching a native head (EP, CoCa, AbMILP or plain linear probing)."""
     from .probe_heads import (is_native_abmilp_head, is_native_aim_head, is_native_cae_head, is_native_coca_head,
-                              is_native_jepa_head, is_native_lp_head, is_native_siglip_head)
+                              is_native_jepa_head, is_native_lp_head, is_native_siglip_head, is_native_simpool_head)
     if is_native_lp_head(head):
         return LinearProbeEngine(head, **kw)
+    if is_native_simpool_head(head):
+        return SimpoolHeadEngine(head, **kw)
     if is_native_aim_head(head):
         return AimHeadEngine(head, **kw)
     if is_native_jepa_head(head):

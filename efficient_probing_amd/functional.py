@@ -850,3 +850,106 @@ def aim_attention(x, heads, training, eps, running_mean, running_var, *tens):
     N.check(lib.ep_aim_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), N.current_stream_ptr(xv.device)),
             "ep_aim_attention")
     return A
+
+
+# --------------------------------------------------------------------------------------------
+# SimPool heads (reference poolings/simpool.py) on the per-image-query token passes
+# --------------------------------------------------------------------------------------------
+SIMPOOL_LN_EPS = 1e-6      # simpool.py:12 / :100  nn.LayerNorm(dim, eps=1e-6)
+
+
+def _simpool_params_struct(ts):
+    ts = list(ts) + [None] * (4 - len(ts))
+    return N.EPSimpoolParams(*[_ptr(t) for t in ts])
+
+
+class _SimPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, linears, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        names = ("norm_patches.weight", "norm_patches.bias", "wq.weight", "wk.weight")
+        tens = [_f32c(t, n) for t, n in zip(tens, names)]
+        dims = N.EPSimpoolDims(B=B, N=Nn, D=D, H=heads, C=0, linears=int(linears))
+        nbytes = lib.ep_simpool_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_simpool_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_simpool_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, 0, SIMPOOL_LN_EPS,
+                                            C.byref(_simpool_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes,
+                                            N.current_stream_ptr(xv.device)), "ep_simpool_pool_forward")
+        ctx.save_for_backward(xv, ws, y, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("SimPool (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, y, *tens = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_simpool_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0, 0, 0,
+                                             SIMPOOL_LN_EPS, C.byref(_simpool_params_struct(tens)), y.data_ptr(), dy.data_ptr(),
+                                             C.byref(_simpool_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                             N.current_stream_ptr(xv.device)), "ep_simpool_pool_backward")
+        return (None, None, None, *grads)
+
+
+def simpool_pool(x, heads, linears, *tens):
+    return _SimPool.apply(x, heads, linears, *tens)
+
+
+def simpool_attention(x, heads, linears, *tens):
+    """(pooled (B, D), attention (B, H, N)) of a SimPool head (reference simpool.py return_attn=True)."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    B, Nn, D = xv.shape
+    tens = [_f32c(t.detach(), "tensor") for t in tens]
+    dims = N.EPSimpoolDims(B=B, N=Nn, D=D, H=heads, C=0, linears=int(linears))
+    nbytes = lib.ep_simpool_pool_workspace_bytes(C.byref(dims))
+    if nbytes == 0:
+        raise RuntimeError(f"ep_simpool_pool_workspace_bytes: {N.last_error()}")
+    ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+    y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    st = N.current_stream_ptr(xv.device)
+    N.check(lib.ep_simpool_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, 0, SIMPOOL_LN_EPS,
+                                        C.byref(_simpool_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes, st),
+            "ep_simpool_pool_forward")
+    A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_simpool_attention(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, ws.data_ptr(),
+                                     A.data_ptr(), st), "ep_simpool_attention")
+    return y, A
+
+
+def imgq_pool_forward(x, u, heads, token_stats=None, pool_ln=False, image_index=None):
+    """Per-image-query token pass over channel slices (csrc/ep_pool_imgq.hip): u (B, D) -> (P (B, D), ML (B, H, 2))."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    u = _f32c(u, "u")
+    P = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    ML = torch.empty((B, heads, 2), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_imgq_pool_forward(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, B, Nn, D, heads, u.data_ptr(),
+                                     _ptr(token_stats), int(pool_ln), P.data_ptr(), ML.data_ptr(),
+                                     N.current_stream_ptr(xv.device)), "ep_imgq_pool_forward")
+    return P, ML
+
+
+def imgq_pool_backward(x, u, heads, P, ML, dP, token_stats=None, pool_ln=False, image_index=None):
+    """d u (B, D) per image of the per-image-query token pass."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    u, dP = _f32c(u, "u"), _f32c(dP, "dP")
+    du = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_imgq_pool_backward(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, B, Nn, D, heads, u.data_ptr(),
+                                      _ptr(token_stats), int(pool_ln), P.data_ptr(), ML.data_ptr(), dP.data_ptr(),
+                                      du.data_ptr(), N.current_stream_ptr(xv.device)), "ep_imgq_pool_backward")
+    return du

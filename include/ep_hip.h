@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 12
+#define EP_ABI_VERSION 13
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -655,6 +655,80 @@ int ep_aim_head_eval_forward(const ep_aim_dims* dims, const void* x, int x_dtype
                              const float* tok_running_var, const float* params, const float* running_mean,
                              const float* running_var, float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes,
                              ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SimPool heads (reference poolings/simpool.py; registry entries probe_heads.py:66-70):
+ *   linears = 1: SimPool(dim, num_heads=1, qkv_bias=False, gamma=None)        (simpool.py:5-91,  --cls_features simpool)
+ *   linears = 0: SimPool_nolinears(dim, num_heads=12, gamma=None)             (simpool.py:93-170, --cls_features esimpool)
+ * The query is derived from the image's own mean token, so the query rows differ per image: these heads run on the
+ * per-image-query token passes (csrc/ep_pool_imgq.hip) with LayerNorm-of-tokens scores (eps 1e-6); simpool pools the
+ * normalised tokens (then applies the LayerNorm's affine part), esimpool pools the raw tokens per head slice.
+ * Tensors: norm_patches.weight .bias (D) [| wq.weight wk.weight (D,D) when linears].
+ * token_stats ((M|B, N, 2) of ep_token_stats with eps = ln_eps) and image_stats ((M|B, 2, D) of ep_channel_stats; row 0 =
+ * the mean token) are optional per-store tables addressed through image_index like the tokens; NULL: computed for the
+ * batch (token_stats must be given when image_index is).  `y` of the backward = the matching forward's output.
+ * ------------------------------------------------------------------------------------------ */
+/* The token passes underneath, usable on their own: per-image query rows u (B, D) over H channel slices (head h scores and
+ * pools channels [h D/H, (h+1) D/H) only; every token is read once for all heads).  token_stats != NULL: scores on the
+ * normalised tokens; pool_ln: pool the normalised tokens (else the raw ones).  Outputs P (B, D) pooled slices and
+ * ML (B, H, 2) = {running max, sum of exponentials}; the backward takes dP (B, D) and returns du (B, D) PER IMAGE. */
+int ep_imgq_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                         int H, const float* u, const float* token_stats, int pool_ln, float* P, float* ML,
+                         ep_stream_t stream);
+int ep_imgq_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                          int H, const float* u, const float* token_stats, int pool_ln, const float* P, const float* ML,
+                          const float* dP, float* du, ep_stream_t stream);
+
+typedef struct ep_simpool_dims {
+  int32_t B, N, D, H, C, linears;
+} ep_simpool_dims;
+
+typedef struct ep_simpool_params {
+  float *norm_w, *norm_b, *wq, *wk;
+} ep_simpool_params;
+
+size_t ep_simpool_pool_workspace_bytes(const ep_simpool_dims* dims);
+int ep_simpool_pool_forward(const ep_simpool_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                            const int32_t* image_index, const float* token_stats, const float* image_stats, float ln_eps,
+                            const ep_simpool_params* params, float* y, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_simpool_pool_backward(const ep_simpool_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                             const int32_t* image_index, const float* token_stats, const float* image_stats, float ln_eps,
+                             const ep_simpool_params* params, const float* y, const float* dy,
+                             const ep_simpool_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                             ep_stream_t stream);
+/* attention weights (B, H, N) of the last forward on this workspace (simpool.py return_attn) */
+int ep_simpool_attention(const ep_simpool_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* token_stats, const void* ws, float* A,
+                         ep_stream_t stream);
+
+typedef struct ep_simpool_step {
+  ep_simpool_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* token_stats; const float* image_stats; float ln_eps;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_simpool_step;
+
+/* flat layout: norm_patches.weight | .bias | wq.weight | wk.weight (empty without linears) | fc.weight | fc.bias */
+int64_t ep_simpool_head_param_offsets(const ep_simpool_dims* dims, int64_t offsets[6]);
+size_t ep_simpool_head_workspace_bytes(const ep_simpool_dims* dims);
+int ep_simpool_head_train_step(const ep_simpool_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_simpool_head_eval_forward(const ep_simpool_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                                 const int32_t* image_index, const float* token_stats, const float* image_stats,
+                                 float ln_eps, const float* params, const float* running_mean, const float* running_var,
+                                 float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes, ep_stream_t stream);
 
 #ifdef __cplusplus
 }

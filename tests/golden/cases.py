@@ -444,3 +444,73 @@ def make_aim_inputs(case: AimCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# SimPool heads (reference poolings/simpool.py behind probe_heads.py:66-70): simpool (linears, 1 head), esimpool (12 heads)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class SimpoolCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    linears: bool = True
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+    @property
+    def heads(self):
+        return 1 if self.linears else 12
+
+    @property
+    def family(self):
+        return "simpool" if self.linears else "esimpool"
+
+
+SIMPOOL_CASES = [
+    SimpoolCase("tiny", B=6, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
+    SimpoolCase("tiny_sharp_strided", B=5, N=16, D=128, C=7, seed=1, strided=True, sharp=True, steps=2),
+    SimpoolCase("vitb16", B=6, N=197, D=768, C=1000, seed=0, full=False, steps=1),
+    SimpoolCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+ESIMPOOL_CASES = [
+    SimpoolCase("tiny", B=6, N=17, D=384, C=10, linears=False, seed=2, weight_decay=1e-4),
+    SimpoolCase("vitb16_sharp_strided", B=5, N=197, D=768, C=100, linears=False, seed=3, strided=True, sharp=True, steps=2),
+    SimpoolCase("so400m", B=5, N=256, D=1152, C=1000, linears=False, seed=4, full=False, steps=1),
+]
+SIMPOOL_INIT_DIMS = [(768, 1000)]
+SIMPOOL_SMALL = ("norm_w", "norm_b", "fc_bias")
+
+
+def simpool_param_names(case):
+    return ["norm_w", "norm_b"] + (["wq", "wk"] if case.linears else []) + ["fc_weight", "fc_bias"]
+
+
+def make_simpool_inputs(case: SimpoolCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(19000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (6.0 if case.sharp else 1.0)
+    # tokens with a per-token offset and scale (what the LayerNorm is for) and a per-image mean (what the GAP query sees)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, n_alloc, 1), dtype=np.float32)
+                   + 0.8 * rng.standard_normal((case.B, 1, D), dtype=np.float32)).astype(np.float32)
+    out = dict(
+        x_buf=tok(), x_buf2=tok(),
+        norm_w=(1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32) * (g if not case.linears else 1.0),
+        norm_b=u(0.2, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
+    if case.linears:
+        out.update(wq=u(bd * g, (D, D)), wk=u(bd * g, (D, D)))
+    return out

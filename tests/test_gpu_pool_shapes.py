@@ -36,3 +36,40 @@ def test_pool_forward_backward_vs_float64(B, N, D, Q, amp):
     ref = torch.einsum("bqn,bnd->qd", dS, xd)
     scale = float(ref.abs().max())
     np.testing.assert_allclose(dcls.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=3e-5 * scale)
+
+
+IMGQ = [(5, 197, 768, 1), (5, 197, 768, 12), (4, 256, 1152, 12), (4, 256, 1152, 1), (3, 50, 384, 12), (3, 50, 384, 1),
+        (4, 100, 1024, 4), (4, 100, 1024, 16), (2, 196, 4096, 1), (3, 33, 2048, 1), (70, 196, 768, 12), (3, 17, 256, 8),
+        (3, 40, 1280, 8), (2, 20, 1536, 1)]
+
+
+@pytest.mark.parametrize("B,N,D,H", IMGQ)
+@pytest.mark.parametrize("mode", ["raw", "ln_scores_raw_pool", "ln"])
+def test_per_image_query_passes_vs_float64(B, N, D, H, mode):
+    """csrc/ep_pool_imgq.hip: per-image query rows over channel slices, per-image query gradients."""
+    from efficient_probing_amd import functional as F_
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + D + H)
+    x = torch.randn(B, N, D, device=DEV, generator=g) * (0.5 + torch.rand(B, N, 1, device=DEV, generator=g) * 2) \
+        + torch.randn(B, N, 1, device=DEV, generator=g)
+    dh = D // H
+    u = torch.randn(B, D, device=DEV, generator=g) * 4.0 / dh ** 0.5
+    ts = F_.token_stats(x, 1e-6) if mode != "raw" else None
+    pool_ln = mode == "ln"
+    P, ML = F_.imgq_pool_forward(x, u, H, ts, pool_ln)
+    xd = x.double()
+    xh = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    k = xd if mode == "raw" else xh
+    v = xh if pool_ln else xd
+    ks, vs, us = k.view(B, N, H, dh), v.view(B, N, H, dh), u.double().view(B, H, dh)
+    s = torch.einsum("bhc,bnhc->bhn", us, ks)
+    A = torch.softmax(s, -1)
+    Pr = torch.einsum("bhn,bnhc->bhc", A, vs)
+    np.testing.assert_allclose(P.cpu().numpy(), Pr.reshape(B, D).cpu().numpy(), rtol=1e-4, atol=5e-5)
+    dP = torch.randn(B, D, device=DEV, generator=g)
+    du = F_.imgq_pool_backward(x, u, H, P, ML, dP, ts, pool_ln)
+    dPs = dP.double().view(B, H, dh)
+    dA = torch.einsum("bhc,bnhc->bhn", dPs, vs)
+    dS = A * (dA - (dPs * Pr).sum(-1, keepdim=True))
+    ref = torch.einsum("bhn,bnhc->bhc", dS, ks).reshape(B, D)
+    # (sharp softmax over scores of magnitude ~10 and |dA| ~ 100: fp32 noise of the scores alone is ~1e-4 of the result)
+    np.testing.assert_allclose(du.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
