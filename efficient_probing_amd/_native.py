@@ -229,6 +229,21 @@ class EPSimpoolStep(C.Structure):
     ] + list(EPCaeStep._fields_[7:])                 # targets ... aux_stream, as in every head step
 
 
+class EPCaitDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("hidden", C.c_int32),
+                ("C", C.c_int32), ("ln_eps", C.c_float), ("final_eps", C.c_float)]
+
+
+class EPCaitParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cls_token", "gamma_1", "gamma_2", "n1_w", "n1_b", "q_w", "q_b", "k_w", "k_b", "v_w",
+                                          "v_b", "proj_w", "proj_b", "n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm_w",
+                                          "norm_b")]
+
+
+class EPCaitStep(C.Structure):
+    _fields_ = [("dims", EPCaitDims)] + list(EPCaeStep._fields_[1:])
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -349,6 +364,16 @@ SIGNATURES = {
     "ep_simpool_head_train_step": (c_int, [C.POINTER(EPSimpoolStep), c_void, c_size, c_void]),
     "ep_simpool_head_eval_forward": (c_int, [C.POINTER(EPSimpoolDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_float,
                                              c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_cait_pool_workspace_bytes": (c_size, [C.POINTER(EPCaitDims)]),
+    "ep_cait_pool_forward": (c_int, [C.POINTER(EPCaitDims), c_void, c_int, c_i64, c_void, c_f32p, C.POINTER(EPCaitParams), c_f32p,
+                                     c_void, c_size, c_void]),
+    "ep_cait_pool_backward": (c_int, [C.POINTER(EPCaitDims), c_void, c_int, c_i64, c_void, c_f32p, C.POINTER(EPCaitParams), c_f32p,
+                                      C.POINTER(EPCaitParams), c_int, c_void, c_size, c_void]),
+    "ep_cait_head_param_offsets": (c_i64, [C.POINTER(EPCaitDims), C.POINTER(c_i64)]),
+    "ep_cait_head_workspace_bytes": (c_size, [C.POINTER(EPCaitDims)]),
+    "ep_cait_head_train_step": (c_int, [C.POINTER(EPCaitStep), c_void, c_size, c_void]),
+    "ep_cait_head_eval_forward": (c_int, [C.POINTER(EPCaitDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
     "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,

@@ -953,3 +953,61 @@ def imgq_pool_backward(x, u, heads, P, ML, dP, token_stats=None, pool_ln=False, 
                                       _ptr(token_stats), int(pool_ln), P.data_ptr(), ML.data_ptr(), dP.data_ptr(),
                                       du.data_ptr(), N.current_stream_ptr(xv.device)), "ep_imgq_pool_backward")
     return du
+
+
+# --------------------------------------------------------------------------------------------
+# CaiT class-attention pooling (reference poolings/other_pool.py:390-507) on the LayerNorm-of-tokens passes
+# --------------------------------------------------------------------------------------------
+CAIT_TENSORS = ("cls_token", "gamma_1", "gamma_2", "norm1.weight", "norm1.bias", "attn.q.weight", "attn.q.bias", "attn.k.weight",
+                "attn.k.bias", "attn.v.weight", "attn.v.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm.weight", "norm.bias")
+CAIT_LN_EPS = 1e-6         # other_pool.py:395 norm_layer = partial(nn.LayerNorm, eps=1e-6)
+CAIT_FINAL_EPS = 1e-5      # other_pool.py:415 nn.LayerNorm(embed_dim)
+
+
+def _cait_params_struct(ts):
+    return N.EPCaitParams(*[t.data_ptr() for t in ts])
+
+
+def cait_dims(B, Nn, D, heads, hidden, C_=0):
+    return N.EPCaitDims(B=B, N=Nn, D=D, H=heads, hidden=hidden, C=C_, ln_eps=CAIT_LN_EPS, final_eps=CAIT_FINAL_EPS)
+
+
+class _CaitPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, hidden, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, CAIT_TENSORS)]
+        dims = cait_dims(B, Nn, D, heads, hidden)
+        nbytes = lib.ep_cait_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_cait_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_cait_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0,
+                                         C.byref(_cait_params_struct(tens)), out.data_ptr(), ws.data_ptr(), nbytes,
+                                         N.current_stream_ptr(xv.device)), "ep_cait_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("CaiT class-attention pooling (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_cait_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0, 0,
+                                          C.byref(_cait_params_struct(tens)), dout.data_ptr(),
+                                          C.byref(_cait_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                          N.current_stream_ptr(xv.device)), "ep_cait_pool_backward")
+        return (None, None, None, *grads)
+
+
+def cait_pool(x, heads, hidden, *tens):
+    return _CaitPool.apply(x, heads, hidden, *tens)

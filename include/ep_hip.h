@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 13
+#define EP_ABI_VERSION 14
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -729,6 +729,65 @@ int ep_simpool_head_eval_forward(const ep_simpool_dims* dims, const void* x, int
                                  const int32_t* image_index, const float* token_stats, const float* image_stats,
                                  float ln_eps, const float* params, const float* running_mean, const float* running_var,
                                  float bn_eps, float* logits, int ldl, void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CaiT class-attention pooling (reference poolings/other_pool.py:390-507 CAPooling with one LayerScale_Block_CA /
+ * Class_Attention as the registry builds it, probe_heads.py:79: CAPooling(embed_dim=dim) -> 4 heads, qkv bias, LayerNorm
+ * eps 1e-6 inside the block, LayerScale vectors, MLP x4 (hidden), final LayerNorm eps 1e-5):
+ *     u = norm1([cls ; x]) ; a = proj(softmax(scale q(u_0) k(u)^T) v(u)) ; c1 = cls + gamma_1 a ;
+ *     c2 = c1 + gamma_2 mlp(norm2(c1)) ; out = norm(c2)
+ * = the LayerNorm-of-tokens mode of the EP passes with derived query rows, plus ONE extra softmax entry per head (the
+ * class row itself, batch independent) merged into the pass's softmax state.  Twenty-one tensors: cls_token (1,1,D) |
+ * gamma_1 gamma_2 | norm1.weight .bias | attn.q.weight .bias attn.k.weight .bias attn.v.weight .bias | attn.proj.weight
+ * .bias | norm2.weight .bias | mlp.fc1.weight (hidden,D) .bias mlp.fc2.weight (D,hidden) .bias | norm.weight .bias.
+ * token_stats: optional (B|M, N, 2) from ep_token_stats with eps = ln_eps.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_cait_dims {
+  int32_t B, N, D, H, hidden, C;
+  float ln_eps, final_eps;
+} ep_cait_dims;
+
+typedef struct ep_cait_params {
+  float *cls_token, *gamma_1, *gamma_2, *n1_w, *n1_b, *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *proj_w, *proj_b, *n2_w, *n2_b,
+      *fc1_w, *fc1_b, *fc2_w, *fc2_b, *norm_w, *norm_b;
+} ep_cait_params;
+
+size_t ep_cait_pool_workspace_bytes(const ep_cait_dims* dims);
+int ep_cait_pool_forward(const ep_cait_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* token_stats, const ep_cait_params* params, float* out,
+                         void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_cait_pool_backward(const ep_cait_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                          const int32_t* image_index, const float* token_stats, const ep_cait_params* params,
+                          const float* dout, const ep_cait_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                          ep_stream_t stream);
+
+typedef struct ep_cait_step {
+  ep_cait_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* token_stats; float ln_eps;            /* ln_eps: unused (dims.ln_eps rules); kept for layout parity */
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_cait_step;
+
+int64_t ep_cait_head_param_offsets(const ep_cait_dims* dims, int64_t offsets[23]);
+size_t ep_cait_head_workspace_bytes(const ep_cait_dims* dims);
+int ep_cait_head_train_step(const ep_cait_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_cait_head_eval_forward(const ep_cait_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                              const int32_t* image_index, const float* token_stats, const float* params,
+                              const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
+                              void* ws, size_t ws_bytes, ep_stream_t stream);
 
 #ifdef __cplusplus
 }

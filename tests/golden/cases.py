@@ -514,3 +514,61 @@ def make_simpool_inputs(case: SimpoolCase) -> Dict[str, np.ndarray]:
     if case.linears:
         out.update(wq=u(bd * g, (D, D)), wk=u(bd * g, (D, D)))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# CaiT class-attention pooling (reference poolings/other_pool.py:390-507 behind probe_heads.py:79)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class CaitCase:
+    name: str
+    B: int
+    N: int
+    D: int
+    C: int
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+CAIT_CASES = [
+    CaitCase("tiny", B=6, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
+    CaitCase("tiny_sharp_strided", B=5, N=16, D=128, C=7, seed=1, strided=True, sharp=True, steps=2),
+    CaitCase("vitb16", B=6, N=197, D=768, C=1000, seed=0, full=False, steps=1),
+    CaitCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+CAIT_INIT_DIMS = [(768, 1000)]
+CAIT_PARAM_NAMES = ["cls_token", "gamma_1", "gamma_2", "n1_w", "n1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj_w",
+                    "proj_b", "n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm_w", "norm_b", "fc_weight", "fc_bias"]
+CAIT_SMALL = ("cls_token", "gamma_1", "gamma_2", "n1_w", "n1_b", "q_b", "k_b", "v_b", "proj_b", "n2_w", "n2_b", "fc1_b", "fc2_b",
+              "norm_w", "norm_b", "fc_bias")
+
+
+def make_cait_inputs(case: CaitCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(23000 + case.seed)
+    D, Hd = case.D, 4 * case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    ln = lambda: (1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32)
+    bd, bh, g = 1.0 / np.sqrt(D), 1.0 / np.sqrt(Hd), (5.0 if case.sharp else 1.0)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, n_alloc, 1), dtype=np.float32)).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        cls_token=(g * rng.standard_normal((1, 1, D), dtype=np.float32)).astype(np.float32),
+        # LayerScale vectors of order one (the reference initialises them at 1e-5: nothing but the class token would move)
+        gamma_1=(0.6 + 0.3 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32),
+        gamma_2=(0.6 + 0.3 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32),
+        n1_w=ln(), n1_b=u(0.2, (D,)),
+        q_w=u(bd, (D, D)), q_b=u(bd, (D,)), k_w=u(bd * g, (D, D)), k_b=u(bd, (D,)), v_w=u(bd, (D, D)), v_b=u(bd, (D,)),
+        proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)), n2_w=ln(), n2_b=u(0.2, (D,)),
+        fc1_w=u(bd, (Hd, D)), fc1_b=u(bd, (Hd,)), fc2_w=u(bh, (D, Hd)), fc2_b=u(bh, (D,)),
+        norm_w=ln(), norm_b=u(0.2, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
