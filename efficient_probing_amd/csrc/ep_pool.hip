@@ -279,12 +279,14 @@ static bool use_mf(const PoolParams& p, bool bwd) {
   return true;
 }
 static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
-// all-matrix-core kernel: forced with mode 3; chosen automatically only where it measured fastest
-// (backward at D = 1152, where the other two kernels run short of LDS / registers)
+// all-matrix-core kernel: forced with mode 3; chosen automatically where it measured fastest: more than 8 queries
+// (16 heads at 256x768: 223 / 228 us against 250 / 266 us of the mixed kernel; at 256x1152: 332 us against 511 us of the
+// vector-ALU kernel), and the backward at D = 1152, where the other two kernels run short of LDS / registers
 static bool use_mm(const PoolParams& p, bool bwd) {
   if (p.tokstat || p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
   if (pool_mode() == 3) return true;
-  return pool_mode() == 0 && bwd && p.D == 1152 && p.Q >= 5;
+  if (pool_mode() != 0) return false;
+  return p.Q > 8 || (bwd && p.D == 1152 && p.Q >= 5);
 }
 
 // what the vector-ALU streaming kernels can take: LayerNorm-of-tokens mode needs fp32 tokens
