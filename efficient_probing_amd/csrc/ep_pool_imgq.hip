@@ -3,8 +3,6 @@
 
 namespace ep {
 
-namespace {
-
 constexpr float IQ_LOG2E = 1.4426950408889634f;
 
 template <int G>
@@ -186,7 +184,7 @@ __global__ void ep_imgq_kernel(ImgqParams p, int HW, int TW) {
 
 struct IqPlan { int G, CPL, TB, HW, TW; bool ok; };
 
-IqPlan iq_plan(int D, int H) {
+static IqPlan iq_plan(int D, int H) {
   IqPlan c{};
   c.ok = false;
   if (H < 1 || D % H != 0 || (D / H) % 4 != 0) return c;
@@ -210,7 +208,7 @@ IqPlan iq_plan(int D, int H) {
 }
 
 template <int G, int CPL, int TB>
-int iq_launch(const ImgqParams& p, const IqPlan& c, bool bwd, hipStream_t st) {
+static int iq_launch(const ImgqParams& p, const IqPlan& c, bool bwd, hipStream_t st) {
   const dim3 grid(p.B), block(64 * c.HW * c.TW);
   const size_t lds = c.TW > 1 ? (size_t)c.HW * c.TW * 64 * IqRec<CPL>::FLOATS * sizeof(float) : 0;
   if (p.x_bf16) {
@@ -224,7 +222,7 @@ int iq_launch(const ImgqParams& p, const IqPlan& c, bool bwd, hipStream_t st) {
   return 0;
 }
 
-int iq_dispatch(const ImgqParams& p, bool bwd, hipStream_t st) {
+static int iq_dispatch(const ImgqParams& p, bool bwd, hipStream_t st) {
   const IqPlan c = iq_plan(p.D, p.H);
   EP_REQUIRE(c.ok, EP_E_UNSUPPORTED, "per-image-query token pass: D=%d with %d heads is not supported "
              "(head width must be a multiple of 32, at most 16 head-waves)", p.D, p.H);
@@ -237,8 +235,6 @@ int iq_dispatch(const ImgqParams& p, bool bwd, hipStream_t st) {
   set_error("per-image-query token pass: no kernel for group %d x %d chunks", c.G, c.CPL);
   return EP_E_UNSUPPORTED;
 }
-
-}  // namespace
 
 bool imgq_supported(int D, int H) { return iq_plan(D, H).ok; }
 int imgq_forward(const ImgqParams& p, hipStream_t st) { return iq_dispatch(p, false, st); }
