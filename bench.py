@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
@@ -179,6 +179,11 @@ def main():
         desc = desc.split(",")[0] + (f", SimPool (mean-token query, LayerNorm-ed keys / values, wq / wk), {Cc} classes"
                                      if args.head == "simpool" else
                                      f", SimPool without linear maps (12 channel-slice heads), {Cc} classes")
+    if args.head == "clip":
+        Q = 4                                              # AttentionPool2d default heads (attention_pool2d.py:117)
+        if Nn not in (196, 256):
+            raise SystemExit("--head clip: the learned position embedding fixes the token count at 14 x 14 or 16 x 16")
+        desc = desc.split(",")[0] + f", CLIP attention pooling (4 heads, mean-row query, position embedding), {Cc} classes"
     if args.head == "cait":
         Q = 4                                              # CAPooling default heads (other_pool.py:392)
         desc = desc.split(",")[0] + f", CaiT class-attention pooling (4 heads, LayerScale, MLP x4), {Cc} classes"
@@ -198,7 +203,8 @@ def main():
             self.head = torch.nn.Linear(D, Cc)
     torch.manual_seed(0)                                   # same init on every rank (DDP broadcasts rank 0's)
     enc = Enc()
-    probe_heads.build_probe_head(enc, Namespace(cls_features=args.head, ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16))
+    probe_heads.build_probe_head(enc, Namespace(cls_features=args.head, ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
+                                                model="capi_vitl14_in1k" if Nn == 256 else "vit_base_patch16"))
     head = enc.head.to(dev).train()
     lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
     eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0)
@@ -262,7 +268,7 @@ def main():
     if imgq:
         cls, scale = torch.randn(B, D, device=dev) * 0.05, 1.0
         tstat = F_.token_stats(xs[0] if args.tokens == "f32" else xs[0].float(), 1e-6)
-    elif args.head in ("coca", "siglip", "cae", "jepa", "aim", "cait"):   # the same kernel, fed with the H derived query rows
+    elif args.head in ("coca", "siglip", "cae", "jepa", "aim", "cait", "clip"):   # the same kernel, fed with the H derived query rows
         cls, scale = torch.randn(Q, D, device=dev) * 0.05, 1.0
     else:
         cls, scale = head[0].cls_token.detach(), head[0].scale
@@ -321,7 +327,7 @@ def main():
                        "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec",
                        "jepa": "JEPA-head train images/sec", "aim": "AIM-head train images/sec",
                        "simpool": "SimPool-head train images/sec", "esimpool": "eSimPool-head train images/sec",
-                       "cait": "CaiT-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
+                       "cait": "CaiT-head train images/sec", "clip": "CLIP-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
@@ -363,6 +369,9 @@ def main():
             if args.head == "aim":
                 from oracle import aim_oracle
                 mk = lambda: aim_oracle.make_head(D, Cc)
+            if args.head == "clip":
+                from oracle import clip_oracle
+                mk = lambda: clip_oracle.make_head(D, Cc, Nn)
             if args.head == "cait":
                 from oracle import cait_oracle
                 mk = lambda: cait_oracle.make_head(D, Cc)

@@ -244,6 +244,18 @@ class EPCaitStep(C.Structure):
     _fields_ = [("dims", EPCaitDims)] + list(EPCaeStep._fields_[1:])
 
 
+class EPClipDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class EPClipParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pos_embed", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm_w", "norm_b")]
+
+
+class EPClipStep(C.Structure):
+    _fields_ = [("dims", EPClipDims)] + list(EPCaeStep._fields_[1:])
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -373,6 +385,18 @@ SIGNATURES = {
     "ep_cait_head_workspace_bytes": (c_size, [C.POINTER(EPCaitDims)]),
     "ep_cait_head_train_step": (c_int, [C.POINTER(EPCaitStep), c_void, c_size, c_void]),
     "ep_cait_head_eval_forward": (c_int, [C.POINTER(EPCaitDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_token_xhat_mean": (c_int, [c_void, c_int, c_i64, c_void, c_f32p, c_int, c_int, c_int, c_f32p, c_void]),
+    "ep_clip_pool_workspace_bytes": (c_size, [C.POINTER(EPClipDims)]),
+    "ep_clip_pool_forward": (c_int, [C.POINTER(EPClipDims), c_void, c_int, c_i64, c_void, c_f32p, C.POINTER(EPClipParams), c_f32p,
+                                     c_void, c_size, c_void]),
+    "ep_clip_pool_backward": (c_int, [C.POINTER(EPClipDims), c_void, c_int, c_i64, c_void, c_f32p, C.POINTER(EPClipParams), c_f32p,
+                                      C.POINTER(EPClipParams), c_int, c_void, c_size, c_void]),
+    "ep_clip_attention": (c_int, [C.POINTER(EPClipDims), c_void, c_f32p, c_void]),
+    "ep_clip_head_param_offsets": (c_i64, [C.POINTER(EPClipDims), C.POINTER(c_i64)]),
+    "ep_clip_head_workspace_bytes": (c_size, [C.POINTER(EPClipDims)]),
+    "ep_clip_head_train_step": (c_int, [C.POINTER(EPClipStep), c_void, c_size, c_void]),
+    "ep_clip_head_eval_forward": (c_int, [C.POINTER(EPClipDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),

@@ -21,6 +21,10 @@ struct PoolParams {
   const float* tokstat;  // optional (M or B, N, 2) per-token {mean, rstd} of a LayerNorm over D (indexed like x): the
                          // pass then pools the NORMALISED tokens xhat = (x - mean) * rstd without materialising them:
                          // scores q.xhat, pooled sum_n A xhat; backward accumulates sum dS xhat
+  // per-(image, query, token) extras, honoured by the generic kernels only (setting any of them selects those):
+  const float* sbias;    // fwd: added to the score before the softmax (the stored S includes it)   (B,Q,N)
+  const float* dabias;   // bwd: added to dA = dP . v_n                                               (B,Q,N)
+  float* dSout;          // bwd: the score gradients dS                                               (B,Q,N)
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
   int kdma;              // 16-byte DMA instructions per wave per ring item
@@ -60,6 +64,8 @@ int pool_forward(const PoolParams& p, hipStream_t st);
 // `side` (optional): extra work to run inside the launch; honoured only when pool_backward_takes_side(p)
 int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st, const SideTasks* side = nullptr);
 bool pool_backward_takes_side(const PoolParams& p);
+// per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
+int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
 int debug_force_generic(int on);
 int token_stats(const void* x, int x_bf16, int64_t bstride, int B, int N, int D, float eps, float* stats, hipStream_t st);

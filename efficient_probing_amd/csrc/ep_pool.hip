@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
       }
       s = wave_sum(s);
       if (ts) s = ts[2 * n + 1] * (s - ts[2 * n] * wsum);
+      if (p.sbias) s += p.sbias[((int64_t)b * Q + q) * N + n];
       if (lane == 0) { sm[n] = s; p.S[((int64_t)b * Q + q) * N + n] = s; }
     }
     __syncthreads();
@@ -168,9 +169,12 @@ __global__ __launch_bounds__(256) void ep_pool_bwd_generic_kernel(PoolParams p) 
       }
       s = wave_sum(s);
       if (ts) s = ts[2 * n + 1] * (s - ts[2 * n] * gsum);                 // dA = dP . xhat_n
+      if (p.dabias) s += p.dabias[((int64_t)b * Q + q) * N + n];
       if (lane == 0) {
         const float a = __builtin_amdgcn_exp2f((p.S[((int64_t)b * Q + q) * N + n] - mx) * LOG2E) * inv;
-        sm[n] = a * (s - delta);
+        const float ds = a * (s - delta);
+        sm[n] = ds;
+        if (p.dSout) p.dSout[((int64_t)b * Q + q) * N + n] = ds;
       }
     }
     __syncthreads();
@@ -268,11 +272,13 @@ static int pool_mode() {
 }
 int debug_force_generic(int mode) { int old = pool_mode(); g_pool_mode = mode; return old; }
 static bool force_generic() { return pool_mode() == 1; }
+static bool needs_generic(const PoolParams& p) { return p.sbias || p.dabias || p.dSout; }
 // Measured on MI355X (tools/compare_modes.sh, bench.py): the vector-ALU kernel wins when it can keep
 // three workgroups per CU (Q <= 8 and D <= 768) and for few queries (purely memory-bound: 6.2 TB/s at
 // Q = 1); the matrix-core kernel wins for wider rows and more queries.
 static bool use_mf(const PoolParams& p, bool bwd) {
   (void)bwd;
+  if (needs_generic(p)) return false;
   if (p.tokstat || p.x_bf16 || pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (c.ok && (p.Q <= 4 || stream_waves_per_cu(c.qw, c.kp, c.nw) == 12)) return false;   // vector-ALU kernel wins
@@ -283,6 +289,7 @@ static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 // (16 heads at 256x768: 223 / 228 us against 250 / 266 us of the mixed kernel; at 256x1152: 332 us against 511 us of the
 // vector-ALU kernel), and the backward at D = 1152, where the other two kernels run short of LDS / registers
 static bool use_mm(const PoolParams& p, bool bwd) {
+  if (needs_generic(p)) return false;
   if (p.tokstat || p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
   if (pool_mode() == 3) return true;
   if (pool_mode() != 0) return false;
@@ -298,7 +305,7 @@ static bool stream_takes(const PoolParams& p) {
 
 // wide rows (D = 2048 / 4096): the row is split across the waves of a workgroup
 static bool use_wide(const PoolParams& p) {
-  return !p.tokstat && pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
+  return !needs_generic(p) && !p.tokstat && pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
 }
 
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) {
@@ -324,7 +331,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
-  if (c.ok && !force_generic() && stream_takes(p)) {
+  if (c.ok && !force_generic() && !needs_generic(p) && stream_takes(p)) {
     if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
     return stream_launch(false, c, p, st);
   }
@@ -339,7 +346,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
 bool pool_backward_takes_side(const PoolParams& p) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
-  if (!allow || p.tokstat || use_wide(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   return c.ok && c.nw == 4;
 }
@@ -360,7 +367,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     const int grid = mf_grid(p.B);
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));
-  } else if (c.ok && !force_generic() && stream_takes(p)) {
+  } else if (c.ok && !force_generic() && !needs_generic(p) && stream_takes(p)) {
     EP_TRY(stream_launch(true, c, p, st, side));
     nparts = c.grid;
   } else {
@@ -371,6 +378,25 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     nparts = p.B;
   }
   return reduce_partials(p.Gpart, nparts, p.Q * p.D, p.scale, accumulate, dcls, p.Gpart + (int64_t)nparts * p.Q * p.D, st);
+}
+
+// The generic kernel writes one (Q,D) partial PER IMAGE: with per-image query rows those partials are the result.
+__global__ void ep_scale_copy_kernel(const float* __restrict__ src, int64_t n, float scale, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * scale;
+}
+int pool_backward_per_image(const PoolParams& p0, float* dq, hipStream_t st) {
+  PoolParams p = p0;
+  p.Gpart = dq;
+  const size_t lds = (size_t)(p.N + 8) * sizeof(float);
+  if (p.x_bf16) hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<false>, dim3(p.B), dim3(256), lds, st, p);
+  if (p.scale != 1.0f) {
+    const int64_t n = (int64_t)p.B * p.Q * p.D;
+    hipLaunchKernelGGL(ep_scale_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dq, n, p.scale, dq);
+  }
+  EP_LAUNCH_CHECK("ep_pool_bwd_generic_kernel (per image)");
+  return 0;
 }
 
 // out[n] (+)= scale * sum_i parts[i][n] in two deterministic stages for many parts:

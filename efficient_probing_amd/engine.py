@@ -565,6 +565,40 @@ class CaitHeadEngine(CaeHeadEngine):
                                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class ClipHeadEngine(CaeHeadEngine):
+    """Fused train / eval step of Sequential(AttentionPool2d (CLIP), BatchNorm1d, Linear) through ``ep_clip_head_train_step``."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_clip_head
+        if not is_native_clip_head(head):
+            raise TypeError("ClipHeadEngine needs Sequential(poolings.clip.AttentionPool2d, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        dims = F_.clip_dims(0, p.pos_embed.shape[0] - 1, p.norm.normalized_shape[0], p.num_heads, self.fc.out_features)
+        offs = (C.c_int64 * 9)()
+        total = int(self.lib.ep_clip_head_param_offsets(C.byref(dims), offs))
+        return dims, list(p._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        s = N.EPClipStep()
+        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.ln_eps = F_.CLIP_LN_EPS
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_clip_head_workspace_bytes(C.byref(self.dims))
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_clip_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_clip_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+                                                  self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                  self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                                  ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+
 class SimpoolHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(SimPool | SimPool_nolinears, BatchNorm1d, Linear) through
     ``ep_simpool_head_train_step`` (per-image-query token passes).  ``token_stats`` (functional.token_stats(store, 1e-6)) and
@@ -686,9 +720,11 @@ def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
         return LinearProbeEngine(head, **kw)
     if is_native_simpool_head(head):
         return SimpoolHeadEngine(head, **kw)
-    from .probe_heads import is_native_cait_head
+    from .probe_heads import is_native_cait_head, is_native_clip_head
     if is_native_cait_head(head):
         return CaitHeadEngine(head, **kw)
+    if is_native_clip_head(head):
+        return ClipHeadEngine(head, **kw)
     if is_native_aim_head(head):
         return AimHeadEngine(head, **kw)
     if is_native_jepa_head(head):

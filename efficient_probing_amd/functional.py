@@ -1011,3 +1011,79 @@ class _CaitPool(torch.autograd.Function):
 
 def cait_pool(x, heads, hidden, *tens):
     return _CaitPool.apply(x, heads, hidden, *tens)
+
+
+# --------------------------------------------------------------------------------------------
+# CLIP attention pooling (reference poolings/clip/attention_pool2d.py:100-169)
+# --------------------------------------------------------------------------------------------
+CLIP_TENSORS = ("pos_embed", "qkv.weight", "qkv.bias", "proj.weight", "proj.bias", "norm.weight", "norm.bias")
+CLIP_LN_EPS = 1e-6         # attention_pool2d.py:138 nn.LayerNorm(in_features, eps=1e-6)
+
+
+def _clip_params_struct(ts):
+    return N.EPClipParams(*[t.data_ptr() for t in ts])
+
+
+def clip_dims(B, Nn, D, heads, C_=0):
+    return N.EPClipDims(B=B, N=Nn, D=D, H=heads, C=C_, ln_eps=CLIP_LN_EPS)
+
+
+class _ClipPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, CLIP_TENSORS)]
+        dims = clip_dims(B, Nn, D, heads)
+        nbytes = lib.ep_clip_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_clip_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_clip_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0,
+                                         C.byref(_clip_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes,
+                                         N.current_stream_ptr(xv.device)), "ep_clip_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("CLIP attention pooling (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_clip_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0, 0,
+                                          C.byref(_clip_params_struct(tens)), dy.data_ptr(),
+                                          C.byref(_clip_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                          N.current_stream_ptr(xv.device)), "ep_clip_pool_backward")
+        return (None, None, *grads)
+
+
+def clip_pool(x, heads, *tens):
+    return _ClipPool.apply(x, heads, *tens)
+
+
+def clip_attention(x, heads, *tens):
+    """(pooled (B, D), attention of the mean-row query over the patch rows (B, H, N))."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    B, Nn, D = xv.shape
+    tens = [_f32c(t.detach(), n) for t, n in zip(tens, CLIP_TENSORS)]
+    dims = clip_dims(B, Nn, D, heads)
+    nbytes = lib.ep_clip_pool_workspace_bytes(C.byref(dims))
+    if nbytes == 0:
+        raise RuntimeError(f"ep_clip_pool_workspace_bytes: {N.last_error()}")
+    ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+    y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    st = N.current_stream_ptr(xv.device)
+    N.check(lib.ep_clip_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0,
+                                     C.byref(_clip_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes, st),
+            "ep_clip_pool_forward")
+    A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_clip_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_clip_attention")
+    return y, A

@@ -14,8 +14,8 @@ Invariants kept from the reference (published numbers depend on them):
   * a ``_all`` suffix selects the same pooling over [CLS]+patch tokens (reference :95);
   * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
 
-Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae``, ``jepa``, ``aim``, ``simpool``, ``esimpool`` and ``cait``
-(pooling, BatchNorm1d and the classifier run in the HIP kernels of libep_hip.so).  The other four names resolve to the reference's own PyTorch modules when the
+Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae``, ``jepa``, ``aim``, ``simpool``, ``esimpool``, ``cait`` and
+``clip`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of libep_hip.so).  The other three names resolve to the reference's own PyTorch modules when the
 reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
 ``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
 """
@@ -37,6 +37,7 @@ from .poolings.jepa import AttentivePooler
 from .poolings.aim import AttentionPoolingClassifier
 from .poolings.simpool import SimPool, SimPool_nolinears
 from .poolings.cait import CAPooling
+from .poolings.clip import AttentionPool2d
 from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
 
 BN_EPS = 1e-6
@@ -146,6 +147,8 @@ POOLINGS["simpool"] = (lambda dim, args, model: SimPool(dim=dim, num_heads=1, qk
 POOLINGS["esimpool"] = (lambda dim, args, model: SimPool_nolinears(dim=dim, num_heads=12, qk_scale=None, gamma=None,
                                                                    use_beta=False), None)      # native (:68-69)
 POOLINGS["cait"] = (lambda dim, args, model: CAPooling(embed_dim=dim), None)                    # native (:79)
+POOLINGS["clip"] = (lambda dim, args, model: AttentionPool2d(                                   # native (:54-57,71)
+    in_features=dim, feat_size=16 if getattr(args, "model", None) == "capi_vitl14_in1k" else 14), None)
 POOLINGS["aim"] = (lambda dim, args, model: AttentionPoolingClassifier(dim=dim, num_heads=args.num_heads), None)   # native (:73)
 
 
@@ -226,6 +229,12 @@ def is_native_cait_head(head: nn.Module) -> bool:
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
 
 
+def is_native_clip_head(head: nn.Module) -> bool:
+    """True for Sequential(poolings.clip.AttentionPool2d, BatchNorm1d, Linear) -- engine.ClipHeadEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], AttentionPool2d)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
 def is_native_lp_head(head: nn.Module) -> bool:
     """True for Sequential(BatchNorm1d(affine=False), Linear): plain linear probing (build_probe_head for names
     without a pooling entry, reference probe_heads.py:96-99) -- engine.LinearProbeEngine."""
@@ -237,7 +246,7 @@ def is_native_head(head: nn.Module) -> bool:
     return (is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
             or is_native_siglip_head(head) or is_native_cae_head(head) or is_native_jepa_head(head)
             or is_native_aim_head(head) or is_native_simpool_head(head) or is_native_cait_head(head)
-            or is_native_lp_head(head))
+            or is_native_clip_head(head) or is_native_lp_head(head))
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

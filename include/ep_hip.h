@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 14
+#define EP_ABI_VERSION 15
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -785,6 +785,67 @@ int64_t ep_cait_head_param_offsets(const ep_cait_dims* dims, int64_t offsets[23]
 size_t ep_cait_head_workspace_bytes(const ep_cait_dims* dims);
 int ep_cait_head_train_step(const ep_cait_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_cait_head_eval_forward(const ep_cait_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                              const int32_t* image_index, const float* token_stats, const float* params,
+                              const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
+                              void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CLIP attention pooling (reference poolings/clip/attention_pool2d.py:100-169 AttentionPool2d as the registry builds it,
+ * probe_heads.py:54-57,71: AttentionPool2d(in_features=dim, feat_size=14 | 16) -> 4 heads, qkv bias, learned absolute
+ * position embedding (N + 1, D) with N = feat_size^2, LayerNorm eps 1e-6 in front).  Rows: t_0 = mean_n LN(x)_n + pos_0,
+ * t_n = LN(x)_n + pos_n; only the attention output of row 0 is returned.  Per-image full-width query rows
+ * u[b,h] = g * (scale Wk_h^T q0[b]_h) on the normalised tokens + additive score bias w . pos_n + the mean row as one extra
+ * softmax entry + the position-embedding part of the values as A . pos (csrc/ep_clip.hip).
+ * Seven tensors: pos_embed (N+1, D) | qkv.weight (3D, D) .bias (3D) | proj.weight (D, D) .bias | norm.weight .bias.
+ * token_stats: optional (B|M, N, 2) from ep_token_stats with eps = ln_eps.
+ * ep_token_xhat_mean: xbar[b] = mean_n (x[b,n] - mean_n) rstd_n, the per-image mean of the normalised tokens.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_clip_dims {
+  int32_t B, N, D, H, C;
+  float ln_eps;
+} ep_clip_dims;
+
+typedef struct ep_clip_params {
+  float *pos_embed, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm_w, *norm_b;
+} ep_clip_params;
+
+int ep_token_xhat_mean(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, const float* token_stats,
+                       int B, int N, int D, float* xbar, ep_stream_t stream);
+size_t ep_clip_pool_workspace_bytes(const ep_clip_dims* dims);
+int ep_clip_pool_forward(const ep_clip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* token_stats, const ep_clip_params* params, float* y,
+                         void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_clip_pool_backward(const ep_clip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                          const int32_t* image_index, const float* token_stats, const ep_clip_params* params,
+                          const float* dy, const ep_clip_params* grads, int accumulate, void* ws, size_t ws_bytes,
+                          ep_stream_t stream);
+/* attention of the mean-row query over the patch rows (B, H, N) of the last forward on this workspace (return_attn) */
+int ep_clip_attention(const ep_clip_dims* dims, const void* ws, float* A, ep_stream_t stream);
+
+typedef struct ep_clip_step {
+  ep_clip_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* token_stats; float ln_eps;            /* ln_eps: unused (dims.ln_eps rules); kept for layout parity */
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_clip_step;
+
+int64_t ep_clip_head_param_offsets(const ep_clip_dims* dims, int64_t offsets[9]);
+size_t ep_clip_head_workspace_bytes(const ep_clip_dims* dims);
+int ep_clip_head_train_step(const ep_clip_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_clip_head_eval_forward(const ep_clip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
                               const int32_t* image_index, const float* token_stats, const float* params,
                               const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
                               void* ws, size_t ws_bytes, ep_stream_t stream);

@@ -572,3 +572,55 @@ def make_cait_inputs(case: CaitCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# CLIP attention pooling (reference poolings/clip/attention_pool2d.py:100-169 behind probe_heads.py:54-57,71)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ClipCase:
+    name: str
+    B: int
+    D: int
+    C: int
+    N: int = 196                  # = feat_size ** 2: the registry builds feat_size 14 (16 for CAPI ViT-L/14)
+    model: str = "vit_base_patch16"
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+CLIP_CASES = [
+    ClipCase("tiny", B=6, D=64, C=10, seed=0, weight_decay=1e-4),
+    ClipCase("tiny_sharp_strided", B=5, D=128, C=7, seed=1, strided=True, sharp=True, steps=2),
+    ClipCase("vitb16", B=6, D=768, C=1000, seed=0, full=False, steps=1),
+    ClipCase("capi_vitl14", B=4, D=1024, C=1000, N=256, model="capi_vitl14_in1k", seed=1, full=False, steps=1, sharp=True),
+]
+CLIP_INIT_DIMS = [(768, 1000)]
+CLIP_PARAM_NAMES = ["pos_embed", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm_w", "norm_b", "fc_weight", "fc_bias"]
+CLIP_SMALL = ("qkv_b", "proj_b", "norm_w", "norm_b", "fc_bias")
+
+
+def make_clip_inputs(case: ClipCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(29000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (5.0 if case.sharp else 1.0)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, n_alloc, 1), dtype=np.float32)
+                   + 0.8 * rng.standard_normal((case.B, 1, D), dtype=np.float32)).astype(np.float32)
+    qkv_w = u(bd, (3 * D, D)); qkv_w[D:2 * D] *= g
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        pos_embed=(0.5 * rng.standard_normal((case.N + 1, D), dtype=np.float32)).astype(np.float32),
+        qkv_w=qkv_w, qkv_b=u(bd, (3 * D,)), proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)),
+        norm_w=(1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32), norm_b=u(0.2, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
