@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "dolg", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
@@ -62,8 +62,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 256 FLOP/cycle/CU x 256
 
 
 def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
-    """--head abmilp: the matrix-core-bound head.  Same contract line; the roofline object
-    prices the dominant kernel (the qkv projection contraction) against the dense fp32 MFMA peak."""
+    """--head abmilp / dolg: the matrix-core-bound heads (f4).  Same contract line; the roofline
+    object prices the dominant kernel (AbMILP: the qkv projection; DOLG: the 1x1 convolution over all token rows) against
+    the dense fp32 MFMA peak."""
+    dolg = args.head == "dolg"
     from argparse import Namespace
     from efficient_probing_amd import probe_heads, functional as F_
     from efficient_probing_amd.engine import make_engine
@@ -75,7 +77,7 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
             self.head = torch.nn.Linear(D, Cc)
     torch.manual_seed(0)
     enc = Enc()
-    probe_heads.build_probe_head(enc, Namespace(cls_features="abmilp", nb_classes=Cc, abmilp_sa="both", abmilp_act="tanh",
+    probe_heads.build_probe_head(enc, Namespace(cls_features=args.head, nb_classes=Cc, abmilp_sa="both", abmilp_act="tanh",
                                                 abmilp_depth=2, abmilp_cond=None, abmilp_content="all"))
     head = enc.head.to(dev).train()
     eng = make_engine(head, optimizer="lars", lr=0.1 * (B * world) / 256, weight_decay=0.0)
@@ -105,7 +107,7 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
     loss_sum, _, _, bad = eng.read_stats()
     # dominant kernel alone: qkv = x Wqkv^T over all B*N token rows (HIP events on the launch stream)
     xf = xs[0].view(B * Nn, D)
-    Wqkv = head[0].self_attn.qkv.weight.detach()
+    Wqkv = head[0].conv1.weight.detach().view(D, D) if dolg else head[0].self_attn.qkv.weight.detach()
     F_.linear_forward(xf, Wqkv, None)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -115,18 +117,20 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
     e1.record()
     torch.cuda.synchronize()
     t_k = e0.elapsed_time(e1) * 1e-3 / args.kernel_iters
-    k_flop = 2.0 * B * Nn * D * 3 * D
-    step_flop_img = 24.0 * Nn * D * D + 12.0 * Nn * Nn * D + 2.0 * Nn * D      # fwd + bwd, no token gradient
+    k_flop = 2.0 * B * Nn * D * (D if dolg else 3 * D)
+    # fwd + bwd, no token gradient (DOLG: the 1x1 convolution and its weight gradient)
+    step_flop_img = 4.0 * Nn * D * D if dolg else 24.0 * Nn * D * D + 12.0 * Nn * Nn * D + 2.0 * Nn * D
     if rank == 0:
         value = B * world * steps / elapsed
         out = {
-            "metric": "AbMILP-head train images/sec", "value": round(value, 1), "unit": "images/s",
+            "metric": ("DOLG-head" if dolg else "AbMILP-head") + " train images/sec", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc.split(",")[0] + f", AbMILP head (self-attention + tanh predictor), {Cc} classes",
+            "config": {"workload": desc.split(",")[0] + (f", DOLG spatial attention (1x1 conv, BatchNorm2d, softplus), {Cc} classes" if dolg
+                                                          else f", AbMILP head (self-attention + tanh predictor), {Cc} classes"),
                        "tokens": Nn, "dim": D, "classes": Cc, "batch_per_gpu": B, "global_batch": B * world,
                        "optimizer": "lars", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "ep_gemm_ws_kernel (qkv projection)",
+            "roofline": {"bound": "mfma", "kernel": "ep_gemm_dma_kernel (" + ("1x1 convolution" if dolg else "qkv projection") + ")",
                          "achieved": round(k_flop / t_k / 1e12, 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k_flop / t_k / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "us_per_launch": round(t_k * 1e6, 1), "algorithmic_flop": k_flop,
@@ -135,12 +139,12 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
             "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, steps), 5), "nonfinite_rows": bad},
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import torch_port, abmilp_oracle
+            from oracle import torch_port, abmilp_oracle, dolg_oracle
             r = torch_port.time_train_steps(8, Nn, D, 1, Cc, budget_s=args.cpu_seconds, threads=min(32, os.cpu_count() or 8),
-                                            make=lambda: abmilp_oracle.make_head(D, Cc))
+                                            make=(lambda: dolg_oracle.make_head(D, Cc)) if dolg else (lambda: abmilp_oracle.make_head(D, Cc)))
             out["cpu_baseline"] = {"value": round(r["value"], 2), "unit": "images/s", "cores": r["threads"], "kind": "port",
                                    "sample": f"{r['steps']} train steps of batch {r['batch']} ({r['seconds']:.1f} s), "
-                                             f"torch-CPU restatement of the reference AbMILP step"}
+                                             f"torch-CPU restatement of the reference {'DOLG' if dolg else 'AbMILP'} step"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -165,8 +169,8 @@ def main():
     torch.cuda.set_device(dev)
 
     Nn, D, Q, Cc, desc = WORKLOADS[args.workload]
-    B = args.batch or (256 if args.head == "abmilp" else 1024)
-    if args.head == "abmilp":
+    B = args.batch or (256 if args.head in ("abmilp", "dolg") else 1024)
+    if args.head in ("abmilp", "dolg"):
         return bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B)
     if args.head == "coca":
         Q = 8                                              # 8 query heads of image query 0 (coca_pytorch.py:259)

@@ -256,6 +256,18 @@ class EPClipStep(C.Structure):
     _fields_ = [("dims", EPClipDims)] + list(EPCaeStep._fields_[1:])
 
 
+class EPDolgDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("C", C.c_int32)]
+
+
+class EPDolgParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "bn_w", "bn_b", "conv2_w", "conv2_b")]
+
+
+class EPDolgStep(C.Structure):
+    _fields_ = [("dims", EPDolgDims)] + list(EPAimStep._fields_[1:])
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -398,6 +410,17 @@ SIGNATURES = {
     "ep_clip_head_train_step": (c_int, [C.POINTER(EPClipStep), c_void, c_size, c_void]),
     "ep_clip_head_eval_forward": (c_int, [C.POINTER(EPClipDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_dolg_pool_workspace_bytes": (c_size, [C.POINTER(EPDolgDims)]),
+    "ep_dolg_pool_forward": (c_int, [C.POINTER(EPDolgDims), c_void, c_int, c_i64, c_int, c_float, c_float, c_f32p, c_f32p, c_void,
+                                     C.POINTER(EPDolgParams), c_f32p, c_void, c_size, c_void]),
+    "ep_dolg_pool_backward": (c_int, [C.POINTER(EPDolgDims), c_void, c_int, c_i64, C.POINTER(EPDolgParams), c_f32p,
+                                      C.POINTER(EPDolgParams), c_int, c_void, c_size, c_void]),
+    "ep_dolg_attention": (c_int, [C.POINTER(EPDolgDims), c_void, c_f32p, c_void]),
+    "ep_dolg_head_param_offsets": (c_i64, [C.POINTER(EPDolgDims), C.POINTER(c_i64)]),
+    "ep_dolg_head_workspace_bytes": (c_size, [C.POINTER(EPDolgDims)]),
+    "ep_dolg_head_train_step": (c_int, [C.POINTER(EPDolgStep), c_void, c_size, c_void]),
+    "ep_dolg_head_eval_forward": (c_int, [C.POINTER(EPDolgDims), c_void, c_int, c_i64, c_float, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
     "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,

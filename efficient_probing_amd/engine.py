@@ -599,6 +599,63 @@ class ClipHeadEngine(CaeHeadEngine):
                                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class DolgHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(SpatialAttention2d (DOLG), BatchNorm1d, Linear) through
+    ``ep_dolg_head_train_step``.  Matrix-core bound (4 N D^2 FLOP per image per train step); tokens must be dense fp32."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_dolg_head
+        if not is_native_dolg_head(head):
+            raise TypeError("DolgHeadEngine needs Sequential(poolings.dolg.SpatialAttention2d, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        dims = N.EPDolgDims(B=0, N=0, D=p.conv1.in_channels, C=self.fc.out_features)
+        offs = (C.c_int64 * 8)()
+        total = int(self.lib.ep_dolg_head_param_offsets(C.byref(dims), offs))
+        return dims, list(p._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        s = N.EPDolgStep()
+        tb = self.pool.bn
+        s.tok_running_mean = tb.running_mean.data_ptr(); s.tok_running_var = tb.running_var.data_ptr()
+        s.tok_num_batches_tracked = tb.num_batches_tracked.data_ptr()
+        s.tok_bn_eps = tb.eps; s.tok_bn_momentum = tb.momentum
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_dolg_head_workspace_bytes(C.byref(self.dims))
+
+    def _tokens(self, x, image_index):
+        if image_index is not None:
+            raise NotImplementedError("DOLG: in-place indexed batches are not supported (gather the batch first)")
+        return F_._contiguous_tokens(x)
+
+    def forward_backward(self, x, targets, image_index=None):
+        super().forward_backward(self._tokens(x, image_index), targets, None)
+
+    def eval_logits(self, x, image_index=None):
+        return super().eval_logits(self._tokens(x, image_index), None)
+
+    def sync_buffers(self):
+        super().sync_buffers()
+        if self.world > 1:
+            tb = self.pool.bn
+            for b in (tb.running_mean, tb.running_var, tb.num_batches_tracked):
+                dist.broadcast(b, src=0, group=self.group)
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_dolg_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        tb = self.pool.bn
+        return self.lib.ep_dolg_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, tb.eps,
+                                                  tb.running_mean.data_ptr(), tb.running_var.data_ptr(), self.flat_p.data_ptr(),
+                                                  self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr(), self.bn.eps,
+                                                  out.data_ptr(), ldl, ws.data_ptr(), ws.numel(),
+                                                  N.current_stream_ptr(self.device))
+
+
 class SimpoolHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(SimPool | SimPool_nolinears, BatchNorm1d, Linear) through
     ``ep_simpool_head_train_step`` (per-image-query token passes).  ``token_stats`` (functional.token_stats(store, 1e-6)) and
@@ -720,7 +777,9 @@ def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
         return LinearProbeEngine(head, **kw)
     if is_native_simpool_head(head):
         return SimpoolHeadEngine(head, **kw)
-    from .probe_heads import is_native_cait_head, is_native_clip_head
+    from .probe_heads import is_native_cait_head, is_native_clip_head, is_native_dolg_head
+    if is_native_dolg_head(head):
+        return DolgHeadEngine(head, **kw)
     if is_native_cait_head(head):
         return CaitHeadEngine(head, **kw)
     if is_native_clip_head(head):

@@ -1087,3 +1087,78 @@ def clip_attention(x, heads, *tens):
     A = torch.empty((B, heads, Nn), device=xv.device, dtype=torch.float32)
     N.check(lib.ep_clip_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_clip_attention")
     return y, A
+
+
+# --------------------------------------------------------------------------------------------
+# DOLG spatial attention pooling (reference poolings/dolg/dolg.py:11-62): matrix-core bound
+# --------------------------------------------------------------------------------------------
+DOLG_TENSORS = ("conv1.weight", "conv1.bias", "bn.weight", "bn.bias", "conv2.weight", "conv2.bias")
+
+
+def _dolg_params_struct(ts):
+    return N.EPDolgParams(*[t.data_ptr() for t in ts])
+
+
+class _DolgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, training, eps, momentum, running_mean, running_var, nbt, *tens):
+        lib = N.load()
+        xv = _contiguous_tokens(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, DOLG_TENSORS)]
+        dims = N.EPDolgDims(B=B, N=Nn, D=D, C=0)
+        nbytes = lib.ep_dolg_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_dolg_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_dolg_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, Nn * D, int(training), float(eps),
+                                         float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                         C.byref(_dolg_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes,
+                                         N.current_stream_ptr(xv.device)), "ep_dolg_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims = dims
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("DOLG spatial attention (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in tens]
+        d = ctx.dims
+        N.check(lib.ep_dolg_pool_backward(C.byref(d), xv.data_ptr(), N.EP_DTYPE_F32, d.N * d.D, C.byref(_dolg_params_struct(tens)),
+                                          dy.data_ptr(), C.byref(_dolg_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                          N.current_stream_ptr(xv.device)), "ep_dolg_pool_backward")
+        return (None,) * 7 + tuple(grads)
+
+
+def dolg_pool(x, training, eps, momentum, running_mean, running_var, nbt, *tens):
+    return _DolgPool.apply(x, training, eps, momentum, running_mean, running_var, nbt, *tens)
+
+
+def dolg_attention(x, training, eps, running_mean, running_var, *tens):
+    """(pooled (B, D), softplus attention scores (B, N)) -- no statistics update."""
+    lib = N.load()
+    xv = _contiguous_tokens(x)
+    B, Nn, D = xv.shape
+    tens = [_f32c(t.detach(), n) for t, n in zip(tens, DOLG_TENSORS)]
+    dims = N.EPDolgDims(B=B, N=Nn, D=D, C=0)
+    nbytes = lib.ep_dolg_pool_workspace_bytes(C.byref(dims))
+    if nbytes == 0:
+        raise RuntimeError(f"ep_dolg_pool_workspace_bytes: {N.last_error()}")
+    ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+    y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    rm = running_mean.clone() if running_mean is not None else None
+    rv = running_var.clone() if running_var is not None else None
+    st = N.current_stream_ptr(xv.device)
+    N.check(lib.ep_dolg_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, Nn * D, int(training), float(eps), 0.0, _ptr(rm),
+                                     _ptr(rv), 0, C.byref(_dolg_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes, st),
+            "ep_dolg_pool_forward")
+    att = torch.empty((B, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_dolg_attention(C.byref(dims), ws.data_ptr(), att.data_ptr(), st), "ep_dolg_attention")
+    return y, att

@@ -14,8 +14,8 @@ Invariants kept from the reference (published numbers depend on them):
   * a ``_all`` suffix selects the same pooling over [CLS]+patch tokens (reference :95);
   * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
 
-Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae``, ``jepa``, ``aim``, ``simpool``, ``esimpool``, ``cait`` and
-``clip`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of libep_hip.so).  The other three names resolve to the reference's own PyTorch modules when the
+Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae``, ``jepa``, ``aim``, ``simpool``, ``esimpool``, ``cait``,
+``clip`` and ``dolg`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of libep_hip.so).  The other two names resolve to the reference's own PyTorch modules when the
 reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
 ``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
 """
@@ -38,6 +38,7 @@ from .poolings.aim import AttentionPoolingClassifier
 from .poolings.simpool import SimPool, SimPool_nolinears
 from .poolings.cait import CAPooling
 from .poolings.clip import AttentionPool2d
+from .poolings.dolg import SpatialAttention2d
 from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
 
 BN_EPS = 1e-6
@@ -149,6 +150,7 @@ POOLINGS["esimpool"] = (lambda dim, args, model: SimPool_nolinears(dim=dim, num_
 POOLINGS["cait"] = (lambda dim, args, model: CAPooling(embed_dim=dim), None)                    # native (:79)
 POOLINGS["clip"] = (lambda dim, args, model: AttentionPool2d(                                   # native (:54-57,71)
     in_features=dim, feat_size=16 if getattr(args, "model", None) == "capi_vitl14_in1k" else 14), None)
+POOLINGS["dolg"] = (lambda dim, args, model: SpatialAttention2d(in_c=dim, s3_dim=dim, with_aspp=False), None)   # native (:82)
 POOLINGS["aim"] = (lambda dim, args, model: AttentionPoolingClassifier(dim=dim, num_heads=args.num_heads), None)   # native (:73)
 
 
@@ -235,6 +237,12 @@ def is_native_clip_head(head: nn.Module) -> bool:
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
 
 
+def is_native_dolg_head(head: nn.Module) -> bool:
+    """True for Sequential(poolings.dolg.SpatialAttention2d, BatchNorm1d, Linear) -- engine.DolgHeadEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], SpatialAttention2d)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
 def is_native_lp_head(head: nn.Module) -> bool:
     """True for Sequential(BatchNorm1d(affine=False), Linear): plain linear probing (build_probe_head for names
     without a pooling entry, reference probe_heads.py:96-99) -- engine.LinearProbeEngine."""
@@ -246,7 +254,7 @@ def is_native_head(head: nn.Module) -> bool:
     return (is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
             or is_native_siglip_head(head) or is_native_cae_head(head) or is_native_jepa_head(head)
             or is_native_aim_head(head) or is_native_simpool_head(head) or is_native_cait_head(head)
-            or is_native_clip_head(head) or is_native_lp_head(head))
+            or is_native_clip_head(head) or is_native_dolg_head(head) or is_native_lp_head(head))
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 15
+#define EP_ABI_VERSION 16
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -847,6 +847,64 @@ size_t ep_clip_head_workspace_bytes(const ep_clip_dims* dims);
 int ep_clip_head_train_step(const ep_clip_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_clip_head_eval_forward(const ep_clip_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
                               const int32_t* image_index, const float* token_stats, const float* params,
+                              const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
+                              void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DOLG spatial attention pooling (reference poolings/dolg/dolg.py:11-62 SpatialAttention2d as the registry builds it,
+ * probe_heads.py:82: SpatialAttention2d(in_c=dim, s3_dim=dim, with_aspp=False)):
+ *     Yh = BatchNorm2d(conv1(x)) over the square token grid ; F = Yh / max(|Yh|_2, 1e-12) per token ;
+ *     att = softplus(conv2(relu(Yh))) ; out[b] = mean_n att[b,n] F[b,n]
+ * Matrix-core bound (one (B N) x D x D contraction per direction).  Six tensors: conv1.weight (D,D,1,1) .bias | bn.weight
+ * .bias | conv2.weight (1,D,1,1) .bias (1); the BatchNorm's running_mean / running_var / num_batches_tracked are buffers.
+ * The tokens must be a dense fp32 (B, N, D) tensor with N a perfect square (as the reference's view(b, c, h, w) needs).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_dolg_dims {
+  int32_t B, N, D, C;
+} ep_dolg_dims;
+
+typedef struct ep_dolg_params {
+  float *conv1_w, *conv1_b, *bn_w, *bn_b, *conv2_w, *conv2_b;
+} ep_dolg_params;
+
+size_t ep_dolg_pool_workspace_bytes(const ep_dolg_dims* dims);
+int ep_dolg_pool_forward(const ep_dolg_dims* dims, const void* x, int x_dtype, int64_t x_bstride, int training, float bn_eps,
+                         float bn_momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         const ep_dolg_params* params, float* y, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_dolg_pool_backward(const ep_dolg_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                          const ep_dolg_params* params, const float* dy, const ep_dolg_params* grads, int accumulate,
+                          void* ws, size_t ws_bytes, ep_stream_t stream);
+/* attention scores (B, N) of the last forward on this workspace (dolg.py return_attn) */
+int ep_dolg_attention(const ep_dolg_dims* dims, const void* ws, float* att, ep_stream_t stream);
+
+typedef struct ep_dolg_step {
+  ep_dolg_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;                        /* must be NULL (gather the batch first) */
+  const float* image_stats;                          /* unused; layout parity with ep_aim_step */
+  float* tok_running_mean; float* tok_running_var; int64_t* tok_num_batches_tracked;   /* 0.bn.* buffers */
+  float tok_bn_eps, tok_bn_momentum;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_dolg_step;
+
+/* flat layout: conv1.weight | conv1.bias | bn.weight | bn.bias | conv2.weight | conv2.bias | fc.weight | fc.bias */
+int64_t ep_dolg_head_param_offsets(const ep_dolg_dims* dims, int64_t offsets[8]);
+size_t ep_dolg_head_workspace_bytes(const ep_dolg_dims* dims);
+int ep_dolg_head_train_step(const ep_dolg_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_dolg_head_eval_forward(const ep_dolg_dims* dims, const void* x, int x_dtype, int64_t x_bstride, float tok_bn_eps,
+                              const float* tok_running_mean, const float* tok_running_var, const float* params,
                               const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
                               void* ws, size_t ws_bytes, ep_stream_t stream);
 

@@ -624,3 +624,53 @@ def make_clip_inputs(case: ClipCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# DOLG spatial attention pooling (reference poolings/dolg/dolg.py:11-62 behind probe_heads.py:82)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class DolgCase:
+    name: str
+    B: int
+    N: int                        # a perfect square: the reference reshapes the tokens to an h x w grid
+    D: int
+    C: int
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+DOLG_CASES = [
+    DolgCase("tiny", B=6, N=16, D=64, C=10, seed=0, weight_decay=1e-4),
+    DolgCase("tiny_sharp_strided", B=5, N=25, D=128, C=7, seed=1, strided=True, sharp=True, steps=2),
+    DolgCase("vitb16", B=6, N=196, D=768, C=1000, seed=0, full=False, steps=1),
+    DolgCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+DOLG_INIT_DIMS = [(768, 1000)]
+DOLG_PARAM_NAMES = ["conv1_w", "conv1_b", "bn_w", "bn_b", "conv2_w", "conv2_b", "fc_weight", "fc_bias"]
+DOLG_SMALL = ("conv1_b", "bn_w", "bn_b", "conv2_w", "conv2_b", "fc_bias")
+
+
+def make_dolg_inputs(case: DolgCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(31000 + case.seed)
+    D = case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    bd, g = 1.0 / np.sqrt(D), (4.0 if case.sharp else 1.0)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, 1, D), dtype=np.float32)).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        conv1_w=u(bd, (D, D, 1, 1)), conv1_b=u(bd, (D,)),
+        bn_w=(1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32), bn_b=u(0.3, (D,)),
+        conv2_w=(g * u(bd, (1, D, 1, 1))).astype(np.float32), conv2_b=u(0.5, (1,)),
+        tok_running_mean=u(0.3, (D,)), tok_running_var=(0.5 + rng.random((D,), dtype=np.float32)).astype(np.float32),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )
