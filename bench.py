@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "dolg", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "dolg", "cbam", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
@@ -183,6 +183,11 @@ def main():
         desc = desc.split(",")[0] + (f", SimPool (mean-token query, LayerNorm-ed keys / values, wq / wk), {Cc} classes"
                                      if args.head == "simpool" else
                                      f", SimPool without linear maps (12 channel-slice heads), {Cc} classes")
+    if args.head == "cbam":
+        Q = 1
+        if int(round(Nn ** 0.5)) ** 2 != Nn:
+            raise SystemExit("--head cbam: the token count must be a perfect square")
+        desc = desc.split(",")[0] + f", CBAM pooling (channel + 7x7 spatial gates), {Cc} classes"
     if args.head == "clip":
         Q = 4                                              # AttentionPool2d default heads (attention_pool2d.py:117)
         if Nn not in (196, 256):
@@ -269,7 +274,10 @@ def main():
         return e0.elapsed_time(e1) * 1e-3 / iters
 
     imgq = args.head in ("simpool", "esimpool")            # per-image-query passes (csrc/ep_pool_imgq.hip)
-    if imgq:
+    cbam = args.head == "cbam"                             # its own streaming passes (csrc/ep_cbam.hip)
+    if cbam:
+        cls, scale = None, 1.0
+    elif imgq:
         cls, scale = torch.randn(B, D, device=dev) * 0.05, 1.0
         tstat = F_.token_stats(xs[0] if args.tokens == "f32" else xs[0].float(), 1e-6)
     elif args.head in ("coca", "siglip", "cae", "jepa", "aim", "cait", "clip"):   # the same kernel, fed with the H derived query rows
@@ -279,12 +287,17 @@ def main():
     keep = {}
 
     def run_fwd(i):
+        if cbam:
+            keep["out"] = F_.cbam_channel_table(xs[i % args.buffers])
+            return
         if imgq:
             keep["out"] = F_.imgq_pool_forward(xs[i % args.buffers], cls, Q, tstat, args.head == "simpool")
         else:
             keep["out"] = F_.pool_forward(xs[i % args.buffers], cls, scale)
     t_fwd = time_kernel(run_fwd, args.kernel_iters)
-    if imgq:
+    if cbam:
+        P = torch.zeros(B, D, device=dev); S = ML = None
+    elif imgq:
         P, ML = keep["out"]
         S = None
     else:
@@ -299,6 +312,9 @@ def main():
 
     def run_bwd(i):
         x = xs[i % args.buffers]
+        if cbam:
+            F_.cbam_channel_table(x)
+            return
         if imgq:
             F_.imgq_pool_backward(x, cls, Q, P, ML, dP, tstat, args.head == "simpool")
             return
@@ -308,8 +324,8 @@ def main():
 
     algo_bytes = B * Nn * D * esize                           # one streaming read of the stored tokens
     dt = 1 if args.tokens == "bf16" else 0
-    kname_f = "ep_imgq_kernel (forward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
-    kname_b = "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
+    kname_f = "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (forward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
+    kname_b = "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic = None
@@ -331,7 +347,8 @@ def main():
                        "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec",
                        "jepa": "JEPA-head train images/sec", "aim": "AIM-head train images/sec",
                        "simpool": "SimPool-head train images/sec", "esimpool": "eSimPool-head train images/sec",
-                       "cait": "CaiT-head train images/sec", "clip": "CLIP-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
+                       "cait": "CaiT-head train images/sec", "clip": "CLIP-head train images/sec",
+                       "cbam": "CBAM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
@@ -373,6 +390,9 @@ def main():
             if args.head == "aim":
                 from oracle import aim_oracle
                 mk = lambda: aim_oracle.make_head(D, Cc)
+            if args.head == "cbam":
+                from oracle import cbam_oracle
+                mk = lambda: cbam_oracle.make_head(D, Cc)
             if args.head == "clip":
                 from oracle import clip_oracle
                 mk = lambda: clip_oracle.make_head(D, Cc, Nn)

@@ -268,6 +268,18 @@ class EPDolgStep(C.Structure):
     _fields_ = [("dims", EPDolgDims)] + list(EPAimStep._fields_[1:])
 
 
+class EPCbamDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("C", C.c_int32), ("rd", C.c_int32), ("ks", C.c_int32)]
+
+
+class EPCbamParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc2_w", "conv_w", "bn_w", "bn_b")]
+
+
+class EPCbamStep(C.Structure):
+    _fields_ = [("dims", EPCbamDims)] + list(EPAimStep._fields_[1:])
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -421,6 +433,17 @@ SIGNATURES = {
     "ep_dolg_head_train_step": (c_int, [C.POINTER(EPDolgStep), c_void, c_size, c_void]),
     "ep_dolg_head_eval_forward": (c_int, [C.POINTER(EPDolgDims), c_void, c_int, c_i64, c_float, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_cbam_channel_table": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
+    "ep_cbam_pool_workspace_bytes": (c_size, [C.POINTER(EPCbamDims)]),
+    "ep_cbam_pool_forward": (c_int, [C.POINTER(EPCbamDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,
+                                     c_f32p, c_void, C.POINTER(EPCbamParams), c_f32p, c_void, c_size, c_void]),
+    "ep_cbam_pool_backward": (c_int, [C.POINTER(EPCbamDims), c_void, c_int, c_i64, c_void, C.POINTER(EPCbamParams), c_f32p,
+                                      C.POINTER(EPCbamParams), c_int, c_void, c_size, c_void]),
+    "ep_cbam_head_param_offsets": (c_i64, [C.POINTER(EPCbamDims), C.POINTER(c_i64)]),
+    "ep_cbam_head_workspace_bytes": (c_size, [C.POINTER(EPCbamDims)]),
+    "ep_cbam_head_train_step": (c_int, [C.POINTER(EPCbamStep), c_void, c_size, c_void]),
+    "ep_cbam_head_eval_forward": (c_int, [C.POINTER(EPCbamDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, c_f32p, c_f32p,
+                                          c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
     "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,

@@ -656,6 +656,61 @@ class DolgHeadEngine(ProbeHeadEngine):
                                                   N.current_stream_ptr(self.device))
 
 
+class CbamHeadEngine(ProbeHeadEngine):
+    """Fused train / eval step of Sequential(CbamPooling, BatchNorm1d, Linear) through ``ep_cbam_head_train_step`` (streaming
+    passes over the tokens).  ``image_stats`` (functional.cbam_channel_table of a resident store, (M, 3, D)) can be passed per
+    call: one streaming read per step less."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_cbam_head
+        if not is_native_cbam_head(head):
+            raise TypeError("CbamHeadEngine needs Sequential(poolings.cbam.CbamPooling, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        p = self.pool
+        dims = N.EPCbamDims(B=0, N=0, D=p.channel.fc1.in_channels, C=self.fc.out_features, rd=p.rd, ks=p.ks)
+        offs = (C.c_int64 * 7)()
+        total = int(self.lib.ep_cbam_head_param_offsets(C.byref(dims), offs))
+        return dims, list(p._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        s = N.EPCbamStep()
+        tb = self.pool.spatial.conv.bn
+        s.image_stats = self._imgstat.data_ptr() if getattr(self, "_imgstat", None) is not None else 0
+        s.tok_running_mean = tb.running_mean.data_ptr(); s.tok_running_var = tb.running_var.data_ptr()
+        s.tok_num_batches_tracked = tb.num_batches_tracked.data_ptr()
+        s.tok_bn_eps = tb.eps; s.tok_bn_momentum = tb.momentum
+        return s
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_cbam_head_workspace_bytes(C.byref(self.dims))
+
+    def train_step(self, x, targets, lr=None, image_index=None, image_stats=None):
+        self._imgstat = image_stats
+        try:
+            super().train_step(x, targets, lr, image_index)
+        finally:
+            self._imgstat = None
+
+    def sync_buffers(self):
+        super().sync_buffers()
+        if self.world > 1:
+            tb = self.pool.spatial.conv.bn
+            for b in (tb.running_mean, tb.running_var, tb.num_batches_tracked):
+                dist.broadcast(b, src=0, group=self.group)
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_cbam_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        tb = self.pool.spatial.conv.bn
+        return self.lib.ep_cbam_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+                                                  tb.eps, tb.running_mean.data_ptr(), tb.running_var.data_ptr(),
+                                                  self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                  self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl, ws.data_ptr(),
+                                                  ws.numel(), N.current_stream_ptr(self.device))
+
+
 class SimpoolHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(SimPool | SimPool_nolinears, BatchNorm1d, Linear) through
     ``ep_simpool_head_train_step`` (per-image-query token passes).  ``token_stats`` (functional.token_stats(store, 1e-6)) and
@@ -780,6 +835,9 @@ def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
     from .probe_heads import is_native_cait_head, is_native_clip_head, is_native_dolg_head
     if is_native_dolg_head(head):
         return DolgHeadEngine(head, **kw)
+    from .probe_heads import is_native_cbam_head
+    if is_native_cbam_head(head):
+        return CbamHeadEngine(head, **kw)
     if is_native_cait_head(head):
         return CaitHeadEngine(head, **kw)
     if is_native_clip_head(head):

@@ -1162,3 +1162,68 @@ def dolg_attention(x, training, eps, running_mean, running_var, *tens):
     att = torch.empty((B, Nn), device=xv.device, dtype=torch.float32)
     N.check(lib.ep_dolg_attention(C.byref(dims), ws.data_ptr(), att.data_ptr(), st), "ep_dolg_attention")
     return y, att
+
+
+# --------------------------------------------------------------------------------------------
+# CBAM pooling (reference poolings/cbam.py:104-139): streaming passes over the tokens
+# --------------------------------------------------------------------------------------------
+CBAM_TENSORS = ("channel.fc1.weight", "channel.fc2.weight", "spatial.conv.conv.weight", "spatial.conv.bn.weight",
+                "spatial.conv.bn.bias")
+
+
+def _cbam_params_struct(ts):
+    return N.EPCbamParams(*[t.data_ptr() for t in ts])
+
+
+def cbam_channel_table(x: torch.Tensor, image_index=None) -> torch.Tensor:
+    """Per-image {mean_n x, max_n x, mean_n relu(x)} per channel -> (B, 3, D) fp32: compute once for a resident token store and
+    hand it to ``CbamHeadEngine.train_step(..., image_stats=...)``."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    out = torch.empty((B, 3, D), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_cbam_channel_table(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, B, Nn, D, out.data_ptr(),
+                                      N.current_stream_ptr(xv.device)), "ep_cbam_channel_table")
+    return out
+
+
+class _CbamPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rd, ks, training, eps, momentum, running_mean, running_var, nbt, *tens):
+        lib = N.load()
+        xv, bstride = as_token_view(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, CBAM_TENSORS)]
+        dims = N.EPCbamDims(B=B, N=Nn, D=D, C=0, rd=rd, ks=ks)
+        nbytes = lib.ep_cbam_pool_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError(f"ep_cbam_pool_workspace_bytes: {N.last_error()}")
+        ws = torch.empty(nbytes, device=xv.device, dtype=torch.uint8)
+        y = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_cbam_pool_forward(C.byref(dims), xv.data_ptr(), token_dtype_code(xv), bstride, 0, 0, int(training), float(eps),
+                                         float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                         C.byref(_cbam_params_struct(tens)), y.data_ptr(), ws.data_ptr(), nbytes,
+                                         N.current_stream_ptr(xv.device)), "ep_cbam_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims, ctx.bstride = dims, bstride
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("CBAM pooling (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        grads = [torch.empty_like(t) for t in tens]
+        N.check(lib.ep_cbam_pool_backward(C.byref(ctx.dims), xv.data_ptr(), token_dtype_code(xv), ctx.bstride, 0,
+                                          C.byref(_cbam_params_struct(tens)), dy.data_ptr(), C.byref(_cbam_params_struct(grads)), 0,
+                                          ws.data_ptr(), ws.numel(), N.current_stream_ptr(xv.device)), "ep_cbam_pool_backward")
+        return (None,) * 9 + tuple(grads)
+
+
+def cbam_pool(x, rd, ks, training, eps, momentum, running_mean, running_var, nbt, *tens):
+    return _CbamPool.apply(x, rd, ks, training, eps, momentum, running_mean, running_var, nbt, *tens)

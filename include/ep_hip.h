@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 16
+#define EP_ABI_VERSION 17
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -904,6 +904,68 @@ int64_t ep_dolg_head_param_offsets(const ep_dolg_dims* dims, int64_t offsets[8])
 size_t ep_dolg_head_workspace_bytes(const ep_dolg_dims* dims);
 int ep_dolg_head_train_step(const ep_dolg_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_dolg_head_eval_forward(const ep_dolg_dims* dims, const void* x, int x_dtype, int64_t x_bstride, float tok_bn_eps,
+                              const float* tok_running_mean, const float* tok_running_var, const float* params,
+                              const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
+                              void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CBAM pooling (reference poolings/cbam.py:104-139 CbamPooling with ChannelAttn :19-36 and SpatialAttn :57-68 as the registry
+ * builds it, probe_heads.py:77: CbamPooling(channels=dim, spatial_kernel_size=7) -> reduction 1/16 (rd = int(D / 16 + 0.5)),
+ * no MLP bias, sigmoid gates, 7x7 convolution + one-channel BatchNorm2d on the square token grid):
+ *     out[b,c] = mean_n relu(x gc gs + x) = R0[b,c] + gc[b,c] mean_n gs[b,n] relu(x[b,n,c])      (both gates lie in (0, 1))
+ * HBM-bound: streaming passes over the frozen tokens (csrc/ep_cbam.hip).  Five tensors: channel.fc1.weight (rd,D,1,1) |
+ * channel.fc2.weight (D,rd,1,1) | spatial.conv.conv.weight (1,2,ks,ks) | spatial.conv.bn.weight .bias (1); the BatchNorm's
+ * running statistics are buffers.  ep_cbam_channel_table: per-image {mean_n x, max_n x, mean_n relu(x)} per channel ((B, 3, D));
+ * it depends on the frozen tokens only, so a resident store computes it once and passes it as `channel_table` (rows addressed
+ * through image_index like the tokens); NULL: computed for the batch (one more streaming read).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_cbam_dims {
+  int32_t B, N, D, C, rd, ks;
+} ep_cbam_dims;
+
+typedef struct ep_cbam_params {
+  float *fc1_w, *fc2_w, *conv_w, *bn_w, *bn_b;
+} ep_cbam_params;
+
+int ep_cbam_channel_table(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                          float* table, ep_stream_t stream);
+size_t ep_cbam_pool_workspace_bytes(const ep_cbam_dims* dims);
+int ep_cbam_pool_forward(const ep_cbam_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                         const int32_t* image_index, const float* channel_table, int training, float bn_eps,
+                         float bn_momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         const ep_cbam_params* params, float* y, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_cbam_pool_backward(const ep_cbam_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                          const int32_t* image_index, const ep_cbam_params* params, const float* dy,
+                          const ep_cbam_params* grads, int accumulate, void* ws, size_t ws_bytes, ep_stream_t stream);
+
+typedef struct ep_cbam_step {
+  ep_cbam_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int32_t* image_index;
+  const float* image_stats;                          /* optional cached (M, 3, D) table of ep_cbam_channel_table */
+  float* tok_running_mean; float* tok_running_var; int64_t* tok_num_batches_tracked;   /* 0.spatial.conv.bn.* buffers */
+  float tok_bn_eps, tok_bn_momentum;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+  ep_stream_t aux_stream;
+} ep_cbam_step;
+
+/* flat layout: channel.fc1.weight | channel.fc2.weight | spatial.conv.conv.weight | bn.weight | bn.bias | fc.weight | fc.bias */
+int64_t ep_cbam_head_param_offsets(const ep_cbam_dims* dims, int64_t offsets[7]);
+size_t ep_cbam_head_workspace_bytes(const ep_cbam_dims* dims);
+int ep_cbam_head_train_step(const ep_cbam_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_cbam_head_eval_forward(const ep_cbam_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                              const int32_t* image_index, const float* channel_table, float tok_bn_eps,
                               const float* tok_running_mean, const float* tok_running_var, const float* params,
                               const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
                               void* ws, size_t ws_bytes, ep_stream_t stream);

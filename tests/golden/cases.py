@@ -674,3 +674,54 @@ def make_dolg_inputs(case: DolgCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# CBAM pooling (reference poolings/cbam.py:104-139 behind probe_heads.py:77)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class CbamCase:
+    name: str
+    B: int
+    N: int                        # a perfect square
+    D: int
+    C: int
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+CBAM_CASES = [
+    CbamCase("tiny", B=6, N=16, D=64, C=10, seed=0, weight_decay=1e-4),
+    CbamCase("tiny_sharp_strided", B=5, N=25, D=128, C=7, seed=1, strided=True, sharp=True, steps=2),
+    CbamCase("vitb16", B=6, N=196, D=768, C=1000, seed=0, full=False, steps=1),
+    CbamCase("so400m", B=5, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+CBAM_INIT_DIMS = [(768, 1000)]
+CBAM_PARAM_NAMES = ["fc1_w", "fc2_w", "conv_w", "bn_w", "bn_b", "fc_weight", "fc_bias"]
+CBAM_SMALL = ("fc1_w", "fc2_w", "conv_w", "bn_w", "bn_b", "fc_bias")
+
+
+def make_cbam_inputs(case: CbamCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(37000 + case.seed)
+    D = case.D
+    rd = max(1, int(D / 16 + 0.5))
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    g = 3.0 if case.sharp else 1.0
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, 1, D), dtype=np.float32)).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        fc1_w=(g * u(1.0 / np.sqrt(D), (rd, D, 1, 1))).astype(np.float32), fc2_w=u(1.0 / np.sqrt(rd), (D, rd, 1, 1)),
+        conv_w=(g * u(1.0 / np.sqrt(98.0), (1, 2, 7, 7))).astype(np.float32),
+        bn_w=(1.0 + 0.2 * rng.standard_normal((1,), dtype=np.float32)).astype(np.float32), bn_b=u(0.3, (1,)),
+        tok_running_mean=u(0.3, (1,)), tok_running_var=(0.5 + rng.random((1,), dtype=np.float32)).astype(np.float32),
+        fc_weight=u(1.0 / np.sqrt(D), (case.C, D)), fc_bias=u(1.0 / np.sqrt(D), (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )

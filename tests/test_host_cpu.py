@@ -110,16 +110,16 @@ def test_registry_surface():
     # a pooling without a native kernel and without the reference on sys.path fails loudly
     enc = StubEncoder(64, 10)
     with pytest.raises(NotImplementedError, match="register_pooling"):
-        probe_heads.build_probe_head(enc, _args(cls_features="cbam"))
+        probe_heads.build_probe_head(enc, _args(cls_features="dinovit"))
     # ... and can be plugged in; it keeps the encoder's classifier
-    probe_heads.register_pooling("cbam", lambda dim, a, m: torch.nn.Identity())
+    probe_heads.register_pooling("dinovit", lambda dim, a, m: torch.nn.Identity())
     try:
         enc = StubEncoder(64, 10)
         own = enc.head
-        probe_heads.build_probe_head(enc, _args(cls_features="cbam"))
+        probe_heads.build_probe_head(enc, _args(cls_features="dinovit"))
         assert isinstance(enc.head[0], torch.nn.Identity) and enc.head[2] is own
     finally:
-        probe_heads.POOLINGS["cbam"] = (probe_heads._reference_pooling("cbam"), None)
+        probe_heads.POOLINGS["dinovit"] = (probe_heads._reference_pooling("dinovit"), None)
     with pytest.raises(KeyError):
         probe_heads.register_pooling("nonsense", lambda *a: None)
 
