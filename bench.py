@@ -44,11 +44,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "dolg", "cbam", "abmilp"],
+    ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "dolg", "cbam", "dinovit", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
-                    help="images per GPU per step (weak scaling); default 1024 (256 for --head abmilp)")
+                    help="images per GPU per step (weak scaling); default 1024 (256 for --head abmilp / dolg / dinovit)")
     ap.add_argument("--buffers", type=int, default=4, help="distinct token buffers rotated through (HBM, not cache)")
     ap.add_argument("--tokens", default="f32", choices=["f32", "bf16"],
                     help="storage type of the tokens in HBM (arithmetic is fp32 either way)")
@@ -62,10 +62,11 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 256 FLOP/cycle/CU x 256
 
 
 def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
-    """--head abmilp / dolg: the matrix-core-bound heads (f4).  Same contract line; the roofline
+    """--head abmilp / dolg / dinovit: the matrix-core-bound heads (f4).  Same contract line; the roofline
     object prices the dominant kernel (AbMILP: the qkv projection; DOLG: the 1x1 convolution over all token rows) against
     the dense fp32 MFMA peak."""
-    dolg = args.head == "dolg"
+    dolg, dino = args.head == "dolg", args.head == "dinovit"
+    label = {"dolg": "DOLG", "dinovit": "DINOv2-block", "abmilp": "AbMILP"}[args.head]
     from argparse import Namespace
     from efficient_probing_amd import probe_heads, functional as F_
     from efficient_probing_amd.engine import make_engine
@@ -107,7 +108,8 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
     loss_sum, _, _, bad = eng.read_stats()
     # dominant kernel alone: qkv = x Wqkv^T over all B*N token rows (HIP events on the launch stream)
     xf = xs[0].view(B * Nn, D)
-    Wqkv = head[0].conv1.weight.detach().view(D, D) if dolg else head[0].self_attn.qkv.weight.detach()
+    Wqkv = (head[0].conv1.weight.detach().view(D, D) if dolg else head[0].dino_block.attn.qkv.weight.detach() if dino
+            else head[0].self_attn.qkv.weight.detach())
     F_.linear_forward(xf, Wqkv, None)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -119,14 +121,19 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
     t_k = e0.elapsed_time(e1) * 1e-3 / args.kernel_iters
     k_flop = 2.0 * B * Nn * D * (D if dolg else 3 * D)
     # fwd + bwd, no token gradient (DOLG: the 1x1 convolution and its weight gradient)
-    step_flop_img = 4.0 * Nn * D * D if dolg else 24.0 * Nn * D * D + 12.0 * Nn * Nn * D + 2.0 * Nn * D
+    # DINOv2 block: 24 D^2 FLOP per token forward in the four projections; backward 32 D^2 (weight and input gradients of
+    # qkv, proj and fc1 -- the fc2 ones collapse to per-image rows under the token mean, ep_dinovit.hip); attention 4 N^2 D
+    # forward and 8 N^2 D backward per image
+    step_flop_img = (4.0 * Nn * D * D if dolg else 56.0 * Nn * D * D + 12.0 * Nn * Nn * D if dino
+                     else 24.0 * Nn * D * D + 12.0 * Nn * Nn * D + 2.0 * Nn * D)
     if rank == 0:
         value = B * world * steps / elapsed
         out = {
-            "metric": ("DOLG-head" if dolg else "AbMILP-head") + " train images/sec", "value": round(value, 1), "unit": "images/s",
+            "metric": label + "-head train images/sec", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc.split(",")[0] + (f", DOLG spatial attention (1x1 conv, BatchNorm2d, softplus), {Cc} classes" if dolg
+                                                          else f", DINOv2 block (8-head self-attention + GELU MLP) and token mean, {Cc} classes" if dino
                                                           else f", AbMILP head (self-attention + tanh predictor), {Cc} classes"),
                        "tokens": Nn, "dim": D, "classes": Cc, "batch_per_gpu": B, "global_batch": B * world,
                        "optimizer": "lars", "parallelism": f"dp{world}"},
@@ -139,12 +146,13 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
             "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, steps), 5), "nonfinite_rows": bad},
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import torch_port, abmilp_oracle, dolg_oracle
+            from oracle import torch_port, abmilp_oracle, dinovit_oracle, dolg_oracle
+            mk = {"dolg": dolg_oracle, "dinovit": dinovit_oracle, "abmilp": abmilp_oracle}[args.head]
             r = torch_port.time_train_steps(8, Nn, D, 1, Cc, budget_s=args.cpu_seconds, threads=min(32, os.cpu_count() or 8),
-                                            make=(lambda: dolg_oracle.make_head(D, Cc)) if dolg else (lambda: abmilp_oracle.make_head(D, Cc)))
+                                            make=lambda: mk.make_head(D, Cc))
             out["cpu_baseline"] = {"value": round(r["value"], 2), "unit": "images/s", "cores": r["threads"], "kind": "port",
                                    "sample": f"{r['steps']} train steps of batch {r['batch']} ({r['seconds']:.1f} s), "
-                                             f"torch-CPU restatement of the reference {'DOLG' if dolg else 'AbMILP'} step"}
+                                             f"torch-CPU restatement of the reference {label} step"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -169,8 +177,8 @@ def main():
     torch.cuda.set_device(dev)
 
     Nn, D, Q, Cc, desc = WORKLOADS[args.workload]
-    B = args.batch or (256 if args.head in ("abmilp", "dolg") else 1024)
-    if args.head in ("abmilp", "dolg"):
+    B = args.batch or (256 if args.head in ("abmilp", "dolg", "dinovit") else 1024)
+    if args.head in ("abmilp", "dolg", "dinovit"):
         return bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B)
     if args.head == "coca":
         Q = 8                                              # 8 query heads of image query 0 (coca_pytorch.py:259)

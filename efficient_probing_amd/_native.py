@@ -280,6 +280,20 @@ class EPCbamStep(C.Structure):
     _fields_ = [("dims", EPCbamDims)] + list(EPAimStep._fields_[1:])
 
 
+class EPDinovitDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("hidden", C.c_int32), ("C", C.c_int32),
+                ("ln_eps", C.c_float)]
+
+
+class EPDinovitParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("n1_w", "n1_b", "qkv_w", "proj_w", "proj_b", "n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w",
+                                          "fc2_b")]
+
+
+class EPDinovitStep(C.Structure):
+    _fields_ = [("dims", EPDinovitDims)] + list(EPAbmilpStep._fields_[1:])
+
+
 # name -> (restype, argtypes); every symbol include/ep_hip.h declares
 SIGNATURES = {
     "ep_version": (c_int, []),
@@ -444,6 +458,17 @@ SIGNATURES = {
     "ep_cbam_head_train_step": (c_int, [C.POINTER(EPCbamStep), c_void, c_size, c_void]),
     "ep_cbam_head_eval_forward": (c_int, [C.POINTER(EPCbamDims), c_void, c_int, c_i64, c_void, c_f32p, c_float, c_f32p, c_f32p,
                                           c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_dinovit_pool_workspace_bytes": (c_size, [C.POINTER(EPDinovitDims)]),
+    "ep_dinovit_pool_forward": (c_int, [C.POINTER(EPDinovitDims), c_void, c_int, c_i64, C.POINTER(EPDinovitParams), c_f32p, c_void,
+                                        c_size, c_void]),
+    "ep_dinovit_pool_backward": (c_int, [C.POINTER(EPDinovitDims), c_void, c_int, c_i64, C.POINTER(EPDinovitParams), c_f32p,
+                                         C.POINTER(EPDinovitParams), c_int, c_void, c_size, c_void]),
+    "ep_dinovit_attention": (c_int, [C.POINTER(EPDinovitDims), c_void, c_f32p, c_void]),
+    "ep_dinovit_head_param_offsets": (c_i64, [C.POINTER(EPDinovitDims), C.POINTER(c_i64)]),
+    "ep_dinovit_head_workspace_bytes": (c_size, [C.POINTER(EPDinovitDims)]),
+    "ep_dinovit_head_train_step": (c_int, [C.POINTER(EPDinovitStep), c_void, c_size, c_void]),
+    "ep_dinovit_head_eval_forward": (c_int, [C.POINTER(EPDinovitDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p, c_float, c_f32p,
+                                             c_int, c_void, c_size, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
     "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,

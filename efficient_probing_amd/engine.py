@@ -362,6 +362,45 @@ class AbmilpHeadEngine(ProbeHeadEngine):
                                                     ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
 
+class DinovitHeadEngine(AbmilpHeadEngine):
+    """Fused train / eval step of Sequential(DinoViTBlockPooling, BatchNorm1d, Linear) through ``ep_dinovit_head_train_step``.
+    Matrix-core bound (one transformer block over every token: about 11.5 GFLOP per image per train step at 256 x 768); tokens
+    must be dense fp32."""
+
+    def _check_head(self, head):
+        from .probe_heads import is_native_dinovit_head
+        if not is_native_dinovit_head(head):
+            raise TypeError("DinovitHeadEngine needs Sequential(poolings.dinovit.DinoViTBlockPooling, BatchNorm1d, Linear)")
+
+    def _layout(self):
+        b = self.pool.dino_block
+        dims = F_.dinovit_dims(0, 0, b.norm1.normalized_shape[0], b.attn.num_heads, b.mlp.fc1.out_features, self.fc.out_features,
+                               b.norm1.eps)
+        offs = (C.c_int64 * 13)()
+        total = int(self.lib.ep_dinovit_head_param_offsets(C.byref(dims), offs))
+        return dims, list(self.pool._tensors()) + [self.fc.weight, self.fc.bias], list(offs), total
+
+    def _new_step(self):
+        return N.EPDinovitStep()
+
+    def _ws_bytes(self) -> int:
+        return self.lib.ep_dinovit_head_workspace_bytes(C.byref(self.dims))
+
+    def _tokens(self, x, image_index):
+        if image_index is not None:
+            raise NotImplementedError("dinovit: in-place indexed batches are not supported (gather the batch first)")
+        return F_._contiguous_tokens(x)
+
+    def _call_train(self, s, ws) -> int:
+        return self.lib.ep_dinovit_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+    def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
+        return self.lib.ep_dinovit_head_eval_forward(C.byref(self.dims), xv.data_ptr(), N.EP_DTYPE_F32, bstride,
+                                                     self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
+                                                     self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
+                                                     ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
+
+
 class SiglipHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(AttentionPoolLatent (SigLIP head), BatchNorm1d, Linear) through
     ``ep_siglip_head_train_step``: the EP token passes with derived queries + proj + residual MLP per image."""
@@ -835,9 +874,11 @@ def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
     from .probe_heads import is_native_cait_head, is_native_clip_head, is_native_dolg_head
     if is_native_dolg_head(head):
         return DolgHeadEngine(head, **kw)
-    from .probe_heads import is_native_cbam_head
+    from .probe_heads import is_native_cbam_head, is_native_dinovit_head
     if is_native_cbam_head(head):
         return CbamHeadEngine(head, **kw)
+    if is_native_dinovit_head(head):
+        return DinovitHeadEngine(head, **kw)
     if is_native_cait_head(head):
         return CaitHeadEngine(head, **kw)
     if is_native_clip_head(head):

@@ -1227,3 +1227,81 @@ class _CbamPool(torch.autograd.Function):
 
 def cbam_pool(x, rd, ks, training, eps, momentum, running_mean, running_var, nbt, *tens):
     return _CbamPool.apply(x, rd, ks, training, eps, momentum, running_mean, running_var, nbt, *tens)
+
+
+# --------------------------------------------------------------------------------------------
+# DINOv2-block pooling (reference poolings/other_pool.py:299-318 + dinov2_layers/block.py:43-113): matrix-core bound
+# --------------------------------------------------------------------------------------------
+DINOVIT_TENSORS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.proj.weight", "attn.proj.bias", "norm2.weight",
+                   "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+DINOVIT_LN_EPS = 1e-5
+
+
+def _dinovit_params_struct(ts):
+    return N.EPDinovitParams(*[t.data_ptr() for t in ts])
+
+
+def dinovit_dims(B, Nn, D, H, hidden, n_classes=0, eps=DINOVIT_LN_EPS):
+    return N.EPDinovitDims(B=B, N=Nn, D=D, H=H, hidden=hidden, C=n_classes, ln_eps=eps)
+
+
+def _dinovit_ws(lib, dims, device):
+    nbytes = lib.ep_dinovit_pool_workspace_bytes(C.byref(dims))
+    if nbytes == 0:
+        raise RuntimeError(f"ep_dinovit_pool_workspace_bytes: {N.last_error()}")
+    return torch.empty(nbytes, device=device, dtype=torch.uint8)
+
+
+class _DinovitPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, eps, *tens):
+        lib = N.load()
+        xv = _contiguous_tokens(x)
+        B, Nn, D = xv.shape
+        tens = [_f32c(t, n) for t, n in zip(tens, DINOVIT_TENSORS)]
+        dims = dinovit_dims(B, Nn, D, H, tens[7].shape[0], eps=eps)
+        ws = _dinovit_ws(lib, dims, xv.device)
+        out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+        N.check(lib.ep_dinovit_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, Nn * D, C.byref(_dinovit_params_struct(tens)),
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), N.current_stream_ptr(xv.device)),
+                "ep_dinovit_pool_forward")
+        ctx.save_for_backward(xv, ws, *tens)
+        ctx.dims = dims
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("DINOv2-block pooling (native): gradient w.r.t. the tokens is not implemented -- "
+                               "the probe trains on a frozen encoder (detach the tokens)")
+        lib = N.load()
+        xv, ws, *tens = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        grads = [torch.empty_like(t) for t in tens]
+        d = ctx.dims
+        N.check(lib.ep_dinovit_pool_backward(C.byref(d), xv.data_ptr(), N.EP_DTYPE_F32, d.N * d.D, C.byref(_dinovit_params_struct(tens)),
+                                             dout.data_ptr(), C.byref(_dinovit_params_struct(grads)), 0, ws.data_ptr(), ws.numel(),
+                                             N.current_stream_ptr(xv.device)), "ep_dinovit_pool_backward")
+        return (None, None, None, *grads)
+
+
+def dinovit_pool(x, H, eps, *tens):
+    """mean over the tokens of one DINOv2 block: (B, D)."""
+    return _DinovitPool.apply(x, H, eps, *tens)
+
+
+def dinovit_attention(x, H, eps, *tens):
+    """(pooled (B, D), attention weights (B, H, N, N)) of the block -- no autograd."""
+    lib = N.load()
+    xv = _contiguous_tokens(x)
+    B, Nn, D = xv.shape
+    tens = [_f32c(t.detach(), n) for t, n in zip(tens, DINOVIT_TENSORS)]
+    dims = dinovit_dims(B, Nn, D, H, tens[7].shape[0], eps=eps)
+    ws = _dinovit_ws(lib, dims, xv.device)
+    out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    st = N.current_stream_ptr(xv.device)
+    N.check(lib.ep_dinovit_pool_forward(C.byref(dims), xv.data_ptr(), N.EP_DTYPE_F32, Nn * D, C.byref(_dinovit_params_struct(tens)),
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), st), "ep_dinovit_pool_forward")
+    A = torch.empty((B, H, Nn, Nn), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_dinovit_attention(C.byref(dims), ws.data_ptr(), A.data_ptr(), st), "ep_dinovit_attention")
+    return out, A

@@ -15,10 +15,10 @@ Invariants kept from the reference (published numbers depend on them):
   * names without an entry (cls, gap, raw, both, ...) get BatchNorm + the encoder's head.
 
 Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae``, ``jepa``, ``aim``, ``simpool``, ``esimpool``, ``cait``,
-``clip``, ``dolg`` and ``cbam`` (pooling, BatchNorm1d and the classifier run in the HIP kernels of libep_hip.so).  The remaining name
-(``dinovit``) resolves to the reference's own PyTorch module when the
-reference repository is importable (``poolings.*`` on sys.path) or to a factory supplied with
-``register_pooling``; they then run as stock PyTorch-ROCm modules behind the native BatchNorm.
+``clip``, ``dolg``, ``cbam`` and ``dinovit`` -- all fourteen names (pooling, BatchNorm1d and the classifier run in the HIP kernels
+of libep_hip.so).  ``_reference_pooling(name)`` is a factory for the reference's own PyTorch module (needs the reference
+repository importable, ``poolings.*`` on sys.path) and ``register_pooling`` plugs in any other; such modules run as stock
+PyTorch-ROCm modules behind the native BatchNorm.
 """
 from __future__ import annotations
 
@@ -39,6 +39,7 @@ from .poolings.aim import AttentionPoolingClassifier
 from .poolings.simpool import SimPool, SimPool_nolinears
 from .poolings.cait import CAPooling
 from .poolings.clip import AttentionPool2d
+from .poolings.dinovit import DinoViTBlockPooling
 from .poolings.dolg import SpatialAttention2d
 from .poolings.cbam import CbamPooling
 from .util.cls_features import ATTENTIVE_POOLINGS, base_pooling_name
@@ -154,6 +155,7 @@ POOLINGS["clip"] = (lambda dim, args, model: AttentionPool2d(                   
     in_features=dim, feat_size=16 if getattr(args, "model", None) == "capi_vitl14_in1k" else 14), None)
 POOLINGS["dolg"] = (lambda dim, args, model: SpatialAttention2d(in_c=dim, s3_dim=dim, with_aspp=False), None)   # native (:82)
 POOLINGS["cbam"] = (lambda dim, args, model: CbamPooling(channels=dim, spatial_kernel_size=7), None)   # native (:77)
+POOLINGS["dinovit"] = (lambda dim, args, model: DinoViTBlockPooling(d_model=dim), None)          # native (:80)
 POOLINGS["aim"] = (lambda dim, args, model: AttentionPoolingClassifier(dim=dim, num_heads=args.num_heads), None)   # native (:73)
 
 
@@ -252,6 +254,12 @@ def is_native_cbam_head(head: nn.Module) -> bool:
             and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
 
 
+def is_native_dinovit_head(head: nn.Module) -> bool:
+    """True for Sequential(poolings.dinovit.DinoViTBlockPooling, BatchNorm1d, Linear) -- engine.DinovitHeadEngine."""
+    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], DinoViTBlockPooling)
+            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+
+
 def is_native_lp_head(head: nn.Module) -> bool:
     """True for Sequential(BatchNorm1d(affine=False), Linear): plain linear probing (build_probe_head for names
     without a pooling entry, reference probe_heads.py:96-99) -- engine.LinearProbeEngine."""
@@ -264,7 +272,7 @@ def is_native_head(head: nn.Module) -> bool:
             or is_native_siglip_head(head) or is_native_cae_head(head) or is_native_jepa_head(head)
             or is_native_aim_head(head) or is_native_simpool_head(head) or is_native_cait_head(head)
             or is_native_clip_head(head) or is_native_dolg_head(head) or is_native_cbam_head(head)
-            or is_native_lp_head(head))
+            or is_native_dinovit_head(head) or is_native_lp_head(head))
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

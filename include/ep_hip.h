@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 17
+#define EP_ABI_VERSION 18
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -969,6 +969,58 @@ int ep_cbam_head_eval_forward(const ep_cbam_dims* dims, const void* x, int x_dty
                               const float* tok_running_mean, const float* tok_running_var, const float* params,
                               const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
                               void* ws, size_t ws_bytes, ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DINOv2-block pooling (reference poolings/other_pool.py:299-318 DinoViTBlockPooling: one poolings/dinov2_layers/block.py:43
+ * Block -- LayerNorm(eps 1e-5) -> 8-head self-attention (attention.py:37, qkv without bias) -> residual -> LayerNorm ->
+ * GELU MLP x4 -> residual -- and the mean over the tokens; registry entry probe_heads.py:80):
+ *     x1 = x + proj(MHSA(norm1(x))) ; x2 = x1 + fc2(gelu(fc1(norm2(x1)))) ; out[b] = mean_n x2[b,n]
+ * Matrix-core bound (24 N D^2 + 4 N^2 D FLOP per image forward).  Eleven tensors: norm1.weight .bias | attn.qkv.weight
+ * (3D, D) | attn.proj.weight .bias | norm2.weight .bias | mlp.fc1.weight (hidden, D) .bias | mlp.fc2.weight (D, hidden)
+ * .bias.  The tokens must be a dense fp32 (B, N, D) tensor; D % H == 0 and D / H, hidden multiples of 4.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ep_dinovit_dims {
+  int32_t B, N, D, H, hidden, C;
+  float ln_eps;                                      /* 1e-5 (block.py:50 norm_layer = nn.LayerNorm) */
+} ep_dinovit_dims;
+
+typedef struct ep_dinovit_params {
+  float *n1_w, *n1_b, *qkv_w, *proj_w, *proj_b, *n2_w, *n2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} ep_dinovit_params;
+
+size_t ep_dinovit_pool_workspace_bytes(const ep_dinovit_dims* dims);
+int ep_dinovit_pool_forward(const ep_dinovit_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                            const ep_dinovit_params* params, float* out, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_dinovit_pool_backward(const ep_dinovit_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
+                             const ep_dinovit_params* params, const float* dout, const ep_dinovit_params* grads, int accumulate,
+                             void* ws, size_t ws_bytes, ep_stream_t stream);
+/* attention weights (B, H, N, N) of the last forward on this workspace (block.py:91 return_attention) */
+int ep_dinovit_attention(const ep_dinovit_dims* dims, const void* ws, float* A, ep_stream_t stream);
+
+typedef struct ep_dinovit_step {
+  ep_dinovit_dims dims;
+  const void* x; int32_t x_dtype; int64_t x_bstride;
+  const int64_t* targets;
+  float* params; float* grads; float* opt_state0; float* opt_state1;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* stats;
+  int32_t* found_inf; float* grad_norm;
+  float bn_eps, bn_momentum;
+  float grad_scale, inv_scale;
+  int32_t accumulate;
+  int32_t optimizer;
+  float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
+  int64_t opt_step;
+  int32_t phases;
+} ep_dinovit_step;
+
+/* flat layout: the eleven tensors above in that order | fc.weight | fc.bias */
+int64_t ep_dinovit_head_param_offsets(const ep_dinovit_dims* dims, int64_t offsets[13]);
+size_t ep_dinovit_head_workspace_bytes(const ep_dinovit_dims* dims);
+int ep_dinovit_head_train_step(const ep_dinovit_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
+int ep_dinovit_head_eval_forward(const ep_dinovit_dims* dims, const void* x, int x_dtype, int64_t x_bstride, const float* params,
+                                 const float* running_mean, const float* running_var, float bn_eps, float* logits, int ldl,
+                                 void* ws, size_t ws_bytes, ep_stream_t stream);
 
 #ifdef __cplusplus
 }

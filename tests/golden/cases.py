@@ -725,3 +725,56 @@ def make_cbam_inputs(case: CbamCase) -> Dict[str, np.ndarray]:
         targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
         targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
     )
+
+
+# --------------------------------------------------------------------------------------------
+# DINOv2-block pooling (reference poolings/other_pool.py:299-318 + dinov2_layers/block.py:43-113 behind probe_heads.py:80)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class DinovitCase:
+    name: str
+    B: int
+    N: int
+    D: int                        # 8 heads: D % 32 == 0
+    C: int
+    seed: int = 0
+    strided: bool = False
+    full: bool = True
+    steps: int = 3
+    weight_decay: float = 0.0
+    sharp: bool = False
+
+
+DINOVIT_CASES = [
+    DinovitCase("tiny", B=6, N=16, D=64, C=10, seed=0, weight_decay=1e-4),
+    DinovitCase("tiny_sharp_strided", B=5, N=25, D=128, C=7, seed=1, strided=True, sharp=True, steps=2),
+    DinovitCase("vitb16", B=4, N=196, D=768, C=1000, seed=0, full=False, steps=1),
+    DinovitCase("so400m", B=3, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),
+]
+DINOVIT_INIT_DIMS = [(768, 1000)]
+DINOVIT_PARAM_NAMES = ["n1_w", "n1_b", "qkv_w", "proj_w", "proj_b", "n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                       "fc_weight", "fc_bias"]
+DINOVIT_SMALL = ("n1_w", "n1_b", "proj_b", "n2_w", "n2_b", "fc1_b", "fc2_b", "fc_bias")
+DINOVIT_ATTN_ROWS = 37            # non-full cases keep attention rows [::37]
+
+
+def make_dinovit_inputs(case: DinovitCase) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(37000 + case.seed)
+    D, Hd = case.D, 4 * case.D
+    n_alloc = case.N + 1 if case.strided else case.N
+    u = lambda bound, shape: rng.uniform(-bound, bound, shape).astype(np.float32)
+    bd, bh, g = 1.0 / np.sqrt(D), 1.0 / np.sqrt(Hd), (3.0 if case.sharp else 1.0)
+    ln_w = lambda: (1.0 + 0.2 * rng.standard_normal((D,), dtype=np.float32)).astype(np.float32)
+    tok = lambda: (rng.standard_normal((case.B, n_alloc, D), dtype=np.float32)
+                   * (0.5 + 2.0 * rng.random((case.B, n_alloc, 1), dtype=np.float32))
+                   + 0.5 * rng.standard_normal((case.B, 1, D), dtype=np.float32)).astype(np.float32)
+    return dict(
+        x_buf=tok(), x_buf2=tok(),
+        n1_w=ln_w(), n1_b=u(0.3, (D,)),
+        qkv_w=(g * u(bd, (3 * D, D))).astype(np.float32), proj_w=u(bd, (D, D)), proj_b=u(bd, (D,)),
+        n2_w=ln_w(), n2_b=u(0.3, (D,)),
+        fc1_w=u(bd, (Hd, D)), fc1_b=u(bd, (Hd,)), fc2_w=u(bh, (D, Hd)), fc2_b=u(bh, (D,)),
+        fc_weight=u(bd, (case.C, D)), fc_bias=u(bd, (case.C,)),
+        targets=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+        targets2=rng.integers(0, case.C, size=(case.B,), dtype=np.int64),
+    )

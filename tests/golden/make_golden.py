@@ -36,6 +36,7 @@ from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_toke
                    JEPA_CASES, JEPA_INIT_DIMS, JEPA_PARAM_NAMES, JEPA_SMALL, make_jepa_inputs,
                    AIM_CASES, AIM_INIT_DIMS, AIM_PARAM_NAMES, AIM_SMALL, make_aim_inputs,
                    CBAM_CASES, CBAM_INIT_DIMS, CBAM_PARAM_NAMES, CBAM_SMALL, make_cbam_inputs,
+                   DINOVIT_CASES, DINOVIT_INIT_DIMS, DINOVIT_PARAM_NAMES, DINOVIT_SMALL, DINOVIT_ATTN_ROWS, make_dinovit_inputs,
                    DOLG_CASES, DOLG_INIT_DIMS, DOLG_PARAM_NAMES, DOLG_SMALL, make_dolg_inputs,
                    CLIP_CASES, CLIP_INIT_DIMS, CLIP_PARAM_NAMES, CLIP_SMALL, make_clip_inputs,
                    CAIT_CASES, CAIT_INIT_DIMS, CAIT_PARAM_NAMES, CAIT_SMALL, make_cait_inputs,
@@ -636,6 +637,79 @@ def dolg_init_fixture():
     return rec
 
 
+def dinovit_ref_params(head):
+    b = head[0].dino_block
+    return [b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.proj.weight, b.attn.proj.bias, b.norm2.weight, b.norm2.bias,
+            b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias, head[2].weight, head[2].bias]
+
+
+def run_dinovit_case(case):
+    """--cls_features dinovit: the REAL DinoViTBlockPooling (poolings/other_pool.py:299-318 around dinov2_layers/block.py:43-113)
+    behind BatchNorm1d + Linear."""
+    inp = make_dinovit_inputs(case)
+    out = {}
+    torch.manual_seed(0)
+    head = build_ref_head(case.D, 32, 1, case.C, cls_features="dinovit")
+    plist = dinovit_ref_params(head)
+    with torch.no_grad():
+        for n, p in zip(DINOVIT_PARAM_NAMES, plist):
+            p.copy_(torch.from_numpy(inp[n]))
+    head.train()
+    opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
+    crit = torch.nn.CrossEntropyLoss()
+    keep = (lambda a: a) if case.full else siglip_sub
+    view = lambda xb: torch.from_numpy(xb[:, 1:] if case.strided else xb)
+    for step in range(case.steps):
+        x = view(inp["x_buf"] if step % 2 == 0 else inp["x_buf2"])
+        t = torch.from_numpy(inp["targets"] if step % 2 == 0 else inp["targets2"])
+        for g in opt.param_groups:
+            g["lr"] = STEP_LRS[step % len(STEP_LRS)]
+        opt.zero_grad()
+        if step == 0:
+            with torch.no_grad():                                            # the block's own return_attention path (block.py:91-92)
+                _, att = head[0].dino_block(x, return_attention=True)
+            out["attn"] = att.numpy() if case.full else att.numpy()[:, :, ::DINOVIT_ATTN_ROWS]
+        pooled = head[0](x)
+        z = head[1](pooled)
+        logits = head[2](z)
+        loss = crit(logits, t)
+        loss.backward()
+        if step == 0:
+            a1, a5 = topk_acc(logits, t)
+            out.update(pooled=pooled.detach().numpy(), z=z.detach().numpy(), logits=logits.detach().numpy(),
+                       loss=np.float32(loss.item()), acc1=np.float32(a1), acc5=np.float32(a5))
+            for n, p in zip(DINOVIT_PARAM_NAMES, plist):
+                g = p.grad.detach().numpy()
+                out[f"grad_{n}"] = g if n in DINOVIT_SMALL else keep(g)
+                out[f"gradnorm_{n}"] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        tag = f"lars{step + 1}"
+        out[f"{tag}_loss"] = np.float32(loss.item())
+        for n, p in zip(DINOVIT_PARAM_NAMES, plist):
+            a = p.detach().numpy().copy()
+            out[f"{tag}_{n}"] = a if n in DINOVIT_SMALL else keep(a)
+            if "mu" in opt.state[p]:
+                mu_ = opt.state[p]["mu"].numpy().copy()
+                out[f"{tag}_mu_{n}"] = mu_ if n in DINOVIT_SMALL else keep(mu_)
+        out[f"{tag}_running_mean"] = head[1].running_mean.numpy().copy()
+        out[f"{tag}_running_var"] = head[1].running_var.numpy().copy()
+    head.eval()
+    with torch.no_grad():
+        out["eval_logits"] = head(view(inp["x_buf"])).numpy()
+    return out
+
+
+def dinovit_init_fixture():
+    rec = {}
+    for dim, C in DINOVIT_INIT_DIMS:
+        torch.manual_seed(0)
+        head = build_ref_head(dim, 32, 1, C, cls_features="dinovit")
+        sd = head.state_dict()
+        rec[f"d{dim}_c{C}"] = {"keys": {k: list(v.shape) for k, v in sd.items()}, "sha256": {k: sha(v) for k, v in sd.items()},
+                               "n_trainable": int(sum(p.numel() for p in head.parameters()))}
+    return rec
+
+
 def clip_ref_params(head):
     p = head[0]
     return [p.pos_embed, p.qkv.weight, p.qkv.bias, p.proj.weight, p.proj.bias, p.norm.weight, p.norm.bias, head[2].weight,
@@ -1170,7 +1244,8 @@ def main():
                             ("siglip", SIGLIP_CASES, run_siglip_case), ("abmilp", ABMILP_CASES, run_abmilp_case),
                             ("simpool", SIMPOOL_CASES, run_simpool_case), ("esimpool", ESIMPOOL_CASES, run_simpool_case),
                             ("cait", CAIT_CASES, run_cait_case), ("clip", CLIP_CASES, run_clip_case),
-                            ("dolg", DOLG_CASES, run_dolg_case), ("cbam", CBAM_CASES, run_cbam_case)):
+                            ("dolg", DOLG_CASES, run_dolg_case), ("cbam", CBAM_CASES, run_cbam_case),
+                            ("dinovit", DINOVIT_CASES, run_dinovit_case)):
         if want(fam):
             for case in cases:
                 dump(fam, case, run(case))
@@ -1186,7 +1261,8 @@ def main():
                          ("cae", "cae_init", cae_init_fixture), ("jepa", "jepa_init", jepa_init_fixture),
                          ("aim", "aim_init", aim_init_fixture), ("simpool", "simpool_init", simpool_init_fixture),
                          ("cait", "cait_init", cait_init_fixture), ("clip", "clip_init", clip_init_fixture),
-                         ("dolg", "dolg_init", dolg_init_fixture), ("cbam", "cbam_init", cbam_init_fixture)):
+                         ("dolg", "dolg_init", dolg_init_fixture), ("cbam", "cbam_init", cbam_init_fixture),
+                         ("dinovit", "dinovit_init", dinovit_init_fixture)):
         if want(fam):
             host[key] = fn()
     with open(hp, "w") as f:

@@ -107,11 +107,16 @@ def test_registry_surface():
     own = enc.head
     probe_heads.build_probe_head(enc, _args(cls_features="cls"))
     assert len(enc.head) == 2 and enc.head[1] is own
-    # a pooling without a native kernel and without the reference on sys.path fails loudly
+    # every registry name is native; the reference's own module stays available as an explicit factory and fails loudly
+    # when the reference repository is not on sys.path
+    assert all(probe_heads.POOLINGS[n][0] is not None for n in ATTENTIVE_POOLINGS)
     enc = StubEncoder(64, 10)
+    probe_heads.build_probe_head(enc, _args(cls_features="dinovit"))
+    assert probe_heads.is_native_dinovit_head(enc.head) and probe_heads.is_native_head(enc.head)
     with pytest.raises(NotImplementedError, match="register_pooling"):
-        probe_heads.build_probe_head(enc, _args(cls_features="dinovit"))
-    # ... and can be plugged in; it keeps the encoder's classifier
+        probe_heads._reference_pooling("dinovit")(64, _args(cls_features="dinovit"), enc)
+    # ... another implementation can be plugged in; it keeps the encoder's classifier
+    native = probe_heads.POOLINGS["dinovit"]
     probe_heads.register_pooling("dinovit", lambda dim, a, m: torch.nn.Identity())
     try:
         enc = StubEncoder(64, 10)
@@ -119,7 +124,7 @@ def test_registry_surface():
         probe_heads.build_probe_head(enc, _args(cls_features="dinovit"))
         assert isinstance(enc.head[0], torch.nn.Identity) and enc.head[2] is own
     finally:
-        probe_heads.POOLINGS["dinovit"] = (probe_heads._reference_pooling("dinovit"), None)
+        probe_heads.POOLINGS["dinovit"] = native
     with pytest.raises(KeyError):
         probe_heads.register_pooling("nonsense", lambda *a: None)
 
