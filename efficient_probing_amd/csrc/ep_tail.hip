@@ -88,6 +88,91 @@ __global__ __launch_bounds__(256) void ep_bn_apply_kernel(const float* __restric
   if (ok) for (int b = r0 + ty; b < r1; b += RL) z[(int64_t)b * Dp + col] = (y[(int64_t)b * Dp + col] - mu) * rs;
 }
 
+// Small batches (B <= 64 * BNF_RPT rows) in ONE launch: a workgroup of 1024 threads owns 16 columns and ALL rows -- 16 column
+// lanes x 64 row lanes, each thread's rows in registers -- so the statistics, the normalisation (or its backward) and the
+// running-statistics update need one read and one write of the (B, Dp) matrix and no partials.  Two-pass variance (mean, then
+// centred squares).  Cross-row reduction: the 4 rows of a wave by lane exchange, the 16 waves through LDS, summed by every
+// thread in the same fixed order.
+constexpr int BNF_RPT = 16;
+__device__ __forceinline__ float bnf_reduce(float v, float (*sm)[16], int tx, int wv) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  __syncthreads();                                  // the previous use of sm is over
+  if ((threadIdx.x & 63) < 16) sm[wv][tx] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += sm[i][tx];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void ep_bn_fused_kernel(const float* __restrict__ y, int B, int Dp, float eps, float momentum,
+                                                         float* __restrict__ z, float* __restrict__ rstd_out,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar,
+                                                         int64_t* __restrict__ nbt) {
+  __shared__ float sm[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 16 + tx;
+  const bool ok = col < Dp;
+  float v[BNF_RPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    const int b = ty + 64 * i;
+    v[i] = (ok && b < B) ? y[(int64_t)b * Dp + col] : 0.f;
+    s += v[i];
+  }
+  const float mu = bnf_reduce(s, sm, tx, wv) / (float)B;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    const float d = (ty + 64 * i < B) ? v[i] - mu : 0.f;
+    q = fmaf(d, d, q);
+  }
+  const float var = bnf_reduce(q, sm, tx, wv) / (float)B;                 // biased: used for normalisation
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (ty == 0 && ok) {
+    rstd_out[col] = rs;
+    const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+    rmean[col] = (1.0f - momentum) * rmean[col] + momentum * mu;
+    rvar[col] = (1.0f - momentum) * rvar[col] + momentum * unbiased;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    const int b = ty + 64 * i;
+    if (ok && b < B) z[(int64_t)b * Dp + col] = (v[i] - mu) * rs;
+  }
+}
+
+__global__ __launch_bounds__(1024) void ep_bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                             const float* __restrict__ rstd, int B, int Dp,
+                                                             float* __restrict__ dy) {
+  __shared__ float sm[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 16 + tx;
+  const bool ok = col < Dp;
+  float g[BNF_RPT], zz[BNF_RPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    const int b = ty + 64 * i;
+    const bool in = ok && b < B;
+    g[i] = in ? dz[(int64_t)b * Dp + col] : 0.f;
+    zz[i] = in ? z[(int64_t)b * Dp + col] : 0.f;
+    s1 += g[i];
+    s2 = fmaf(g[i], zz[i], s2);
+  }
+  const float m1 = bnf_reduce(s1, sm, tx, wv) / (float)B;
+  const float m2 = bnf_reduce(s2, sm, tx, wv) / (float)B;
+  const float rs = ok ? rstd[col] : 0.f;
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    const int b = ty + 64 * i;
+    if (ok && b < B) dy[(int64_t)b * Dp + col] = rs * (g[i] - m1 - zz[i] * m2);
+  }
+}
+
 __global__ void ep_bn_eval_kernel(const float* __restrict__ y, int64_t total, int Dp, float eps,
                                   const float* __restrict__ rmean, const float* __restrict__ rvar,
                                   float* __restrict__ z) {
@@ -267,10 +352,22 @@ static int bn_row_splits(int B) {
   if (rs > RS_MAX) rs = RS_MAX;
   return rs;
 }
+// one-launch kernels for batches whose rows fit the registers of one workgroup (EP_BN_FUSED=0: the two-launch path)
+static bool bn_fused(int B) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_BN_FUSED"); on = e ? atoi(e) : 1; }
+  return on && B <= 64 * BNF_RPT;
+}
 size_t bn_workspace_bytes(int B, int Dp) { (void)B; return round_up((size_t)RS_MAX * 2 * Dp * sizeof(float), 256); }
 
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
                      float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st) {
+  if (bn_fused(B)) {
+    hipLaunchKernelGGL(ep_bn_fused_kernel, dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean, rvar,
+                       nbt);
+    EP_LAUNCH_CHECK("ep_bn_fused_kernel");
+    return 0;
+  }
   const dim3 grid((Dp + CG - 1) / CG, bn_row_splits(B));
   hipLaunchKernelGGL(ep_bn_stats_kernel, grid, dim3(256), 0, st, y, B, Dp, partial);
   hipLaunchKernelGGL(ep_bn_apply_kernel, grid, dim3(256), 0, st, y, B, Dp, eps, momentum, partial, z, rstd, rmean,
@@ -288,6 +385,11 @@ int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean
 }
 int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, float* partial,
                 hipStream_t st) {
+  if (bn_fused(B)) {
+    hipLaunchKernelGGL(ep_bn_bwd_fused_kernel, dim3((Dp + 15) / 16), dim3(1024), 0, st, dz, z, rstd, B, Dp, dy);
+    EP_LAUNCH_CHECK("ep_bn_bwd_fused_kernel");
+    return 0;
+  }
   const dim3 grid((Dp + CG - 1) / CG, bn_row_splits(B));
   hipLaunchKernelGGL(ep_bn_bwd_stats_kernel, grid, dim3(256), 0, st, dz, z, B, Dp, partial);
   hipLaunchKernelGGL(ep_bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, z, rstd, B, Dp, partial, dy);

@@ -70,12 +70,17 @@ def f64_reference(case, inp):
     return rec
 
 
-def close_to_truth(name, got, gold, truth, rtol=2e-4, floor=3e-5):
+# d loss / d mlp.fc2.bias = sum_b dout[b] is exactly zero in exact arithmetic (dout comes out of the BatchNorm1d backward, whose
+# columns sum to zero): rounding noise of the size of one ulp of the summands on both sides
+NOISE = {"fc2_b": 1e-6}
+
+
+def close_to_truth(name, got, gold, truth, rtol=2e-4, floor=3e-5, abs_floor=1e-7):
     """`got` (the HIP path) must be as close to the float64 truth as the real reference's own fp32 result `gold` is (x4), or
     within the usual fp32 floor."""
     scale = max(float(np.abs(truth).max()), 1e-12)
     ref_noise = float(np.abs(gold - truth).max())
-    np.testing.assert_allclose(got, truth, rtol=rtol, atol=max(4.0 * ref_noise, floor * scale, 1e-7), err_msg=name)
+    np.testing.assert_allclose(got, truth, rtol=rtol, atol=max(4.0 * ref_noise, floor * scale, abs_floor), err_msg=name)
 
 
 @pytest.mark.parametrize("case", DINOVIT_CASES, ids=lambda c: c.name)
@@ -101,7 +106,8 @@ def test_module_forward_backward_vs_reference(case):
     for n, p, tr in zip(DINOVIT_PARAM_NAMES, plist, truth):
         gr = p.grad.cpu().numpy()
         small = n in DINOVIT_SMALL
-        close_to_truth(n, gr if small else keep(gr), g[f"grad_{n}"], (tr if small else keep(tr)).astype(np.float64).reshape(g[f"grad_{n}"].shape))
+        close_to_truth(n, gr if small else keep(gr), g[f"grad_{n}"], (tr if small else keep(tr)).astype(np.float64).reshape(g[f"grad_{n}"].shape),
+                       abs_floor=NOISE.get(n, 1e-7))
 
 
 @pytest.mark.parametrize("case", DINOVIT_CASES, ids=lambda c: c.name)
