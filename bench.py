@@ -283,12 +283,17 @@ def main():
 
     imgq = args.head in ("simpool", "esimpool")            # per-image-query passes (csrc/ep_pool_imgq.hip)
     cbam = args.head == "cbam"                             # its own streaming passes (csrc/ep_cbam.hip)
-    if cbam:
+    rowq = args.head == "clip"                             # full-width per-image query rows (ep_imgqf_kernel)
+    if rowq:
+        cls, scale = torch.randn(B, Q, D, device=dev) * 0.05, 1.0
+        tstat = F_.token_stats(xs[0] if args.tokens == "f32" else xs[0].float(), 1e-6)
+        sbias = torch.randn(B, Q, Nn, device=dev) * 0.1
+    elif cbam:
         cls, scale = None, 1.0
     elif imgq:
         cls, scale = torch.randn(B, D, device=dev) * 0.05, 1.0
         tstat = F_.token_stats(xs[0] if args.tokens == "f32" else xs[0].float(), 1e-6)
-    elif args.head in ("coca", "siglip", "cae", "jepa", "aim", "cait", "clip"):   # the same kernel, fed with the H derived query rows
+    elif args.head in ("coca", "siglip", "cae", "jepa", "aim", "cait"):   # the same kernel, fed with the H derived query rows
         cls, scale = torch.randn(Q, D, device=dev) * 0.05, 1.0
     else:
         cls, scale = head[0].cls_token.detach(), head[0].scale
@@ -298,7 +303,9 @@ def main():
         if cbam:
             keep["out"] = F_.cbam_channel_table(xs[i % args.buffers])
             return
-        if imgq:
+        if rowq:
+            keep["out"] = F_.rowq_pool_forward(xs[i % args.buffers], cls, tstat, sbias)
+        elif imgq:
             keep["out"] = F_.imgq_pool_forward(xs[i % args.buffers], cls, Q, tstat, args.head == "simpool")
         else:
             keep["out"] = F_.pool_forward(xs[i % args.buffers], cls, scale)
@@ -323,6 +330,9 @@ def main():
         if cbam:
             F_.cbam_channel_table(x)
             return
+        if rowq:
+            F_.rowq_pool_backward(x, S, ML, dP, tstat, sbias, True)
+            return
         if imgq:
             F_.imgq_pool_backward(x, cls, Q, P, ML, dP, tstat, args.head == "simpool")
             return
@@ -332,8 +342,8 @@ def main():
 
     algo_bytes = B * Nn * D * esize                           # one streaming read of the stored tokens
     dt = 1 if args.tokens == "bf16" else 0
-    kname_f = "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (forward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
-    kname_b = "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
+    kname_f = "ep_imgqf_kernel (forward)" if rowq else "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (forward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
+    kname_b = "ep_imgqf_kernel (backward)" if rowq else "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic = None

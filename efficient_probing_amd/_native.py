@@ -469,6 +469,10 @@ SIGNATURES = {
     "ep_dinovit_head_train_step": (c_int, [C.POINTER(EPDinovitStep), c_void, c_size, c_void]),
     "ep_dinovit_head_eval_forward": (c_int, [C.POINTER(EPDinovitDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p, c_float, c_f32p,
                                              c_int, c_void, c_size, c_void]),
+    "ep_rowq_pool_forward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                     c_f32p, c_void]),
+    "ep_rowq_pool_backward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                      c_f32p, c_f32p, c_void]),
     "ep_channel_stats": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_aim_pool_workspace_bytes": (c_size, [C.POINTER(EPAimDims)]),
     "ep_aim_pool_forward": (c_int, [C.POINTER(EPAimDims), c_void, c_int, c_i64, c_void, c_f32p, c_int, c_float, c_float, c_f32p,

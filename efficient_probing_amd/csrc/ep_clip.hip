@@ -10,8 +10,9 @@
 // i.e. a token pass with per-image query rows u = g * w on the normalised tokens, an additive score bias w . pos_n (one
 // small contraction), the mean row as one extra softmax entry (merged after the pass, as in the CaiT head), and the
 // position-embedding part of the values as A . pos (another small contraction on the explicit attention weights).
-// The pass runs on the generic token-pass kernels (per-image rows + score bias + explicit dS): every head re-reads the
-// image from L2 / Infinity Cache, which is the price of this head's full-width per-image queries for now.
+// The passes run on ep_imgqf_kernel (ep_pool_imgq.hip): full-width per-image rows + score bias + explicit dS with every
+// token read once for all heads; the generic token-pass kernels implement the same contract (one read per head) and are
+// what the tests compare it with (ep_debug_force_generic_pool).
 #include "ep_side.h"
 #include "ep_headkernels.h"
 
@@ -88,19 +89,24 @@ __global__ void ep_clip_vin_kernel(const float* __restrict__ Ph, const float* __
   vin[i] = fmaf(g[d], pp, fmaf(a0, pos0[d], Apos[i]) + beta[d]);
 }
 
-// column reductions over `rows` rows of width D (16 columns per workgroup, fixed order):
+// column reductions over `rows` rows of width D (16 columns per workgroup; the rows split over gridDim.y chunks, fixed order):
 //   o1[d] (+)= sum_r a[r,d] * (b ? b[brow(r),d] : 1) ;  o2[d] (+)= sum_r a[r,d] * wgt[r]   (o2 / wgt optional)
-// brow(r) = r / bdiv (bdiv = H when b is a per-image table, 1 when it has one row per r)
+// brow(r) = r / bdiv (bdiv = H when b is a per-image table, 1 when it has one row per r).  With gridDim.y > 1 the chunk sums
+// go to part[0 | 1][chunk][D] and clip_colred() finishes with ep_reduce_partials_kernel.
+constexpr int CLIP_RS = 32;
 __global__ __launch_bounds__(256) void ep_clip_colred_kernel(const float* __restrict__ a, const float* __restrict__ bm, int bdiv,
                                                            const float* __restrict__ wgt, int wstride, int rows, int D,
-                                                           int acc1, float* __restrict__ o1, int acc2, float* __restrict__ o2) {
+                                                           int acc1, float* __restrict__ o1, int acc2, float* __restrict__ o2,
+                                                           float* __restrict__ part) {
   __shared__ float sm[RL][CG];
   const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
   const int c = blockIdx.x * CG + tx;
   const bool ok = c < D;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
   float s1 = 0.f, s2 = 0.f;
   if (ok)
-    for (int r = ty; r < rows; r += RL) {
+    for (int r = r0 + ty; r < r1; r += RL) {
       const float v = a[(int64_t)r * D + c];
       s1 = bm ? fmaf(v, bm[(int64_t)(r / bdiv) * D + c], s1) : s1 + v;
       if (wgt) s2 = fmaf(v, wgt[(int64_t)r * wstride], s2);
@@ -108,9 +114,28 @@ __global__ __launch_bounds__(256) void ep_clip_colred_kernel(const float* __rest
   s1 = colreduce(s1, sm, tx, ty);
   s2 = colreduce(s2, sm, tx, ty);
   if (ty == 0 && ok) {
-    if (o1) o1[c] = acc1 ? o1[c] + s1 : s1;
-    if (o2) o2[c] = acc2 ? o2[c] + s2 : s2;
+    if (gridDim.y > 1) {
+      part[(int64_t)blockIdx.y * D + c] = s1;
+      part[((int64_t)gridDim.y + blockIdx.y) * D + c] = s2;
+    } else {
+      if (o1) o1[c] = acc1 ? o1[c] + s1 : s1;
+      if (o2) o2[c] = acc2 ? o2[c] + s2 : s2;
+    }
   }
+}
+
+static int clip_colred(const float* a, const float* bm, int bdiv, const float* wgt, int wstride, int rows, int D, int acc1, float* o1,
+                       int acc2, float* o2, float* part, hipStream_t st) {
+  int rs = rows / 128;
+  rs = rs < 1 ? 1 : (rs > CLIP_RS ? CLIP_RS : rs);
+  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3((D + CG - 1) / CG, rs), dim3(256), 0, st, a, bm, bdiv, wgt, wstride, rows, D, acc1, o1,
+                     acc2, o2, part);
+  EP_LAUNCH_CHECK("ep_clip_colred_kernel");
+  if (rs > 1) {
+    if (o1) EP_TRY(reduce_partials(part, rs, D, 1.0f, acc1, o1, nullptr, st));
+    if (o2) EP_TRY(reduce_partials(part + (size_t)rs * D, rs, D, 1.0f, acc2, o2, nullptr, st));
+  }
+  return 0;
 }
 
 // dPpr = dvin * g        (element-wise over (B*H, D))
@@ -165,7 +190,7 @@ __global__ void ep_clip_dw_kernel(float* __restrict__ du, const float* __restric
 constexpr int CLIP_NT = 9;    // pos_embed | qkv.weight qkv.bias | proj.weight proj.bias | norm.weight norm.bias | fc.weight fc.bias
 struct ClipWs {
   float *tstat, *xbar, *t0, *q0, *w, *u, *sb, *s0, *P, *S, *ML, *ML2, *mix, *A, *Apos, *Ppr, *vin, *o;
-  float *dO, *dvin, *dPpr, *dAp, *dS, *ds0, *du, *dwp, *dw, *dq0, *dt0;
+  float *dO, *dvin, *dPpr, *dAp, *dS, *ds0, *du, *dwp, *dw, *dq0, *dt0, *cpart;
   void* pool_ws; size_t pool_ws_bytes;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
@@ -201,7 +226,7 @@ static ClipWs clip_carve(const ep_clip_dims& d, void* base, bool head) {
   w.A = take(B * H * N); w.Apos = take(B * H * D); w.Ppr = take(B * H * D); w.vin = take(B * H * D); w.o = take(B * D);
   w.dO = take(B * D); w.dvin = take(B * H * D); w.dPpr = take(B * H * D); w.dAp = take(B * H * N); w.dS = take(B * H * N);
   w.ds0 = take(B * H); w.du = take(B * H * D); w.dwp = take(B * H * D); w.dw = take(B * H * D); w.dq0 = take(B * D);
-  w.dt0 = take(B * D);
+  w.dt0 = take(B * D); w.cpart = take((size_t)2 * CLIP_RS * D);
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
     w.y = take(B * D); w.z = take(B * D); w.rstd = take(D);
@@ -330,10 +355,10 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
     EP_TRY(gemm(true, false, g, H, st));
   }
   // vin = g * Ppr + Apos + a0 pos_0 + b :  d g = sum dvin Ppr ; d b = sum dvin ; d pos_0 = sum a0 dvin ; dPpr = dvin g
-  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3(cgrid), dim3(256), 0, st, w.dvin, w.Ppr, 1, (const float*)nullptr, 0, BH, D, acc,
-                     gr.norm_w, 0, (float*)nullptr);
-  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3(cgrid), dim3(256), 0, st, w.dvin, (const float*)nullptr, 1, w.mix + 1, 2, BH, D, acc,
-                     gr.norm_b, acc, dpos0);
+  EP_TRY(clip_colred(w.dvin, w.Ppr, 1, (const float*)nullptr, 0, BH, D, acc,
+                     gr.norm_w, 0, (float*)nullptr, w.cpart, st));
+  EP_TRY(clip_colred(w.dvin, (const float*)nullptr, 1, w.mix + 1, 2, BH, D, acc,
+                     gr.norm_b, acc, dpos0, w.cpart, st));
   hipLaunchKernelGGL(ep_clip_dppr_kernel, dim3(eh), dim3(256), 0, st, w.dvin, pr.norm_w, nhd, D, w.dPpr);
   EP_LAUNCH_CHECK("ep_clip value backward kernels");
   // Apos = A pos[1:] :  d pos[1:] = A^T dvin ; dAp = dvin pos[1:]^T
@@ -349,10 +374,10 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   // dw = g * (du0 + dS_0 xbar) + dS pos[1:] + dS_0 pos_0 ;  d g += sum du w ;  d pos[1:] += dS^T w ; d pos_0 += sum dS_0 w
   { GemmParams g = kg(w.dS, N, posN, D, w.dwp, D, BH, D, N); g.extB = D; EP_TRY(gemm(true, false, g, 1, st)); }
   hipLaunchKernelGGL(ep_clip_dw_kernel, dim3(eh), dim3(256), 0, st, w.du, w.dwp, w.ds0, w.xbar, pr.norm_w, pos0, nhd, D, H, w.dw);
-  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3(cgrid), dim3(256), 0, st, w.du, w.w, 1, (const float*)nullptr, 0, BH, D, 1,
-                     gr.norm_w, 0, (float*)nullptr);
-  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3(cgrid), dim3(256), 0, st, w.w, (const float*)nullptr, 1, w.ds0, 1, BH, D, 0,
-                     (float*)nullptr, 1, dpos0);
+  EP_TRY(clip_colred(w.du, w.w, 1, (const float*)nullptr, 0, BH, D, 1,
+                     gr.norm_w, 0, (float*)nullptr, w.cpart, st));
+  EP_TRY(clip_colred(w.w, (const float*)nullptr, 1, w.ds0, 1, BH, D, 0,
+                     (float*)nullptr, 1, dpos0, w.cpart, st));
   EP_LAUNCH_CHECK("ep_clip key backward kernels");
   { GemmParams g = kg(w.dS, N, w.w, D, dposN, D, N, D, BH); g.accumulate = 1; EP_TRY(gemm(false, false, g, 1, st)); }
   // w_h = scale q0_h Wk_h :  dq0_h = scale dw_h Wk_h^T ; dWk_h = scale q0_h^T dw_h ; d bk = 0
@@ -371,10 +396,10 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   EP_TRY(colsum(w.dq0, B, D, D, acc, gr.qkv_b, st));
   { GemmParams g = kg(w.dq0, D, w.t0, D, dWq, D, D, D, B); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }
   EP_TRY(gemm(true, false, kg(w.dq0, D, Wq, D, w.dt0, D, B, D, D), 1, st));                                          // dt0 = dq0 Wq
-  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3(cgrid), dim3(256), 0, st, w.dt0, w.xbar, 1, (const float*)nullptr, 0, B, D, 1,
-                     gr.norm_w, 0, (float*)nullptr);
-  hipLaunchKernelGGL(ep_clip_colred_kernel, dim3(cgrid), dim3(256), 0, st, w.dt0, (const float*)nullptr, 1, (const float*)nullptr, 0,
-                     B, D, 1, gr.norm_b, 0, (float*)nullptr);
+  EP_TRY(clip_colred(w.dt0, w.xbar, 1, (const float*)nullptr, 0, B, D, 1,
+                     gr.norm_w, 0, (float*)nullptr, w.cpart, st));
+  EP_TRY(clip_colred(w.dt0, (const float*)nullptr, 1, (const float*)nullptr, 0,
+                     B, D, 1, gr.norm_b, 0, (float*)nullptr, w.cpart, st));
   EP_TRY(colsum(w.dt0, B, D, D, 1, dpos0, st));
   EP_LAUNCH_CHECK("ep_clip query backward kernels");
   return 0;

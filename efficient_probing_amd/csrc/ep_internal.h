@@ -21,7 +21,8 @@ struct PoolParams {
   const float* tokstat;  // optional (M or B, N, 2) per-token {mean, rstd} of a LayerNorm over D (indexed like x): the
                          // pass then pools the NORMALISED tokens xhat = (x - mean) * rstd without materialising them:
                          // scores q.xhat, pooled sum_n A xhat; backward accumulates sum dS xhat
-  // per-(image, query, token) extras, honoured by the generic kernels only (setting any of them selects those):
+  // per-(image, query, token) extras, honoured by the generic kernels and the full-width per-image-query kernel
+  // (ep_pool_imgq.hip) only (setting any of them selects those):
   const float* sbias;    // fwd: added to the score before the softmax (the stored S includes it)   (B,Q,N)
   const float* dabias;   // bwd: added to dA = dP . v_n                                               (B,Q,N)
   float* dSout;          // bwd: the score gradients dS                                               (B,Q,N)

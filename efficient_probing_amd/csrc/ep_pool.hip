@@ -21,6 +21,7 @@
 #include "ep_common.h"
 #include "ep_internal.h"
 #include "ep_pool_stream.h"
+#include "ep_pool_imgq.h"
 
 namespace ep {
 
@@ -327,6 +328,8 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
+  // per-image query rows with score extras (CLIP): every token read once for all heads instead of once per head
+  if (needs_generic(p) && !force_generic() && imgqf_supported(p)) return imgqf_forward(p, st);
   if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B, p.x_bf16), st);
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
@@ -387,6 +390,7 @@ __global__ void ep_scale_copy_kernel(const float* __restrict__ src, int64_t n, f
 }
 int pool_backward_per_image(const PoolParams& p0, float* dq, hipStream_t st) {
   PoolParams p = p0;
+  if (!force_generic() && imgqf_supported(p)) return imgqf_backward(p, dq, st);
   p.Gpart = dq;
   const size_t lds = (size_t)(p.N + 8) * sizeof(float);
   if (p.x_bf16) hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);

@@ -41,4 +41,9 @@ bool imgq_supported(int D, int H);
 int imgq_forward(const ImgqParams& p, hipStream_t st);
 int imgq_backward(const ImgqParams& p, hipStream_t st);
 
+// full-width per-image query rows on the PoolParams contract of the generic kernels (CLIP): see ep_pool_imgq.hip
+bool imgqf_supported(const PoolParams& p);
+int imgqf_forward(const PoolParams& p, hipStream_t st);
+int imgqf_backward(const PoolParams& p, float* dq, hipStream_t st);
+
 }  // namespace ep

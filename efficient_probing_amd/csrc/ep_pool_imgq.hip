@@ -240,4 +240,247 @@ bool imgq_supported(int D, int H) { return iq_plan(D, H).ok; }
 int imgq_forward(const ImgqParams& p, hipStream_t st) { return iq_dispatch(p, false, st); }
 int imgq_backward(const ImgqParams& p, hipStream_t st) { return iq_dispatch(p, true, st); }
 
+// =============================================================================================
+// FULL-WIDTH per-image query rows (CLIP attention pooling: the query is the image's own mean row, H = 4 heads that each
+// score and pool the WHOLE token row): PoolParams semantics of the generic kernels -- per-image rows p.cls (+ cls_bstride),
+// optional LayerNorm-of-tokens mode, additive score bias, explicit scores S; backward with the stored scores, an additive
+// dA term, explicit dS and PER-IMAGE query gradients -- but every token is read from HBM once for all heads.
+// One 4-wave workgroup per image; a wave walks its tokens TB at a time, a lane owns CPL 16-byte chunks of the row for ALL
+// heads (registers: HQ x CPL query / dP chunks and as many accumulators), a score is a lane-local dot product plus one
+// full-wave reduction.  The four waves are merged through LDS head by head at the end of the image (fixed order).
+// =============================================================================================
+constexpr int IQF_NW = 4;
+
+template <int CPL, int HQ, int TB, bool BF16, bool BWD>
+__global__ __launch_bounds__(IQF_NW * 64) void ep_imgqf_kernel(PoolParams p, float* __restrict__ dq) {
+  constexpr int REC = 4 + 4 * CPL;
+  __shared__ __attribute__((aligned(16))) float rec_lds[IQF_NW * 64 * REC];
+  const int b = blockIdx.x;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int D = p.D, N = p.N, Q = p.Q;
+  int ch[CPL];
+  bool cv[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    cv[j] = c < D;
+    ch[j] = cv[j] ? c : 0;
+  }
+  const int64_t img = (int64_t)(p.index ? p.index[b] : b);
+  const void* xb = BF16 ? static_cast<const void*>(reinterpret_cast<const uint16_t*>(p.x) + img * p.x_bstride)
+                        : static_cast<const void*>(p.x + img * p.x_bstride);
+  const float* ts = p.tokstat ? p.tokstat + img * N * 2 : nullptr;
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+  f4 qv[HQ][CPL], acc[HQ][CPL];                      // forward: scaled query rows; backward: dP rows
+  float qsum[HQ], m[HQ], l[HQ], cacc[HQ], delta[HQ];
+#pragma unroll
+  for (int h = 0; h < HQ; ++h) {
+    const bool hv = h < Q;
+    const float* row = BWD ? p.dP + ((int64_t)b * Q + (hv ? h : 0)) * D
+                           : p.cls + (int64_t)b * p.cls_bstride + (int64_t)(hv ? h : 0) * D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      f4 v = (hv && cv[j]) ? *reinterpret_cast<const f4*>(row + ch[j]) : z4;
+      if (!BWD) v = v * p.scale;
+      qv[h][j] = v;
+      acc[h][j] = z4;
+      s += sum4(v);
+    }
+    qsum[h] = wave_sum(s);
+    cacc[h] = 0.f;
+    if (BWD) {
+      const float* ml = p.ML + ((int64_t)b * Q + (hv ? h : 0)) * 4;
+      m[h] = ml[0]; l[h] = 1.0f / ml[1]; delta[h] = ml[2];
+    } else {
+      m[h] = -INFINITY; l[h] = 0.f; delta[h] = 0.f;
+    }
+  }
+
+  // Per-iteration scalars ride in lanes: lane i < HQ*TB owns (head i / TB, token i % TB) of the iteration -- its score bias
+  // (forward) or stored score and dA term (backward), and the score / dS it writes back; lane i < 2*TB owns the i-th float of
+  // the iteration's {mean, rstd} pairs.  v_readlane hands them to the whole wave.
+  const int eh = lane / TB, et = lane % TB;
+  const bool elane = eh < HQ && eh < Q;
+  const int64_t erow = ((int64_t)b * Q + (elane ? eh : 0)) * N;
+  auto rl = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
+  auto load = [&](int n0, f4 (&xv)[TB][CPL], float& tsv, float& e0, float& e1) {
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const int n = (n0 + t) < N ? (n0 + t) : N - 1;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) xv[t][j] = cv[j] ? load_tok4<BF16>(xb, (int64_t)n * D + ch[j]) : z4;
+    }
+    {
+      int e = 2 * n0 + lane; e = e < 2 * N ? e : 2 * N - 1;
+      tsv = (ts && lane < 2 * TB) ? ts[e] : ((lane & 1) ? 1.f : 0.f);
+    }
+    const bool ev = elane && (n0 + et) < N;
+    const int64_t ei = erow + (ev ? n0 + et : 0);
+    if (!BWD) { e0 = (ev && p.sbias) ? p.sbias[ei] : 0.f; e1 = 0.f; }
+    else { e0 = ev ? p.S[ei] : 0.f; e1 = (ev && p.dabias) ? p.dabias[ei] : 0.f; }
+  };
+  auto compute = [&](int n0, const f4 (&xv)[TB][CPL], float tsv, float e0, float e1) {
+    float mean[TB], rstd[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) { mean[t] = rl(tsv, 2 * t); rstd[t] = rl(tsv, 2 * t + 1); }
+    float outv = 0.f;                                  // this lane's score / dS of the iteration
+#pragma unroll
+    for (int h = 0; h < HQ; ++h) {
+      if (h >= Q) continue;
+      float s[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) d += dot4(qv[h][j], xv[t][j]);
+        d = wave_sum(d);
+        s[t] = rstd[t] * (d - mean[t] * qsum[h]);      // (mean 0, rstd 1 without token statistics)
+      }
+      if constexpr (!BWD) {
+        float bm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          s[t] += rl(e0, h * TB + t);
+          outv = lane == h * TB + t ? s[t] : outv;
+          if (n0 + t >= N) s[t] = -INFINITY;
+          bm = fmaxf(bm, s[t]);
+        }
+        const float mn = fmaxf(m[h], bm);               // finite: token n0 is valid
+        const float corr = __builtin_amdgcn_exp2f((m[h] - mn) * IQ_LOG2E);   // m = -inf -> 0
+        l[h] *= corr; cacc[h] *= corr;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[h][j] *= corr;
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const float pt = __builtin_amdgcn_exp2f((s[t] - mn) * IQ_LOG2E);
+          l[h] += pt;
+          const float wt = pt * rstd[t];
+          cacc[h] = fmaf(wt, mean[t], cacc[h]);
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[h][j] += wt * xv[t][j];
+        }
+        m[h] = mn;
+      } else {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const float dA = s[t] + rl(e1, h * TB + t);  // dP . v_n (v = xhat or x) + the additive term
+          const float a = __builtin_amdgcn_exp2f((rl(e0, h * TB + t) - m[h]) * IQ_LOG2E) * l[h];
+          const float dS = (n0 + t < N) ? a * (dA - delta[h]) : 0.f;
+          outv = lane == h * TB + t ? dS : outv;
+          const float wt = dS * rstd[t];
+          cacc[h] = fmaf(wt, mean[t], cacc[h]);
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[h][j] += wt * xv[t][j];
+        }
+      }
+    }
+    float* dst = BWD ? p.dSout : p.S;
+    if (dst && elane && (n0 + et) < N) dst[erow + n0 + et] = outv;
+  };
+  // two register sets: the loads of the next iteration are in flight while this one is computed
+  {
+    constexpr int STEP = IQF_NW * TB;
+    f4 xa[TB][CPL], xc[TB][CPL];
+    float ta = 0.f, tc = 0.f, a0 = 0.f, a1 = 0.f, c0 = 0.f, c1 = 0.f;
+    int n0 = w * TB;
+    if (n0 < N) load(n0, xa, ta, a0, a1);
+    while (n0 < N) {
+      const int n1 = n0 + STEP;
+      if (n1 < N) load(n1, xc, tc, c0, c1);
+      compute(n0, xa, ta, a0, a1);
+      if (n1 >= N) break;
+      const int n2 = n1 + STEP;
+      if (n2 < N) load(n2, xa, ta, a0, a1);
+      compute(n1, xc, tc, c0, c1);
+      n0 = n2;
+    }
+  }
+
+  // ---- merge the waves head by head (wave h % NW ends up with head h) and store ----
+#pragma unroll
+  for (int h = 0; h < HQ; ++h) {
+    if (h >= Q) continue;
+    float* rec = rec_lds + ((size_t)w * 64 + lane) * REC;
+    __syncthreads();                                   // the previous head's records have been consumed
+    rec[0] = m[h]; rec[1] = l[h]; rec[2] = cacc[h];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) *reinterpret_cast<f4*>(rec + 4 + 4 * j) = acc[h][j];
+    __syncthreads();
+    if (w != (h % IQF_NW)) continue;
+    float mm = -INFINITY, ll = 0.f, cc = 0.f;
+    f4 aa[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) aa[j] = z4;
+    for (int i = 0; i < IQF_NW; ++i) {                 // fixed order 0..NW-1 whichever wave merges
+      const float* o = rec_lds + ((size_t)i * 64 + lane) * REC;
+      if constexpr (!BWD) {
+        const float mi = o[0];
+        if (mi > -INFINITY) {
+          const float mn = fmaxf(mm, mi);
+          const float f0 = __builtin_amdgcn_exp2f((mm - mn) * IQ_LOG2E), fi = __builtin_amdgcn_exp2f((mi - mn) * IQ_LOG2E);
+          ll = ll * f0 + o[1] * fi;
+          cc = cc * f0 + o[2] * fi;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) aa[j] = aa[j] * f0 + *reinterpret_cast<const f4*>(o + 4 + 4 * j) * fi;
+          mm = mn;
+        }
+      } else {
+        cc += o[2];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) aa[j] += *reinterpret_cast<const f4*>(o + 4 + 4 * j);
+      }
+    }
+    if constexpr (!BWD) {
+      const float inv = 1.0f / ll;
+      float* Pq = p.P + ((int64_t)b * Q + h) * D;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+        if (cv[j]) *reinterpret_cast<f4*>(Pq + ch[j]) = (aa[j] - cc) * inv;
+      if (lane == 0) *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + h) * 4) = f4{mm, ll, 0.f, 0.f};
+    } else {
+      float* gq = dq + ((int64_t)b * Q + h) * D;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+        if (cv[j]) *reinterpret_cast<f4*>(gq + ch[j]) = (aa[j] - cc) * p.scale;
+    }
+  }
+}
+
+static int iqf_cpl(int D) { return (D / 4 + 63) / 64; }
+bool imgqf_supported(const PoolParams& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_IMGQF"); on = e ? atoi(e) : 1; }
+  return on && p.cls_bstride != 0 && p.Q >= 1 && p.Q <= 4 && p.D % 4 == 0 && iqf_cpl(p.D) <= 5 && p.N >= 1;
+}
+
+template <int CPL, int TB>
+static int iqf_launch(const PoolParams& p, float* dq, bool bwd, hipStream_t st) {
+  const dim3 grid(p.B), block(IQF_NW * 64);
+  if (p.x_bf16) {
+    if (bwd) hipLaunchKernelGGL((ep_imgqf_kernel<CPL, 4, TB, true, true>), grid, block, 0, st, p, dq);
+    else hipLaunchKernelGGL((ep_imgqf_kernel<CPL, 4, TB, true, false>), grid, block, 0, st, p, dq);
+  } else {
+    if (bwd) hipLaunchKernelGGL((ep_imgqf_kernel<CPL, 4, TB, false, true>), grid, block, 0, st, p, dq);
+    else hipLaunchKernelGGL((ep_imgqf_kernel<CPL, 4, TB, false, false>), grid, block, 0, st, p, dq);
+  }
+  EP_LAUNCH_CHECK(bwd ? "ep_imgqf_kernel (backward)" : "ep_imgqf_kernel (forward)");
+  return 0;
+}
+
+static int iqf_dispatch(const PoolParams& p, float* dq, bool bwd, hipStream_t st) {
+  EP_REQUIRE(imgqf_supported(p), EP_E_UNSUPPORTED, "full-width per-image-query token pass: Q=%d D=%d not supported", p.Q, p.D);
+  switch (iqf_cpl(p.D)) {
+    case 1: return iqf_launch<1, 4>(p, dq, bwd, st);
+    case 2: return iqf_launch<2, 4>(p, dq, bwd, st);
+    case 3: return iqf_launch<3, 2>(p, dq, bwd, st);
+    case 4: return iqf_launch<4, 2>(p, dq, bwd, st);
+    default: return iqf_launch<5, 2>(p, dq, bwd, st);
+  }
+}
+int imgqf_forward(const PoolParams& p, hipStream_t st) { return iqf_dispatch(p, nullptr, false, st); }
+int imgqf_backward(const PoolParams& p, float* dq, hipStream_t st) { return iqf_dispatch(p, dq, true, st); }
+
 }  // namespace ep

@@ -359,6 +359,38 @@ int ep_imgq_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const i
   return imgq_backward(q, (hipStream_t)stream);
 }
 
+static int rowq_params(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D, int Q,
+                       const float* tokstat, PoolParams& p) {
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  p = pool_params(x, x_bstride, B, N, D, Q, 1.0f, x_dtype);
+  p.index = image_index; p.tokstat = tokstat; p.cls_bstride = (int64_t)Q * D;
+  EP_REQUIRE(imgqf_supported(p), EP_E_UNSUPPORTED, "full-width per-image-query pass: 1 <= Q <= 4, D %% 4 == 0, D <= 1280 (Q=%d D=%d)",
+             Q, D);
+  return 0;
+}
+
+int ep_rowq_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D, int Q,
+                         const float* u, const float* token_stats_, const float* score_bias, float* P, float* S, float* ML,
+                         ep_stream_t stream) {
+  EP_REQUIRE(u && P && S && ML && aligned16(u) && aligned16(P) && aligned16(ML), EP_E_ARG,
+             "ep_rowq_pool_forward: u / P / S / ML null or not 16-byte aligned");
+  PoolParams p;
+  EP_TRY(rowq_params(x, x_dtype, x_bstride, image_index, B, N, D, Q, token_stats_, p));
+  p.cls = u; p.sbias = score_bias; p.P = P; p.S = S; p.ML = ML;
+  return imgqf_forward(p, (hipStream_t)stream);
+}
+
+int ep_rowq_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D, int Q,
+                          const float* token_stats_, const float* S, const float* ML, const float* dP, const float* dA_bias,
+                          float* dS_out, float* du, ep_stream_t stream) {
+  EP_REQUIRE(S && ML && dP && du && aligned16(dP) && aligned16(du) && aligned16(ML), EP_E_ARG,
+             "ep_rowq_pool_backward: S / ML / dP / du null or not 16-byte aligned");
+  PoolParams p;
+  EP_TRY(rowq_params(x, x_dtype, x_bstride, image_index, B, N, D, Q, token_stats_, p));
+  p.S = const_cast<float*>(S); p.ML = const_cast<float*>(ML); p.dP = dP; p.dabias = dA_bias; p.dSout = dS_out;
+  return imgqf_backward(p, du, (hipStream_t)stream);
+}
+
 size_t ep_simpool_pool_workspace_bytes(const ep_simpool_dims* dims) {
   if (!dims || sp_check(*dims, false) != 0) return 0;
   return sp_carve(*dims, nullptr, false).total;

@@ -955,6 +955,42 @@ def imgq_pool_backward(x, u, heads, P, ML, dP, token_stats=None, pool_ln=False, 
     return du
 
 
+def rowq_pool_forward(x, u, token_stats=None, score_bias=None, image_index=None):
+    """Full-width per-image-query token pass (csrc/ep_pool_imgq.hip, ep_imgqf_kernel): u (B, Q <= 4, D) ->
+    (P (B, Q, D), S (B, Q, N), ML (B, Q, 4))."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    u = _f32c(u, "u")
+    Q = u.shape[1]
+    P = torch.empty((B, Q, D), device=xv.device, dtype=torch.float32)
+    S = torch.empty((B, Q, Nn), device=xv.device, dtype=torch.float32)
+    ML = torch.empty((B, Q, 4), device=xv.device, dtype=torch.float32)
+    sb = _f32c(score_bias, "score_bias") if score_bias is not None else None
+    N.check(lib.ep_rowq_pool_forward(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, B, Nn, D, Q, u.data_ptr(), _ptr(token_stats),
+                                     _ptr(sb), P.data_ptr(), S.data_ptr(), ML.data_ptr(), N.current_stream_ptr(xv.device)),
+            "ep_rowq_pool_forward")
+    return P, S, ML
+
+
+def rowq_pool_backward(x, S, ML, dP, token_stats=None, dA_bias=None, want_dS=False, image_index=None):
+    """(du (B, Q, D) per image, dS (B, Q, N) | None) of the full-width per-image-query token pass; ML[..., 2] = delta."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    dP = _f32c(dP, "dP")
+    Q = dP.shape[1]
+    du = torch.empty((B, Q, D), device=xv.device, dtype=torch.float32)
+    dS = torch.empty((B, Q, Nn), device=xv.device, dtype=torch.float32) if want_dS else None
+    db = _f32c(dA_bias, "dA_bias") if dA_bias is not None else None
+    N.check(lib.ep_rowq_pool_backward(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, B, Nn, D, Q, _ptr(token_stats), S.data_ptr(),
+                                      ML.data_ptr(), dP.data_ptr(), _ptr(db), _ptr(dS), du.data_ptr(),
+                                      N.current_stream_ptr(xv.device)), "ep_rowq_pool_backward")
+    return du, dS
+
+
 # --------------------------------------------------------------------------------------------
 # CaiT class-attention pooling (reference poolings/other_pool.py:390-507) on the LayerNorm-of-tokens passes
 # --------------------------------------------------------------------------------------------

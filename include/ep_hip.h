@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 18
+#define EP_ABI_VERSION 19
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -678,6 +678,22 @@ int ep_imgq_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const in
 int ep_imgq_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
                           int H, const float* u, const float* token_stats, int pool_ln, const float* P, const float* ML,
                           const float* dP, float* du, ep_stream_t stream);
+
+/* FULL-WIDTH per-image query rows (the CLIP head's passes, usable on their own): Q <= 4 rows u (B, Q, D) per image, each
+ * scoring and pooling the whole token row; every token is read once for all rows (csrc/ep_pool_imgq.hip: ep_imgqf_kernel).
+ *   forward : S[b,q,n] = u[b,q] . k[b,n] (+ score_bias[b,q,n]) ; A = softmax_n S ; P[b,q] = sum_n A k[b,n]
+ *             k = x, or the normalised token xhat when token_stats != NULL.  Outputs P (B,Q,D), S (B,Q,N) and
+ *             ML (B,Q,4) = {row max, sum of exponentials, 0, 0}.
+ *   backward: dA = dP[b,q] . k[b,n] (+ dA_bias[b,q,n]) ; dS = A (dA - ML[b,q,2]) with A from the stored S and ML[b,q,0:2]
+ *             (the caller puts its softmax correction term delta into ML[...,2]); du[b,q] = sum_n dS k[b,n] PER IMAGE;
+ *             dS_out (B,Q,N) optional.
+ * D % 4 == 0, D <= 1280. */
+int ep_rowq_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                         int Q, const float* u, const float* token_stats, const float* score_bias, float* P, float* S,
+                         float* ML, ep_stream_t stream);
+int ep_rowq_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
+                          int Q, const float* token_stats, const float* S, const float* ML, const float* dP,
+                          const float* dA_bias, float* dS_out, float* du, ep_stream_t stream);
 
 typedef struct ep_simpool_dims {
   int32_t B, N, D, H, C, linears;

@@ -154,3 +154,31 @@ def test_full_size_batch_vs_oracle_and_indexed_store_with_cached_statistics():
     e1.train_step(store, t, lr=0.5, image_index=idx, token_stats=stats)
     e2.train_step(store[idx.long()].contiguous(), t, lr=0.5)
     assert torch.equal(e1.flat_p, e2.flat_p)
+
+
+@pytest.mark.parametrize("shape", [(7, 36, 64, False), (5, 196, 768, False), (3, 100, 1152, True), (4, 256, 768, True), (6, 64, 128, False), (2, 144, 1024, False)],
+                         ids=lambda s: "B%d_N%d_D%d%s" % (s[0], s[1], s[2], "_bf16" if s[3] else ""))
+def test_full_width_per_image_query_kernel_vs_generic_kernels(shape):
+    """The token passes of this head run on ep_imgqf_kernel (every token read once for all four heads); the generic kernels
+    (one read per head) are the independent implementation of the same contract: pooled rows, scores, softmax statistics,
+    per-image query gradients and explicit dS must agree to fp32 summation-order noise, ragged N and bf16 tokens included."""
+    from efficient_probing_amd import _native as N_
+    from efficient_probing_amd import functional as F_
+    B, Nn, D, bf16 = shape
+    case = ClipCase("k", B=B, N=Nn, D=D, C=10, seed=11, sharp=True)
+    inp = make_clip_inputs(case)
+    lib = N_.load()
+    outs = []
+    for mode in (0, 1):
+        lib.ep_debug_force_generic_pool(mode)
+        try:
+            head, plist = native_head(case, inp)
+            x = tokens(case, inp["x_buf"])
+            x = x.to(torch.bfloat16) if bf16 else x
+            y = head[0](x)
+            (y * torch.linspace(-1.0, 1.0, y.numel(), device=DEV).view_as(y)).sum().backward()
+            outs.append([y.detach().float().cpu().numpy()] + [p.grad.cpu().numpy() for p in plist[:-2]])
+        finally:
+            lib.ep_debug_force_generic_pool(0)
+    for a, g in zip(*outs):
+        np.testing.assert_allclose(a, g, rtol=2e-4, atol=2e-5 * max(1e-3, float(np.abs(g).max())))

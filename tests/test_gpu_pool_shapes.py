@@ -73,3 +73,48 @@ def test_per_image_query_passes_vs_float64(B, N, D, H, mode):
     ref = torch.einsum("bhn,bnhc->bhc", dS, ks).reshape(B, D)
     # (sharp softmax over scores of magnitude ~10 and |dA| ~ 100: fp32 noise of the scores alone is ~1e-4 of the result)
     np.testing.assert_allclose(du.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+
+
+ROWQ = [(5, 256, 768, 4), (3, 197, 768, 4), (4, 49, 64, 4), (3, 100, 1152, 4), (2, 256, 1024, 3), (6, 37, 128, 1), (2, 64, 1280, 2),
+        (70, 256, 768, 4)]
+
+
+@pytest.mark.parametrize("B,N,D,Q", ROWQ)
+@pytest.mark.parametrize("mode", ["raw", "ln", "ln_bias_bf16"])
+def test_full_width_per_image_query_passes_vs_float64(B, N, D, Q, mode):
+    """ep_rowq_pool_forward / backward (ep_imgqf_kernel): Q <= 4 full-width query rows PER IMAGE, optional LayerNorm-of-tokens
+    mode, additive score bias, additive dA term, explicit dS, per-image query gradients -- against a float64 evaluation;
+    ragged token counts (tails of the 2- / 4-token iterations and of the four token waves) and bf16 tokens included."""
+    from efficient_probing_amd import functional as F_
+    g = torch.Generator(device=DEV).manual_seed(B * 977 + D + 3 * Q + N)
+    x = torch.randn(B, N, D, device=DEV, generator=g) * (0.5 + torch.rand(B, N, 1, device=DEV, generator=g)) + 0.3
+    bf16 = mode.endswith("bf16")
+    if bf16:
+        x = x.to(torch.bfloat16)
+    xd = x.double()
+    ln = mode != "raw"
+    tstat = F_.token_stats(x, 1e-6) if ln else None
+    if ln:
+        ts = tstat.double()
+        xd = (xd - ts[..., :1]) * ts[..., 1:]
+    u = torch.randn(B, Q, D, device=DEV, generator=g) * 3.0 / D ** 0.5
+    sb = torch.randn(B, Q, N, device=DEV, generator=g) if "bias" in mode else None
+    P, S, ML = F_.rowq_pool_forward(x, u, tstat, sb)
+    s = torch.einsum("bqd,bnd->bqn", u.double(), xd) + (sb.double() if sb is not None else 0.0)
+    A = torch.softmax(s, -1)
+    Pr = torch.einsum("bqn,bnd->bqd", A, xd)
+    np.testing.assert_allclose(S.cpu().numpy(), s.cpu().numpy(), rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(P.cpu().numpy(), Pr.cpu().numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(ML[:, :, 0].cpu().numpy(), s.max(-1).values.cpu().numpy(), rtol=1e-5, atol=3e-5)
+    lsum = torch.exp(s - ML[:, :, :1].double()).sum(-1)
+    np.testing.assert_allclose(ML[:, :, 1].cpu().numpy(), lsum.cpu().numpy(), rtol=2e-5)
+    dP = torch.randn(B, Q, D, device=DEV, generator=g)
+    db = torch.randn(B, Q, N, device=DEV, generator=g) if sb is not None else None
+    dA = torch.einsum("bqd,bnd->bqn", dP.double(), xd) + (db.double() if db is not None else 0.0)
+    delta = (A * dA).sum(-1)
+    ML[:, :, 2] = delta.float()
+    du, dS = F_.rowq_pool_backward(x, S, ML, dP, tstat, db, True)
+    dSr = A * (dA - delta[..., None])
+    ref = torch.einsum("bqn,bnd->bqd", dSr, xd)
+    np.testing.assert_allclose(dS.cpu().numpy(), dSr.cpu().numpy(), rtol=1e-4, atol=3e-6 * float(dSr.abs().max()) + 1e-7)
+    np.testing.assert_allclose(du.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=3e-5 * float(ref.abs().max()))
