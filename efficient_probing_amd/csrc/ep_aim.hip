@@ -287,7 +287,7 @@ static int aim_backward_core(const ep_aim_dims& d, const void* x, int x_dtype, i
     }
   }
   // dWv = d(Wv r) diag(r) + dbo nb^T   (the unused r / nb gradients of the shared kernel go to scratch)
-  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dWvs, w.dbo, pr.v_w, w.r, w.nb, D, acc,
+  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.v_w, w.r, w.nb, D, acc,
                      gr.v_w, w.scr, w.scr + D, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(ep_aim_dwk_kernel, dim3((D + 255) / 256, D), dim3(256), 0, st, w.dw, pr.cls_token, w.r, D, dh, scale, acc,
                      gr.k_w);

@@ -142,28 +142,40 @@ __global__ __launch_bounds__(256) void ep_cait_clsgrad_kernel(const float* __res
 // batch reductions of the class entry, per 16 columns d:
 //   dw[h,d]   += chat[d] sum_b dS_c[b,h]
 //   dchat[d]   = sum_h wq[h,d] sum_b dS_c[b,h] + sum_b sum_h a_c[b,h] dP[b,h,d]
-__global__ __launch_bounds__(256) void ep_cait_clsred_kernel(const float* __restrict__ csc, const float* __restrict__ dP,
-                                                           const float* __restrict__ wq, const float* __restrict__ chat, int B,
-                                                           int H, int D, float* __restrict__ dw, float* __restrict__ dchat) {
-  __shared__ float sm[RL][CG];
+__global__ __launch_bounds__(1024) void ep_cait_clsred_kernel(const float* __restrict__ csc, const float* __restrict__ dP,
+                                                            const float* __restrict__ wq, const float* __restrict__ chat, int B,
+                                                            int H, int D, float* __restrict__ dw, float* __restrict__ dchat) {
+  // 1024 threads = 32 column lanes x 32 row lanes over the B H rows of dP (grid (D + 31) / 32)
+  __shared__ float sm[32][33];
   __shared__ float sds[32];
-  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
-  const int d = blockIdx.x * CG + tx;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx;
   const bool ok = d < D;
-  // sum_b dS_c[b,h] for every head (H <= 32): thread t < H walks the batch in order (deterministic)
-  if ((int)threadIdx.x < H) {
+  // sum_b dS_c[b,h] for every head (H <= 32): row lane ty sums b = ty, ty + 32, ..., the 32 partials in a fixed order
+  for (int h = 0; h < H; ++h) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += csc[((int64_t)b * H + threadIdx.x) * 2];
-    sds[threadIdx.x] = s;
+    if (tx == 0) for (int b = ty; b < B; b += 32) s += csc[((int64_t)b * H + h) * 2];
+    __syncthreads();
+    if (tx == 0) sm[ty][0] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < 32; ++i) t += sm[i][0];
+      sds[h] = t;
+    }
+  }
+  float acc = 0.f;
+  if (ok) {
+    const int64_t rows = (int64_t)B * H;
+    for (int64_t r = ty; r < rows; r += 32) acc = fmaf(csc[r * 2 + 1], dP[r * D + d], acc);
   }
   __syncthreads();
-  float acc = 0.f;
-  if (ok)
-    for (int b = ty; b < B; b += RL)
-      for (int h = 0; h < H; ++h) acc = fmaf(csc[((int64_t)b * H + h) * 2 + 1], dP[((int64_t)b * H + h) * D + d], acc);
-  acc = colreduce(acc, sm, tx, ty);
+  sm[ty][tx] = acc;
+  __syncthreads();
   if (ty == 0 && ok) {
-    float g = acc;
+    float g = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g += sm[i][tx];
     const float ch = chat[d];
     for (int h = 0; h < H; ++h) {
       g = fmaf(wq[(int64_t)h * D + d], sds[h], g);
@@ -334,7 +346,7 @@ static int cait_forward_core(const ep_cait_dims& d, const void* x, int x_dtype, 
   hipLaunchKernelGGL(ep_cait_cls_kernel, dim3(1), dim3(256), 0, st, pr.cls_token, pr.n1_w, pr.n1_b, D, d.ln_eps, w.chat, w.un0,
                      w.lnstat);
   hipLaunchKernelGGL(ep_siglip_q_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.un0, pr.q_w, pr.q_b, D, w.q);
-  hipLaunchKernelGGL(ep_siglip_u_kernel, dim3((D + 255) / 256, H), dim3(256), 0, st, w.q, pr.k_w, D, dh, scale, w.u);
+  EP_TRY(siglip_u(w.q, pr.k_w, D, H, dh, scale, w.u, st));
   hipLaunchKernelGGL(ep_rowscale_kernel, dim3((H * D + 255) / 256), dim3(256), 0, st, w.u, pr.n1_w, H, D, w.wq);
   hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.v_w, pr.n1_w, pr.n1_b, D, w.Wvs, w.bo, pr.v_b);
   hipLaunchKernelGGL(ep_cait_clsrow_kernel, dim3((D + H + 3) / 4), dim3(256), 0, st, w.Wvs, w.wq, w.chat, D, H, w.vc, w.sc);
@@ -374,8 +386,8 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   // out = norm(c2)
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dout, w.c2, w.statf, pr.norm_w, (const float*)nullptr,
                      B, D, w.dc2);
-  hipLaunchKernelGGL(ep_lnaffine_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, st, dout, w.c2, w.statf, B, D, acc, gr.norm_w,
-                     gr.norm_b);
+  EP_TRY(lnaffine_grad(dout, w.c2, w.statf, B, D, acc, gr.norm_w,
+                     gr.norm_b, st));
   // c2 = c1 + gamma_2 * m2 ;  m2 = fc2(gelu(fc1(norm2(c1))))
   hipLaunchKernelGGL(ep_cait_scale_bwd_kernel, dim3(cgrid), dim3(256), 0, st, w.dc2, w.m2, pr.gamma_2, B, D, acc, w.dm2, gr.gamma_2,
                      (float*)nullptr);
@@ -387,8 +399,8 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
   EP_TRY(gemm(true, false, cgm(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.c1, w.stat2, pr.n2_w, w.dc2, B, D, w.dc1);
-  hipLaunchKernelGGL(ep_lnaffine_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dh2, w.c1, w.stat2, B, D, acc, gr.n2_w,
-                     gr.n2_b);
+  EP_TRY(lnaffine_grad(w.dh2, w.c1, w.stat2, B, D, acc, gr.n2_w,
+                     gr.n2_b, st));
   // c1 = c + gamma_1 * z1 ;  z1 = ya Wp^T + bp          (dcsum = sum_b dc1: the direct path to the class token)
   hipLaunchKernelGGL(ep_cait_scale_bwd_kernel, dim3(cgrid), dim3(256), 0, st, w.dc1, w.z1, pr.gamma_1, B, D, acc, w.dz1, gr.gamma_1,
                      w.dcsum);
@@ -433,10 +445,10 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
     }
   }
   // class entry: dw += chat sum_b dS_c ; dchat ; dWv' += dvc chat^T
-  hipLaunchKernelGGL(ep_cait_clsred_kernel, dim3(cgrid), dim3(256), 0, st, w.csc, w.dP, w.wq, w.chat, B, H, D, w.dw, w.dchat);
+  hipLaunchKernelGGL(ep_cait_clsred_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.csc, w.dP, w.wq, w.chat, B, H, D, w.dw, w.dchat);
   hipLaunchKernelGGL(ep_cait_rank1_kernel, dim3((D + 255) / 256, D), dim3(256), 0, st, w.dvc, w.chat, D, w.dWvs);
   // value side: d v.weight, and the value-side parts of d norm1.weight / bias ; d v.bias = dbo
-  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dWvs, w.dbo, pr.v_w, pr.n1_w, pr.n1_b, D, acc,
+  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.v_w, pr.n1_w, pr.n1_b, D, acc,
                      gr.v_w, gr.n1_w, gr.n1_b, (float*)nullptr, (float*)nullptr);
   EP_LAUNCH_CHECK("ep_cait value backward kernels");
   EP_TRY(colsum(w.dya, B, D, D, acc, gr.v_b, st));
@@ -445,8 +457,8 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   // query chain: d q.weight / bias, d k.weight, d k.bias = 0, dun0 = Wq^T dq
   hipLaunchKernelGGL(ep_siglip_dq_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.du, pr.k_w, D, dh, scale, acc, w.dq, gr.q_b);
   if (acc) EP_HIP(hipMemsetAsync(w.dun0, 0, (size_t)D * sizeof(float), st));   // (the kernel accumulates all its outputs alike)
-  hipLaunchKernelGGL(ep_siglip_qgrad_kernel, dim3((D + 63) / 64), dim3(256), (size_t)(2 * D + 256) * 4, st, w.q, w.dq, w.du,
-                     w.un0, pr.q_w, D, dh, scale, acc, gr.k_w, gr.q_w, w.dun0, gr.k_b);
+  EP_TRY(siglip_qgrad(w.q, w.dq, w.du,
+                     w.un0, pr.q_w, D, dh, scale, acc, gr.k_w, gr.q_w, w.dun0, gr.k_b, st));
   // class token: LayerNorm backward with both gradient kinds + the direct residual path
   hipLaunchKernelGGL(ep_cait_clsln_bwd_kernel, dim3(1), dim3(256), 0, st, w.dun0, w.dchat, w.chat, pr.n1_w, w.lnstat, w.dcsum, D, acc,
                      gr.n1_w, gr.n1_b, gr.cls_token);

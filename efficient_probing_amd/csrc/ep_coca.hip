@@ -648,7 +648,7 @@ static int cae_backward_core(const ep_cae_dims& d, const void* x, int x_dtype, i
       EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
     }
   }
-  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dWvs, w.dbo, pr.v_w, pr.nv_w, pr.nv_b, D, acc,
+  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.v_w, pr.nv_w, pr.nv_b, D, acc,
                      gr.v_w, gr.nv_w, gr.nv_b, gr.n2_w, gr.n2_b);
   hipLaunchKernelGGL(ep_cae_du_kernel, dim3((D + 255) / 256), dim3(256), 0, st, w.dw, w.u, pr.nk_w, D, d.H, acc, w.du, gr.nk_w,
                      gr.nk_b);

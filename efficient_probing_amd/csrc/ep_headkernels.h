@@ -8,6 +8,18 @@
 
 namespace ep {
 
+// Column work over many rows: 1024-thread workgroups = 32 column lanes x 32 row lanes (a row lane walks rows ty, ty + 32, ...);
+// the 32 row-lane partials of a column are summed in a fixed order.
+__device__ __forceinline__ float red32(float v, float (*sm)[33], int tx, int ty) {
+  __syncthreads();
+  sm[ty][tx] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t += sm[i][tx];
+  return t;
+}
+
 // q[j] = Wq[j,:] . latent + bq[j]      (one wave per output)
 static __global__ __launch_bounds__(256) void ep_siglip_q_kernel(const float* __restrict__ latent, const float* __restrict__ Wq,
                                                         const float* __restrict__ bq, int D, float* __restrict__ q) {
@@ -20,14 +32,22 @@ static __global__ __launch_bounds__(256) void ep_siglip_q_kernel(const float* __
   if (lane == 0) q[j] = acc + bq[j];
 }
 
-// u[h,d] = scale * sum_c q[h*dh + c] * Wk[h*dh + c, d]
-static __global__ __launch_bounds__(256) void ep_siglip_u_kernel(const float* __restrict__ q, const float* __restrict__ Wk, int D,
-                                                        int dh, float scale, float* __restrict__ u) {
-  const int d = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
-  if (d >= D) return;
+// u[h,d] = scale * sum_c q[h*dh + c] * Wk[h*dh + c, d]        (grid (D / 32, H), 1024 threads)
+static __global__ __launch_bounds__(1024) void ep_siglip_u_kernel(const float* __restrict__ q, const float* __restrict__ Wk, int D,
+                                                         int dh, float scale, float* __restrict__ u) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx, h = blockIdx.y;
   float acc = 0.f;
-  for (int c = 0; c < dh; ++c) acc = fmaf(q[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
-  u[(int64_t)h * D + d] = acc * scale;
+  if (d < D)
+    for (int c = ty; c < dh; c += 32) acc = fmaf(q[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
+  acc = red32(acc, sm, tx, ty);
+  if (ty == 0 && d < D) u[(int64_t)h * D + d] = acc * scale;
+}
+static inline int siglip_u(const float* q, const float* Wk, int D, int H, int dh, float scale, float* u, hipStream_t st) {
+  hipLaunchKernelGGL(ep_siglip_u_kernel, dim3((D + 31) / 32, H), dim3(1024), 0, st, q, Wk, D, dh, scale, u);
+  EP_LAUNCH_CHECK("ep_siglip_u_kernel");
+  return 0;
 }
 
 // dq[j] = scale * Wk[j,:] . du[h(j),:]   (one wave per output; also d q.bias)
@@ -45,38 +65,48 @@ static __global__ __launch_bounds__(256) void ep_siglip_dq_kernel(const float* _
 
 // per 64-column block of d:  dWk[j,d] (+)= scale q[j] du[h(j),d];  dWq[j,d] (+)= dq[j] latent[d];
 // dlatent[d] (+)= sum_j Wq[j,d] dq[j];  d kv.bias[:D] <- 0
+// Two launches: the outer products (grid (D / 64, 16): 64 columns x 4 row lanes over a sixteenth of the rows) and the
+// (1 x D) . (D x D) product for d latent (grid D / 32, 1024 threads).
 static __global__ __launch_bounds__(256) void ep_siglip_qgrad_kernel(const float* __restrict__ q, const float* __restrict__ dq,
                                                             const float* __restrict__ du, const float* __restrict__ latent,
-                                                            const float* __restrict__ Wq, int D, int dh, float scale,
-                                                            int accumulate, float* __restrict__ dWk, float* __restrict__ dWq,
-                                                            float* __restrict__ dlatent, float* __restrict__ dbk) {
-  extern __shared__ float sh[];          // q[D] | dq[D] | partial[4][64]
-  float* s_q = sh; float* s_dq = sh + D; float* part = sh + 2 * D;
+                                                            int D, int dh, float scale, int accumulate,
+                                                            float* __restrict__ dWk, float* __restrict__ dWq,
+                                                            float* __restrict__ dbk) {
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  for (int i = tid; i < D; i += 256) { s_q[i] = q[i]; s_dq[i] = dq[i]; }
-  __syncthreads();
   const int d = blockIdx.x * 64 + tx;
-  const bool ok = d < D;
+  if (d >= D) return;
+  const int per = (D + gridDim.y - 1) / gridDim.y;
+  const int j0 = blockIdx.y * per, j1 = (j0 + per) < D ? (j0 + per) : D;
+  const float ld = latent[d];
+  for (int j = j0 + ty; j < j1; j += 4) {
+    const float gk = scale * q[j] * du[(int64_t)(j / dh) * D + d];
+    float* ok_ = dWk + (int64_t)j * D + d;
+    *ok_ = accumulate ? *ok_ + gk : gk;
+    const float gq = dq[j] * ld;
+    float* oq = dWq + (int64_t)j * D + d;
+    *oq = accumulate ? *oq + gq : gq;
+  }
+  if (!accumulate && ty == 0 && blockIdx.y == 0) dbk[d] = 0.f;
+}
+// dlatent[d] (+)= sum_j Wq[j,d] dq[j]
+static __global__ __launch_bounds__(1024) void ep_siglip_dlatent_kernel(const float* __restrict__ dq, const float* __restrict__ Wq,
+                                                               int D, int accumulate, float* __restrict__ dlatent) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx;
   float acc = 0.f;
-  if (ok) {
-    const float ld = latent[d];
-    for (int j = ty; j < D; j += 4) {
-      const float gk = scale * s_q[j] * du[(int64_t)(j / dh) * D + d];
-      float* ok_ = dWk + (int64_t)j * D + d;
-      *ok_ = accumulate ? *ok_ + gk : gk;
-      const float gq = s_dq[j] * ld;
-      float* oq = dWq + (int64_t)j * D + d;
-      *oq = accumulate ? *oq + gq : gq;
-      acc = fmaf(Wq[(int64_t)j * D + d], s_dq[j], acc);
-    }
-    if (!accumulate && ty == 0) dbk[d] = 0.f;
-  }
-  part[ty * 64 + tx] = acc;
-  __syncthreads();
-  if (ty == 0 && ok) {
-    const float g = (part[tx] + part[64 + tx]) + (part[128 + tx] + part[192 + tx]);
-    dlatent[d] = accumulate ? dlatent[d] + g : g;
-  }
+  if (d < D)
+    for (int j = ty; j < D; j += 32) acc = fmaf(Wq[(int64_t)j * D + d], dq[j], acc);
+  acc = red32(acc, sm, tx, ty);
+  if (ty == 0 && d < D) dlatent[d] = accumulate ? dlatent[d] + acc : acc;
+}
+static inline int siglip_qgrad(const float* q, const float* dq, const float* du, const float* latent, const float* Wq, int D, int dh,
+                               float scale, int accumulate, float* dWk, float* dWq, float* dlatent, float* dbk, hipStream_t st) {
+  hipLaunchKernelGGL(ep_siglip_qgrad_kernel, dim3((D + 63) / 64, 16), dim3(256), 0, st, q, dq, du, latent, D, dh, scale, accumulate,
+                     dWk, dWq, dbk);
+  hipLaunchKernelGGL(ep_siglip_dlatent_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, dq, Wq, D, accumulate, dlatent);
+  EP_LAUNCH_CHECK("ep_siglip_qgrad kernels");
+  return 0;
 }
 
 // exact GELU (nn.GELU default, erf form): h = gelu(pre)
@@ -141,25 +171,29 @@ static __global__ __launch_bounds__(256) void ep_rowln_bwd_kernel(const float* _
   }
 }
 // d g[d] (+)= sum_b dh[b,d] xhat[b,d];  d beta[d] (+)= sum_b dh[b,d]     (64 columns per workgroup, 4 row lanes)
-static __global__ __launch_bounds__(256) void ep_lnaffine_grad_kernel(const float* __restrict__ dh, const float* __restrict__ x,
-                                                             const float* __restrict__ stats, int B, int D, int accumulate,
-                                                             float* __restrict__ dg, float* __restrict__ dbeta) {
-  __shared__ float pg[4][64], pb[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int d = blockIdx.x * 64 + tx;
+static __global__ __launch_bounds__(1024) void ep_lnaffine_grad_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                              const float* __restrict__ stats, int B, int D, int accumulate,
+                                                              float* __restrict__ dg, float* __restrict__ dbeta) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx;
   float ag = 0.f, ab = 0.f;
   if (d < D)
-    for (int b = ty; b < B; b += 4) {
+    for (int b = ty; b < B; b += 32) {
       const float v = dh[(int64_t)b * D + d];
       ag = fmaf(v, (x[(int64_t)b * D + d] - stats[2 * b]) * stats[2 * b + 1], ag); ab += v;
     }
-  pg[ty][tx] = ag; pb[ty][tx] = ab;
-  __syncthreads();
+  const float sg = red32(ag, sm, tx, ty), sb = red32(ab, sm, tx, ty);
   if (ty == 0 && d < D) {
-    const float sg = (pg[0][tx] + pg[1][tx]) + (pg[2][tx] + pg[3][tx]), sb = (pb[0][tx] + pb[1][tx]) + (pb[2][tx] + pb[3][tx]);
     dg[d] = accumulate ? dg[d] + sg : sg;
     dbeta[d] = accumulate ? dbeta[d] + sb : sb;
   }
+}
+static inline int lnaffine_grad(const float* dh, const float* x, const float* stats, int B, int D, int accumulate, float* dg,
+                                float* dbeta, hipStream_t st) {
+  hipLaunchKernelGGL(ep_lnaffine_grad_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, dh, x, stats, B, D, accumulate, dg, dbeta);
+  EP_LAUNCH_CHECK("ep_lnaffine_grad_kernel");
+  return 0;
 }
 
 

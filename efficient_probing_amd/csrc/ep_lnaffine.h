@@ -40,21 +40,21 @@ static __global__ __launch_bounds__(256) void ep_cae_du_kernel(const float* __re
   if (!accumulate) dbk[d] = 0.f;
 }
 
-// value side, per 64-column block of d: dWv[r,d] (+)= dWvs[r,d] gv[d] + dbo[r] bv[d];
+// value side, per 32-column block of d (1024 threads = 32 column lanes x 32 row lanes; launch with grid (D + 31) / 32): dWv[r,d] (+)= dWvs[r,d] gv[d] + dbo[r] bv[d];
 // d gv[d] (+)= sum_r dWvs[r,d] Wv[r,d];  d bv[d] (+)= sum_r dbo[r] Wv[r,d];  unused norm2_cross gradients <- 0
-static __global__ __launch_bounds__(256) void ep_cae_dwv_kernel(const float* __restrict__ dWvs, const float* __restrict__ dbo,
-                                                       const float* __restrict__ Wv, const float* __restrict__ gv,
-                                                       const float* __restrict__ bv, int D, int accumulate,
-                                                       float* __restrict__ dWv, float* __restrict__ dgv, float* __restrict__ dbv,
-                                                       float* __restrict__ dn2w, float* __restrict__ dn2b) {
-  __shared__ float pg[4][64], pb[4][64];
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const int d = blockIdx.x * 64 + tx;
+static __global__ __launch_bounds__(1024) void ep_cae_dwv_kernel(const float* __restrict__ dWvs, const float* __restrict__ dbo,
+                                                        const float* __restrict__ Wv, const float* __restrict__ gv,
+                                                        const float* __restrict__ bv, int D, int accumulate,
+                                                        float* __restrict__ dWv, float* __restrict__ dgv, float* __restrict__ dbv,
+                                                        float* __restrict__ dn2w, float* __restrict__ dn2b) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 column lanes x 32 row lanes
+  const int d = blockIdx.x * 32 + tx;
   const bool ok = d < D;
   float ag = 0.f, ab = 0.f;
   if (ok) {
     const float g = gv[d], b = bv[d];
-    for (int r = ty; r < D; r += 4) {
+    for (int r = ty; r < D; r += 32) {
       const float ds = dWvs[(int64_t)r * D + d], wv = Wv[(int64_t)r * D + d], db = dbo[r];
       const float v = fmaf(ds, g, db * b);
       float* o = dWv + (int64_t)r * D + d;
@@ -62,11 +62,15 @@ static __global__ __launch_bounds__(256) void ep_cae_dwv_kernel(const float* __r
       ag = fmaf(ds, wv, ag); ab = fmaf(db, wv, ab);
     }
   }
-  pg[ty][tx] = ag; pb[ty][tx] = ab;
-  __syncthreads();
+  __syncthreads(); sm[ty][tx] = ag; __syncthreads();
+  float sg = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) sg += sm[i][tx];
+  __syncthreads(); sm[ty][tx] = ab; __syncthreads();
+  float sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) sb += sm[i][tx];
   if (ty == 0 && ok) {
-    const float sg = (pg[0][tx] + pg[1][tx]) + (pg[2][tx] + pg[3][tx]);
-    const float sb = (pb[0][tx] + pb[1][tx]) + (pb[2][tx] + pb[3][tx]);
     dgv[d] = accumulate ? dgv[d] + sg : sg;
     dbv[d] = accumulate ? dbv[d] + sb : sb;
     if (!accumulate && dn2w) { dn2w[d] = 0.f; dn2b[d] = 0.f; }

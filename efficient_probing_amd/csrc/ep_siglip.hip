@@ -107,7 +107,7 @@ static int sig_forward_core(const ep_siglip_dims& d, const void* x, int x_dtype,
   const int D = d.D, dh = D / d.H, Hd = d.hidden;
   const float scale = (float)pow((double)dh, -0.5);                        // attention_pool.py:40
   hipLaunchKernelGGL(ep_siglip_q_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.latent, pr.q_w, pr.q_b, D, w.q);
-  hipLaunchKernelGGL(ep_siglip_u_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.q, pr.kv_w, D, dh, scale, w.u);
+  EP_TRY(siglip_u(w.q, pr.kv_w, D, d.H, dh, scale, w.u, st));
   EP_LAUNCH_CHECK("ep_siglip_q/u kernels");
   EP_TRY(pool_forward(sig_pool_params(d, x, x_dtype, bstride, index, w), st));
   {
@@ -179,8 +179,8 @@ static int sig_backward_core(const ep_siglip_dims& d, const void* x, int x_dtype
   }
   // query chain
   hipLaunchKernelGGL(ep_siglip_dq_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.du, pr.kv_w, D, dh, scale, acc, w.dq, gr.q_b);
-  hipLaunchKernelGGL(ep_siglip_qgrad_kernel, dim3((D + 63) / 64), dim3(256), (size_t)(2 * D + 256) * 4, st, w.q, w.dq, w.du,
-                     pr.latent, pr.q_w, D, dh, scale, acc, gr.kv_w, gr.q_w, gr.latent, gr.kv_b);
+  EP_TRY(siglip_qgrad(w.q, w.dq, w.du,
+                     pr.latent, pr.q_w, D, dh, scale, acc, gr.kv_w, gr.q_w, gr.latent, gr.kv_b, st));
   EP_LAUNCH_CHECK("ep_siglip backward kernels");
   return 0;
 }
@@ -288,7 +288,7 @@ static int jepa_forward_core(const ep_jepa_dims& d, const void* x, int x_dtype, 
     tokstat = w.tstat;
   }
   hipLaunchKernelGGL(ep_siglip_q_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.query, pr.q_w, pr.q_b, D, w.q);
-  hipLaunchKernelGGL(ep_siglip_u_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.q, pr.kv_w, D, dh, scale, w.u);
+  EP_TRY(siglip_u(w.q, pr.kv_w, D, d.H, dh, scale, w.u, st));
   hipLaunchKernelGGL(ep_rowscale_kernel, dim3((d.H * D + 255) / 256), dim3(256), 0, st, w.u, pr.n1_w, d.H, D, w.wq);
   hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.kv_w + (int64_t)D * D, pr.n1_w, pr.n1_b, D, w.Wvs,
                      w.bo, pr.kv_b + D);                                    // Wv diag(g1);  Wv b1 + bv
@@ -327,8 +327,8 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
   EP_TRY(gemm(true, false, mkg(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.q1, w.qstat, pr.n2_w, dout, B, D, w.dq1);
-  hipLaunchKernelGGL(ep_lnaffine_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dh2, w.q1, w.qstat, B, D, acc, gr.n2_w,
-                     gr.n2_b);
+  EP_TRY(lnaffine_grad(w.dh2, w.q1, w.qstat, B, D, acc, gr.n2_w,
+                     gr.n2_b, st));
   EP_LAUNCH_CHECK("ep_jepa LN2 backward kernels");
   EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
   EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
@@ -367,7 +367,7 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
     }
   }
   // value side: d kv.weight[D:], d kv.bias[D:], and the value-side parts of d norm1.weight / bias
-  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 63) / 64), dim3(256), 0, st, w.dWvs, w.dbo, pr.kv_w + (int64_t)D * D, pr.n1_w,
+  hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.kv_w + (int64_t)D * D, pr.n1_w,
                      pr.n1_b, D, acc, gr.kv_w + (int64_t)D * D, gr.n1_w, gr.n1_b, (float*)nullptr, (float*)nullptr);
   EP_TRY(colsum(w.dya, B, D, D, acc, gr.kv_b + D, st));
   // key side: du = g1 * dw;  d norm1.weight += sum_h u_h * dw_h   (accumulating onto the value-side part)
@@ -375,8 +375,8 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
                      gr.n1_b);
   // query chain (as in the SigLIP head): d q.weight / bias, d kv.weight[:D], d kv.bias[:D] = 0, d query += Wq^T dq
   hipLaunchKernelGGL(ep_siglip_dq_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.du, pr.kv_w, D, dh, scale, acc, w.dq, gr.q_b);
-  hipLaunchKernelGGL(ep_siglip_qgrad_kernel, dim3((D + 63) / 64), dim3(256), (size_t)(2 * D + 256) * 4, st, w.q, w.dq, w.du,
-                     pr.query, pr.q_w, D, dh, scale, acc, gr.kv_w, gr.q_w, gr.query, gr.kv_b);
+  EP_TRY(siglip_qgrad(w.q, w.dq, w.du,
+                     pr.query, pr.q_w, D, dh, scale, acc, gr.kv_w, gr.q_w, gr.query, gr.kv_b, st));
   EP_LAUNCH_CHECK("ep_jepa backward kernels");
   EP_TRY(colsum(w.dq1, B, D, D, 1, gr.query, st));             // + the direct path q1 = q0 + ... (added onto Wq^T dq)
   return 0;

@@ -69,6 +69,12 @@ def f64_reference(case, inp):
     return rec
 
 
+# d loss / d norm.bias = sum_b dout[b] is exactly zero in exact arithmetic (dout comes out of the BatchNorm1d backward, whose
+# columns sum to zero): the parameter drifts by lr x rounding noise on both sides -- a different sample of that noise for every
+# summation order, so "4x the reference's own error" is not a bound there; 1e-3 of the tensor's scale is.
+NOISE_FLOOR = {"norm_b": 1e-3}
+
+
 def close_to_truth(name, got, gold, truth, rtol=2e-4, floor=3e-5):
     """`got` (the HIP path) must be as close to the float64 truth as the real reference's own fp32 result `gold` is (x4), or
     within the usual fp32 floor -- the gradients of this head are sums of batch-cancelling rows (tests/test_cait_cpu.py)."""
@@ -119,7 +125,7 @@ def test_engine_lars_steps_vs_reference(case):
             pv = p.detach().cpu().numpy()
             gold = g[f"{tag}_{n}"]
             close_to_truth(f"{tag} {n}", pv if small else keep(pv), gold, (tr if small else keep(tr)).reshape(gold.shape), rtol=3e-4,
-                           floor=1e-5)
+                           floor=NOISE_FLOOR.get(n, 1e-5))
         np.testing.assert_allclose(head[1].running_mean.cpu().numpy(), g[f"{tag}_running_mean"], rtol=1e-4, atol=5e-6)
         np.testing.assert_allclose(head[1].running_var.cpu().numpy(), g[f"{tag}_running_var"], rtol=2e-4, atol=5e-6)
     close_to_truth("eval logits", eng.eval_logits(tokens(case, inp["x_buf"])).cpu().numpy(), g["eval_logits"],
