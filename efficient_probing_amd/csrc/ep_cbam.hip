@@ -193,99 +193,148 @@ __global__ __launch_bounds__(256) void ep_cbam_conv_bwd_kernel(const float* __re
   dmaps[i] = acc;
 }
 // d w[ch,dy,dx] (+)= sum_{b,p} dconv[b,p] maps[b,ch,p+d]      (one workgroup per weight element, fixed order)
+// grid (2 KS KS, RS): the images split over RS chunks -> part[chunk][2 KS KS]; ep_cbam_conv_wfin_kernel sums the chunks in order
 __global__ __launch_bounds__(256) void ep_cbam_conv_wgrad_kernel(const float* __restrict__ dconv, const float* __restrict__ maps,
-                                                               int B, int side, int KS, int accumulate, float* __restrict__ dw) {
+                                                               int B, int side, int KS, float* __restrict__ part) {
   __shared__ float red[4];
   const int e = blockIdx.x, chn = e / (KS * KS), dy = (e / KS) % KS, dx = e % KS;
   const int N = side * side, pad = KS / 2;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = (b0 + per) < B ? (b0 + per) : B;
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < (int64_t)B * N; i += 256) {
+  for (int64_t i = (int64_t)b0 * N + threadIdx.x; i < (int64_t)b1 * N; i += 256) {
     const int64_t b = i / N; const int p = (int)(i % N), y = p / side + dy - pad, xq = p % side + dx - pad;
     if (y >= 0 && y < side && xq >= 0 && xq < side) s = fmaf(dconv[i], maps[(b * 2 + chn) * N + y * side + xq], s);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (red[0] + red[1]) + (red[2] + red[3]);
-    dw[e] = accumulate ? dw[e] + t : t;
-  }
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + e] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void ep_cbam_conv_wfin_kernel(const float* __restrict__ part, int n, int rs, int accumulate, float* __restrict__ dw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float t = 0.f;
+  for (int r = 0; r < rs; ++r) t += part[(int64_t)r * n + e];
+  dw[e] = accumulate ? dw[e] + t : t;
 }
 
 // ---- one-channel BatchNorm2d over all B*N values + sigmoid (single workgroup of 1024 threads, two passes, fixed order) ----
 //   train: batch mean / biased variance, running statistics updated (unbiased variance) ; st = {mean, rstd}
+// One-channel BatchNorm2d over all n = B N values + the sigmoid gate, on up to 64 workgroups:
+//   ep_cbam_bn1_part_kernel : per chunk {count, mean, M2} (two passes inside the chunk)              [training only]
+//   ep_cbam_bn1_kernel      : every workgroup combines the chunks in the same fixed order (Chan), applies its own chunk;
+//                             workgroup 0 updates the running statistics and leaves {mean, rstd} in st
+constexpr int CBAM_BN_G = 64;
+__device__ __forceinline__ float cbam_block_sum(float v, float* red) {      // 1024 threads; result in every thread
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k];
+  return t;
+}
+__device__ __forceinline__ void cbam_chunk(int64_t n, int64_t& c0, int64_t& c1) {
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+  c0 = (int64_t)blockIdx.x * per; c0 = c0 < n ? c0 : n;
+  c1 = (c0 + per) < n ? (c0 + per) : n;
+}
+__global__ __launch_bounds__(1024) void ep_cbam_bn1_part_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ part) {
+  __shared__ float red[16];
+  int64_t c0, c1;
+  cbam_chunk(n, c0, c1);
+  float s = 0.f;
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 1024) s += v[i];
+  const float cnt = (float)(c1 - c0);
+  const float mean = cnt > 0.f ? cbam_block_sum(s, red) / cnt : 0.f;
+  float q = 0.f;
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 1024) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  q = cbam_block_sum(q, red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 4 + 0] = cnt; part[blockIdx.x * 4 + 1] = mean; part[blockIdx.x * 4 + 2] = q; }
+}
 __global__ __launch_bounds__(1024) void ep_cbam_bn1_kernel(const float* __restrict__ v, int64_t n, int training, float eps,
                                                          float momentum, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ rmean,
                                                          float* __restrict__ rvar, int64_t* __restrict__ nbt,
-                                                         float* __restrict__ st, float* __restrict__ gs) {
-  __shared__ float red[16];
+                                                         const float* __restrict__ part, float* __restrict__ st,
+                                                         float* __restrict__ gs) {
   __shared__ float bc[2];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float mean, rstd;
-  if (training) {
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) s += v[i];
-    s = wave_sum(s);
-    if (lane == 0) red[w] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += red[k]; bc[0] = t / (float)n; }
-    __syncthreads();
-    mean = bc[0];
-    float q = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) { const float d = v[i] - mean; q = fmaf(d, d, q); }
-    q = wave_sum(q);
-    __syncthreads();
-    if (lane == 0) red[w] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f; for (int k = 0; k < 16; ++k) t += red[k];
-      const float var = t / (float)n;
-      bc[1] = 1.0f / sqrtf(var + eps);
-      if (rmean) {
-        rmean[0] = (1.0f - momentum) * rmean[0] + momentum * mean;
-        rvar[0] = (1.0f - momentum) * rvar[0] + momentum * (n > 1 ? t / (float)(n - 1) : var);
+  if (threadIdx.x == 0) {
+    if (training) {
+      float cn = 0.f, mu = 0.f, m2 = 0.f;                  // Chan's combination, chunks in order
+      for (int g = 0; g < (int)gridDim.x; ++g) {
+        const float nb = part[g * 4], mb = part[g * 4 + 1], qb = part[g * 4 + 2];
+        if (nb > 0.f) {
+          const float tot = cn + nb, dl = mb - mu;
+          mu += dl * (nb / tot);
+          m2 += qb + dl * dl * (cn * nb / tot);
+          cn = tot;
+        }
       }
-      if (nbt) *nbt += 1;
+      const float var = m2 / (float)n;
+      bc[0] = mu; bc[1] = 1.0f / sqrtf(var + eps);
+      if (blockIdx.x == 0) {
+        if (rmean) {
+          rmean[0] = (1.0f - momentum) * rmean[0] + momentum * mu;
+          rvar[0] = (1.0f - momentum) * rvar[0] + momentum * (n > 1 ? m2 / (float)(n - 1) : var);
+        }
+        if (nbt) *nbt += 1;
+      }
+    } else {
+      bc[0] = rmean[0]; bc[1] = 1.0f / sqrtf(rvar[0] + eps);
     }
-    __syncthreads();
-    rstd = bc[1];
-  } else {
-    mean = rmean[0]; rstd = 1.0f / sqrtf(rvar[0] + eps);
+    if (blockIdx.x == 0) { st[0] = bc[0]; st[1] = bc[1]; }
   }
+  __syncthreads();
+  const float mean = bc[0], rstd = bc[1];
   const float g = gamma[0], be = beta[0];
-  for (int64_t i = threadIdx.x; i < n; i += 1024) gs[i] = 1.0f / (1.0f + expf(-fmaf(g, (v[i] - mean) * rstd, be)));
-  if (threadIdx.x == 0) { st[0] = mean; st[1] = rstd; }
+  int64_t c0, c1;
+  cbam_chunk(n, c0, c1);
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 1024) gs[i] = 1.0f / (1.0f + expf(-fmaf(g, (v[i] - mean) * rstd, be)));
 }
 // backward: dpre = dgs gs (1 - gs) ; d gamma (+)= sum dpre zhat ; d beta (+)= sum dpre ;
 //           dconv = gamma rstd (dpre - mean(dpre) - zhat mean(dpre zhat))          (batch statistics)
-__global__ __launch_bounds__(1024) void ep_cbam_bn1_bwd_kernel(const float* __restrict__ dgs, const float* __restrict__ gs,
-                                                             const float* __restrict__ v, int64_t n, const float* __restrict__ st,
-                                                             const float* __restrict__ gamma, int accumulate,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ dconv) {
-  __shared__ float red[2][16];
-  __shared__ float bc[2];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// backward of the gate + BatchNorm: ep_cbam_bn1_bwd_part_kernel leaves per chunk {sum dp, sum dp vhat}; ep_cbam_bn1_bwd_kernel
+// sums the chunks in order in every workgroup and back-propagates its own chunk (workgroup 0 writes d gamma / d beta)
+__global__ __launch_bounds__(1024) void ep_cbam_bn1_bwd_part_kernel(const float* __restrict__ dgs, const float* __restrict__ gs,
+                                                                  const float* __restrict__ v, int64_t n,
+                                                                  const float* __restrict__ st, float* __restrict__ part) {
+  __shared__ float red[16];
   const float mean = st[0], rstd = st[1];
+  int64_t c0, c1;
+  cbam_chunk(n, c0, c1);
   float s1 = 0.f, s2 = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 1024) {
     const float a = gs[i], dp = dgs[i] * a * (1.0f - a);
     s1 += dp; s2 = fmaf(dp, (v[i] - mean) * rstd, s2);
   }
-  s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
-  __syncthreads();
+  s1 = cbam_block_sum(s1, red);
+  s2 = cbam_block_sum(s2, red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 4 + 0] = s1; part[blockIdx.x * 4 + 1] = s2; }
+}
+__global__ __launch_bounds__(1024) void ep_cbam_bn1_bwd_kernel(const float* __restrict__ dgs, const float* __restrict__ gs,
+                                                             const float* __restrict__ v, int64_t n, const float* __restrict__ st,
+                                                             const float* __restrict__ gamma, int accumulate,
+                                                             const float* __restrict__ part, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dconv) {
+  __shared__ float bc[2];
+  const float mean = st[0], rstd = st[1];
   if (threadIdx.x == 0) {
     float t1 = 0.f, t2 = 0.f;
-    for (int k = 0; k < 16; ++k) { t1 += red[0][k]; t2 += red[1][k]; }
-    dgamma[0] = accumulate ? dgamma[0] + t2 : t2;
-    dbeta[0] = accumulate ? dbeta[0] + t1 : t1;
+    for (int g = 0; g < (int)gridDim.x; ++g) { t1 += part[g * 4]; t2 += part[g * 4 + 1]; }
+    if (blockIdx.x == 0) {
+      dgamma[0] = accumulate ? dgamma[0] + t2 : t2;
+      dbeta[0] = accumulate ? dbeta[0] + t1 : t1;
+    }
     bc[0] = t1 / (float)n; bc[1] = t2 / (float)n;
   }
   __syncthreads();
   const float m1 = bc[0], m2 = bc[1], gr = gamma[0] * rstd;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+  int64_t c0, c1;
+  cbam_chunk(n, c0, c1);
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 1024) {
     const float a = gs[i], dp = dgs[i] * a * (1.0f - a);
     dconv[i] = gr * (dp - m1 - (v[i] - mean) * rstd * m2);
   }
@@ -321,8 +370,10 @@ __global__ void ep_cbam_dh_kernel(const float* __restrict__ dh, const float* __r
 
 // ---------------------------------------------------------------------------------------------
 constexpr int CBAM_NT = 7;    // fc1.weight (rd,D) | fc2.weight (D,rd) | conv.weight (2 KS KS) | bn.weight | bn.bias | fc.weight fc.bias
+constexpr int CBAM_WRS = 64;
+static int cbam_bn_groups(int64_t n) { const int64_t g = n / 2048; return g < 1 ? 1 : (g > CBAM_BN_G ? CBAM_BN_G : (int)g); }
 struct CbamWs {
-  float *tab, *ha, *hm, *hs, *pre, *gc, *maps, *conv, *gs, *st, *T;
+  float *tab, *ha, *hm, *hs, *pre, *gc, *maps, *conv, *gs, *st, *T, *red, *wpart;
   int* arg;
   float *dT, *dgs, *dconv, *dmaps, *E, *dpre, *dh, *dha, *dhm;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
@@ -354,7 +405,7 @@ static CbamWs cbam_carve(const ep_cbam_dims& d, void* base, bool head) {
   };
   const size_t B = d.B, D = d.D, N = d.N, rd = d.rd;
   w.tab = take(B * 3 * D); w.ha = take(B * rd); w.hm = take(B * rd); w.hs = take(B * rd); w.pre = take(B * D); w.gc = take(B * D);
-  w.maps = take(B * 2 * N); w.conv = take(B * N); w.gs = take(B * N); w.st = take(4); w.T = take(B * D);
+  w.maps = take(B * 2 * N); w.conv = take(B * N); w.gs = take(B * N); w.st = take(4); w.T = take(B * D); w.red = take(CBAM_BN_G * 4); w.wpart = take((size_t)CBAM_WRS * 2 * d.ks * d.ks);
   w.arg = reinterpret_cast<int*>(take(B * N));
   w.dT = take(B * D); w.dgs = take(B * N); w.dconv = take(B * N); w.dmaps = take(B * 2 * N); w.E = take(B * D); w.dpre = take(B * D);
   w.dh = take(B * rd); w.dha = take(B * rd); w.dhm = take(B * rd);
@@ -468,8 +519,10 @@ static int cbam_forward_core(const ep_cbam_dims& d, const CbamTok& t, const floa
   // spatial gate
   EP_TRY(cbam_rows<0>(d, t, w.gc, w.maps, w.arg, st));
   hipLaunchKernelGGL(ep_cbam_conv_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, w.maps, pr.conv_w, side, d.ks, nn, w.conv);
-  hipLaunchKernelGGL(ep_cbam_bn1_kernel, dim3(1), dim3(1024), 0, st, w.conv, nn, bn.training, bn.eps, bn.momentum, pr.bn_w, pr.bn_b,
-                     bn.running_mean, bn.running_var, bn.nbt, w.st, w.gs);
+  const int bng = cbam_bn_groups(nn);
+  if (bn.training) hipLaunchKernelGGL(ep_cbam_bn1_part_kernel, dim3(bng), dim3(1024), 0, st, w.conv, nn, w.red);
+  hipLaunchKernelGGL(ep_cbam_bn1_kernel, dim3(bng), dim3(1024), 0, st, w.conv, nn, bn.training, bn.eps, bn.momentum, pr.bn_w, pr.bn_b,
+                     bn.running_mean, bn.running_var, bn.nbt, w.red, w.st, w.gs);
   EP_LAUNCH_CHECK("ep_cbam spatial gate kernels");
   return cbam_acc<0>(d, t, w.gs, nullptr, w.tab, w.gc, w.T, y, st);
 }
@@ -484,9 +537,14 @@ static int cbam_backward_core(const ep_cbam_dims& d, const CbamTok& t, const ep_
                      (float*)nullptr, w.dT);
   EP_LAUNCH_CHECK("ep_cbam_dpre_kernel (dT)");
   EP_TRY(cbam_rows<1>(d, t, w.dT, w.dgs, nullptr, st));                                   // pass D: d gs
-  hipLaunchKernelGGL(ep_cbam_bn1_bwd_kernel, dim3(1), dim3(1024), 0, st, w.dgs, w.gs, w.conv, nn, w.st, pr.bn_w, acc, gr.bn_w, gr.bn_b,
-                     w.dconv);
-  hipLaunchKernelGGL(ep_cbam_conv_wgrad_kernel, dim3(2 * d.ks * d.ks), dim3(256), 0, st, w.dconv, w.maps, B, side, d.ks, acc, gr.conv_w);
+  const int bng = cbam_bn_groups(nn);
+  hipLaunchKernelGGL(ep_cbam_bn1_bwd_part_kernel, dim3(bng), dim3(1024), 0, st, w.dgs, w.gs, w.conv, nn, w.st, w.red);
+  hipLaunchKernelGGL(ep_cbam_bn1_bwd_kernel, dim3(bng), dim3(1024), 0, st, w.dgs, w.gs, w.conv, nn, w.st, pr.bn_w, acc, w.red, gr.bn_w,
+                     gr.bn_b, w.dconv);
+  const int nw = 2 * d.ks * d.ks;
+  int wrs = B / 16; wrs = wrs < 1 ? 1 : (wrs > CBAM_WRS ? CBAM_WRS : wrs);
+  hipLaunchKernelGGL(ep_cbam_conv_wgrad_kernel, dim3(nw, wrs), dim3(256), 0, st, w.dconv, w.maps, B, side, d.ks, w.wpart);
+  hipLaunchKernelGGL(ep_cbam_conv_wfin_kernel, dim3((nw + 127) / 128), dim3(128), 0, st, w.wpart, nw, wrs, acc, gr.conv_w);
   hipLaunchKernelGGL(ep_cbam_conv_bwd_kernel, dim3((unsigned)((2 * nn + 255) / 256)), dim3(256), 0, st, w.dconv, pr.conv_w, side, d.ks,
                      2 * nn, w.dmaps);
   EP_LAUNCH_CHECK("ep_cbam spatial backward kernels");

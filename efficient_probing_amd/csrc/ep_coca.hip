@@ -59,13 +59,22 @@ __global__ __launch_bounds__(256) void ep_coca_q_kernel(const float* __restrict_
 }
 
 // u[h,d] = sum_c qh[h*dh + c] * Wk[c,d]   (Wk = to_kv.weight[0:dh], coca_pytorch.py:320)
-__global__ __launch_bounds__(256) void ep_coca_u_kernel(const float* __restrict__ qh, const float* __restrict__ Wk,
-                                                      int D, int dh, float* __restrict__ u) {
-  const int d = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
-  if (d >= D) return;
+__global__ __launch_bounds__(1024) void ep_coca_u_kernel(const float* __restrict__ qh, const float* __restrict__ Wk,
+                                                       int D, int dh, float* __restrict__ u) {
+  __shared__ float sm[32][33];                       // grid (D / 32, H): 32 column lanes x 32 row lanes over the dh key rows
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx, h = blockIdx.y;
   float acc = 0.f;
-  for (int c = 0; c < dh; ++c) acc = fmaf(qh[h * dh + c], Wk[(int64_t)c * D + d], acc);
-  u[(int64_t)h * D + d] = acc;
+  if (d < D)
+    for (int c = ty; c < dh; c += 32) acc = fmaf(qh[h * dh + c], Wk[(int64_t)c * D + d], acc);
+  sm[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && d < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
+    u[(int64_t)h * D + d] = t;
+  }
 }
 
 // dqh[h*dh + c] = du[h] . Wk[c]
@@ -82,41 +91,54 @@ __global__ __launch_bounds__(256) void ep_coca_dqh_kernel(const float* __restric
 
 // Per 64-column block of d:  dWk[c,d] (+)= sum_h qh[h,c] du[h,d];  dWq[j,d] (+)= scale dqh[j] qn[d];
 // dqn[d] = scale sum_j Wq[j,d] dqh[j];  rows 1..M-1 of d img_queries <- 0 (no gradient path) unless accumulating.
+// (two launches: the row-wise parts on grid (D / 64, 8), every row range split eight ways, and the (1 x HD) . (HD x D)
+// product for d qn on grid D / 32 with 1024 threads = 32 column lanes x 32 row lanes)
 __global__ __launch_bounds__(256) void ep_coca_qgrad_kernel(const float* __restrict__ qh, const float* __restrict__ dqh,
-                                                          const float* __restrict__ du, const float* __restrict__ qn,
-                                                          const float* __restrict__ Wq, int D, int H, int dh, int M,
-                                                          float scale, int accumulate, float* __restrict__ dWk,
-                                                          float* __restrict__ dWq, float* __restrict__ dqn,
-                                                          float* __restrict__ dimgq) {
-  extern __shared__ float sh[];          // qh[HD] | dqh[HD] | partial[4][64]
+                                                          const float* __restrict__ du, const float* __restrict__ qn, int D, int H,
+                                                          int dh, int M, float scale, int accumulate, float* __restrict__ dWk,
+                                                          float* __restrict__ dWq, float* __restrict__ dimgq) {
   const int HD = H * dh;
-  float* s_qh = sh; float* s_dqh = sh + HD; float* part = sh + 2 * HD;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  for (int i = tid; i < HD; i += 256) { s_qh[i] = qh[i]; s_dqh[i] = dqh[i]; }
-  __syncthreads();
   const int d = blockIdx.x * 64 + tx;
-  const bool ok = d < D;
-  float acc = 0.f;
-  if (ok) {
-    for (int c = ty; c < dh; c += 4) {
-      float g = 0.f;
-      for (int h = 0; h < H; ++h) g = fmaf(s_qh[h * dh + c], du[(int64_t)h * D + d], g);
-      float* o = dWk + (int64_t)c * D + d;
-      *o = accumulate ? *o + g : g;
-    }
-    const float qd = qn[d] * scale;
-    for (int j = ty; j < HD; j += 4) {
-      acc = fmaf(Wq[(int64_t)j * D + d], s_dqh[j], acc);
-      float* o = dWq + (int64_t)j * D + d;
-      const float g = s_dqh[j] * qd;
-      *o = accumulate ? *o + g : g;
-    }
-    if (!accumulate)
-      for (int r = 1 + ty; r < M; r += 4) dimgq[(int64_t)r * D + d] = 0.f;
+  if (d >= D) return;
+  const int gy = gridDim.y, by = blockIdx.y;
+  auto range = [&](int n, int& r0, int& r1) { const int per = (n + gy - 1) / gy; r0 = by * per; r1 = (r0 + per) < n ? (r0 + per) : n; };
+  int r0, r1;
+  range(dh, r0, r1);
+  for (int c = r0 + ty; c < r1; c += 4) {
+    float g = 0.f;
+    for (int h = 0; h < H; ++h) g = fmaf(qh[h * dh + c], du[(int64_t)h * D + d], g);
+    float* o = dWk + (int64_t)c * D + d;
+    *o = accumulate ? *o + g : g;
   }
-  part[ty * 64 + tx] = acc;
+  const float qd = qn[d] * scale;
+  range(HD, r0, r1);
+  for (int j = r0 + ty; j < r1; j += 4) {
+    float* o = dWq + (int64_t)j * D + d;
+    const float g = dqh[j] * qd;
+    *o = accumulate ? *o + g : g;
+  }
+  if (!accumulate) {
+    range(M - 1, r0, r1);
+    for (int r = 1 + r0 + ty; r < 1 + r1; r += 4) dimgq[(int64_t)r * D + d] = 0.f;
+  }
+}
+__global__ __launch_bounds__(1024) void ep_coca_dqn_kernel(const float* __restrict__ dqh, const float* __restrict__ Wq, int D, int HD,
+                                                         float scale, float* __restrict__ dqn) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx;
+  float acc = 0.f;
+  if (d < D)
+    for (int j = ty; j < HD; j += 32) acc = fmaf(Wq[(int64_t)j * D + d], dqh[j], acc);
+  sm[ty][tx] = acc;
   __syncthreads();
-  if (ty == 0 && ok) dqn[d] = ((part[tx] + part[64 + tx]) + (part[128 + tx] + part[192 + tx])) * scale;
+  if (ty == 0 && d < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
+    dqn[d] = t * scale;
+  }
 }
 
 // LayerNorm backward of the single live row: dgamma (+)= dqn * xhat; d img_queries[0] (+)= the usual
@@ -222,7 +244,7 @@ static int coca_forward_core(const ep_coca_dims& d, const void* x, int x_dtype, 
   const float scale = (float)pow((double)d.dh, -0.5);                   // coca_pytorch.py:266
   hipLaunchKernelGGL(ep_coca_q_kernel, dim3((HD + 3) / 4), dim3(256), (size_t)D * 4, st, pr.img_queries, pr.gamma,
                      pr.beta, pr.to_q, D, HD, ln_eps, scale, w.xhat, w.qn, w.lnstat, w.qh);
-  hipLaunchKernelGGL(ep_coca_u_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.qh, pr.to_kv, D, d.dh, w.u);
+  hipLaunchKernelGGL(ep_coca_u_kernel, dim3((D + 31) / 32, d.H), dim3(1024), 0, st, w.qh, pr.to_kv, D, d.dh, w.u);
   EP_LAUNCH_CHECK("ep_coca_q/u kernels");
   EP_TRY(pool_forward(coca_pool_params(d, x, bstride, index, w, x_dtype), st));
   const float* Wv = pr.to_kv + (int64_t)d.dh * D;
@@ -293,9 +315,9 @@ static int coca_backward_core(const ep_coca_dims& d, const void* x, int x_dtype,
   // dWv = sum over heads of the partials -> rows dh..2dh-1 of d to_kv
   EP_TRY(reduce_partials(w.dWvp, d.H, d.dh * D, 1.0f, accumulate, gr.to_kv + (int64_t)d.dh * D, nullptr, st));
   hipLaunchKernelGGL(ep_coca_dqh_kernel, dim3((HD + 3) / 4), dim3(256), 0, st, w.du, pr.to_kv, D, d.dh, HD, w.dqh);
-  hipLaunchKernelGGL(ep_coca_qgrad_kernel, dim3((D + 63) / 64), dim3(256), (size_t)(2 * HD + 256) * 4, st, w.qh, w.dqh,
-                     w.du, w.qn, pr.to_q, D, d.H, d.dh, d.M, scale, accumulate, gr.to_kv, gr.to_q, w.dqn,
-                     gr.img_queries);
+  hipLaunchKernelGGL(ep_coca_qgrad_kernel, dim3((D + 63) / 64, 8), dim3(256), 0, st, w.qh, w.dqh, w.du, w.qn, D, d.H, d.dh, d.M,
+                     scale, accumulate, gr.to_kv, gr.to_q, gr.img_queries);
+  hipLaunchKernelGGL(ep_coca_dqn_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dqh, pr.to_q, D, HD, scale, w.dqn);
   hipLaunchKernelGGL(ep_coca_lnbwd_kernel, dim3(1), dim3(256), 0, st, w.dqn, w.xhat, pr.gamma, w.lnstat, D, accumulate,
                      gr.gamma, gr.img_queries, (float*)nullptr);
   EP_LAUNCH_CHECK("ep_coca backward kernels");
@@ -448,15 +470,24 @@ int ep_coca_head_eval_forward(const ep_coca_dims* dims, const void* x, int x_dty
 namespace ep {
 
 // w[h,d] = gk[d] * u[h,d],  u[h,d] = sum_c qh[h*dh + c] Wk[h*dh + c, d]
-__global__ __launch_bounds__(256) void ep_cae_w_kernel(const float* __restrict__ qh, const float* __restrict__ Wk,
-                                                     const float* __restrict__ gk, int D, int dh, float* __restrict__ u,
-                                                     float* __restrict__ wq) {
-  const int d = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
-  if (d >= D) return;
+__global__ __launch_bounds__(1024) void ep_cae_w_kernel(const float* __restrict__ qh, const float* __restrict__ Wk,
+                                                      const float* __restrict__ gk, int D, int dh, float* __restrict__ u,
+                                                      float* __restrict__ wq) {
+  __shared__ float sm[32][33];                       // grid (D / 32, H): 32 column lanes x 32 row lanes over the head's dh rows
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx, h = blockIdx.y;
   float acc = 0.f;
-  for (int c = 0; c < dh; ++c) acc = fmaf(qh[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
-  u[(int64_t)h * D + d] = acc;
-  wq[(int64_t)h * D + d] = acc * gk[d];
+  if (d < D)
+    for (int c = ty; c < dh; c += 32) acc = fmaf(qh[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
+  sm[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && d < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
+    u[(int64_t)h * D + d] = t;
+    wq[(int64_t)h * D + d] = t * gk[d];
+  }
 }
 
 // dqh[j] = Wk[j,:] . du[h(j),:]
@@ -473,34 +504,43 @@ __global__ __launch_bounds__(256) void ep_cae_dqh_kernel(const float* __restrict
 
 // per 64-column block of d:  dWk[j,d] (+)= qh[j] du[h(j),d];  dWq[j,d] (+)= scale dqh[j] qn[d];
 // dqn[d] = scale sum_j Wq[j,d] dqh[j]
+// (two launches: the outer products on grid (D / 64, 16) -- 64 columns x 4 row lanes over a sixteenth of the rows -- and
+// the (1 x D) . (D x D) product for d qn on grid D / 32 with 1024 threads = 32 column lanes x 32 row lanes)
 __global__ __launch_bounds__(256) void ep_cae_qgrad_kernel(const float* __restrict__ qh, const float* __restrict__ dqh,
-                                                         const float* __restrict__ du, const float* __restrict__ qn,
-                                                         const float* __restrict__ Wq, int D, int dh, float scale,
-                                                         int accumulate, float* __restrict__ dWk, float* __restrict__ dWq,
-                                                         float* __restrict__ dqn) {
-  extern __shared__ float sh[];          // qh[D] | dqh[D] | partial[4][64]
-  float* s_qh = sh; float* s_dqh = sh + D; float* part = sh + 2 * D;
+                                                         const float* __restrict__ du, const float* __restrict__ qn, int D, int dh,
+                                                         float scale, int accumulate, float* __restrict__ dWk,
+                                                         float* __restrict__ dWq) {
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  for (int i = tid; i < D; i += 256) { s_qh[i] = qh[i]; s_dqh[i] = dqh[i]; }
-  __syncthreads();
   const int d = blockIdx.x * 64 + tx;
-  const bool ok = d < D;
-  float acc = 0.f;
-  if (ok) {
-    const float qd = qn[d] * scale;
-    for (int j = ty; j < D; j += 4) {
-      const float gk_ = s_qh[j] * du[(int64_t)(j / dh) * D + d];
-      float* o1 = dWk + (int64_t)j * D + d;
-      *o1 = accumulate ? *o1 + gk_ : gk_;
-      const float gq = s_dqh[j] * qd;
-      float* o2 = dWq + (int64_t)j * D + d;
-      *o2 = accumulate ? *o2 + gq : gq;
-      acc = fmaf(Wq[(int64_t)j * D + d], s_dqh[j], acc);
-    }
+  if (d >= D) return;
+  const int per = (D + gridDim.y - 1) / gridDim.y;
+  const int j0 = blockIdx.y * per, j1 = (j0 + per) < D ? (j0 + per) : D;
+  const float qd = qn[d] * scale;
+  for (int j = j0 + ty; j < j1; j += 4) {
+    const float gk_ = qh[j] * du[(int64_t)(j / dh) * D + d];
+    float* o1 = dWk + (int64_t)j * D + d;
+    *o1 = accumulate ? *o1 + gk_ : gk_;
+    const float gq = dqh[j] * qd;
+    float* o2 = dWq + (int64_t)j * D + d;
+    *o2 = accumulate ? *o2 + gq : gq;
   }
-  part[ty * 64 + tx] = acc;
+}
+__global__ __launch_bounds__(1024) void ep_cae_dqn_kernel(const float* __restrict__ dqh, const float* __restrict__ Wq, int D,
+                                                        float scale, float* __restrict__ dqn) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx;
+  float acc = 0.f;
+  if (d < D)
+    for (int j = ty; j < D; j += 32) acc = fmaf(Wq[(int64_t)j * D + d], dqh[j], acc);
+  sm[ty][tx] = acc;
   __syncthreads();
-  if (ty == 0 && ok) dqn[d] = ((part[tx] + part[64 + tx]) + (part[128 + tx] + part[192 + tx])) * scale;
+  if (ty == 0 && d < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
+    dqn[d] = t * scale;
+  }
 }
 
 constexpr int CAE_NT = 16;
@@ -597,7 +637,7 @@ static int cae_forward_core(const ep_cae_dims& d, const void* x, int x_dtype, in
   }
   hipLaunchKernelGGL(ep_coca_q_kernel, dim3((D + 3) / 4), dim3(256), (size_t)D * 4, st, pr.query, pr.nq_w, pr.nq_b, pr.q_w, D, D,
                      ln_eps, scale, w.xhat, w.qn, w.lnstat, w.qh);
-  hipLaunchKernelGGL(ep_cae_w_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, w.qh, pr.k_w, pr.nk_w, D, dh, w.u, w.wq);
+  hipLaunchKernelGGL(ep_cae_w_kernel, dim3((D + 31) / 32, d.H), dim3(1024), 0, st, w.qh, pr.k_w, pr.nk_w, D, dh, w.u, w.wq);
   hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.v_w, pr.nv_w, pr.nv_b, D, w.Wvs, w.bo,
                      (const float*)nullptr);
   EP_LAUNCH_CHECK("ep_cae query kernels");
@@ -653,8 +693,9 @@ static int cae_backward_core(const ep_cae_dims& d, const void* x, int x_dtype, i
   hipLaunchKernelGGL(ep_cae_du_kernel, dim3((D + 255) / 256), dim3(256), 0, st, w.dw, w.u, pr.nk_w, D, d.H, acc, w.du, gr.nk_w,
                      gr.nk_b);
   hipLaunchKernelGGL(ep_cae_dqh_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.du, pr.k_w, D, dh, w.dqh);
-  hipLaunchKernelGGL(ep_cae_qgrad_kernel, dim3((D + 63) / 64), dim3(256), (size_t)(2 * D + 256) * 4, st, w.qh, w.dqh, w.du, w.qn,
-                     pr.q_w, D, dh, scale, acc, gr.k_w, gr.q_w, w.dqn);
+  hipLaunchKernelGGL(ep_cae_qgrad_kernel, dim3((D + 63) / 64, 16), dim3(256), 0, st, w.qh, w.dqh, w.du, w.qn, D, dh, scale, acc,
+                     gr.k_w, gr.q_w);
+  hipLaunchKernelGGL(ep_cae_dqn_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dqh, pr.q_w, D, scale, w.dqn);
   hipLaunchKernelGGL(ep_coca_lnbwd_kernel, dim3(1), dim3(256), 0, st, w.dqn, w.xhat, pr.nq_w, w.lnstat, D, acc, gr.nq_w,
                      gr.query, gr.nq_b);
   EP_LAUNCH_CHECK("ep_cae backward kernels");
