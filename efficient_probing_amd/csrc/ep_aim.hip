@@ -46,29 +46,34 @@ __global__ __launch_bounds__(256) void ep_chanstats_kernel(const void* __restric
 // ---- combine the B per-image rows: mu, r, nb = -mu r; running statistics (momentum, unbiased variance) -------------
 // equal counts N per image:  mean = (1/B) sum_b mean_b ;  M2 = sum_b M2_b + N sum_b (mean_b - mean)^2
 // 16 columns x 16 row-lanes per workgroup; every partial sum has a fixed order (reproducible).
-__global__ __launch_bounds__(256) void ep_chancombine_kernel(const float* __restrict__ img, const int* __restrict__ index,
-                                                           int B, int N, int D, float eps, float momentum,
-                                                           float* __restrict__ mu_out, float* __restrict__ r_out,
-                                                           float* __restrict__ nb_out, float* __restrict__ rmean,
-                                                           float* __restrict__ rvar, int64_t* __restrict__ nbt) {
-  __shared__ float sm[RL][CG];
-  __shared__ float bc[CG];
-  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
-  const int c = blockIdx.x * CG + tx;
+__global__ __launch_bounds__(1024) void ep_chancombine_kernel(const float* __restrict__ img, const int* __restrict__ index,
+                                                            int B, int N, int D, float eps, float momentum,
+                                                            float* __restrict__ mu_out, float* __restrict__ r_out,
+                                                            float* __restrict__ nb_out, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, int64_t* __restrict__ nbt) {
+  __shared__ float sm[32][33];                       // 32 column lanes x 32 row lanes over the B image rows (grid (D + 31) / 32)
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   const bool ok = c < D;
+  auto colsum32 = [&](float v) {
+    __syncthreads();
+    sm[ty][tx] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
+    return t;
+  };
   float s = 0.f;
-  if (ok) for (int b = ty; b < B; b += RL) s += img[(int64_t)(index ? index[b] : b) * 2 * D + c];
-  s = colreduce(s, sm, tx, ty);
-  if (ty == 0) bc[tx] = s / (float)B;
-  __syncthreads();
-  const float mean = bc[tx];
+  if (ok) for (int b = ty; b < B; b += 32) s += img[(int64_t)(index ? index[b] : b) * 2 * D + c];
+  const float mean = colsum32(s) / (float)B;
   float q = 0.f;
-  if (ok) for (int b = ty; b < B; b += RL) {
+  if (ok) for (int b = ty; b < B; b += 32) {
     const float* row = img + (int64_t)(index ? index[b] : b) * 2 * D;
     const float dm = row[c] - mean;
     q += fmaf((float)N * dm, dm, row[D + c]);
   }
-  q = colreduce(q, sm, tx, ty);
+  q = colsum32(q);
   if (ty == 0 && ok) {
     const float n = (float)B * (float)N;
     const float var = q / n;                                  // biased: used for the normalisation
@@ -93,14 +98,23 @@ __global__ void ep_aim_evalstats_kernel(const float* __restrict__ rmean, const f
 }
 
 // u[h,d] = scale sum_c cls[h dh + c] Wk[h dh + c, d] ;  wq[h,d] = r[d] u[h,d]
-__global__ __launch_bounds__(256) void ep_aim_w_kernel(const float* __restrict__ cls, const float* __restrict__ Wk,
-                                                     const float* __restrict__ r, int D, int dh, float scale,
-                                                     float* __restrict__ wq) {
-  const int d = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
-  if (d >= D) return;
+__global__ __launch_bounds__(1024) void ep_aim_w_kernel(const float* __restrict__ cls, const float* __restrict__ Wk,
+                                                      const float* __restrict__ r, int D, int dh, float scale,
+                                                      float* __restrict__ wq) {
+  __shared__ float sm[32][33];                       // grid (D / 32, H): 32 column lanes x 32 row lanes over the head's dh rows
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx, h = blockIdx.y;
   float acc = 0.f;
-  for (int c = 0; c < dh; ++c) acc = fmaf(cls[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
-  wq[(int64_t)h * D + d] = acc * scale * r[d];
+  if (d < D)
+    for (int c = ty; c < dh; c += 32) acc = fmaf(cls[h * dh + c], Wk[(int64_t)(h * dh + c) * D + d], acc);
+  sm[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && d < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
+    wq[(int64_t)h * D + d] = t * scale * r[d];
+  }
 }
 
 // du[h,d] = r[d] dw[h,d] ;  dcls[j] (+)= scale Wk[j,:] . du[h(j),:]      (one wave per row j)
@@ -233,14 +247,14 @@ static int aim_forward_core(const ep_aim_dims& d, const void* x, int x_dtype, in
       EP_TRY(channel_stats(x, x_dtype, bstride, index, d.B, d.N, D, w.img, st));
       img = w.img; iidx = nullptr;
     }
-    hipLaunchKernelGGL(ep_chancombine_kernel, dim3((D + CG - 1) / CG), dim3(256), 0, st, img, iidx, d.B, d.N, D, bn.eps,
+    hipLaunchKernelGGL(ep_chancombine_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, img, iidx, d.B, d.N, D, bn.eps,
                        bn.momentum, w.mu, w.r, w.nb, bn.running_mean, bn.running_var, bn.nbt);
   } else {
     EP_REQUIRE(bn.running_mean && bn.running_var, EP_E_ARG, "aim eval: running statistics missing");
     hipLaunchKernelGGL(ep_aim_evalstats_kernel, dim3((D + 255) / 256), dim3(256), 0, st, bn.running_mean, bn.running_var, D,
                        bn.eps, w.mu, w.r, w.nb);
   }
-  hipLaunchKernelGGL(ep_aim_w_kernel, dim3((D + 255) / 256, d.H), dim3(256), 0, st, pr.cls_token, pr.k_w, w.r, D, dh, scale, w.wq);
+  hipLaunchKernelGGL(ep_aim_w_kernel, dim3((D + 31) / 32, d.H), dim3(1024), 0, st, pr.cls_token, pr.k_w, w.r, D, dh, scale, w.wq);
   hipLaunchKernelGGL(ep_cae_wv_kernel, dim3((D + 3) / 4), dim3(256), 0, st, pr.v_w, w.r, w.nb, D, w.Wvs, w.bo,
                      (const float*)nullptr);
   EP_LAUNCH_CHECK("ep_aim query kernels");

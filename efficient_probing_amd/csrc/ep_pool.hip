@@ -218,9 +218,50 @@ __global__ __launch_bounds__(256) void ep_token_stats_kernel(const void* __restr
   if (lane == 0) { stats[r * 2] = mean; stats[r * 2 + 1] = rstd; }
 }
 
+// rows of up to 1280 values: the row stays in registers (CPL 16-byte chunks per lane) -- ONE read of the tokens; same
+// operations in the same order as ep_token_stats_kernel, so the two give the same bits
+template <bool BF16, int CPL>
+__global__ __launch_bounds__(256) void ep_token_stats_reg_kernel(const void* __restrict__ x, int64_t bstride, int N, int64_t rows,
+                                                               int D, float eps, float* __restrict__ stats) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = (r / N) * bstride + (r % N) * (int64_t)D;
+  f4 v[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = lane * 4 + 256 * k;
+    v[k] = d < D ? load_tok4<BF16>(x, e0 + d) : f4{0.f, 0.f, 0.f, 0.f};
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+    if (lane * 4 + 256 * k < D) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+    if (lane * 4 + 256 * k < D) {
+      const f4 c = v[k] - mean;
+      q = fmaf(c.x, c.x, q); q = fmaf(c.y, c.y, q); q = fmaf(c.z, c.z, q); q = fmaf(c.w, c.w, q);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { stats[r * 2] = mean; stats[r * 2 + 1] = rstd; }
+}
+
 int token_stats(const void* x, int x_bf16, int64_t bstride, int B, int N, int D, float eps, float* stats, hipStream_t st) {
   const int64_t rows = (int64_t)B * N;
   const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int cpl = (D + 255) / 256;
+#define EP_TS(C_)                                                                                                          \
+  if (cpl == C_) {                                                                                                         \
+    if (x_bf16) hipLaunchKernelGGL((ep_token_stats_reg_kernel<true, C_>), dim3(grid), dim3(256), 0, st, x, bstride, N, rows, D, eps, stats); \
+    else hipLaunchKernelGGL((ep_token_stats_reg_kernel<false, C_>), dim3(grid), dim3(256), 0, st, x, bstride, N, rows, D, eps, stats);       \
+    EP_LAUNCH_CHECK("ep_token_stats_reg_kernel");                                                                          \
+    return 0;                                                                                                              \
+  }
+  EP_TS(1) EP_TS(2) EP_TS(3) EP_TS(4) EP_TS(5)
+#undef EP_TS
   if (x_bf16) hipLaunchKernelGGL(ep_token_stats_kernel<true>, dim3(grid), dim3(256), 0, st, x, bstride, N, rows, D, eps, stats);
   else hipLaunchKernelGGL(ep_token_stats_kernel<false>, dim3(grid), dim3(256), 0, st, x, bstride, N, rows, D, eps, stats);
   EP_LAUNCH_CHECK("ep_token_stats_kernel");

@@ -48,19 +48,19 @@ __global__ void ep_sp_dphat_kernel(const float* __restrict__ dy, const float* __
   if (i < total) dPh[i] = dy[i] * g[i % D];
 }
 // simpool, after the second pass:  dt = scale g * du ;  d g (+)= sum_b (dy Phat + scale du t) ;  d beta (+)= sum_b dy
-__global__ __launch_bounds__(256) void ep_sp_colgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Ph,
-                                                          const float* __restrict__ du, const float* __restrict__ t,
-                                                          const float* __restrict__ g, int B, int D, float scale,
-                                                          int accumulate, float* __restrict__ dt, float* __restrict__ dg,
-                                                          float* __restrict__ dbeta) {
-  __shared__ float sm[RL][CG];
-  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
-  const int c = blockIdx.x * CG + tx;
+__global__ __launch_bounds__(1024) void ep_sp_colgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Ph,
+                                                           const float* __restrict__ du, const float* __restrict__ t,
+                                                           const float* __restrict__ g, int B, int D, float scale,
+                                                           int accumulate, float* __restrict__ dt, float* __restrict__ dg,
+                                                           float* __restrict__ dbeta) {
+  __shared__ float sm[32][33];                       // 32 column lanes x 32 row lanes (grid (D + 31) / 32)
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   const bool ok = c < D;
   float sg = 0.f, sb = 0.f;
   if (ok) {
     const float gc = g[c] * scale;
-    for (int b = ty; b < B; b += RL) {
+    for (int b = ty; b < B; b += 32) {
       const int64_t i = (int64_t)b * D + c;
       const float d_ = du[i], y_ = dy[i];
       dt[i] = gc * d_;
@@ -68,11 +68,17 @@ __global__ __launch_bounds__(256) void ep_sp_colgrad_kernel(const float* __restr
       sb += y_;
     }
   }
-  sg = colreduce(sg, sm, tx, ty);
-  sb = colreduce(sb, sm, tx, ty);
+  __syncthreads(); sm[ty][tx] = sg; __syncthreads();
+  float tg = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) tg += sm[i][tx];
+  __syncthreads(); sm[ty][tx] = sb; __syncthreads();
+  float tb = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) tb += sm[i][tx];
   if (ty == 0 && ok) {
-    dg[c] = accumulate ? dg[c] + sg : sg;
-    dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+    dg[c] = accumulate ? dg[c] + tg : tg;
+    dbeta[c] = accumulate ? dbeta[c] + tb : tb;
   }
 }
 
@@ -298,7 +304,7 @@ static int sp_backward_core(const ep_simpool_dims& d, const void* x, int x_dtype
     hipLaunchKernelGGL(ep_sp_dphat_kernel, dim3(eg), dim3(256), 0, st, dy, pr.norm_w, total, D, w.dPh);
     q.dP = w.dPh;
     EP_TRY(imgq_backward(q, st));
-    hipLaunchKernelGGL(ep_sp_colgrad_kernel, dim3((D + CG - 1) / CG), dim3(256), 0, st, dy, w.Ph, w.du, w.t, pr.norm_w, B, D,
+    hipLaunchKernelGGL(ep_sp_colgrad_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, dy, w.Ph, w.du, w.t, pr.norm_w, B, D,
                        scale, acc, w.dt, gr.norm_w, gr.norm_b);
     EP_LAUNCH_CHECK("simpool backward kernels");
     if (gidx) { gap = w.ghat; gap_ld = D; }           // gathered by the forward
