@@ -18,9 +18,27 @@
 
 namespace ep {
 
-// ---- per-image column statistics: img[b][0][c] = mean_n x[b,n,c], img[b][1][c] = sum_n (x - mean)^2 ----------------
-// one workgroup per (image, 1024-channel slab); a thread owns 4 channels and walks the N tokens (rows are read
-// coalesced, 16 B per lane).  Single pass with the first token as the shift (the shifted-data algorithm).
+// Per-image sums over the tokens are taken as FOUR partial sums (tokens n = w, w + 4, ... in increasing n) combined as
+// (p0 + p1) + (p2 + p3) -- the order shared by ep_chanstats_kernel, ep_xhat_mean_kernel (ep_clip.hip) and the fused
+// ep_tokimg_kernel below, so cached tables and tables recomputed for a batch hold the same bits.
+__device__ __forceinline__ void chan_finish(const f4& k, const f4& s1, const f4& s2, float inv, f4& mean, f4& m2) {
+  mean = f4{__fadd_rn(k.x, __fmul_rn(s1.x, inv)), __fadd_rn(k.y, __fmul_rn(s1.y, inv)), __fadd_rn(k.z, __fmul_rn(s1.z, inv)),
+            __fadd_rn(k.w, __fmul_rn(s1.w, inv))};
+  m2 = f4{__fsub_rn(s2.x, __fmul_rn(__fmul_rn(s1.x, s1.x), inv)), __fsub_rn(s2.y, __fmul_rn(__fmul_rn(s1.y, s1.y), inv)),
+          __fsub_rn(s2.z, __fmul_rn(__fmul_rn(s1.z, s1.z), inv)), __fsub_rn(s2.w, __fmul_rn(__fmul_rn(s1.w, s1.w), inv))};
+}
+__device__ __forceinline__ void chan_acc(f4& s1, f4& s2, const f4& v, const f4& k) {
+  const f4 d = {__fsub_rn(v.x, k.x), __fsub_rn(v.y, k.y), __fsub_rn(v.z, k.z), __fsub_rn(v.w, k.w)};
+  s1.x = __fadd_rn(s1.x, d.x); s1.y = __fadd_rn(s1.y, d.y); s1.z = __fadd_rn(s1.z, d.z); s1.w = __fadd_rn(s1.w, d.w);
+  s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
+}
+__device__ __forceinline__ f4 sum4parts(const f4& a, const f4& b, const f4& c, const f4& d) {
+  return f4{__fadd_rn(__fadd_rn(a.x, b.x), __fadd_rn(c.x, d.x)), __fadd_rn(__fadd_rn(a.y, b.y), __fadd_rn(c.y, d.y)),
+            __fadd_rn(__fadd_rn(a.z, b.z), __fadd_rn(c.z, d.z)), __fadd_rn(__fadd_rn(a.w, b.w), __fadd_rn(c.w, d.w))};
+}
+
+// per image and channel, shifted by the first token k: mean = k + s1 / N, M2 = s2 - s1^2 / N with s1 = sum (x - k),
+// s2 = sum (x - k)^2     (a thread owns 4 channels and walks the tokens)
 template <bool BF16>
 __global__ __launch_bounds__(256) void ep_chanstats_kernel(const void* __restrict__ x, int64_t bstride,
                                                          const int* __restrict__ index, int N, int D,
@@ -30,17 +48,102 @@ __global__ __launch_bounds__(256) void ep_chanstats_kernel(const void* __restric
   if (c >= D) return;
   const int64_t e0 = (int64_t)(index ? index[b] : b) * bstride + c;
   const f4 k = load_tok4<BF16>(x, e0);
-  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int n = 1; n < N; ++n) {
-    const f4 v = load_tok4<BF16>(x, e0 + (int64_t)n * D) - k;
-    s1 += v;
-    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  f4 s1[4] = {z, z, z, z}, s2[4] = {z, z, z, z};
+  for (int n0 = 0; n0 < N; n0 += 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (n0 + t < N) chan_acc(s1[t], s2[t], load_tok4<BF16>(x, e0 + (int64_t)(n0 + t) * D), k);
   }
+  const f4 a1 = sum4parts(s1[0], s1[1], s1[2], s1[3]), a2 = sum4parts(s2[0], s2[1], s2[2], s2[3]);
   const float inv = 1.0f / (float)N;
+  f4 mean, m2;
+  chan_finish(k, a1, a2, inv, mean, m2);
   float* o = img + (int64_t)b * 2 * D + c;
-  *reinterpret_cast<f4*>(o) = k + s1 * inv;
-  *reinterpret_cast<f4*>(o + D) = s2 - s1 * s1 * inv;
+  *reinterpret_cast<f4*>(o) = mean;
+  *reinterpret_cast<f4*>(o + D) = m2;
+}
+
+// xhat accumulation of the fused kernel and of ep_xhat_mean_kernel: s += (x - mean) * rstd, one fma per component
+__device__ __forceinline__ void xhat_acc(f4& s, const f4& v, float mean, float rstd) {
+  s.x = fmaf(__fsub_rn(v.x, mean), rstd, s.x); s.y = fmaf(__fsub_rn(v.y, mean), rstd, s.y);
+  s.z = fmaf(__fsub_rn(v.z, mean), rstd, s.z); s.w = fmaf(__fsub_rn(v.w, mean), rstd, s.w);
+}
+
+// ONE read of the tokens for the per-token LayerNorm statistics AND a per-image table: one 4-wave workgroup per image, wave w
+// takes the tokens n = w, w + 4, ... with the row in registers (CPL 16-byte chunks per lane) -- the statistics exactly as
+// ep_token_stats_reg_kernel computes them -- and every lane accumulates its channels:
+//   MODE 0: the shifted channel sums of ep_chanstats_kernel -> img (B, 2, D)        (SimPool: the mean token)
+//   MODE 1: sum_n xhat -> xbar (B, D) = mean_n xhat                                  (CLIP: the mean row)
+template <bool BF16, int CPL, int MODE>
+__global__ __launch_bounds__(256) void ep_tokimg_kernel(const void* __restrict__ x, int64_t bstride, int N, int D, float eps,
+                                                      float* __restrict__ stats, float* __restrict__ out) {
+  constexpr int NA = MODE == 0 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float part[4 * 64 * CPL * NA * 4];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t e0 = (int64_t)b * bstride;
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  f4 k[CPL], a1[CPL], a2[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int d = lane * 4 + 256 * j;
+    k[j] = (MODE == 0 && d < D) ? load_tok4<BF16>(x, e0 + d) : z;
+    a1[j] = z; a2[j] = z;
+  }
+  for (int n = w; n < N; n += 4) {
+    f4 v[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int d = lane * 4 + 256 * j;
+      v[j] = d < D ? load_tok4<BF16>(x, e0 + (int64_t)n * D + d) : z;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      if (lane * 4 + 256 * j < D) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      if (lane * 4 + 256 * j < D) {
+        const f4 c = v[j] - mean;
+        q = fmaf(c.x, c.x, q); q = fmaf(c.y, c.y, q); q = fmaf(c.z, c.z, q); q = fmaf(c.w, c.w, q);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { stats[((int64_t)b * N + n) * 2] = mean; stats[((int64_t)b * N + n) * 2 + 1] = rstd; }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      if (lane * 4 + 256 * j >= D) continue;
+      if (MODE == 0) chan_acc(a1[j], a2[j], v[j], k[j]);
+      else xhat_acc(a1[j], v[j], mean, rstd);
+    }
+  }
+  f4* mine = reinterpret_cast<f4*>(part) + ((size_t)w * 64 + lane) * CPL * NA;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) { mine[j * NA] = a1[j]; if (MODE == 0) mine[j * NA + 1] = a2[j]; }
+  __syncthreads();
+  if (w != 0) return;
+  const f4* p0 = reinterpret_cast<const f4*>(part) + (size_t)lane * CPL * NA;
+  const size_t ws = (size_t)64 * CPL * NA;
+  const float inv = 1.0f / (float)N;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int d = lane * 4 + 256 * j;
+    if (d >= D) continue;
+    const f4 t1 = sum4parts(p0[j * NA], p0[ws + j * NA], p0[2 * ws + j * NA], p0[3 * ws + j * NA]);
+    if (MODE == 0) {
+      const f4 t2 = sum4parts(p0[j * NA + 1], p0[ws + j * NA + 1], p0[2 * ws + j * NA + 1], p0[3 * ws + j * NA + 1]);
+      f4 mean, m2;
+      chan_finish(k[j], t1, t2, inv, mean, m2);
+      float* o = out + (int64_t)b * 2 * D + d;
+      *reinterpret_cast<f4*>(o) = mean;
+      *reinterpret_cast<f4*>(o + D) = m2;
+    } else {
+      *reinterpret_cast<f4*>(out + (int64_t)b * D + d) =
+          f4{__fmul_rn(t1.x, inv), __fmul_rn(t1.y, inv), __fmul_rn(t1.z, inv), __fmul_rn(t1.w, inv)};
+    }
+  }
 }
 
 // ---- combine the B per-image rows: mu, r, nb = -mu r; running statistics (momentum, unbiased variance) -------------
@@ -211,6 +314,24 @@ int channel_stats(const void* x, int x_dtype, int64_t bstride, const int32_t* in
   else
     hipLaunchKernelGGL(ep_chanstats_kernel<false>, grid, dim3(256), 0, st, x, bstride, index, N, D, img);
   EP_LAUNCH_CHECK("ep_chanstats_kernel");
+  return 0;
+}
+
+// token statistics (B, N, 2) + a per-image table in one read of a dense batch (mode 0: channel statistics (B, 2, D);
+// mode 1: the mean normalised row (B, D)) for rows of up to 1280 values (the callers check: otherwise the two kernels)
+int token_image_stats(const void* x, int x_dtype, int64_t bstride, int B, int N, int D, float eps, int mode, float* stats, float* out,
+                      hipStream_t st) {
+  const int cpl = (D + 255) / 256;
+  EP_REQUIRE(cpl <= 5 && D % 4 == 0 && (mode == 0 || mode == 1), EP_E_UNSUPPORTED, "token_image_stats: D=%d mode=%d", D, mode);
+  const bool bf = x_dtype == EP_DTYPE_BF16;
+#define EP_TI(C_, M_)                                                                                                          \
+  if (cpl == C_ && mode == M_) {                                                                                               \
+    if (bf) hipLaunchKernelGGL((ep_tokimg_kernel<true, C_, M_>), dim3(B), dim3(256), 0, st, x, bstride, N, D, eps, stats, out);  \
+    else hipLaunchKernelGGL((ep_tokimg_kernel<false, C_, M_>), dim3(B), dim3(256), 0, st, x, bstride, N, D, eps, stats, out);    \
+  }
+  EP_TI(1, 0) EP_TI(2, 0) EP_TI(3, 0) EP_TI(4, 0) EP_TI(5, 0) EP_TI(1, 1) EP_TI(2, 1) EP_TI(3, 1) EP_TI(4, 1) EP_TI(5, 1)
+#undef EP_TI
+  EP_LAUNCH_CHECK("ep_tokimg_kernel");
   return 0;
 }
 

@@ -18,6 +18,9 @@
 
 namespace ep {
 
+int token_image_stats(const void* x, int x_dtype, int64_t bstride, int B, int N, int D, float eps, int mode, float* stats, float* out,
+                      hipStream_t st);   // ep_aim.hip
+
 // xbar[b,:] = mean_n xhat[b,n,:],  xhat = (x - mean_n) rstd_n      (a thread owns 4 channels and walks the tokens)
 template <bool BF16>
 __global__ __launch_bounds__(256) void ep_xhat_mean_kernel(const void* __restrict__ x, int64_t bstride,
@@ -29,10 +32,23 @@ __global__ __launch_bounds__(256) void ep_xhat_mean_kernel(const void* __restric
   const int64_t img = (int64_t)(index ? index[b] : b);
   const int64_t e0 = img * bstride + c;
   const float* ts = tokstat + img * N * 2;
-  f4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int n = 0; n < N; ++n) s += (load_tok4<BF16>(x, e0 + (int64_t)n * D) - ts[2 * n]) * ts[2 * n + 1];
-  *reinterpret_cast<f4*>(xbar + (int64_t)b * D + c) = s * (1.0f / (float)N);
+  // four partial sums (n = w, w + 4, ...) combined as (p0 + p1) + (p2 + p3): the order of ep_tokimg_kernel (ep_aim.hip)
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  f4 s[4] = {z, z, z, z};
+  for (int n0 = 0; n0 < N; n0 += 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (n0 + t < N) {
+        const f4 v = load_tok4<BF16>(x, e0 + (int64_t)(n0 + t) * D);
+        const float mean = ts[2 * (n0 + t)], rstd = ts[2 * (n0 + t) + 1];
+        s[t].x = fmaf(__fsub_rn(v.x, mean), rstd, s[t].x); s[t].y = fmaf(__fsub_rn(v.y, mean), rstd, s[t].y);
+        s[t].z = fmaf(__fsub_rn(v.z, mean), rstd, s[t].z); s[t].w = fmaf(__fsub_rn(v.w, mean), rstd, s[t].w);
+      }
+  }
+  const float inv = 1.0f / (float)N;
+  const f4 t = {__fadd_rn(__fadd_rn(s[0].x, s[1].x), __fadd_rn(s[2].x, s[3].x)), __fadd_rn(__fadd_rn(s[0].y, s[1].y), __fadd_rn(s[2].y, s[3].y)),
+                __fadd_rn(__fadd_rn(s[0].z, s[1].z), __fadd_rn(s[2].z, s[3].z)), __fadd_rn(__fadd_rn(s[0].w, s[1].w), __fadd_rn(s[2].w, s[3].w))};
+  *reinterpret_cast<f4*>(xbar + (int64_t)b * D + c) = f4{__fmul_rn(t.x, inv), __fmul_rn(t.y, inv), __fmul_rn(t.z, inv), __fmul_rn(t.w, inv)};
 }
 
 // t0 = g * xbar + b + pos_0
@@ -288,12 +304,16 @@ static int clip_forward_core(const ep_clip_dims& d, const void* x, int x_dtype, 
   const float scale = (float)pow((double)dh, -0.5);                        // attention_pool2d.py:124
   const float* pos0 = pr.pos_embed; const float* posN = pr.pos_embed + D;  // row 0: the mean row; rows 1..N: the patch rows
   const float* Wq = pr.qkv_w; const float* Wk = pr.qkv_w + (int64_t)D * D; const float* Wv = pr.qkv_w + 2 * (int64_t)D * D;
+  bool have_xbar = false;
   if (!tokstat) {
     EP_REQUIRE(!index, EP_E_ARG, "clip: an indexed token store needs precomputed token statistics");
-    EP_TRY(token_stats(x, x_dtype == EP_DTYPE_BF16, bstride, B, N, D, d.ln_eps, w.tstat, st));
+    // statistics and the mean normalised row in ONE read of the batch (same bits as the two separate kernels)
+    have_xbar = (D + 255) / 256 <= 5;
+    if (have_xbar) EP_TRY(token_image_stats(x, x_dtype, bstride, B, N, D, d.ln_eps, 1, w.tstat, w.xbar, st));
+    else EP_TRY(token_stats(x, x_dtype == EP_DTYPE_BF16, bstride, B, N, D, d.ln_eps, w.tstat, st));
     tokstat = w.tstat;
   }
-  EP_TRY(xhat_mean(x, x_dtype, bstride, index, tokstat, B, N, D, w.xbar, st));
+  if (!have_xbar) EP_TRY(xhat_mean(x, x_dtype, bstride, index, tokstat, B, N, D, w.xbar, st));
   const int64_t nd = (int64_t)B * D, nhd = (int64_t)BH * D;
   hipLaunchKernelGGL(ep_clip_t0_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, w.xbar, pr.norm_w, pr.norm_b, pos0, nd,
                      D, w.t0);

@@ -19,6 +19,8 @@
 
 namespace ep {
 
+int token_image_stats(const void* x, int x_dtype, int64_t bstride, int B, int N, int D, float eps, int mode, float* stats, float* out,
+                      hipStream_t st);   // ep_aim.hip
 int channel_stats(const void* x, int x_dtype, int64_t bstride, const int32_t* index, int B, int N, int D, float* img,
                   hipStream_t st);                                   // ep_aim.hip
 
@@ -242,6 +244,12 @@ static int sp_tables(const ep_simpool_dims& d, const void* x, int x_dtype, int64
                      const SpCache& c, float ln_eps, const SpWs& w, bool compute, const float*& tokstat, const float*& gap,
                      int64_t& gap_ld, const int32_t*& gap_index, hipStream_t st) {
   tokstat = c.token_stats;
+  if (!tokstat && !c.image_stats && !index && (d.D + 255) / 256 <= 5) {
+    // neither table is cached: both in ONE read of the batch (same bits as the two separate kernels)
+    if (compute) EP_TRY(token_image_stats(x, x_dtype, bstride, d.B, d.N, d.D, ln_eps, 0, w.stats, w.img, st));
+    tokstat = w.stats; gap = w.img; gap_index = nullptr; gap_ld = 2 * (int64_t)d.D;
+    return 0;
+  }
   if (!tokstat) {
     EP_REQUIRE(!index, EP_E_ARG, "simpool: an indexed token store needs precomputed token statistics");
     if (compute) EP_TRY(token_stats(x, x_dtype == EP_DTYPE_BF16, bstride, d.B, d.N, d.D, ln_eps, w.stats, st));
