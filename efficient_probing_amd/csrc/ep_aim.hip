@@ -50,7 +50,15 @@ __global__ __launch_bounds__(256) void ep_chanstats_kernel(const void* __restric
   const f4 k = load_tok4<BF16>(x, e0);
   const f4 z = {0.f, 0.f, 0.f, 0.f};
   f4 s1[4] = {z, z, z, z}, s2[4] = {z, z, z, z};
-  for (int n0 = 0; n0 < N; n0 += 4) {
+  int n0 = 0;
+  for (; n0 + 8 <= N; n0 += 8) {                       // eight independent row loads in flight
+    f4 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = load_tok4<BF16>(x, e0 + (int64_t)(n0 + t) * D);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) chan_acc(s1[t & 3], s2[t & 3], v[t], k);
+  }
+  for (; n0 < N; n0 += 4) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       if (n0 + t < N) chan_acc(s1[t], s2[t], load_tok4<BF16>(x, e0 + (int64_t)(n0 + t) * D), k);

@@ -35,7 +35,20 @@ __global__ __launch_bounds__(256) void ep_xhat_mean_kernel(const void* __restric
   // four partial sums (n = w, w + 4, ...) combined as (p0 + p1) + (p2 + p3): the order of ep_tokimg_kernel (ep_aim.hip)
   const f4 z = {0.f, 0.f, 0.f, 0.f};
   f4 s[4] = {z, z, z, z};
-  for (int n0 = 0; n0 < N; n0 += 4) {
+  int n0 = 0;
+  for (; n0 + 8 <= N; n0 += 8) {                       // eight independent row loads in flight
+    f4 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = load_tok4<BF16>(x, e0 + (int64_t)(n0 + t) * D);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float mean = ts[2 * (n0 + t)], rstd = ts[2 * (n0 + t) + 1];
+      f4& a = s[t & 3];
+      a.x = fmaf(__fsub_rn(v[t].x, mean), rstd, a.x); a.y = fmaf(__fsub_rn(v[t].y, mean), rstd, a.y);
+      a.z = fmaf(__fsub_rn(v[t].z, mean), rstd, a.z); a.w = fmaf(__fsub_rn(v[t].w, mean), rstd, a.w);
+    }
+  }
+  for (; n0 < N; n0 += 4) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       if (n0 + t < N) {
