@@ -475,7 +475,7 @@ static int iqf_dispatch(const PoolParams& p, float* dq, bool bwd, hipStream_t st
   switch (iqf_cpl(p.D)) {
     case 1: return iqf_launch<1, 4>(p, dq, bwd, st);
     case 2: return iqf_launch<2, 4>(p, dq, bwd, st);
-    case 3: return iqf_launch<3, 2>(p, dq, bwd, st);
+    case 3: return iqf_launch<3, 4>(p, dq, bwd, st);
     case 4: return iqf_launch<4, 2>(p, dq, bwd, st);
     default: return iqf_launch<5, 2>(p, dq, bwd, st);
   }

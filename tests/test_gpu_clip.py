@@ -180,5 +180,7 @@ def test_full_width_per_image_query_kernel_vs_generic_kernels(shape):
             outs.append([y.detach().float().cpu().numpy()] + [p.grad.cpu().numpy() for p in plist[:-2]])
         finally:
             lib.ep_debug_force_generic_pool(0)
-    for a, g in zip(*outs):
-        np.testing.assert_allclose(a, g, rtol=2e-4, atol=2e-5 * max(1e-3, float(np.abs(g).max())))
+    for i, (a, g) in enumerate(zip(*outs)):
+        # with bf16 tokens the module returns the pooled rows in bf16: values 1e-7 apart can round to neighbouring bf16 numbers
+        rtol = 1e-2 if (bf16 and i == 0) else 2e-4
+        np.testing.assert_allclose(a, g, rtol=rtol, atol=2e-5 * max(1e-3, float(np.abs(g).max())))
