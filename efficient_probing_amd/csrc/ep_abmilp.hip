@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void ep_sum_kernel(const float* __restrict__ v
 
 // ---------------------------------------------------------------------------------------------
 struct AbWs {
-  float *QKV, *SA, *O, *Xa, *H, *s, *a, *da, *ds, *dXa, *dS, *dQKV, *part, *stage;
+  float *QKV, *SA, *O, *Xa, *H, *s, *a, *da, *ds, *dXa, *dS, *dQKV, *part, *stage, *skws;
+  size_t skws_floats;
   size_t pool_total;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
@@ -214,6 +215,7 @@ static AbWs ab_carve(const ep_abmilp_dims& d, void* base, bool head) {
   w.s = take(BN); w.a = take(BN); w.da = take(BN); w.ds = take(BN);
   w.dXa = take(BN * D); w.dS = take(BN * d.N); w.dQKV = take(BN * 3 * D);
   w.part = take((size_t)WCS_RS * D); w.stage = take(16 * D);
+  w.skws_floats = (size_t)16 * D * D; w.skws = take(w.skws_floats);     // split-K slices of the D x D weight gradients
   w.pool_total = off;
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
@@ -316,6 +318,7 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
   EP_TRY(wcolsum(w.H, nullptr, BN, D, acc, gr.b1, w, st));
   {
     GemmParams g = mk(w.H, D, w.Xa, D, gr.w1, D, D, D, BN); g.accumulate = acc;       // dW1 = dG^T Xa
+    g.skws = w.skws; g.skws_floats = w.skws_floats;
     EP_TRY(gemm(false, false, g, 1, st));
   }
   hipLaunchKernelGGL(ep_outer_rows_kernel, dim3(eg), dim3(256), 0, st, w.a, dout, (int64_t)BN, N, D / 4, w.dXa);
@@ -328,6 +331,7 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
   EP_TRY(wcolsum(w.dXa, nullptr, BN, D, acc, gr.proj_b, w, st));
   {
     GemmParams g = mk(w.dXa, D, w.O, D, gr.proj_w, D, D, D, BN); g.accumulate = acc;  // dWp = dXa^T O
+    g.skws = w.skws; g.skws_floats = w.skws_floats;
     EP_TRY(gemm(false, false, g, 1, st));
   }
   float* dO = w.H;                                                                   // dG is dead from here on
@@ -357,6 +361,7 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
   }
   {
     GemmParams g = mk(w.dQKV, 3 * D, x, D, gr.qkv, D, 3 * D, D, BN); g.accumulate = acc;   // dWqkv = dQKV^T x
+    g.skws = w.skws; g.skws_floats = w.skws_floats;
     EP_TRY(gemm(false, false, g, 1, st));
   }
   return 0;

@@ -131,7 +131,8 @@ static int dv_colsum(const float* a, const float* x, const float* stats, int64_t
 constexpr int DV_NT = 13;     // n1.w n1.b | qkv.w | proj.w proj.b | n2.w n2.b | fc1.w fc1.b | fc2.w fc2.b | fc.weight fc.bias
 struct DvWs {
   float *stat1, *h, *QKV, *S, *ctx, *x1, *stat2, *h2, *pre, *h1, *x2, *h1sum;
-  float *g0, *g1, *dx1, *dh2, *dctx, *dS, *dQKV, *scr;
+  float *g0, *g1, *dx1, *dh2, *dctx, *dS, *dQKV, *scr, *skws;
+  size_t skws_floats;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
@@ -167,6 +168,7 @@ static DvWs dv_carve(const ep_dinovit_dims& d, void* base, bool head) {
   w.dS = take(B * H * N * N); w.dQKV = take(R * 3 * D);
   const size_t wmax = 3 * D > Hd ? 3 * D : Hd;
   w.scr = take((size_t)(DV_RS + 16 + 2) * 2 * wmax);
+  w.skws_floats = (size_t)16 * D * D; w.skws = take(w.skws_floats);      // split-K slices of the weight gradients
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
     w.y = take(B * D); w.z = take(B * D); w.rstd = take(D);
@@ -272,7 +274,8 @@ static int dv_backward_core(const ep_dinovit_dims& d, const float* x, const ep_d
   EP_LAUNCH_CHECK("ep_dinovit LN2 backward kernels");
   // x1 = x + ctx Wp^T + bp
   EP_TRY(dv_colsum(w.dx1, nullptr, nullptr, R, D, acc, gr.proj_b, nullptr, w.scr, st));
-  { GemmParams g = vg(w.dx1, D, w.ctx, D, gr.proj_w, D, D, D, R); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }      // d Wp
+  { GemmParams g = vg(w.dx1, D, w.ctx, D, gr.proj_w, D, D, D, R); g.accumulate = acc; g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(gemm(false, false, g, 1, st)); }                                                               // d Wp
   EP_TRY(gemm(true, false, vg(w.dx1, D, pr.proj_w, D, w.dctx, D, R, D, D), 1, st));                       // dctx = dx1 Wp
   const int64_t s3 = (int64_t)N * 3 * D, sS = (int64_t)H * N * N, sD = (int64_t)N * D;
   for (int hh = 0; hh < H; ++hh) {
@@ -290,7 +293,8 @@ static int dv_backward_core(const ep_dinovit_dims& d, const float* x, const ep_d
       g.sAz = sS; g.extA = N; g.sBz = s3; g.extB = dh; g.sCz = s3; g.alpha = scale; EP_TRY(gemm(false, false, g, B, st)); }
   }
   // QKV = h Wqkv^T ; h = LayerNorm1(x): the tokens are frozen, only the affine parameters take a gradient
-  { GemmParams g = vg(w.dQKV, 3 * D, w.h, D, gr.qkv_w, D, 3 * D, D, R); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }
+  { GemmParams g = vg(w.dQKV, 3 * D, w.h, D, gr.qkv_w, D, 3 * D, D, R); g.accumulate = acc; g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(gemm(false, false, g, 1, st)); }
   EP_TRY(gemm(true, false, vg(w.dQKV, 3 * D, pr.qkv_w, D, w.dh2, D, R, D, 3 * D), 1, st));               // dh (reusing dh2)
   EP_TRY(dv_colsum(w.dh2, x, w.stat1, R, D, acc, gr.n1_w, gr.n1_b, w.scr, st));
   return 0;

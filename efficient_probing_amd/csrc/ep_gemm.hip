@@ -431,8 +431,46 @@ bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k) {
          vec_ok(p.A, p.lda, p.sAz, p.extA) && vec_ok(p.B, p.ldb, p.sBz, p.extB);
 }
 
+// Few output tiles and a very long K (weight gradients over all B N token rows): the tiles cannot fill the chip, so K is cut
+// into `splits` slices that run as the batch dimension into the caller's scratch and are summed in slice order
+// (ep_reduce_partials_kernel: deterministic).  Needs a contiguous C, no bias, one batch.
+static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st, bool* done) {
+  *done = false;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_SPLITK"); on = e ? atoi(e) : 1; }
+  if (!on || !p.skws || p.bias || p.ldc != p.N || p.alpha != 1.0f || p.K < 8192 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
+  const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
+  const long cus = cu_count();
+  if (tiles >= 2 * cus) return 0;
+  // the matrix pipe of a CU is shared by its workgroups: makespan ~ ceil(tiles * s / CUs) * (K / s); pick the s <= 16 with
+  // the smallest one (ties: fewer slices) among those that divide K into whole K-tiles and fit the scratch
+  const int64_t mn = (int64_t)p.M * p.N;
+  int splits = 1;
+  double best = (double)((tiles + cus - 1) / cus);
+  for (int sp = 2; sp <= 16; ++sp) {
+    if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < 1024) continue;
+    const double cost = (double)((tiles * sp + cus - 1) / cus) / sp;
+    if (cost < best * 0.95) { best = cost; splits = sp; }
+  }
+  if (splits < 2) return 0;
+  const int kc = p.K / splits;
+  GemmParams q = p;
+  q.K = kc; q.C = p.skws; q.ldc = p.N; q.sCz = mn; q.accumulate = 0; q.skws = nullptr;
+  q.sAz = a_k ? kc : (int64_t)kc * p.lda;
+  q.sBz = b_k ? kc : (int64_t)kc * p.ldb;
+  EP_TRY(gemm(a_k, b_k, q, splits, st));
+  EP_TRY(reduce_partials(p.skws, splits, (int)mn, 1.0f, p.accumulate, p.C, nullptr, st));
+  *done = true;
+  return 0;
+}
+
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
+  if (batch == 1 && p.skws) {
+    bool done = false;
+    EP_TRY(gemm_split_k(a_k, b_k, p, st, &done));
+    if (done) return 0;
+  }
   const bool vec = vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
   const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;
   static int force_bm = -1;

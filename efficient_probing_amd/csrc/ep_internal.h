@@ -43,6 +43,7 @@ struct GemmParams {
   float alpha;
   int accumulate;
   int side;                         // 1: runs on the aux stream beside a token pass (kernel choice hint)
+  float* skws; size_t skws_floats;  // optional scratch for a split of K (few output tiles, very long K): >= 2 M N floats
 };
 
 // Work appended to the launch of the second token pass (ep_side.h: run_side_task)
