@@ -173,6 +173,127 @@ __global__ __launch_bounds__(1024) void ep_bn_bwd_fused_kernel(const float* __re
   }
 }
 
+// Many rows (B > 4096: the BatchNorm over all B N token rows of the DOLG head): the same two-stage scheme with 1024-thread
+// workgroups of 64 column lanes x 16 row lanes -- 256-byte row segments instead of 64-byte ones.
+constexpr int BNW_C = 64, BNW_R = 16;
+__device__ __forceinline__ float bnw_reduce(float v, float (*sm)[BNW_C], int tx, int ty) {
+  __syncthreads();
+  sm[ty][tx] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < BNW_R; ++i) t += sm[i][tx];
+  return t;
+}
+__global__ __launch_bounds__(1024) void ep_bnw_stats_kernel(const float* __restrict__ y, int B, int Dp, float* __restrict__ partial) {
+  __shared__ float sm[BNW_R][BNW_C];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * BNW_C + tx;
+  const bool ok = col < Dp;
+  int r0, r1;
+  chunk_rows(B, gridDim.y, blockIdx.y, r0, r1);
+  const int n = r1 - r0;
+  float s = 0.f;
+  if (ok) for (int b = r0 + ty; b < r1; b += BNW_R) s += y[(int64_t)b * Dp + col];
+  const float mu = n > 0 ? bnw_reduce(s, sm, tx, ty) / (float)n : 0.f;
+  float q = 0.f;
+  if (ok) for (int b = r0 + ty; b < r1; b += BNW_R) { const float d = y[(int64_t)b * Dp + col] - mu; q = fmaf(d, d, q); }
+  q = bnw_reduce(q, sm, tx, ty);
+  if (ty == 0 && ok) {
+    partial[((int64_t)blockIdx.y * 2 + 0) * Dp + col] = mu;
+    partial[((int64_t)blockIdx.y * 2 + 1) * Dp + col] = q;
+  }
+}
+__global__ __launch_bounds__(1024) void ep_bnw_apply_kernel(const float* __restrict__ y, int B, int Dp, float eps, float momentum,
+                                                          const float* __restrict__ partial, float* __restrict__ z,
+                                                          float* __restrict__ rstd_out, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, int64_t* __restrict__ nbt) {
+  __shared__ float bc[2][BNW_C];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * BNW_C + tx;
+  const bool ok = col < Dp;
+  const int nrs = gridDim.y;
+  if (ty == 0 && ok) {
+    float tot = 0.f;
+    for (int r = 0; r < nrs; ++r) {
+      int a0, a1; chunk_rows(B, nrs, r, a0, a1);
+      tot += (float)(a1 - a0) * partial[((int64_t)r * 2 + 0) * Dp + col];
+    }
+    const float mu = tot / (float)B;
+    float m2 = 0.f;
+    for (int r = 0; r < nrs; ++r) {
+      int a0, a1; chunk_rows(B, nrs, r, a0, a1);
+      const float d = partial[((int64_t)r * 2 + 0) * Dp + col] - mu;
+      m2 += partial[((int64_t)r * 2 + 1) * Dp + col] + (float)(a1 - a0) * d * d;
+    }
+    const float var = m2 / (float)B;
+    const float rs = 1.0f / sqrtf(var + eps);
+    bc[0][tx] = mu; bc[1][tx] = rs;
+    if (blockIdx.y == 0) {
+      rstd_out[col] = rs;
+      const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+      rmean[col] = (1.0f - momentum) * rmean[col] + momentum * mu;
+      rvar[col] = (1.0f - momentum) * rvar[col] + momentum * unbiased;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  __syncthreads();
+  const float mu = bc[0][tx], rs = bc[1][tx];
+  int r0, r1;
+  chunk_rows(B, nrs, blockIdx.y, r0, r1);
+  if (ok) for (int b = r0 + ty; b < r1; b += BNW_R) z[(int64_t)b * Dp + col] = (y[(int64_t)b * Dp + col] - mu) * rs;
+}
+__global__ __launch_bounds__(1024) void ep_bnw_bwd_stats_kernel(const float* __restrict__ dz, const float* __restrict__ z, int B, int Dp,
+                                                              float* __restrict__ partial) {
+  __shared__ float sm[BNW_R][BNW_C];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * BNW_C + tx;
+  const bool ok = col < Dp;
+  int r0, r1;
+  chunk_rows(B, gridDim.y, blockIdx.y, r0, r1);
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) for (int b = r0 + ty; b < r1; b += BNW_R) {
+    const float g = dz[(int64_t)b * Dp + col];
+    s1 += g;
+    s2 = fmaf(g, z[(int64_t)b * Dp + col], s2);
+  }
+  s1 = bnw_reduce(s1, sm, tx, ty);
+  s2 = bnw_reduce(s2, sm, tx, ty);
+  if (ty == 0 && ok) {
+    partial[((int64_t)blockIdx.y * 2 + 0) * Dp + col] = s1;
+    partial[((int64_t)blockIdx.y * 2 + 1) * Dp + col] = s2;
+  }
+}
+// (dy may alias dz: every element is read before it is written by the same thread)
+__global__ __launch_bounds__(1024) void ep_bnw_bwd_apply_kernel(const float* dz, const float* __restrict__ z,
+                                                              const float* __restrict__ rstd, int B, int Dp,
+                                                              const float* __restrict__ partial, float* dy) {
+  __shared__ float bc[2][BNW_C];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * BNW_C + tx;
+  const bool ok = col < Dp;
+  const int nrs = gridDim.y;
+  if (ty == 0 && ok) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nrs; ++r) {
+      s1 += partial[((int64_t)r * 2 + 0) * Dp + col];
+      s2 += partial[((int64_t)r * 2 + 1) * Dp + col];
+    }
+    bc[0][tx] = s1 / (float)B; bc[1][tx] = s2 / (float)B;
+  }
+  __syncthreads();
+  const float m1 = bc[0][tx], m2 = bc[1][tx];
+  int r0, r1;
+  chunk_rows(B, nrs, blockIdx.y, r0, r1);
+  if (ok) {
+    const float rs = rstd[col];
+    for (int b = r0 + ty; b < r1; b += BNW_R) {
+      const int64_t i = (int64_t)b * Dp + col;
+      dy[i] = rs * (dz[i] - m1 - z[i] * m2);
+    }
+  }
+}
+
 __global__ void ep_bn_eval_kernel(const float* __restrict__ y, int64_t total, int Dp, float eps,
                                   const float* __restrict__ rmean, const float* __restrict__ rvar,
                                   float* __restrict__ z) {
@@ -368,6 +489,13 @@ int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, f
     EP_LAUNCH_CHECK("ep_bn_fused_kernel");
     return 0;
   }
+  if (B > 4096) {
+    const dim3 gw((Dp + BNW_C - 1) / BNW_C, RS_MAX);
+    hipLaunchKernelGGL(ep_bnw_stats_kernel, gw, dim3(1024), 0, st, y, B, Dp, partial);
+    hipLaunchKernelGGL(ep_bnw_apply_kernel, gw, dim3(1024), 0, st, y, B, Dp, eps, momentum, partial, z, rstd, rmean, rvar, nbt);
+    EP_LAUNCH_CHECK("ep_bnw_train kernels");
+    return 0;
+  }
   const dim3 grid((Dp + CG - 1) / CG, bn_row_splits(B));
   hipLaunchKernelGGL(ep_bn_stats_kernel, grid, dim3(256), 0, st, y, B, Dp, partial);
   hipLaunchKernelGGL(ep_bn_apply_kernel, grid, dim3(256), 0, st, y, B, Dp, eps, momentum, partial, z, rstd, rmean,
@@ -388,6 +516,13 @@ int bn_backward(const float* dz, const float* z, const float* rstd, int B, int D
   if (bn_fused(B)) {
     hipLaunchKernelGGL(ep_bn_bwd_fused_kernel, dim3((Dp + 15) / 16), dim3(1024), 0, st, dz, z, rstd, B, Dp, dy);
     EP_LAUNCH_CHECK("ep_bn_bwd_fused_kernel");
+    return 0;
+  }
+  if (B > 4096) {
+    const dim3 gw((Dp + BNW_C - 1) / BNW_C, RS_MAX);
+    hipLaunchKernelGGL(ep_bnw_bwd_stats_kernel, gw, dim3(1024), 0, st, dz, z, B, Dp, partial);
+    hipLaunchKernelGGL(ep_bnw_bwd_apply_kernel, gw, dim3(1024), 0, st, dz, z, rstd, B, Dp, partial, dy);
+    EP_LAUNCH_CHECK("ep_bnw_bwd kernels");
     return 0;
   }
   const dim3 grid((Dp + CG - 1) / CG, bn_row_splits(B));
