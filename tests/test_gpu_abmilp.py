@@ -124,3 +124,26 @@ def test_batch_that_fills_the_chip_vs_oracle_and_determinism():
         for n, a, p in zip(ABMILP_PARAM_NAMES, ref, eng.params_list):
             close(n, p.grad.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, floor=1e-6)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_weight_gradients_over_many_token_rows_vs_oracle():
+    """40 images of 256 x 256 tokens: 10240 token rows put the D x D and 3D x D weight-gradient contractions on the K-split path
+    (gemm_split_k: few output tiles, K >= 8192) -- every gradient against the CPU oracle's autograd."""
+    from efficient_probing_amd import functional as F_
+    case = AbmilpCase("rows", B=40, N=256, D=256, C=50, seed=5, sharp=True)
+    inp = make_abmilp_inputs(case)
+    head, plist = native_head(case, inp)
+    x, t = torch.from_numpy(inp["x_buf"]).to(DEV), torch.from_numpy(inp["targets"]).to(DEV)
+    loss, _ = F_.cross_entropy_loss(head(x), t)
+    loss.backward()
+    oh = AO.make_head(case.D, case.C)
+    oparams = AO.head_params(oh)
+    with torch.no_grad():
+        for n, p in zip(ABMILP_PARAM_NAMES, oparams):
+            p.copy_(torch.from_numpy(inp[n]))
+    oh.train()
+    oloss = torch.nn.functional.cross_entropy(oh(torch.from_numpy(inp["x_buf"])), torch.from_numpy(inp["targets"]))
+    oloss.backward()
+    assert loss.item() == pytest.approx(oloss.item(), rel=2e-5)
+    for n, p, q in zip(ABMILP_PARAM_NAMES, plist, oparams):
+        close(n, p.grad.cpu().numpy(), q.grad.numpy().reshape(p.shape), rtol=2e-4, floor=2e-5)
