@@ -76,11 +76,6 @@ __global__ void ep_dv_gelu_bwd_bcast_kernel(const float* __restrict__ pre, const
   auto dg = [](float x) { return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x); };
   reinterpret_cast<f4*>(dpre)[i] = f4{u.x * dg(v.x), u.y * dg(v.y), u.z * dg(v.z), u.w * dg(v.w)};
 }
-// out = a + b   (float4)
-__global__ void ep_dv_add_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t total4, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total4) reinterpret_cast<f4*>(out)[i] = reinterpret_cast<const f4*>(a)[i] + reinterpret_cast<const f4*>(b)[i];
-}
 
 // Column reductions over MANY rows in two deterministic stages: grid (ceil(W / 64), RS); a workgroup = 64 columns x 4 row lanes
 // over its row chunk -> part[which][rs][col]; the partials are summed by ep_reduce_partials_kernel.
