@@ -142,10 +142,32 @@ __global__ __launch_bounds__(256) void ep_cait_clsgrad_kernel(const float* __res
 // batch reductions of the class entry, per 16 columns d:
 //   dw[h,d]   += chat[d] sum_b dS_c[b,h]
 //   dchat[d]   = sum_h wq[h,d] sum_b dS_c[b,h] + sum_b sum_h a_c[b,h] dP[b,h,d]
-__global__ __launch_bounds__(1024) void ep_cait_clsred_kernel(const float* __restrict__ csc, const float* __restrict__ dP,
+// (two launches: ep_cait_clsred_part_kernel sums dS_c[r] dP[r,:] over a sixteenth of the B H rows per workgroup row --
+// 1024 threads = 32 column lanes x 32 row lanes -- into part[chunk][D]; ep_cait_clsred_kernel adds the chunks in order and
+// finishes the class-row terms)
+constexpr int CAIT_RS = 16;
+__global__ __launch_bounds__(1024) void ep_cait_clsred_part_kernel(const float* __restrict__ csc, const float* __restrict__ dP,
+                                                                 int64_t rows, int D, float* __restrict__ part) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + tx;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+  float acc = 0.f;
+  if (d < D)
+    for (int64_t r = r0 + ty; r < r1; r += 32) acc = fmaf(csc[r * 2 + 1], dP[r * D + d], acc);
+  sm[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && d < D) {
+    float g = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g += sm[i][tx];
+    part[(int64_t)blockIdx.y * D + d] = g;
+  }
+}
+__global__ __launch_bounds__(1024) void ep_cait_clsred_kernel(const float* __restrict__ csc, const float* __restrict__ part, int nparts,
                                                             const float* __restrict__ wq, const float* __restrict__ chat, int B,
                                                             int H, int D, float* __restrict__ dw, float* __restrict__ dchat) {
-  // 1024 threads = 32 column lanes x 32 row lanes over the B H rows of dP (grid (D + 31) / 32)
   __shared__ float sm[32][33];
   __shared__ float sds[32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -164,18 +186,10 @@ __global__ __launch_bounds__(1024) void ep_cait_clsred_kernel(const float* __res
       sds[h] = t;
     }
   }
-  float acc = 0.f;
-  if (ok) {
-    const int64_t rows = (int64_t)B * H;
-    for (int64_t r = ty; r < rows; r += 32) acc = fmaf(csc[r * 2 + 1], dP[r * D + d], acc);
-  }
-  __syncthreads();
-  sm[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && ok) {
     float g = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) g += sm[i][tx];
+    for (int i = 0; i < nparts; ++i) g += part[(int64_t)i * D + d];
     const float ch = chat[d];
     for (int h = 0; h < H; ++h) {
       g = fmaf(wq[(int64_t)h * D + d], sds[h], g);
@@ -245,7 +259,7 @@ constexpr int CAIT_NT = 23;   // cls | gamma_1 gamma_2 | n1.w n1.b | q.w q.b k.w
 struct CaitWs {
   float *P, *S, *ML, *ML2, *mix, *csc, *tstat, *ya0, *ya, *z1, *c1, *stat2, *h2, *pre, *h1, *m2, *c2, *statf;
   float *dc2, *dm2, *dh1, *dh2, *dc1, *dz1, *dya, *dya0, *dP;
-  float *chat, *un0, *lnstat, *q, *u, *wq, *sc, *vc, *dvc, *dw, *du, *dq, *dun0, *dchat, *dcsum, *Wvs, *bo, *dWvs, *dbo, *scr;
+  float *chat, *un0, *lnstat, *q, *u, *wq, *sc, *vc, *dvc, *dw, *du, *dq, *dun0, *dchat, *dcsum, *Wvs, *bo, *dWvs, *dbo, *scr, *cpart;
   void* pool_ws; size_t pool_ws_bytes;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
@@ -283,7 +297,7 @@ static CaitWs cait_carve(const ep_cait_dims& d, void* base, bool head) {
   w.dc2 = take(B * D); w.dm2 = take(B * D); w.dh1 = take(B * Hd); w.dh2 = take(B * D); w.dc1 = take(B * D); w.dz1 = take(B * D);
   w.dya = take(B * D); w.dya0 = take(B * D); w.dP = take(B * H * D);
   w.chat = take(D); w.un0 = take(D); w.lnstat = take(4); w.q = take(D); w.u = take(H * D); w.wq = take(H * D); w.sc = take(32);
-  w.vc = take(D); w.dvc = take(D); w.dw = take(H * D); w.du = take(H * D); w.dq = take(D); w.dun0 = take(D); w.dchat = take(D);
+  w.vc = take(D); w.dvc = take(D); w.dw = take(H * D); w.du = take(H * D); w.dq = take(D); w.dun0 = take(D); w.dchat = take(D); w.cpart = take((size_t)CAIT_RS * D);
   w.dcsum = take(D); w.Wvs = take(D * D); w.bo = take(D); w.dWvs = take(D * D); w.dbo = take(D); w.scr = take(2 * D);
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.H);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
@@ -445,7 +459,9 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
     }
   }
   // class entry: dw += chat sum_b dS_c ; dchat ; dWv' += dvc chat^T
-  hipLaunchKernelGGL(ep_cait_clsred_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.csc, w.dP, w.wq, w.chat, B, H, D, w.dw, w.dchat);
+  hipLaunchKernelGGL(ep_cait_clsred_part_kernel, dim3((D + 31) / 32, CAIT_RS), dim3(1024), 0, st, w.csc, w.dP, (int64_t)B * H, D, w.cpart);
+  hipLaunchKernelGGL(ep_cait_clsred_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.csc, w.cpart, CAIT_RS, w.wq, w.chat, B, H, D, w.dw,
+                     w.dchat);
   hipLaunchKernelGGL(ep_cait_rank1_kernel, dim3((D + 255) / 256, D), dim3(256), 0, st, w.dvc, w.chat, D, w.dWvs);
   // value side: d v.weight, and the value-side parts of d norm1.weight / bias ; d v.bias = dbo
   hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.v_w, pr.n1_w, pr.n1_b, D, acc,
