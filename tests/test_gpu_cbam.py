@@ -136,3 +136,32 @@ def test_full_size_batch_vs_oracle_indexed_store_bf16_and_determinism():
     e16 = make_engine(native_head(case, inp)[0], optimizer="lars"); e16.train_step(xb, t, lr=0.3)
     e32 = make_engine(native_head(case, inp)[0], optimizer="lars"); e32.train_step(xb.float(), t, lr=0.3)
     np.testing.assert_allclose(e16.flat_p.cpu().numpy(), e32.flat_p.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_gradients_of_a_batch_that_spans_several_workgroups_vs_oracle():
+    """B = 96 images of 8 x 8 tokens: the one-channel BatchNorm2d (6144 values -> three workgroups), its backward and the 7 x 7
+    weight gradient (six image chunks) leave their single-workgroup forms -- every gradient against the oracle's autograd in
+    float64."""
+    from efficient_probing_amd import functional as F_
+    case = CbamCase("wide", B=96, N=64, D=128, C=20, seed=8, sharp=True)
+    inp = make_cbam_inputs(case)
+    head, plist = native_head(case, inp)
+    x, t = tokens(case, inp["x_buf"]), torch.from_numpy(inp["targets"]).to(DEV)
+    loss, _ = F_.cross_entropy_loss(head(x), t)
+    loss.backward()
+    oh = AO.make_head(case.D, case.C).double()
+    oparams = AO.head_params(oh)
+    with torch.no_grad():
+        for n, p in zip(CBAM_PARAM_NAMES, oparams):
+            p.copy_(torch.from_numpy(inp[n]).double())
+        oh[0].bn.running_mean.copy_(torch.from_numpy(inp["tok_running_mean"]).double())
+        oh[0].bn.running_var.copy_(torch.from_numpy(inp["tok_running_var"]).double())
+    oh.train()
+    oloss = torch.nn.functional.cross_entropy(oh(torch.from_numpy(inp["x_buf"]).double()), torch.from_numpy(inp["targets"]))
+    oloss.backward()
+    assert loss.item() == pytest.approx(oloss.item(), rel=2e-5)
+    for n, p, q in zip(CBAM_PARAM_NAMES, plist, oparams):
+        close(n, p.grad.cpu().numpy(), q.grad.numpy().reshape(p.shape), rtol=3e-4, floor=1e-4)
+    nbn = head[0].spatial.conv.bn
+    np.testing.assert_allclose(nbn.running_mean.cpu().numpy(), oh[0].bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(nbn.running_var.cpu().numpy(), oh[0].bn.running_var.numpy(), rtol=1e-5, atol=1e-6)

@@ -184,3 +184,21 @@ def test_full_width_per_image_query_kernel_vs_generic_kernels(shape):
         # with bf16 tokens the module returns the pooled rows in bf16: values 1e-7 apart can round to neighbouring bf16 numbers
         rtol = 1e-2 if (bf16 and i == 0) else 2e-4
         np.testing.assert_allclose(a, g, rtol=rtol, atol=2e-5 * max(1e-3, float(np.abs(g).max())))
+
+
+def test_gradients_of_a_batch_with_many_image_head_rows_vs_float64():
+    """B = 96 images of 8 x 8 tokens: 384 (image, head) rows put the column reductions of the backward on several row chunks --
+    every gradient against the oracle in float64 (floor 1e-4 of the tensor's scale: the gradients of this head are sums of
+    batch-cancelling rows)."""
+    from efficient_probing_amd import functional as F_
+    case = ClipCase("rows", B=96, N=64, D=128, C=20, seed=9, sharp=True)
+    inp = make_clip_inputs(case)
+    head, plist = native_head(case, inp)
+    x, t = tokens(case, inp["x_buf"]), torch.from_numpy(inp["targets"]).to(DEV)
+    loss, _ = F_.cross_entropy_loss(head(x), t)
+    loss.backward()
+    truth = f64_reference(ClipCase("rows", B=96, N=64, D=128, C=20, seed=9, sharp=True, steps=1), inp)[0]
+    assert loss.item() == pytest.approx(truth["loss"], rel=2e-5)
+    for n, p, tr in zip(CLIP_PARAM_NAMES, plist, truth["grads"]):
+        scale = max(float(np.abs(tr).max()), 1e-12)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), tr.reshape(p.shape), rtol=3e-4, atol=max(1e-4 * scale, 1e-7), err_msg=n)
