@@ -338,6 +338,14 @@ static bool use_mm(const PoolParams& p, bool bwd) {
   return p.Q > 8 || (bwd && p.D == 1152 && p.Q >= 5);
 }
 
+// bf16-stored tokens: both contractions on the bf16 matrix cores (ep_pool_mb.hip), fp32 operand split into three bf16
+// terms.  EP_POOL_MB=0 disables it (the vector-ALU kernels then widen the tokens on load).
+static bool use_mb(const PoolParams& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_POOL_MB"); on = e ? atoi(e) : 1; }
+  return on && p.x_bf16 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mb_supported(p.D, p.Q, p.cls_bstride);
+}
+
 // what the vector-ALU streaming kernels can take: LayerNorm-of-tokens mode needs fp32 tokens
 static bool stream_takes(const PoolParams& p) {
   static int ln = -1;
@@ -354,6 +362,7 @@ const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) 
   PoolParams p{};
   p.B = B; p.N = N; p.D = D; p.Q = Q; p.x_bf16 = x_bf16;
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
+  if (use_mb(p)) return bwd ? "ep_pool_mb_bwd_kernel" : "ep_pool_mb_fwd_kernel";
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
   if (stream_plan(B, N, D, Q).ok && !force_generic() && stream_takes(p)) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
@@ -372,6 +381,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
   // per-image query rows with score extras (CLIP): every token read once for all heads instead of once per head
   if (needs_generic(p) && !force_generic() && imgqf_supported(p)) return imgqf_forward(p, st);
   if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B, p.x_bf16), st);
+  if (use_mb(p)) return mb_launch(false, p, mf_grid(p.B), st);
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
@@ -390,7 +400,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
 bool pool_backward_takes_side(const PoolParams& p) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
-  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   return c.ok && c.nw == 4;
 }
@@ -404,6 +414,9 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   if (use_wide(p)) {
     nparts = wide_grid(p.D, p.B, p.x_bf16);
     EP_TRY(wide_launch(true, p, nparts, st));
+  } else if (use_mb(p)) {
+    nparts = mf_grid(p.B);
+    EP_TRY(mb_launch(true, p, nparts, st));
   } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);
     EP_TRY(mm_launch(true, p, nparts, st));

@@ -1,0 +1,529 @@
+// EP attentive pooling over bf16-STORED tokens on the bf16 matrix cores (gfx950 / CDNA4), fp32 results.
+//
+// With bf16 token storage a token pass moves half the bytes, and the vector-ALU kernels (widen + 12 k FMA per token)
+// become the bound (0.35 of the HBM peak).  Here BOTH contractions of a token tile run on v_mfma_f32_16x16x32_bf16:
+//
+//   scores   S[t][q]   = sum_d x[t][d] * (cls[q][d]*scale)        A = x tile (bf16, as stored),  B = queries
+//   pooling  P^T[d][q] = sum_t x[t][d] * softmax-weight[q][t]     A = x tile^T,                  B = weights
+//
+// (reference poolings/ep.py:35-44 forward; the backward is the same pair with dP in place of the queries and
+// A*(dA-delta) in place of the softmax weights.)  The tokens ARE bf16, so they enter the matrix cores unchanged; the
+// fp32 operand of each contraction (queries / dP rows / softmax weights) is split into three bf16 terms
+// hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation: the split is exact to 2^-24) and fed as three MFMAs into the
+// same fp32 accumulator.  Every bf16 x bf16 product is exact in fp32, so the result is the fp32 contraction of the
+// stored values up to summation order -- the contract of the bf16 storage mode (tests/test_gpu_bf16.py) -- at 3/16 of
+// the matrix time the fp32 instruction would need.
+//
+// One 8-wave workgroup per CU streams whole images through a ring of 32-token tiles filled by LDS-DMA (rows
+// XOR-swizzled on the DMA source address).  Wave w owns the D-slice [D/8*w, D/8*(w+1)) for both contractions:
+//   1. partial scores of its slice for the two 16-token blocks of the tile (D/256 k-steps x 3 terms MFMAs each), summed
+//      across the waves through LDS; the MFMA D layout of a score block (lane = (query, token group g), 4 tokens in 4
+//      registers) is exactly the B-operand slot layout of step 3, so the weights never move between lanes;
+//   2. lazy-max online softmax on 8 values per lane (every wave redundantly: same values, same order);
+//   3. pooling of its slice: the A operand (x^T: 8 tokens of one channel per lane) is built from b32 reads of channel
+//      PAIRS and two v_perm_b32 per register pair -- the even channels feed one MFMA, the odd ones the next.
+// Per 32-token tile and wave: 12 NK MFMAs (36 at D = 768), 2 NK b128 + 8 NK b32 + 16 b128 LDS reads, two barriers.
+#include "ep_common.h"
+#include "ep_internal.h"
+#include "ep_pool_stream.h"
+
+namespace ep {
+
+typedef __attribute__((address_space(3))) void* mb_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* mb_gptr_t;
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int MB_TT = 32;             // tokens per tile (two 16-token MFMA blocks)
+constexpr int MB_NW = 8;              // waves per workgroup (one workgroup per CU)
+constexpr float MB_LOG2E = 1.4426950408889634f;
+constexpr float MB_LAZY_MAX_THR = 12.0f;
+
+template <int NK>                     // D = 256 * NK
+struct MbCfg {
+  static constexpr int D = 256 * NK;
+  static constexpr int ROWB = 2 * D;                 // bytes per token row
+  static constexpr int NCH = D / 8;                  // 16-byte chunks per row (multiple of 32)
+  static constexpr int SLOT = MB_TT * ROWB;
+  static constexpr int KDMA = SLOT / (MB_NW * 1024); // 1 KiB DMA pieces per wave per tile (= 2 NK)
+  static constexpr int SPART = 2 * MB_NW * 1024;     // partial score blocks [block][wave][lane] f4
+  static constexpr int LDS_TOTAL = 160 * 1024;
+  static constexpr int NSLOT = ((LDS_TOTAL - SPART) / SLOT) > 3 ? 3 : ((LDS_TOTAL - SPART) / SLOT);
+  static constexpr bool VALID = NSLOT >= 2;
+};
+
+__device__ __forceinline__ void mb_wait_vmcnt(int n) {
+#define EP_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    EP_W(0) EP_W(1) EP_W(2) EP_W(3) EP_W(4) EP_W(5) EP_W(6) EP_W(7) EP_W(8) EP_W(9)
+    EP_W(10) EP_W(11) EP_W(12) EP_W(13) EP_W(14) EP_W(15) EP_W(16)
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+  }
+#undef EP_W
+}
+__device__ __forceinline__ void mb_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// combine a per-lane value over the 4 lanes that share a query (lane, lane^16, lane^32, lane^48)
+__device__ __forceinline__ float mb_q4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float mb_q4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// fp32 -> three bf16 terms by truncation (hi + mid + lo == v to 2^-24 |v|); the terms are returned as fp32 bit
+// patterns whose low 16 bits are zero
+__device__ __forceinline__ void mb_split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(h);                    // exact
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);                   // exact
+  l = __float_as_uint(r2) & 0xffff0000u;
+}
+// two truncated terms -> one register of two bf16 (element 0 = a in the low half)
+__device__ __forceinline__ unsigned mb_pack_hi(unsigned a, unsigned b) {
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+// eight fp32 values -> the three bf16x8 operands
+__device__ __forceinline__ void mb_split8(const float (&v)[8], u4 (&t)[3]) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mb_split3(v[e], h[e], m[e], l[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    t[0][e] = mb_pack_hi(h[2 * e], h[2 * e + 1]);
+    t[1][e] = mb_pack_hi(m[2 * e], m[2 * e + 1]);
+    t[2][e] = mb_pack_hi(l[2 * e], l[2 * e + 1]);
+  }
+}
+__device__ __forceinline__ f4 mb_mfma(u4 a, u4 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+// LDS position p = (t, c') of a tile holds source chunk c' ^ (t & 15) of row t
+template <int NK>
+__device__ __forceinline__ void mb_source_offsets(int w, int lane, unsigned (&soff)[2 * NK]) {
+  constexpr int NCH = 32 * NK;
+#pragma unroll
+  for (int jj = 0; jj < 2 * NK; ++jj) {
+    const int pos = (w + MB_NW * jj) * 64 + lane;
+    const int t = pos / NCH, c = pos - t * NCH;
+    soff[jj] = (unsigned)(t * (512 * NK) + ((c ^ (t & 15)) << 4));
+  }
+}
+template <int NK>
+__device__ __forceinline__ void mb_dma_tile(const char* src, unsigned limit, char* slot, int w,
+                                            const unsigned (&soff)[2 * NK]) {
+#pragma unroll
+  for (int jj = 0; jj < 2 * NK; ++jj) {
+    const unsigned off = soff[jj] < limit ? soff[jj] : limit;
+    __builtin_amdgcn_global_load_lds((mb_gptr_t)(src + off), (mb_lds_ptr_t)(slot + (w + MB_NW * jj) * 1024), 16, 0,
+                                     EP_DMA_AUX);
+  }
+}
+
+// step 1: (2 x 16 tokens) x 16 queries over this wave's D-slice -> LDS scratch; `mid` (the ring refill) is issued in the
+// shadow of the first MFMAs.  A operand: lane (i = token of the block, g): chunk 4*NK*w + 4*ks + g of row i.
+template <int NK, typename F>
+__device__ __forceinline__ void mb_scores(const char* tile, const int (&aoff)[NK], const u4 (&bq)[NK][3], char* spart,
+                                          int w, int lane, F&& mid) {
+  constexpr int ROWB = 512 * NK;
+  u4 xa[2][NK];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) xa[blk][ks] = *reinterpret_cast<const u4*>(tile + blk * 16 * ROWB + aoff[ks]);
+  f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+    for (int term = 2; term >= 0; --term) {                    // small terms first
+      acc[0] = mb_mfma(xa[0][ks], bq[ks][term], acc[0]);
+      acc[1] = mb_mfma(xa[1][ks], bq[ks][term], acc[1]);
+    }
+    if (ks == 0) mid();
+  }
+  *reinterpret_cast<f4*>(spart + ((0 * MB_NW + w) * 64 + lane) * 16) = acc[0];
+  *reinterpret_cast<f4*>(spart + ((1 * MB_NW + w) * 64 + lane) * 16) = acc[1];
+}
+// full scores of (query j = lane & 15, tokens 16*blk + 4*g + r): the same lane slot of every wave's block, fixed order
+__device__ __forceinline__ void mb_gather(const char* spart, int lane, float (&s)[8]) {
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    f4 v = *reinterpret_cast<const f4*>(spart + ((blk * MB_NW) * 64 + lane) * 16);
+#pragma unroll
+    for (int ws = 1; ws < MB_NW; ++ws) v += *reinterpret_cast<const f4*>(spart + ((blk * MB_NW + ws) * 64 + lane) * 16);
+    s[4 * blk + 0] = v.x; s[4 * blk + 1] = v.y; s[4 * blk + 2] = v.z; s[4 * blk + 3] = v.w;
+  }
+}
+// step 3: for each group of 32 channels dg of the slice: accE[dg] (rows = even channels) and accO[dg] (odd channels),
+// 16 channels x 16 queries each, += x_tile^T * wgt.  Operand slot (g, e) <-> token 16*(e>>2) + 4*g + (e&3) on both sides.
+// Lane (i, g) reads the channel pair (2i, 2i+1) of the group: bytes 4*i of the 64-byte segment at chunk
+// c0 = 4*NK*w + 4*dg, i.e. chunk c0 + (i>>2), stored at chunk position (c0 + (i>>2)) ^ (4g + r) of row t
+// (conflict-free: the four g land in four different 64-byte segments of a 256-byte window).
+template <int NK>
+__device__ __forceinline__ void mb_pool(const char* tile, const int (&poff)[4], const int (&pseg)[NK],
+                                        const float (&wgt)[8], f4 (&accE)[NK], f4 (&accO)[NK]) {
+  constexpr int ROWB = 512 * NK;
+  u4 bw[3];
+  mb_split8(wgt, bw);
+  unsigned xr[NK][8];
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      xr[dg][e] = *reinterpret_cast<const unsigned*>(tile + (e >> 2) * 16 * ROWB + poff[e & 3] + pseg[dg]);
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) {
+    u4 ae, ao;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ae[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x05040100u);   // (lo of 2e, lo of 2e+1)
+      ao[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x07060302u);   // (hi of 2e, hi of 2e+1)
+    }
+#pragma unroll
+    for (int term = 2; term >= 0; --term) {
+      accE[dg] = mb_mfma(ae, bw[term], accE[dg]);
+      accO[dg] = mb_mfma(ao, bw[term], accO[dg]);
+    }
+  }
+}
+// per-lane address parts of the pooling A operand: row 4g + r, chunk-in-segment (i>>2) ^ r, channel pair i & 3;
+// 64-byte segment (NK*w + dg) ^ g of the row
+template <int NK>
+__device__ __forceinline__ void mb_pool_offsets(int w, int i, int g, int (&poff)[4], int (&pseg)[NK]) {
+  constexpr int ROWB = 512 * NK;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) poff[r] = (4 * g + r) * ROWB + (((i >> 2) ^ r) << 4) + 4 * (i & 3);
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) pseg[dg] = ((NK * w + dg) ^ g) << 6;
+}
+// accumulators of one 32-channel group -> 8 consecutive channels per lane: d = 32*dg + 8*g + {0..7}
+__device__ __forceinline__ void mb_store8(float* dst, f4 e, f4 o, float f) {
+  *reinterpret_cast<f4*>(dst) = f4{e.x * f, o.x * f, e.y * f, o.y * f};
+  *reinterpret_cast<f4*>(dst + 4) = f4{e.z * f, o.z * f, e.w * f, o.w * f};
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <int NK>
+__global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
+  using C = MbCfg<NK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* ring = lds;
+  char* spart = lds + NSLOT * SLOT;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int N = p.N, Q = p.Q;
+  const bool n4 = (N & 3) == 0;
+  const int tiles_per_img = (N + MB_TT - 1) / MB_TT;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * tiles_per_img;
+  if (n_items <= 0) return;
+  const int j = lane & 15, g = lane >> 4;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+
+  // B operand of the score MFMAs: queries pre-scaled like the reference (ep.py:39), split into three bf16 terms
+  u4 bq[NK][3];
+  int aoff[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j < Q) {
+      const float* src = p.cls + (int64_t)j * D + 32 * NK * w + 32 * ks + 8 * g;
+      const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+      v[0] = a.x * p.scale; v[1] = a.y * p.scale; v[2] = a.z * p.scale; v[3] = a.w * p.scale;
+      v[4] = b.x * p.scale; v[5] = b.y * p.scale; v[6] = b.z * p.scale; v[7] = b.w * p.scale;
+    }
+    mb_split8(v, bq[ks]);
+    aoff[ks] = j * ROWB + (((4 * NK * w + 4 * ks + g) ^ j) << 4);
+  }
+  unsigned soff[2 * NK];
+  mb_source_offsets<NK>(w, lane, soff);
+  int poff[4], pseg[NK];
+  mb_pool_offsets<NK>(w, j, g, poff, pseg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+  const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
+  auto produce = [&]() {
+    if (pi < n_items) {
+      const int left = N - ptile * MB_TT;
+      const unsigned limit = (unsigned)((left < MB_TT ? left : MB_TT) * ROWB - 16);
+      mb_dma_tile<NK>(psrc, limit, ring + pslot * SLOT, w, soff);
+      ++pi;
+      pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+      if (++ptile == tiles_per_img) {
+        ptile = 0; ++pimg;
+        psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+      } else {
+        psrc += SLOT;
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+  f4 accE[NK], accO[NK];
+  float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;     // per lane: running max / partial sum of query j
+  int cimg = 0, ctile = 0, cslot = 0;
+  for (int it = 0; it < n_items; ++it) {
+    mb_wait_vmcnt((pi - 1 - it) * KDMA);
+    mb_barrier();                                   // tile `it` landed everywhere; the slot of tile it-1 is free
+    const int b = wg + cimg * G;
+    const int n0 = ctile * MB_TT;
+    const int nvalid = (N - n0) < MB_TT ? (N - n0) : MB_TT;
+    const char* tile = ring + cslot * SLOT;
+    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+    if (ctile == 0) {
+      m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
+#pragma unroll
+      for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    mb_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+    mb_barrier();                                   // all partial score blocks are in the scratch
+    float sc[8], ue[8];
+    mb_gather(spart, lane, sc);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ue[e] = (16 * (e >> 2) + 4 * g + (e & 3)) < nvalid ? sc[e] : -INFINITY;
+      mx = fmaxf(mx, ue[e]);
+    }
+    if (__builtin_amdgcn_ballot_w64(mx > m_j + MB_LAZY_MAX_THR) != 0ull) {    // rare
+      const float mn = fmaxf(m_j, mb_q4_max(mx));
+      const float f = __builtin_amdgcn_exp2f((m_j - mn) * MB_LOG2E);           // m = -inf -> 0
+      m_j = mn; mL_j = mn * MB_LOG2E;
+      lsum *= f;
+#pragma unroll
+      for (int dg = 0; dg < NK; ++dg) { accE[dg] *= f; accO[dg] *= f; }       // my column is query j
+    }
+    float wgt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));          // invalid tokens: 0
+      lsum += wgt[e];
+    }
+    if (w == (it & 7) && j < Q) {                   // every wave holds the same scores: one writes them
+      float* Srow = p.S + ((int64_t)b * Q + j) * N + n0;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int t0 = 16 * blk + 4 * g;
+        if (n4) {
+          if (t0 < nvalid) *reinterpret_cast<f4*>(Srow + t0) = f4{sc[4 * blk], sc[4 * blk + 1], sc[4 * blk + 2], sc[4 * blk + 3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (t0 + r < nvalid) Srow[t0 + r] = sc[4 * blk + r];
+        }
+      }
+    }
+    mb_pool<NK>(tile, poff, pseg, wgt, accE, accO);
+    if (ctile == tiles_per_img - 1) {
+      const float l = mb_q4_sum(lsum);
+      const float inv = 1.0f / l;
+      if (j < Q) {
+        float* Pq = p.P + ((int64_t)b * Q + j) * D + 32 * NK * w + 8 * g;
+#pragma unroll
+        for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
+        if (w == 0 && g == 0) {
+          const f4 rec = {m_j, l, 0.f, 0.f};
+          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + j) * 4) = rec;
+        }
+      }
+      ctile = 0; ++cimg;
+    } else {
+      ++ctile;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward.  Per image: the Q rows of dP[b] (this wave's slice, split into bf16 terms) and the ML row of query j are
+// fetched into registers one image ahead; the saved scores of a tile (8 per lane, the lane's operand slots) one tile
+// ahead.  These plain loads are issued BEFORE the ring refill of their iteration, so the counted wait at the top of
+// the next iteration (which leaves only the newest tile's DMA outstanding) covers them.
+// ---------------------------------------------------------------------------------------
+template <int NK>
+__global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p) {
+  using C = MbCfg<NK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* ring = lds;
+  char* spart = lds + NSLOT * SLOT;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int N = p.N, Q = p.Q;
+  const bool n4 = (N & 3) == 0;
+  const int tiles_per_img = (N + MB_TT - 1) / MB_TT;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * tiles_per_img;
+  const int j = lane & 15, g = lane >> 4;
+  const int jq = j < Q ? j : Q - 1;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+
+  f4 gE[NK], gO[NK];
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) { gE[dg] = f4{0.f, 0.f, 0.f, 0.f}; gO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+
+  if (n_items > 0) {
+    int aoff[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) aoff[ks] = j * ROWB + (((4 * NK * w + 4 * ks + g) ^ j) << 4);
+    unsigned soff[2 * NK];
+    mb_source_offsets<NK>(w, lane, soff);
+    int poff[4], pseg[NK];
+    mb_pool_offsets<NK>(w, j, g, poff, pseg);
+
+    // header of image `img` (index into this workgroup's images) -> registers
+    f4 hq[NK][2], hml;
+    auto load_header = [&](int img) {
+      const int b = wg + img * G;
+      const float* src = p.dP + ((int64_t)b * Q + jq) * D + 32 * NK * w + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        hq[ks][0] = *reinterpret_cast<const f4*>(src + 32 * ks);
+        hq[ks][1] = *reinterpret_cast<const f4*>(src + 32 * ks + 4);
+      }
+      hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
+    };
+    // saved scores of tile (img, tile): S[b, j, n0 + 16 blk + 4 g + r]
+    float sv[8];
+    auto load_scores = [&](int img, int tl) {
+      const int b = wg + img * G;
+      const float* Srow = p.S + ((int64_t)b * Q + jq) * N;
+      const int n0 = tl * MB_TT;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        int t0 = n0 + 16 * blk + 4 * g;
+        if (n4) {
+          t0 = t0 < N ? t0 : N - 4;
+          const f4 v = *reinterpret_cast<const f4*>(Srow + t0);
+          sv[4 * blk] = v.x; sv[4 * blk + 1] = v.y; sv[4 * blk + 2] = v.z; sv[4 * blk + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[4 * blk + r] = Srow[(t0 + r) < N ? (t0 + r) : N - 1];
+        }
+      }
+    };
+
+    load_header(0);
+    load_scores(0, 0);
+    int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+    const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
+    auto produce = [&]() {
+      if (pi < n_items) {
+        const int left = N - ptile * MB_TT;
+        const unsigned limit = (unsigned)((left < MB_TT ? left : MB_TT) * ROWB - 16);
+        mb_dma_tile<NK>(psrc, limit, ring + pslot * SLOT, w, soff);
+        ++pi;
+        pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+        if (++ptile == tiles_per_img) {
+          ptile = 0; ++pimg;
+          psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+        } else {
+          psrc += SLOT;
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+    u4 bq[NK][3];
+    float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
+    int cimg = 0, ctile = 0, cslot = 0;
+    for (int it = 0; it < n_items; ++it) {
+      mb_wait_vmcnt((pi - 1 - it) * KDMA);
+      mb_barrier();
+      const int n0 = ctile * MB_TT;
+      const int nvalid = (N - n0) < MB_TT ? (N - n0) : MB_TT;
+      const char* tile = ring + cslot * SLOT;
+      cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+      if (ctile == 0) {                              // new image: its header is in hq / hml
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          float v[8] = {hq[ks][0].x, hq[ks][0].y, hq[ks][0].z, hq[ks][0].w, hq[ks][1].x, hq[ks][1].y, hq[ks][1].z, hq[ks][1].w};
+          if (j >= Q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          }
+          mb_split8(v, bq[ks]);
+        }
+        mL_j = hml.x * MB_LOG2E; il_j = 1.0f / hml.y; dl_j = hml.z;
+        if (cimg + 1 < n_img) load_header(cimg + 1);
+      }
+      float cur[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cur[e] = sv[e];
+      {                                              // scores of the next tile (before the refill: see above)
+        int nimg = cimg, ntile = ctile + 1;
+        if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
+        if (nimg < n_img) load_scores(nimg, ntile);
+      }
+      mb_scores<NK>(tile, aoff, bq, spart, w, lane, produce);      // dA partial blocks
+      mb_barrier();
+      float u[8], wgt[8];
+      mb_gather(spart, lane, u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
+        wgt[e] = ((16 * (e >> 2) + 4 * g + (e & 3)) < nvalid && j < Q) ? a * (u[e] - dl_j) : 0.f;
+      }
+      mb_pool<NK>(tile, poff, pseg, wgt, gE, gO);
+      if (++ctile == tiles_per_img) { ctile = 0; ++cimg; }
+    }
+  }
+  if (j < Q) {
+    float* Gq = p.Gpart + ((int64_t)wg * Q + j) * D + 32 * NK * w + 8 * g;
+#pragma unroll
+    for (int dg = 0; dg < NK; ++dg) mb_store8(Gq + 32 * dg, gE[dg], gO[dg], 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int NK>
+static int mb_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  using C = MbCfg<NK>;
+  if constexpr (!C::VALID) {
+    set_error("no bf16 matrix-core pooling kernel for D=%d", 256 * NK);
+    return EP_E_UNSUPPORTED;
+  } else {
+    const size_t lds = (size_t)C::NSLOT * C::SLOT + C::SPART;
+    auto kf = ep_pool_mb_fwd_kernel<NK>;
+    auto kb = ep_pool_mb_bwd_kernel<NK>;
+    const void* fn = bwd ? (const void*)kb : (const void*)kf;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+    if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(MB_NW * 64), lds, st, p);
+    else hipLaunchKernelGGL(kf, dim3(grid), dim3(MB_NW * 64), lds, st, p);
+    EP_LAUNCH_CHECK(bwd ? "ep_pool_mb_bwd_kernel" : "ep_pool_mb_fwd_kernel");
+    return 0;
+  }
+}
+
+// bf16 tokens, D in {256, 512, 768, 1024}, up to 16 shared query rows
+bool mb_supported(int D, int Q, int64_t cls_bstride) {
+  return D % 256 == 0 && D >= 256 && D <= 1024 && Q >= 1 && Q <= 16 && cls_bstride == 0;
+}
+
+int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  switch (p.D / 256) {
+    case 1: return mb_launch_one<1>(bwd, p, grid, st);
+    case 2: return mb_launch_one<2>(bwd, p, grid, st);
+    case 3: return mb_launch_one<3>(bwd, p, grid, st);
+    case 4: return mb_launch_one<4>(bwd, p, grid, st);
+  }
+  set_error("no bf16 matrix-core pooling kernel for D=%d", p.D);
+  return EP_E_UNSUPPORTED;
+}
+
+}  // namespace ep

@@ -104,3 +104,51 @@ def test_bf16_resident_store_trains_in_place(tmp_path):
         e1.train_step(tokens, targets, lr=0.5, image_index=idx)
         e2.train_step(tokens[idx.long()].float().contiguous(), targets, lr=0.5)     # gathered fp32 copy
     np.testing.assert_allclose(e1.flat_p.cpu().numpy(), e2.flat_p.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+MB_SHAPES = [(5, 50, 256, 8), (9, 197, 768, 8), (600, 256, 768, 8), (7, 196, 1024, 8), (3, 31, 512, 16), (4, 64, 768, 1),
+             (2, 257, 768, 12)]
+
+
+@pytest.mark.parametrize("shape", MB_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_bf16_matrix_core_pass_against_float64(shape):
+    """ep_pool_mb_*_kernel (bf16 tokens on the bf16 matrix cores, the fp32 operand split into three bf16 terms) against a
+    float64 evaluation of reference poolings/ep.py:35-44 and of its gradient on the same stored values: the split keeps
+    the fp32 contract (same tolerances as the fp32 token passes), partial last tiles, N % 4 != 0, more images than
+    workgroups and up to 16 query rows included."""
+    from efficient_probing_amd import functional as F_, _native
+    B, Nn, D, Q = shape
+    lib = _native.load()
+    assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1).decode() == "ep_pool_mb_fwd_kernel"
+    assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1).decode() == "ep_pool_mb_bwd_kernel"
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    xb = torch.randn(B, Nn, D, generator=gen).to(torch.bfloat16)
+    cls = torch.randn(Q, D, generator=gen) * 0.5
+    dP = torch.randn(B, Q, D, generator=gen)
+    scale = D ** -0.5
+    x64 = xb.double()
+    S64 = torch.einsum("qd,bnd->bqn", cls.double() * scale, x64)
+    A64 = torch.softmax(S64, dim=-1)
+    P64 = torch.einsum("bqn,bnd->bqd", A64, x64)
+    P, S, ML = F_.pool_forward(xb.to(DEV), cls.to(DEV), scale)
+    np.testing.assert_allclose(S.cpu().numpy(), S64.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(P.cpu().numpy(), P64.numpy(), rtol=1e-5, atol=1e-6)
+    lse = torch.logsumexp(S64, dim=-1)
+    got_lse = (ML[:, :, 0].double() + torch.log(ML[:, :, 1].double())).cpu()
+    np.testing.assert_allclose(got_lse.numpy(), lse.numpy(), rtol=1e-6, atol=1e-6)
+    # backward: dcls = scale * sum_b,n dS[b,q,n] x[b,n,:], dS = A (dA - delta), dA = dP . x_n, delta = sum_n A dA
+    dA64 = torch.einsum("bqd,bnd->bqn", dP.double(), x64)
+    delta64 = (A64 * dA64).sum(-1)
+    dS64 = A64 * (dA64 - delta64[..., None])
+    g64 = scale * torch.einsum("bqn,bnd->qd", dS64, x64)
+    ML2 = ML.clone(); ML2[:, :, 2] = delta64.float().to(DEV)
+    g = F_.pool_backward(xb.to(DEV), S, ML2, dP.to(DEV), scale)
+    np.testing.assert_allclose(g.cpu().numpy(), g64.numpy(), rtol=1e-4, atol=2e-5 * float(g64.abs().max()))
+    # the vector-ALU / generic kernels on the same stored values agree to summation order
+    old = lib.ep_debug_force_generic_pool(1)
+    try:
+        Pg, Sg, _ = F_.pool_forward(xb.to(DEV), cls.to(DEV), scale)
+    finally:
+        lib.ep_debug_force_generic_pool(old)
+    np.testing.assert_allclose(S.cpu().numpy(), Sg.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(P.cpu().numpy(), Pg.cpu().numpy(), rtol=2e-5, atol=2e-6)
