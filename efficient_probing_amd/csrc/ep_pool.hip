@@ -381,7 +381,10 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
   // per-image query rows with score extras (CLIP): every token read once for all heads instead of once per head
   if (needs_generic(p) && !force_generic() && imgqf_supported(p)) return imgqf_forward(p, st);
   if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B, p.x_bf16), st);
-  if (use_mb(p)) return mb_launch(false, p, mf_grid(p.B), st);
+  if (use_mb(p)) {
+    if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
+    return mb_launch(false, p, mf_grid(p.B), st);
+  }
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);

@@ -14,11 +14,14 @@
 // stored values up to summation order -- the contract of the bf16 storage mode (tests/test_gpu_bf16.py) -- at 3/16 of
 // the matrix time the fp32 instruction would need.
 //
-// One 8-wave workgroup per CU streams whole images through a ring of 32-token tiles filled by LDS-DMA (rows
-// XOR-swizzled on the DMA source address).  Wave w owns the D-slice [D/8*w, D/8*(w+1)) for both contractions:
-//   1. partial scores of its slice for the two 16-token blocks of the tile (D/256 k-steps x 3 terms MFMAs each), summed
+// One workgroup of NW = 8 or 12 waves per CU streams whole images through a ring of 32-token tiles filled by LDS-DMA
+// (rows XOR-swizzled on the DMA source address).  Wave w owns the D-slice [D/NW*w, D/NW*(w+1)) (32*NK channels) for both
+// contractions; D = 32*NK*NW (768 = 12 waves x 64 channels: three waves per SIMD):
+//   1. partial scores of its slice for the two 16-token blocks of the tile (NK k-steps x 3 terms MFMAs each), summed
 //      across the waves through LDS; the MFMA D layout of a score block (lane = (query, token group g), 4 tokens in 4
-//      registers) is exactly the B-operand slot layout of step 3, so the weights never move between lanes;
+//      registers) is exactly the B-operand slot layout of step 3, so the weights never move between lanes.  With up to
+//      8 queries (PK) the two blocks share one 1 KiB record per wave: lanes 8-15 of every row carry block 1 of query
+//      lane-8 (one DPP row shift each way), which halves the exchange;
 //   2. lazy-max online softmax on 8 values per lane (every wave redundantly: same values, same order);
 //   3. pooling of its slice: the A operand (x^T: 8 tokens of one channel per lane) is built from b32 reads of channel
 //      PAIRS and two v_perm_b32 per register pair -- the even channels feed one MFMA, the odd ones the next.
@@ -35,21 +38,20 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB_TT = 32;             // tokens per tile (two 16-token MFMA blocks)
-constexpr int MB_NW = 8;              // waves per workgroup (one workgroup per CU)
 constexpr float MB_LOG2E = 1.4426950408889634f;
 constexpr float MB_LAZY_MAX_THR = 12.0f;
 
-template <int NK>                     // D = 256 * NK
+template <int NK, int NW, bool PK>    // D = 32 * NK * NW;  PK: packed score exchange (Q <= 8)
 struct MbCfg {
-  static constexpr int D = 256 * NK;
+  static constexpr int D = 32 * NK * NW;
   static constexpr int ROWB = 2 * D;                 // bytes per token row
-  static constexpr int NCH = D / 8;                  // 16-byte chunks per row (multiple of 32)
+  static constexpr int NCH = D / 8;                  // 16-byte chunks per row (multiple of 16)
   static constexpr int SLOT = MB_TT * ROWB;
-  static constexpr int KDMA = SLOT / (MB_NW * 1024); // 1 KiB DMA pieces per wave per tile (= 2 NK)
-  static constexpr int SPART = 2 * MB_NW * 1024;     // partial score blocks [block][wave][lane] f4
+  static constexpr int KDMA = SLOT / (NW * 1024);    // 1 KiB DMA pieces per wave per tile
+  static constexpr int SPART = (PK ? 1 : 2) * NW * 1024;   // partial score records [block][wave][lane] f4
   static constexpr int LDS_TOTAL = 160 * 1024;
   static constexpr int NSLOT = ((LDS_TOTAL - SPART) / SLOT) > 3 ? 3 : ((LDS_TOTAL - SPART) / SLOT);
-  static constexpr bool VALID = NSLOT >= 2;
+  static constexpr bool VALID = NSLOT >= 2 && NCH % 16 == 0 && SLOT % (NW * 1024) == 0;
 };
 
 __device__ __forceinline__ void mb_wait_vmcnt(int n) {
@@ -106,33 +108,32 @@ __device__ __forceinline__ f4 mb_mfma(u4 a, u4 b, f4 c) {
 }
 
 // LDS position p = (t, c') of a tile holds source chunk c' ^ (t & 15) of row t
-template <int NK>
-__device__ __forceinline__ void mb_source_offsets(int w, int lane, unsigned (&soff)[2 * NK]) {
-  constexpr int NCH = 32 * NK;
+template <int NCH, int NW, int KDMA>
+__device__ __forceinline__ void mb_source_offsets(int w, int lane, unsigned (&soff)[KDMA]) {
 #pragma unroll
-  for (int jj = 0; jj < 2 * NK; ++jj) {
-    const int pos = (w + MB_NW * jj) * 64 + lane;
+  for (int jj = 0; jj < KDMA; ++jj) {
+    const int pos = (w + NW * jj) * 64 + lane;
     const int t = pos / NCH, c = pos - t * NCH;
-    soff[jj] = (unsigned)(t * (512 * NK) + ((c ^ (t & 15)) << 4));
+    soff[jj] = (unsigned)(t * (16 * NCH) + ((c ^ (t & 15)) << 4));
   }
 }
-template <int NK>
+template <int NW, int KDMA>
 __device__ __forceinline__ void mb_dma_tile(const char* src, unsigned limit, char* slot, int w,
-                                            const unsigned (&soff)[2 * NK]) {
+                                            const unsigned (&soff)[KDMA]) {
 #pragma unroll
-  for (int jj = 0; jj < 2 * NK; ++jj) {
+  for (int jj = 0; jj < KDMA; ++jj) {
     const unsigned off = soff[jj] < limit ? soff[jj] : limit;
-    __builtin_amdgcn_global_load_lds((mb_gptr_t)(src + off), (mb_lds_ptr_t)(slot + (w + MB_NW * jj) * 1024), 16, 0,
+    __builtin_amdgcn_global_load_lds((mb_gptr_t)(src + off), (mb_lds_ptr_t)(slot + (w + NW * jj) * 1024), 16, 0,
                                      EP_DMA_AUX);
   }
 }
 
 // step 1: (2 x 16 tokens) x 16 queries over this wave's D-slice -> LDS scratch; `mid` (the ring refill) is issued in the
 // shadow of the first MFMAs.  A operand: lane (i = token of the block, g): chunk 4*NK*w + 4*ks + g of row i.
-template <int NK, typename F>
+template <int NK, int NW, bool PK, typename F>
 __device__ __forceinline__ void mb_scores(const char* tile, const int (&aoff)[NK], const u4 (&bq)[NK][3], char* spart,
                                           int w, int lane, F&& mid) {
-  constexpr int ROWB = 512 * NK;
+  constexpr int ROWB = 64 * NK * NW;
   u4 xa[2][NK];
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk)
@@ -148,17 +149,36 @@ __device__ __forceinline__ void mb_scores(const char* tile, const int (&aoff)[NK
     }
     if (ks == 0) mid();
   }
-  *reinterpret_cast<f4*>(spart + ((0 * MB_NW + w) * 64 + lane) * 16) = acc[0];
-  *reinterpret_cast<f4*>(spart + ((1 * MB_NW + w) * 64 + lane) * 16) = acc[1];
+  if (PK) {                                                    // lanes 8-15 of a row: block 1 of query lane - 8
+    const bool up = (lane & 8) != 0;
+    const float s0 = dpp_f<0x118>(acc[1].x), s1 = dpp_f<0x118>(acc[1].y);   // row_shr:8 (all lanes active)
+    const float s2 = dpp_f<0x118>(acc[1].z), s3 = dpp_f<0x118>(acc[1].w);
+    f4 v;
+    v.x = up ? s0 : acc[0].x; v.y = up ? s1 : acc[0].y; v.z = up ? s2 : acc[0].z; v.w = up ? s3 : acc[0].w;
+    *reinterpret_cast<f4*>(spart + (w * 64 + lane) * 16) = v;
+  } else {
+    *reinterpret_cast<f4*>(spart + ((0 * NW + w) * 64 + lane) * 16) = acc[0];
+    *reinterpret_cast<f4*>(spart + ((1 * NW + w) * 64 + lane) * 16) = acc[1];
+  }
 }
-// full scores of (query j = lane & 15, tokens 16*blk + 4*g + r): the same lane slot of every wave's block, fixed order
+// full scores of (query j = lane & 15, tokens 16*blk + 4*g + r): the same lane slot of every wave's record, fixed order
+template <int NW, bool PK>
 __device__ __forceinline__ void mb_gather(const char* spart, int lane, float (&s)[8]) {
+  if (PK) {
+    f4 v = *reinterpret_cast<const f4*>(spart + lane * 16);
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    f4 v = *reinterpret_cast<const f4*>(spart + ((blk * MB_NW) * 64 + lane) * 16);
+    for (int ws = 1; ws < NW; ++ws) v += *reinterpret_cast<const f4*>(spart + (ws * 64 + lane) * 16);
+    s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;            // lanes 0-7 of a row: block 0 of query j
+    s[4] = dpp_f<0x108>(v.x); s[5] = dpp_f<0x108>(v.y);        // row_shl:8: block 1 from lane + 8
+    s[6] = dpp_f<0x108>(v.z); s[7] = dpp_f<0x108>(v.w);
+  } else {
 #pragma unroll
-    for (int ws = 1; ws < MB_NW; ++ws) v += *reinterpret_cast<const f4*>(spart + ((blk * MB_NW + ws) * 64 + lane) * 16);
-    s[4 * blk + 0] = v.x; s[4 * blk + 1] = v.y; s[4 * blk + 2] = v.z; s[4 * blk + 3] = v.w;
+    for (int blk = 0; blk < 2; ++blk) {
+      f4 v = *reinterpret_cast<const f4*>(spart + ((blk * NW) * 64 + lane) * 16);
+#pragma unroll
+      for (int ws = 1; ws < NW; ++ws) v += *reinterpret_cast<const f4*>(spart + ((blk * NW + ws) * 64 + lane) * 16);
+      s[4 * blk + 0] = v.x; s[4 * blk + 1] = v.y; s[4 * blk + 2] = v.z; s[4 * blk + 3] = v.w;
+    }
   }
 }
 // step 3: for each group of 32 channels dg of the slice: accE[dg] (rows = even channels) and accO[dg] (odd channels),
@@ -166,10 +186,10 @@ __device__ __forceinline__ void mb_gather(const char* spart, int lane, float (&s
 // Lane (i, g) reads the channel pair (2i, 2i+1) of the group: bytes 4*i of the 64-byte segment at chunk
 // c0 = 4*NK*w + 4*dg, i.e. chunk c0 + (i>>2), stored at chunk position (c0 + (i>>2)) ^ (4g + r) of row t
 // (conflict-free: the four g land in four different 64-byte segments of a 256-byte window).
-template <int NK>
+template <int NK, int NW>
 __device__ __forceinline__ void mb_pool(const char* tile, const int (&poff)[4], const int (&pseg)[NK],
                                         const float (&wgt)[8], f4 (&accE)[NK], f4 (&accO)[NK]) {
-  constexpr int ROWB = 512 * NK;
+  constexpr int ROWB = 64 * NK * NW;
   u4 bw[3];
   mb_split8(wgt, bw);
   unsigned xr[NK][8];
@@ -195,9 +215,9 @@ __device__ __forceinline__ void mb_pool(const char* tile, const int (&poff)[4], 
 }
 // per-lane address parts of the pooling A operand: row 4g + r, chunk-in-segment (i>>2) ^ r, channel pair i & 3;
 // 64-byte segment (NK*w + dg) ^ g of the row
-template <int NK>
+template <int NK, int NW>
 __device__ __forceinline__ void mb_pool_offsets(int w, int i, int g, int (&poff)[4], int (&pseg)[NK]) {
-  constexpr int ROWB = 512 * NK;
+  constexpr int ROWB = 64 * NK * NW;
 #pragma unroll
   for (int r = 0; r < 4; ++r) poff[r] = (4 * g + r) * ROWB + (((i >> 2) ^ r) << 4) + 4 * (i & 3);
 #pragma unroll
@@ -212,10 +232,10 @@ __device__ __forceinline__ void mb_store8(float* dst, f4 e, f4 o, float f) {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int NK>
-__global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
-  using C = MbCfg<NK>;
-  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA;
+template <int NK, int NW, bool PK>
+__global__ __launch_bounds__(NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
+  using C = MbCfg<NK, NW, PK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* ring = lds;
   char* spart = lds + NSLOT * SLOT;
@@ -246,10 +266,10 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p
     mb_split8(v, bq[ks]);
     aoff[ks] = j * ROWB + (((4 * NK * w + 4 * ks + g) ^ j) << 4);
   }
-  unsigned soff[2 * NK];
-  mb_source_offsets<NK>(w, lane, soff);
+  unsigned soff[KDMA];
+  mb_source_offsets<NCH, NW, KDMA>(w, lane, soff);
   int poff[4], pseg[NK];
-  mb_pool_offsets<NK>(w, j, g, poff, pseg);
+  mb_pool_offsets<NK, NW>(w, j, g, poff, pseg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p
     if (pi < n_items) {
       const int left = N - ptile * MB_TT;
       const unsigned limit = (unsigned)((left < MB_TT ? left : MB_TT) * ROWB - 16);
-      mb_dma_tile<NK>(psrc, limit, ring + pslot * SLOT, w, soff);
+      mb_dma_tile<NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
       ++pi;
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
       if (++ptile == tiles_per_img) {
@@ -288,10 +308,16 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p
 #pragma unroll
       for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
     }
-    mb_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
-    mb_barrier();                                   // all partial score blocks are in the scratch
+    if (p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
+    mb_scores<NK, NW, PK>(tile, aoff, bq, spart, w, lane, produce);
     float sc[8], ue[8];
-    mb_gather(spart, lane, sc);
+    if (p.ablate == 2) {                            // diagnostic: no exchange
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc[e] = 0.f;
+    } else {
+      mb_barrier();                                 // all partial score blocks are in the scratch
+      mb_gather<NW, PK>(spart, lane, sc);
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -312,21 +338,22 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p
       wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));          // invalid tokens: 0
       lsum += wgt[e];
     }
-    if (w == (it & 7) && j < Q) {                   // every wave holds the same scores: one writes them
-      float* Srow = p.S + ((int64_t)b * Q + j) * N + n0;
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const int t0 = 16 * blk + 4 * g;
-        if (n4) {
-          if (t0 < nvalid) *reinterpret_cast<f4*>(Srow + t0) = f4{sc[4 * blk], sc[4 * blk + 1], sc[4 * blk + 2], sc[4 * blk + 3]};
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (t0 + r < nvalid) Srow[t0 + r] = sc[4 * blk + r];
-        }
+    // every wave holds the same scores: wave w writes token group (w >> 1) & 3 of block w & 1 (waves 8-11: nothing)
+    if (w < 8 && g == (w >> 1) && j < Q) {
+      const int blk = w & 1;
+      const int t0 = 16 * blk + 4 * g;
+      float* Srow = p.S + ((int64_t)b * Q + j) * N + n0 + t0;
+      const float s0 = blk ? sc[4] : sc[0], s1 = blk ? sc[5] : sc[1], s2 = blk ? sc[6] : sc[2], s3 = blk ? sc[7] : sc[3];
+      if (n4) {
+        if (t0 < nvalid) *reinterpret_cast<f4*>(Srow) = f4{s0, s1, s2, s3};
+      } else {
+        if (t0 + 0 < nvalid) Srow[0] = s0;
+        if (t0 + 1 < nvalid) Srow[1] = s1;
+        if (t0 + 2 < nvalid) Srow[2] = s2;
+        if (t0 + 3 < nvalid) Srow[3] = s3;
       }
     }
-    mb_pool<NK>(tile, poff, pseg, wgt, accE, accO);
+    if (p.ablate != 3) mb_pool<NK, NW>(tile, poff, pseg, wgt, accE, accO);
     if (ctile == tiles_per_img - 1) {
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
@@ -352,10 +379,10 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p
 // ahead.  These plain loads are issued BEFORE the ring refill of their iteration, so the counted wait at the top of
 // the next iteration (which leaves only the newest tile's DMA outstanding) covers them.
 // ---------------------------------------------------------------------------------------
-template <int NK>
-__global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p) {
-  using C = MbCfg<NK>;
-  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA;
+template <int NK, int NW, bool PK>
+__global__ __launch_bounds__(NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p) {
+  using C = MbCfg<NK, NW, PK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* ring = lds;
   char* spart = lds + NSLOT * SLOT;
@@ -379,10 +406,10 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p
     int aoff[NK];
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) aoff[ks] = j * ROWB + (((4 * NK * w + 4 * ks + g) ^ j) << 4);
-    unsigned soff[2 * NK];
-    mb_source_offsets<NK>(w, lane, soff);
+    unsigned soff[KDMA];
+    mb_source_offsets<NCH, NW, KDMA>(w, lane, soff);
     int poff[4], pseg[NK];
-    mb_pool_offsets<NK>(w, j, g, poff, pseg);
+    mb_pool_offsets<NK, NW>(w, j, g, poff, pseg);
 
     // header of image `img` (index into this workgroup's images) -> registers
     f4 hq[NK][2], hml;
@@ -424,7 +451,7 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p
       if (pi < n_items) {
         const int left = N - ptile * MB_TT;
         const unsigned limit = (unsigned)((left < MB_TT ? left : MB_TT) * ROWB - 16);
-        mb_dma_tile<NK>(psrc, limit, ring + pslot * SLOT, w, soff);
+        mb_dma_tile<NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
         ++pi;
         pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
         if (++ptile == tiles_per_img) {
@@ -469,16 +496,16 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p
         if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
         if (nimg < n_img) load_scores(nimg, ntile);
       }
-      mb_scores<NK>(tile, aoff, bq, spart, w, lane, produce);      // dA partial blocks
+      mb_scores<NK, NW, PK>(tile, aoff, bq, spart, w, lane, produce);      // dA partial blocks
       mb_barrier();
       float u[8], wgt[8];
-      mb_gather(spart, lane, u);
+      mb_gather<NW, PK>(spart, lane, u);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
         wgt[e] = ((16 * (e >> 2) + 4 * g + (e & 3)) < nvalid && j < Q) ? a * (u[e] - dl_j) : 0.f;
       }
-      mb_pool<NK>(tile, poff, pseg, wgt, gE, gO);
+      mb_pool<NK, NW>(tile, poff, pseg, wgt, gE, gO);
       if (++ctile == tiles_per_img) { ctile = 0; ++cimg; }
     }
   }
@@ -490,39 +517,49 @@ __global__ __launch_bounds__(MB_NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NK>
+template <int NK, int NW, bool PK>
 static int mb_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  using C = MbCfg<NK>;
-  if constexpr (!C::VALID) {
-    set_error("no bf16 matrix-core pooling kernel for D=%d", 256 * NK);
-    return EP_E_UNSUPPORTED;
-  } else {
-    const size_t lds = (size_t)C::NSLOT * C::SLOT + C::SPART;
-    auto kf = ep_pool_mb_fwd_kernel<NK>;
-    auto kb = ep_pool_mb_bwd_kernel<NK>;
-    const void* fn = bwd ? (const void*)kb : (const void*)kf;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
-    if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(MB_NW * 64), lds, st, p);
-    else hipLaunchKernelGGL(kf, dim3(grid), dim3(MB_NW * 64), lds, st, p);
-    EP_LAUNCH_CHECK(bwd ? "ep_pool_mb_bwd_kernel" : "ep_pool_mb_fwd_kernel");
-    return 0;
-  }
+  using C = MbCfg<NK, NW, PK>;
+  static_assert(C::VALID, "bf16 matrix-core pooling configuration does not fit");
+  const size_t lds = (size_t)C::NSLOT * C::SLOT + C::SPART;
+  auto kf = ep_pool_mb_fwd_kernel<NK, NW, PK>;
+  auto kb = ep_pool_mb_bwd_kernel<NK, NW, PK>;
+  const void* fn = bwd ? (const void*)kb : (const void*)kf;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+  if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(NW * 64), lds, st, p);
+  else hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, st, p);
+  EP_LAUNCH_CHECK(bwd ? "ep_pool_mb_bwd_kernel" : "ep_pool_mb_fwd_kernel");
+  return 0;
 }
 
-// bf16 tokens, D in {256, 512, 768, 1024}, up to 16 shared query rows
+// bf16 tokens, shared query rows.  Up to 8 queries (packed exchange): D in {256, 384, 512, 768, 1024, 1152};
+// 9-16 queries: D in {256, 512, 768, 1024}.
 bool mb_supported(int D, int Q, int64_t cls_bstride) {
-  return D % 256 == 0 && D >= 256 && D <= 1024 && Q >= 1 && Q <= 16 && cls_bstride == 0;
+  if (cls_bstride != 0 || Q < 1 || Q > 16) return false;
+  if (D == 256 || D == 512 || D == 768 || D == 1024) return true;
+  return Q <= 8 && (D == 384 || D == 1152);
+}
+
+static int mb_variant() {             // diagnostic: EP_POOL_MB_WAVES=12 runs D = 768 on the 12-wave form (measured 94 vs 90 us)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EP_POOL_MB_WAVES"); v = e ? atoi(e) : 0; }
+  return v;
 }
 
 int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  switch (p.D / 256) {
-    case 1: return mb_launch_one<1>(bwd, p, grid, st);
-    case 2: return mb_launch_one<2>(bwd, p, grid, st);
-    case 3: return mb_launch_one<3>(bwd, p, grid, st);
-    case 4: return mb_launch_one<4>(bwd, p, grid, st);
+  const bool pk = p.Q <= 8;
+  switch (p.D) {
+    case 256: return pk ? mb_launch_one<1, 8, true>(bwd, p, grid, st) : mb_launch_one<1, 8, false>(bwd, p, grid, st);
+    case 384: if (pk) return mb_launch_one<1, 12, true>(bwd, p, grid, st); break;
+    case 512: return pk ? mb_launch_one<2, 8, true>(bwd, p, grid, st) : mb_launch_one<2, 8, false>(bwd, p, grid, st);
+    case 768:
+      if (!pk) return mb_launch_one<3, 8, false>(bwd, p, grid, st);
+      return mb_variant() == 12 ? mb_launch_one<2, 12, true>(bwd, p, grid, st) : mb_launch_one<3, 8, true>(bwd, p, grid, st);
+    case 1024: return pk ? mb_launch_one<4, 8, true>(bwd, p, grid, st) : mb_launch_one<4, 8, false>(bwd, p, grid, st);
+    case 1152: if (pk) return mb_launch_one<3, 12, true>(bwd, p, grid, st); break;
   }
-  set_error("no bf16 matrix-core pooling kernel for D=%d", p.D);
+  set_error("no bf16 matrix-core pooling kernel for D=%d, Q=%d", p.D, p.Q);
   return EP_E_UNSUPPORTED;
 }
 

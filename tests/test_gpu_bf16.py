@@ -107,7 +107,7 @@ def test_bf16_resident_store_trains_in_place(tmp_path):
 
 
 MB_SHAPES = [(5, 50, 256, 8), (9, 197, 768, 8), (600, 256, 768, 8), (7, 196, 1024, 8), (3, 31, 512, 16), (4, 64, 768, 1),
-             (2, 257, 768, 12)]
+             (2, 257, 768, 12), (5, 196, 384, 1), (4, 256, 1152, 8), (3, 40, 1024, 12), (3, 100, 256, 16), (3, 65, 512, 5)]
 
 
 @pytest.mark.parametrize("shape", MB_SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -115,7 +115,8 @@ def test_bf16_matrix_core_pass_against_float64(shape):
     """ep_pool_mb_*_kernel (bf16 tokens on the bf16 matrix cores, the fp32 operand split into three bf16 terms) against a
     float64 evaluation of reference poolings/ep.py:35-44 and of its gradient on the same stored values: the split keeps
     the fp32 contract (same tolerances as the fp32 token passes), partial last tiles, N % 4 != 0, more images than
-    workgroups and up to 16 query rows included."""
+    workgroups, the 8- and 12-wave forms, the packed (Q <= 8) and the plain score exchange and up to 16 query rows
+    included."""
     from efficient_probing_amd import functional as F_, _native
     B, Nn, D, Q = shape
     lib = _native.load()

@@ -11,11 +11,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--D", type=int, default=768); ap.add_argument("--Q", type=int, default=8)
 ap.add_argument("--iters", type=int, default=30); ap.add_argument("--bufs", type=int, default=1)
-ap.add_argument("--bwd", action="store_true")
+ap.add_argument("--bwd", action="store_true"); ap.add_argument("--bf16", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 lib = N_.load()
-xs = [torch.randn(a.B, a.N, a.D, device=dev) for _ in range(a.bufs)]
+xs = [torch.randn(a.B, a.N, a.D, device=dev).to(torch.bfloat16 if a.bf16 else torch.float32) for _ in range(a.bufs)]
+DT = N_.EP_DTYPE_BF16 if a.bf16 else N_.EP_DTYPE_F32
 cls = torch.randn(a.Q, a.D, device=dev) * 0.02
 scale = a.D ** -0.5
 P = torch.empty(a.B, a.Q, a.D, device=dev); S = torch.empty(a.B, a.Q, a.N, device=dev)
@@ -27,11 +28,11 @@ st = N_.current_stream_ptr(dev)
 
 def fwd(i):
     x = xs[i % a.bufs]
-    N_.check(lib.ep_pool_forward(x.data_ptr(), N_.EP_DTYPE_F32, a.N * a.D, 0, a.B, a.N, a.D, cls.data_ptr(), 0, a.Q,
+    N_.check(lib.ep_pool_forward(x.data_ptr(), DT, a.N * a.D, 0, a.B, a.N, a.D, cls.data_ptr(), 0, a.Q,
                                  scale, P.data_ptr(), S.data_ptr(), ML.data_ptr(), ws.data_ptr(), nws, st), "fwd")
 def bwd(i):
     x = xs[i % a.bufs]
-    N_.check(lib.ep_pool_backward(x.data_ptr(), N_.EP_DTYPE_F32, a.N * a.D, 0, a.B, a.N, a.D, a.Q, scale, S.data_ptr(),
+    N_.check(lib.ep_pool_backward(x.data_ptr(), DT, a.N * a.D, 0, a.B, a.N, a.D, a.Q, scale, S.data_ptr(),
                                   ML.data_ptr(), dP.data_ptr(), dcls.data_ptr(), 0, ws.data_ptr(), nws, st), "bwd")
 def timeit(fn):
     for i in range(3): fn(i)
@@ -44,7 +45,7 @@ def timeit(fn):
     return statistics.median(ts), ts[0]
 
 res = {"B": a.B}
-gb = a.B * a.N * a.D * 4 / 1e3
+gb = a.B * a.N * a.D * (2 if a.bf16 else 4) / 1e3
 t, tmin = timeit(fwd)
 res.update(fwd_us=round(t, 1), fwd_min=round(tmin, 1), fwd_GBs=round(gb / t, 1), fwd_kernel=N_.pool_kernel_name(a.B, a.N, a.D, a.Q, False)
            if hasattr(N_, "pool_kernel_name") else "")
