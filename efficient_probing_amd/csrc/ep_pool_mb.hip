@@ -538,7 +538,8 @@ static int mb_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st
 bool mb_supported(int D, int Q, int64_t cls_bstride) {
   if (cls_bstride != 0 || Q < 1 || Q > 16) return false;
   if (D == 256 || D == 512 || D == 768 || D == 1024) return true;
-  return Q <= 8 && (D == 384 || D == 1152);
+  // D = 384 with one or two queries: the vector-ALU kernel is as fast forward and faster backward (59 vs 67 us at 196x384)
+  return Q <= 8 && ((D == 384 && Q >= 3) || D == 1152);
 }
 
 static int mb_variant() {             // diagnostic: EP_POOL_MB_WAVES=12 runs D = 768 on the 12-wave form (measured 94 vs 90 us)
