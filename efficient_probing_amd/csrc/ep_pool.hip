@@ -383,7 +383,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
   if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B, p.x_bf16), st);
   if (use_mb(p)) {
     if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
-    return mb_launch(false, p, mf_grid(p.B), st);
+    return mb_launch(false, p, mb_grid(p.D, p.B), st);
   }
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
@@ -418,7 +418,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     nparts = wide_grid(p.D, p.B, p.x_bf16);
     EP_TRY(wide_launch(true, p, nparts, st));
   } else if (use_mb(p)) {
-    nparts = mf_grid(p.B);
+    nparts = mb_grid(p.D, p.B);
     EP_TRY(mb_launch(true, p, nparts, st));
   } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);

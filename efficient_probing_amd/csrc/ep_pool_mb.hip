@@ -516,6 +516,376 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p) {
   }
 }
 
+// =======================================================================================
+// Two-workgroup form (D = 128*NK <= 768): 4-wave workgroups, TWO per CU, 16-token tiles.  Each workgroup has its own
+// ring and its own barriers, so one workgroup's rendezvous and LDS latencies are covered by the other's arithmetic; a
+// wave owns 32*NK channels (192 at D = 768), which halves the redundant softmax / operand-split work per token.  The
+// pooling contraction runs on v_mfma_f32_16x16x16_bf16 (K = the 16 tokens of the tile): operand slot (g, e) <-> token
+// 4g + e, which is the D layout of the score block.
+// =======================================================================================
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+constexpr int MB2_TT = 16, MB2_NW = 4;
+
+template <int NK>
+struct Mb2Cfg {
+  static constexpr int D = 128 * NK;
+  static constexpr int ROWB = 2 * D;
+  static constexpr int NCH = D / 8;
+  static constexpr int SLOT = MB2_TT * ROWB;
+  static constexpr int KDMA = SLOT / (MB2_NW * 1024);   // = NK
+  static constexpr int SPART = MB2_NW * 1024;
+  static constexpr int NSLOT = 3;
+  static constexpr int LDS = NSLOT * SLOT + SPART;      // 77824 at D = 768: two workgroups per CU
+};
+
+__device__ __forceinline__ f4 mb2_mfma16(u2 a, u2 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, a), __builtin_bit_cast(s4v, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mb2_split4(const float (&v)[4], u2 (&t)[3]) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) mb_split3(v[e], h[e], m[e], l[e]);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    t[0][e] = mb_pack_hi(h[2 * e], h[2 * e + 1]);
+    t[1][e] = mb_pack_hi(m[2 * e], m[2 * e + 1]);
+    t[2][e] = mb_pack_hi(l[2 * e], l[2 * e + 1]);
+  }
+}
+// partial scores of the 16-token tile over this wave's slice -> its record in the scratch
+template <int NK, typename F>
+__device__ __forceinline__ void mb2_scores(const char* tile, const int (&aoff)[NK], const u4 (&bq)[NK][3], char* spart,
+                                           int w, int lane, F&& mid) {
+  u4 xa[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) xa[ks] = *reinterpret_cast<const u4*>(tile + aoff[ks]);
+  f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+    for (int term = 2; term >= 0; --term) acc[ks & 1] = mb_mfma(xa[ks], bq[ks][term], acc[ks & 1]);
+    if (ks == 0) mid();
+  }
+  *reinterpret_cast<f4*>(spart + (w * 64 + lane) * 16) = acc[0] + acc[1];
+}
+__device__ __forceinline__ void mb2_gather(const char* spart, int lane, float (&s)[4]) {
+  f4 v = *reinterpret_cast<const f4*>(spart + lane * 16);
+#pragma unroll
+  for (int ws = 1; ws < MB2_NW; ++ws) v += *reinterpret_cast<const f4*>(spart + (ws * 64 + lane) * 16);
+  s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+}
+template <int NK>
+__device__ __forceinline__ void mb2_pool(const char* tile, const int (&poff)[4], const int (&pseg)[NK],
+                                         const float (&wgt)[4], f4 (&accE)[NK], f4 (&accO)[NK]) {
+  u2 bw[3];
+  mb2_split4(wgt, bw);
+  unsigned xr[NK][4];
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xr[dg][e] = *reinterpret_cast<const unsigned*>(tile + poff[e] + pseg[dg]);
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) {
+    u2 ae, ao;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ae[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x05040100u);
+      ao[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x07060302u);
+    }
+#pragma unroll
+    for (int term = 2; term >= 0; --term) {
+      accE[dg] = mb2_mfma16(ae, bw[term], accE[dg]);
+      accO[dg] = mb2_mfma16(ao, bw[term], accO[dg]);
+    }
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolParams p) {
+  using C = Mb2Cfg<NK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* ring = lds;
+  char* spart = lds + NSLOT * SLOT;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int N = p.N, Q = p.Q;
+  const bool n4 = (N & 3) == 0;
+  const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * tiles_per_img;
+  if (n_items <= 0) return;
+  const int j = lane & 15, g = lane >> 4;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+
+  u4 bq[NK][3];
+  int aoff[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j < Q) {
+      const float* src = p.cls + (int64_t)j * D + 32 * NK * w + 32 * ks + 8 * g;
+      const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+      v[0] = a.x * p.scale; v[1] = a.y * p.scale; v[2] = a.z * p.scale; v[3] = a.w * p.scale;
+      v[4] = b.x * p.scale; v[5] = b.y * p.scale; v[6] = b.z * p.scale; v[7] = b.w * p.scale;
+    }
+    mb_split8(v, bq[ks]);
+    aoff[ks] = j * ROWB + (((4 * NK * w + 4 * ks + g) ^ j) << 4);
+  }
+  unsigned soff[KDMA];
+  mb_source_offsets<NCH, MB2_NW, KDMA>(w, lane, soff);
+  int poff[4], pseg[NK];
+  mb_pool_offsets<NK, MB2_NW>(w, j, g, poff, pseg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+  const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
+  auto produce = [&]() {
+    if (pi < n_items) {
+      const int left = N - ptile * MB2_TT;
+      const unsigned limit = (unsigned)((left < MB2_TT ? left : MB2_TT) * ROWB - 16);
+      mb_dma_tile<MB2_NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
+      ++pi;
+      pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+      if (++ptile == tiles_per_img) {
+        ptile = 0; ++pimg;
+        psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+      } else {
+        psrc += SLOT;
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+  f4 accE[NK], accO[NK];
+  float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;
+  int cimg = 0, ctile = 0, cslot = 0;
+  for (int it = 0; it < n_items; ++it) {
+    mb_wait_vmcnt((pi - 1 - it) * KDMA);
+    mb_barrier();
+    const int b = wg + cimg * G;
+    const int n0 = ctile * MB2_TT;
+    const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+    const char* tile = ring + cslot * SLOT;
+    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+    if (ctile == 0) {
+      m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
+#pragma unroll
+      for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+    mb_barrier();
+    float sc[4], ue[4];
+    mb2_gather(spart, lane, sc);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ue[e] = (4 * g + e) < nvalid ? sc[e] : -INFINITY;
+      mx = fmaxf(mx, ue[e]);
+    }
+    if (__builtin_amdgcn_ballot_w64(mx > m_j + MB_LAZY_MAX_THR) != 0ull) {
+      const float mn = fmaxf(m_j, mb_q4_max(mx));
+      const float f = __builtin_amdgcn_exp2f((m_j - mn) * MB_LOG2E);
+      m_j = mn; mL_j = mn * MB_LOG2E;
+      lsum *= f;
+#pragma unroll
+      for (int dg = 0; dg < NK; ++dg) { accE[dg] *= f; accO[dg] *= f; }
+    }
+    float wgt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));
+      lsum += wgt[e];
+    }
+    if (w == (it & 3) && j < Q) {                   // every wave holds the same scores: one writes the tile
+      float* Srow = p.S + ((int64_t)b * Q + j) * N + n0 + 4 * g;
+      if (n4) {
+        if (4 * g < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[0], sc[1], sc[2], sc[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g + r < nvalid) Srow[r] = sc[r];
+      }
+    }
+    mb2_pool<NK>(tile, poff, pseg, wgt, accE, accO);
+    if (ctile == tiles_per_img - 1) {
+      const float l = mb_q4_sum(lsum);
+      const float inv = 1.0f / l;
+      if (j < Q) {
+        float* Pq = p.P + ((int64_t)b * Q + j) * D + 32 * NK * w + 8 * g;
+#pragma unroll
+        for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
+        if (w == 0 && g == 0) {
+          const f4 rec = {m_j, l, 0.f, 0.f};
+          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + j) * 4) = rec;
+        }
+      }
+      ctile = 0; ++cimg;
+    } else {
+      ++ctile;
+    }
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolParams p) {
+  using C = Mb2Cfg<NK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* ring = lds;
+  char* spart = lds + NSLOT * SLOT;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int N = p.N, Q = p.Q;
+  const bool n4 = (N & 3) == 0;
+  const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * tiles_per_img;
+  const int j = lane & 15, g = lane >> 4;
+  const int jq = j < Q ? j : Q - 1;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+
+  f4 gE[NK], gO[NK];
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) { gE[dg] = f4{0.f, 0.f, 0.f, 0.f}; gO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+
+  if (n_items > 0) {
+    int aoff[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) aoff[ks] = j * ROWB + (((4 * NK * w + 4 * ks + g) ^ j) << 4);
+    unsigned soff[KDMA];
+    mb_source_offsets<NCH, MB2_NW, KDMA>(w, lane, soff);
+    int poff[4], pseg[NK];
+    mb_pool_offsets<NK, MB2_NW>(w, j, g, poff, pseg);
+
+    float sv[4];
+    auto load_scores = [&](int img, int tl) {
+      const int b = wg + img * G;
+      const float* Srow = p.S + ((int64_t)b * Q + jq) * N;
+      int t0 = tl * MB2_TT + 4 * g;
+      if (n4) {
+        t0 = t0 < N ? t0 : N - 4;
+        const f4 v = *reinterpret_cast<const f4*>(Srow + t0);
+        sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = Srow[(t0 + r) < N ? (t0 + r) : N - 1];
+      }
+    };
+    load_scores(0, 0);
+    int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+    const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
+    auto produce = [&]() {
+      if (pi < n_items) {
+        const int left = N - ptile * MB2_TT;
+        const unsigned limit = (unsigned)((left < MB2_TT ? left : MB2_TT) * ROWB - 16);
+        mb_dma_tile<MB2_NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
+        ++pi;
+        pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+        if (++ptile == tiles_per_img) {
+          ptile = 0; ++pimg;
+          psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+        } else {
+          psrc += SLOT;
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+    u4 bq[NK][3];
+    float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
+    int cimg = 0, ctile = 0, cslot = 0;
+    for (int it = 0; it < n_items; ++it) {
+      mb_wait_vmcnt((pi - 1 - it) * KDMA);
+      mb_barrier();
+      const int n0 = ctile * MB2_TT;
+      const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+      const char* tile = ring + cslot * SLOT;
+      cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+      if (ctile == 0) {                              // new image: its dP rows (this wave's slice) and ML row; the other
+        const int b = wg + cimg * G;                 // workgroup of the CU covers the wait
+        const float* src = p.dP + ((int64_t)b * Q + jq) * D + 32 * NK * w + 8 * g;
+        const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          const f4 a = *reinterpret_cast<const f4*>(src + 32 * ks), c = *reinterpret_cast<const f4*>(src + 32 * ks + 4);
+          float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+          if (j >= Q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          }
+          mb_split8(v, bq[ks]);
+        }
+        mL_j = hml.x * MB_LOG2E; il_j = 1.0f / hml.y; dl_j = hml.z;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // keeps the counted waits below exact
+      }
+      float cur[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[e] = sv[e];
+      {
+        int nimg = cimg, ntile = ctile + 1;
+        if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
+        if (nimg < n_img) load_scores(nimg, ntile);
+      }
+      mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+      mb_barrier();
+      float u[4], wgt[4];
+      mb2_gather(spart, lane, u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
+        wgt[e] = ((4 * g + e) < nvalid && j < Q) ? a * (u[e] - dl_j) : 0.f;
+      }
+      mb2_pool<NK>(tile, poff, pseg, wgt, gE, gO);
+      if (++ctile == tiles_per_img) { ctile = 0; ++cimg; }
+    }
+  }
+  if (j < Q) {
+    float* Gq = p.Gpart + ((int64_t)wg * Q + j) * D + 32 * NK * w + 8 * g;
+#pragma unroll
+    for (int dg = 0; dg < NK; ++dg) mb_store8(Gq + 32 * dg, gE[dg], gO[dg], 1.0f);
+  }
+}
+
+template <int NK>
+static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  using C = Mb2Cfg<NK>;
+  const size_t lds = C::LDS;
+  auto kf = ep_pool_mb2_fwd_kernel<NK>;
+  auto kb = ep_pool_mb2_bwd_kernel<NK>;
+  const void* fn = bwd ? (const void*)kb : (const void*)kf;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+  if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
+  else hipLaunchKernelGGL(kf, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
+  EP_LAUNCH_CHECK(bwd ? "ep_pool_mb2_bwd_kernel" : "ep_pool_mb2_fwd_kernel");
+  return 0;
+}
+// the two-workgroup form is the default for every D it supports (256, 384, 512, 768: measured faster on all of them,
+// e.g. 80 / 83 us against 91 / 100 us at 256x768, 42 / 51 against 62 / 73 at 196x384); EP_POOL_MB2=0 switches it off
+static bool mb2_use(int D) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EP_POOL_MB2"); v = e ? atoi(e) : 1; }
+  if (v == 0) return false;
+  return D == 256 || D == 384 || D == 512 || D == 768;
+}
+// resident workgroups per CU of the two-workgroup form: what LDS (3 slots of 32 D bytes + 4 KiB) and registers allow
+static int mb2_wgs_per_cu(int D) {
+  static int ov = -1;
+  if (ov < 0) { const char* e = getenv("EP_POOL_MB2_WGS"); ov = e ? atoi(e) : 0; }
+  if (ov > 0) return ov;
+  return D <= 384 ? 4 : 2;     // measured: 512 runs 54 us on two, 58 us on four
+}
+int mb_grid(int D, int B) {
+  const int g = cu_count() * (mb2_use(D) ? mb2_wgs_per_cu(D) : 1);
+  return g < B ? g : B;
+}
+
 // ---------------------------------------------------------------------------------------
 template <int NK, int NW, bool PK>
 static int mb_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
@@ -538,8 +908,8 @@ static int mb_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st
 bool mb_supported(int D, int Q, int64_t cls_bstride) {
   if (cls_bstride != 0 || Q < 1 || Q > 16) return false;
   if (D == 256 || D == 512 || D == 768 || D == 1024) return true;
-  // D = 384 with one or two queries: the vector-ALU kernel is as fast forward and faster backward (59 vs 67 us at 196x384)
-  return Q <= 8 && ((D == 384 && Q >= 3) || D == 1152);
+  if (D == 384) return true;
+  return Q <= 8 && D == 1152;
 }
 
 static int mb_variant() {             // diagnostic: EP_POOL_MB_WAVES=12 runs D = 768 on the 12-wave form (measured 94 vs 90 us)
@@ -550,6 +920,14 @@ static int mb_variant() {             // diagnostic: EP_POOL_MB_WAVES=12 runs D 
 
 int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   const bool pk = p.Q <= 8;
+  if (mb2_use(p.D)) {
+    switch (p.D) {
+      case 256: return mb2_launch_one<2>(bwd, p, grid, st);
+      case 384: return mb2_launch_one<3>(bwd, p, grid, st);
+      case 512: return mb2_launch_one<4>(bwd, p, grid, st);
+      case 768: return mb2_launch_one<6>(bwd, p, grid, st);
+    }
+  }
   switch (p.D) {
     case 256: return pk ? mb_launch_one<1, 8, true>(bwd, p, grid, st) : mb_launch_one<1, 8, false>(bwd, p, grid, st);
     case 384: if (pk) return mb_launch_one<1, 12, true>(bwd, p, grid, st); break;

@@ -68,6 +68,7 @@ int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // bf16-token matrix-core variant (ep_pool_mb.hip): bf16-stored tokens, D in {256, 384, 512, 768, 1024, 1152}, Q <= 16
 bool mb_supported(int D, int Q, int64_t cls_bstride);
 int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
+int mb_grid(int D, int B);
 // wide-row variant (ep_pool_wide.hip): D = 2048 / 4096, Q <= 8, row split across the waves
 bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16 = 0);
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
