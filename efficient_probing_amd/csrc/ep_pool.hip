@@ -362,7 +362,7 @@ const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) 
   PoolParams p{};
   p.B = B; p.N = N; p.D = D; p.Q = Q; p.x_bf16 = x_bf16;
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
-  if (use_mb(p)) return bwd ? "ep_pool_mb_bwd_kernel" : "ep_pool_mb_fwd_kernel";
+  if (use_mb(p)) return mb_kernel_name(D, bwd != 0);
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
   if (stream_plan(B, N, D, Q).ok && !force_generic() && stream_takes(p)) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";

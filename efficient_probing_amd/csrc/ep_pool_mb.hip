@@ -881,6 +881,10 @@ static int mb2_wgs_per_cu(int D) {
   if (ov > 0) return ov;
   return D <= 384 ? 4 : 2;     // measured: 512 runs 54 us on two, 58 us on four
 }
+const char* mb_kernel_name(int D, bool bwd) {
+  if (mb2_use(D)) return bwd ? "ep_pool_mb2_bwd_kernel" : "ep_pool_mb2_fwd_kernel";
+  return bwd ? "ep_pool_mb_bwd_kernel" : "ep_pool_mb_fwd_kernel";
+}
 int mb_grid(int D, int B) {
   const int g = cu_count() * (mb2_use(D) ? mb2_wgs_per_cu(D) : 1);
   return g < B ? g : B;

@@ -69,6 +69,7 @@ int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 bool mb_supported(int D, int Q, int64_t cls_bstride);
 int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 int mb_grid(int D, int B);
+const char* mb_kernel_name(int D, bool bwd);
 // wide-row variant (ep_pool_wide.hip): D = 2048 / 4096, Q <= 8, row split across the waves
 bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16 = 0);
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);

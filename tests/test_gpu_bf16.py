@@ -112,7 +112,7 @@ MB_SHAPES = [(5, 50, 256, 8), (9, 197, 768, 8), (600, 256, 768, 8), (7, 196, 102
 
 @pytest.mark.parametrize("shape", MB_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_bf16_matrix_core_pass_against_float64(shape):
-    """ep_pool_mb_*_kernel (bf16 tokens on the bf16 matrix cores, the fp32 operand split into three bf16 terms) against a
+    """ep_pool_mb_*_kernel / ep_pool_mb2_*_kernel (bf16 tokens on the bf16 matrix cores, the fp32 operand split into three bf16 terms) against a
     float64 evaluation of reference poolings/ep.py:35-44 and of its gradient on the same stored values: the split keeps
     the fp32 contract (same tolerances as the fp32 token passes), partial last tiles, N % 4 != 0, more images than
     workgroups, the 8- and 12-wave forms, the packed (Q <= 8) and the plain score exchange and up to 16 query rows
@@ -120,8 +120,9 @@ def test_bf16_matrix_core_pass_against_float64(shape):
     from efficient_probing_amd import functional as F_, _native
     B, Nn, D, Q = shape
     lib = _native.load()
-    assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1).decode() == "ep_pool_mb_fwd_kernel"
-    assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1).decode() == "ep_pool_mb_bwd_kernel"
+    fam = "mb2" if D in (256, 384, 512, 768) else "mb"       # 4-wave workgroups on 16-token tiles / 8-12 waves on 32
+    assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1).decode() == f"ep_pool_{fam}_fwd_kernel"
+    assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1).decode() == f"ep_pool_{fam}_bwd_kernel"
     gen = torch.Generator(device="cpu").manual_seed(11)
     xb = torch.randn(B, Nn, D, generator=gen).to(torch.bfloat16)
     cls = torch.randn(Q, D, generator=gen) * 0.5
