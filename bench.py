@@ -12,7 +12,9 @@ update.  Default workload: BASELINE.json configs[1] (DINOv2 ViT-B/14 tokens 256x
 One JSON line is printed by rank 0 (see the driver contract in the task statement) with two extra
 objects: ``roofline`` for the dominant kernel (the EP pooling forward pass, HBM-bound) measured
 live with HIP events, and ``cpu_baseline`` = the op-for-op torch-CPU port of the reference step
-(oracle/torch_port.py) timed on this box's host cores for a bounded ~15 s sample.
+(oracle/torch_port.py) timed on this box's host cores for a bounded ~15 s sample.  The default EP run at N = 1 adds
+``bf16_token_storage``: the same step on the same tokens stored as bf16 (fp32 arithmetic and results) -- a secondary
+figure, never ``value``.
 """
 from __future__ import annotations
 
@@ -53,6 +55,7 @@ def parse():
     ap.add_argument("--tokens", default="f32", choices=["f32", "bf16"],
                     help="storage type of the tokens in HBM (arithmetic is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-secondary", action="store_true", help="skip the bf16-token-storage line of the default EP run")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
@@ -357,6 +360,37 @@ def main():
     fwd_gbs = algo_bytes / t_fwd / 1e9
     bwd_gbs = algo_bytes / t_bwd / 1e9
 
+    # ---- secondary (N = 1 only): the same step on the same tokens STORED as bf16 (fp32 arithmetic and results; the
+    # token passes run on the bf16 matrix cores, csrc/ep_pool_mb.hip).  Not the headline: `value` above is fp32 storage.
+    bf16_line = None
+    if world == 1 and args.head == "ep" and args.tokens == "f32" and not args.no_bf16_secondary:
+        torch.manual_seed(0)
+        enc2 = Enc()
+        probe_heads.build_probe_head(enc2, Namespace(cls_features=args.head, ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
+                                                     model="capi_vitl14_in1k" if Nn == 256 else "vit_base_patch16"))
+        eng2 = make_engine(enc2.head.to(dev).train(), optimizer="lars", lr=lr, weight_decay=0.0)
+        xb = [x.to(torch.bfloat16) for x in xs]
+        k2 = max(10, min(args.steps, 50))
+        for i in range(5):
+            eng2.train_step(xb[i % args.buffers], ts[i % args.buffers])
+        eng2.flush(); eng2.read_stats()
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for i in range(k2):
+            eng2.train_step(xb[i % args.buffers], ts[i % args.buffers])
+        eng2.flush()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - tb0
+        l2 = eng2.read_stats()[0]
+        tf2 = time_kernel(lambda i: F_.pool_forward(xb[i % args.buffers], cls, scale), args.kernel_iters)
+        bf16_line = {"value": round(B * k2 / el2, 1), "unit": "images/s", "steps": k2, "ms_per_step": round(el2 / k2 * 1e3, 4),
+                     "token_storage": "bf16", "arithmetic": "f32",
+                     "kernel": eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1).decode(),
+                     "us_per_launch": round(tf2 * 1e6, 2), "algorithmic_bytes": B * Nn * D * 2,
+                     "frac": round(B * Nn * D * 2 / tf2 / 1e9 / HBM_PEAK_GBS, 4),
+                     "mean_loss_over_timed_steps": round(l2 / k2, 5)}
+        del xb, eng2
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
@@ -385,6 +419,8 @@ def main():
                       "step_ms_device": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}},
             "eval_forward": {"value": round(B / eval_s, 1), "unit": "images/s per GPU", "ms_per_batch": round(eval_s * 1e3, 4)},
         }
+        if bf16_line is not None:
+            out["bf16_token_storage"] = bf16_line
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port
             cb = max(8, min(128, B))
