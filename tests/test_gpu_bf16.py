@@ -107,7 +107,8 @@ def test_bf16_resident_store_trains_in_place(tmp_path):
 
 
 MB_SHAPES = [(5, 50, 256, 8), (9, 197, 768, 8), (600, 256, 768, 8), (7, 196, 1024, 8), (3, 31, 512, 16), (4, 64, 768, 1),
-             (2, 257, 768, 12), (5, 196, 384, 4), (4, 256, 1152, 8), (3, 40, 1024, 12), (3, 100, 256, 16), (3, 65, 512, 5)]
+             (2, 257, 768, 12), (5, 196, 384, 4), (4, 256, 1152, 8), (3, 40, 1024, 12), (3, 100, 256, 16), (3, 65, 512, 5),
+             (3, 5, 256, 2), (2, 16, 768, 8), (1, 1, 512, 1), (1300, 33, 384, 8), (2, 3, 1152, 3)]
 
 
 @pytest.mark.parametrize("shape", MB_SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -145,7 +146,9 @@ def test_bf16_matrix_core_pass_against_float64(shape):
     g64 = scale * torch.einsum("bqn,bnd->qd", dS64, x64)
     ML2 = ML.clone(); ML2[:, :, 2] = delta64.float().to(DEV)
     g = F_.pool_backward(xb.to(DEV), S, ML2, dP.to(DEV), scale)
-    np.testing.assert_allclose(g.cpu().numpy(), g64.numpy(), rtol=1e-4, atol=2e-5 * float(g64.abs().max()))
+    # (noise floor: with one token the gradient is exactly zero and what is left is the fp32 rounding of delta)
+    floor = 1e-6 * scale * B * float(dA64.abs().max()) * float(x64.abs().max())
+    np.testing.assert_allclose(g.cpu().numpy(), g64.numpy(), rtol=1e-4, atol=2e-5 * float(g64.abs().max()) + floor)
     # the vector-ALU / generic kernels on the same stored values agree to summation order
     old = lib.ep_debug_force_generic_pool(1)
     try:
