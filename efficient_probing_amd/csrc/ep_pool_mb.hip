@@ -527,7 +527,7 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 constexpr int MB2_TT = 16, MB2_NW = 4;
 
-template <int NK>
+template <int NK, int NS = 3>
 struct Mb2Cfg {
   static constexpr int D = 128 * NK;
   static constexpr int ROWB = 2 * D;
@@ -535,7 +535,7 @@ struct Mb2Cfg {
   static constexpr int SLOT = MB2_TT * ROWB;
   static constexpr int KDMA = SLOT / (MB2_NW * 1024);   // = NK
   static constexpr int SPART = MB2_NW * 1024;
-  static constexpr int NSLOT = 3;
+  static constexpr int NSLOT = NS;                      // ring slots (2 where three do not leave room for two workgroups)
   static constexpr int LDS = NSLOT * SLOT + SPART;      // 77824 at D = 768: two workgroups per CU
 };
 
@@ -601,9 +601,9 @@ __device__ __forceinline__ void mb2_pool(const char* tile, const int (&poff)[4],
   }
 }
 
-template <int NK>
+template <int NK, int NS>
 __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolParams p) {
-  using C = Mb2Cfg<NK>;
+  using C = Mb2Cfg<NK, NS>;
   constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* ring = lds;
@@ -730,9 +730,9 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
   }
 }
 
-template <int NK>
+template <int NK, int NS>
 __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolParams p) {
-  using C = Mb2Cfg<NK>;
+  using C = Mb2Cfg<NK, NS>;
   constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* ring = lds;
@@ -852,12 +852,12 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
   }
 }
 
-template <int NK>
+template <int NK, int NS = 3>
 static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
-  using C = Mb2Cfg<NK>;
+  using C = Mb2Cfg<NK, NS>;
   const size_t lds = C::LDS;
-  auto kf = ep_pool_mb2_fwd_kernel<NK>;
-  auto kb = ep_pool_mb2_bwd_kernel<NK>;
+  auto kf = ep_pool_mb2_fwd_kernel<NK, NS>;
+  auto kb = ep_pool_mb2_bwd_kernel<NK, NS>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
@@ -866,13 +866,15 @@ static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t s
   EP_LAUNCH_CHECK(bwd ? "ep_pool_mb2_bwd_kernel" : "ep_pool_mb2_fwd_kernel");
   return 0;
 }
-// the two-workgroup form is the default for every D it supports (256, 384, 512, 768: measured faster on all of them,
+// the two-workgroup form is the default for every D it supports (256, 384, 512, 768, 1024: measured faster on all of them,
 // e.g. 80 / 83 us against 91 / 100 us at 256x768, 42 / 51 against 62 / 73 at 196x384); EP_POOL_MB2=0 switches it off
 static bool mb2_use(int D) {
   static int v = -1;
   if (v < 0) { const char* e = getenv("EP_POOL_MB2"); v = e ? atoi(e) : 1; }
   if (v == 0) return false;
-  return D == 256 || D == 384 || D == 512 || D == 768;
+  // D = 1024: ring of two 32 KiB slots so that two workgroups fit (82 / 85 us against 93 / 101 us of the 8-wave form);
+  // D = 1152 would spill (10 / 22 registers: 190 / 249 us) and stays on the 12-wave form
+  return D == 256 || D == 384 || D == 512 || D == 768 || D == 1024;
 }
 // resident workgroups per CU of the two-workgroup form: what LDS (3 slots of 32 D bytes + 4 KiB) and registers allow
 static int mb2_wgs_per_cu(int D) {
@@ -930,6 +932,7 @@ int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
       case 384: return mb2_launch_one<3>(bwd, p, grid, st);
       case 512: return mb2_launch_one<4>(bwd, p, grid, st);
       case 768: return mb2_launch_one<6>(bwd, p, grid, st);
+      case 1024: return mb2_launch_one<8, 2>(bwd, p, grid, st);
     }
   }
   switch (p.D) {

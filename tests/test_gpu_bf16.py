@@ -121,7 +121,7 @@ def test_bf16_matrix_core_pass_against_float64(shape):
     from efficient_probing_amd import functional as F_, _native
     B, Nn, D, Q = shape
     lib = _native.load()
-    fam = "mb2" if D in (256, 384, 512, 768) else "mb"       # 4-wave workgroups on 16-token tiles / 8-12 waves on 32
+    fam = "mb2" if D in (256, 384, 512, 768, 1024) else "mb"       # 4-wave workgroups on 16-token tiles / 8-12 waves on 32
     assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1).decode() == f"ep_pool_{fam}_fwd_kernel"
     assert lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1).decode() == f"ep_pool_{fam}_bwd_kernel"
     gen = torch.Generator(device="cpu").manual_seed(11)
