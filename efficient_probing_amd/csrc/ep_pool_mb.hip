@@ -676,10 +676,16 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
 #pragma unroll
       for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
     }
+    if (p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
     mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
-    mb_barrier();
     float sc[4], ue[4];
-    mb2_gather(spart, lane, sc);
+    if (p.ablate == 2) {                            // diagnostic: no exchange
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = 0.f;
+    } else {
+      mb_barrier();
+      mb2_gather(spart, lane, sc);
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));
       lsum += wgt[e];
     }
-    if (w == (it & 3) && j < Q) {                   // every wave holds the same scores: one writes the tile
+    if (w == (it & 3) && j < Q && p.ablate != 4) {  // every wave holds the same scores: one writes the tile
       float* Srow = p.S + ((int64_t)b * Q + j) * N + n0 + 4 * g;
       if (n4) {
         if (4 * g < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[0], sc[1], sc[2], sc[3]};
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
           if (4 * g + r < nvalid) Srow[r] = sc[r];
       }
     }
-    mb2_pool<NK>(tile, poff, pseg, wgt, accE, accO);
+    if (p.ablate != 3) mb2_pool<NK>(tile, poff, pseg, wgt, accE, accO);
     if (ctile == tiles_per_img - 1) {
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
