@@ -346,11 +346,12 @@ static bool use_mb(const PoolParams& p) {
   return on && p.x_bf16 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mb_supported(p.D, p.Q, p.cls_bstride);
 }
 
-// what the vector-ALU streaming kernels can take: LayerNorm-of-tokens mode needs fp32 tokens
+// what the vector-ALU streaming kernels can take (LayerNorm-of-tokens mode on bf16 tokens: where a tile's scores and
+// statistics fit one 64-lane piece)
 static bool stream_takes(const PoolParams& p) {
   static int ln = -1;
   if (ln < 0) { const char* e = getenv("EP_POOL_LN_STREAM"); ln = e ? atoi(e) : 1; }
-  return !p.tokstat || (ln && !p.x_bf16 && stream_ln_supported(p.D, p.Q));
+  return !p.tokstat || (ln && (p.x_bf16 ? stream_ln_bf16_supported(p.D, p.Q) : stream_ln_supported(p.D, p.Q)));
 }
 
 // wide rows (D = 2048 / 4096): the row is split across the waves of a workgroup

@@ -76,6 +76,7 @@ int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 int wide_grid(int D, int B, int x_bf16 = 0);
 // LayerNorm-of-tokens mode (PoolParams.tokstat) in the vector-ALU streaming kernels
 bool stream_ln_supported(int D, int Q);
+bool stream_ln_bf16_supported(int D, int Q);
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side = nullptr);
 
 }  // namespace ep

@@ -577,7 +577,11 @@ static int launch_cfg(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
       if (p.D == 256 * KP && !p.tokstat) return launch_one<QW, KP, NW, 256 * KP, true, false>(bwd, p, grid, st, side);
     }
     if (p.tokstat) {
-      if (p.x_bf16) { set_error("LayerNorm-of-tokens mode takes fp32 tokens"); return EP_E_UNSUPPORTED; }
+      if (p.x_bf16) {
+        // bf16 tiles hold twice the tokens: scores and token statistics of a tile must still fit one 64-lane piece
+        if constexpr (QW * 2 * Cfg::TT + 2 * 2 * Cfg::TT <= 64) return launch_one<QW, KP, NW, 0, true, true>(bwd, p, grid, st, side);
+        else { set_error("LayerNorm-of-tokens mode on bf16 tokens: no kernel for qw=%d nw=%d", QW, NW); return EP_E_UNSUPPORTED; }
+      }
       return launch_one<QW, KP, NW, 0, false, true>(bwd, p, grid, st, side);
     }
     if (p.x_bf16) return launch_one<QW, KP, NW, 0, true, false>(bwd, p, grid, st, side);
@@ -600,6 +604,12 @@ static int dispatch_kp(bool bwd, int kp, const PoolParams& p, int grid, hipStrea
 }
 
 bool stream_ln_supported(int D, int Q) { return stream_plan(1 << 20, 1, D, Q).ok; }
+bool stream_ln_bf16_supported(int D, int Q) {
+  const StreamPlan c = stream_plan(1 << 20, 1, D, Q);
+  if (!c.ok) return false;
+  const int tt = 2 * stream_tt(c.qw, c.kp, c.nw);
+  return c.qw * tt + 2 * tt <= 64;
+}
 
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side) {
   if (c.qw == 1 && c.nw == 4) return dispatch_kp<1, 4>(bwd, c.kp, p, c.grid, st, side);

@@ -57,3 +57,36 @@ def test_ln_mode_with_an_indexed_store():
     sub = store[idx.long()].contiguous()
     P2, S2, _ = F_.pool_forward_ln(sub, cls, 0.0625, F_.token_stats(sub))
     assert torch.equal(P1, P2) and torch.equal(S1, S2)
+
+
+@pytest.mark.parametrize("shape", [(5, 50, 256, 8), (9, 197, 768, 8), (300, 33, 384, 1), (7, 196, 1024, 8), (5, 64, 768, 16),
+                                   (6, 256, 768, 4)], ids=lambda s: "x".join(map(str, s)))
+def test_ln_mode_on_bf16_stored_tokens(shape):
+    """The same mode on bf16-STORED tokens (statistics and passes read the bf16 values in place, fp32 arithmetic): equal to
+    the plain fp32 passes on layer_norm of the same stored values, for the streaming kernels and the generic ones."""
+    from efficient_probing_amd import functional as F_, _native
+    B, Nn, D, Q = shape
+    gen = torch.Generator(device="cpu").manual_seed(16)
+    xb = (torch.randn(B, Nn, D, generator=gen) * (0.5 + 3 * torch.rand(B, Nn, 1, generator=gen))
+          + 0.5 * torch.randn(B, Nn, 1, generator=gen)).to(torch.bfloat16).to(DEV)
+    cls = (torch.randn(Q, D, generator=gen) * 0.3).to(DEV)
+    dP = torch.randn(B, Q, D, generator=gen).to(DEV)
+    scale, eps = D ** -0.5, 1e-5
+    xhat = torch.nn.functional.layer_norm(xb.float(), (D,), eps=eps)
+    stats = F_.token_stats(xb, eps)
+    Pr, Sr, MLr = F_.pool_forward(xhat.contiguous(), cls, scale)
+    MLr2 = MLr.clone(); MLr2[:, :, 2] = (dP * Pr).sum(-1)
+    gr = F_.pool_backward(xhat.contiguous(), Sr, MLr2, dP, scale)
+    lib = _native.load()
+    for mode in (0, 1):
+        lib.ep_debug_force_generic_pool(mode)
+        try:
+            P, S, ML = F_.pool_forward_ln(xb, cls, scale, stats)
+            ML2 = ML.clone(); ML2[:, :, 2] = (dP * P).sum(-1)
+            g = F_.pool_backward_ln(xb, S, ML2, dP, scale, stats)
+        finally:
+            lib.ep_debug_force_generic_pool(0)
+        np.testing.assert_allclose(S.cpu().numpy(), Sr.cpu().numpy(), rtol=2e-5, atol=3e-5, err_msg=f"S mode {mode}")
+        np.testing.assert_allclose(P.cpu().numpy(), Pr.cpu().numpy(), rtol=2e-5, atol=3e-5, err_msg=f"P mode {mode}")
+        np.testing.assert_allclose(g.cpu().numpy(), gr.cpu().numpy(), rtol=1e-4, atol=5e-5 * float(gr.abs().max()),
+                                   err_msg=f"dcls mode {mode}")
