@@ -14,9 +14,12 @@
 // stored values up to summation order -- the contract of the bf16 storage mode (tests/test_gpu_bf16.py) -- at 3/16 of
 // the matrix time the fp32 instruction would need.
 //
-// One workgroup of NW = 8 or 12 waves per CU streams whole images through a ring of 32-token tiles filled by LDS-DMA
+// Two forms.  The default for D in {256, 384, 512, 768, 1024} is the second half of this file (ep_pool_mb2_*: independent
+// 4-wave workgroups, two to four per CU, 16-token tiles); the form described here runs D = 1152 and is the fallback
+// (EP_POOL_MB2=0) for the others:
+// one workgroup of NW = 8 or 12 waves per CU streams whole images through a ring of 32-token tiles filled by LDS-DMA
 // (rows XOR-swizzled on the DMA source address).  Wave w owns the D-slice [D/NW*w, D/NW*(w+1)) (32*NK channels) for both
-// contractions; D = 32*NK*NW (768 = 12 waves x 64 channels: three waves per SIMD):
+// contractions; D = 32*NK*NW (1152 = 12 waves x 96 channels: three waves per SIMD):
 //   1. partial scores of its slice for the two 16-token blocks of the tile (NK k-steps x 3 terms MFMAs each), summed
 //      across the waves through LDS; the MFMA D layout of a score block (lane = (query, token group g), 4 tokens in 4
 //      registers) is exactly the B-operand slot layout of step 3, so the weights never move between lanes.  With up to
