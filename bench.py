@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--head", default="ep", choices=["ep", "coca", "siglip", "cae", "jepa", "aim", "simpool", "esimpool", "cait", "clip", "dolg", "cbam", "dinovit", "abmilp"],
                     help="probe head: ep (the headline), the CoCa attentional pooler or the SigLIP attention-pool head on "
@@ -56,9 +56,59 @@ def parse():
                     help="storage type of the tokens in HBM (arithmetic is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-secondary", action="store_true", help="skip the bf16-token-storage line of the default EP run")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the north-star-shape (197x768) object of the default EP run")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check without a GPU: spawn / join the ranks (gloo), all-reduce a flat buffer of the "
+                         "gradient's size once and print the rank count -- no kernels, no throughput")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N fresh child processes, one per GPU (what the reference
+    gets from ``torchrun`` / main_linprobe.py:581-583 + util/misc.py:214-257), BEFORE this process touches the GPU;
+    the children rendezvous on 127.0.0.1 and rank 0 prints the one JSON line.  Returns the worst child exit code."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def rendezvous_only(args, world, rank):
+    """The launcher / rendezvous / collective plumbing on CPU (gloo): what ``tests/test_bench_launcher.py`` runs."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    Nn, D, Q, Cc, _ = WORKLOADS[args.workload]
+    flat = torch.full((Q * D + D * D + Cc * D + Cc,), float(rank + 1))
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        ranks = dist.get_world_size()
+    else:
+        ranks = 1
+    ok = bool((flat == world * (world + 1) / 2).all())
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo",
+                          "allreduce_elements": flat.numel(), "allreduce_ok": ok}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok and ranks == args.gpus else 3
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 256 FLOP/cycle/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
@@ -163,19 +213,32 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become the launcher (nothing below this line runs in the parent)
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.exit(rendezvous_only(args, world, rank))
     import torch
     import torch.distributed as dist
     from argparse import Namespace
     from efficient_probing_amd import probe_heads, functional as F_
     from efficient_probing_amd.engine import make_engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)     # "nccl" IS RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -349,47 +412,78 @@ def main():
     kname_b = "ep_imgqf_kernel (backward)" if rowq else "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01", f"{args.workload}_hbm_traffic_pmc.json")
-    if os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
-        try:
-            pk = json.load(open(tpath))["per_kernel"]
-            traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pk.items() if k.startswith(kname_f)), None)
-        except Exception:
-            traffic = None
+    traffic, traffic_source = None, None
+    for rnd in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", rnd, f"{args.workload}_hbm_traffic_pmc.json")
+        if traffic is None and os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
+            try:
+                pk = json.load(open(tpath))["per_kernel"]
+                traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pk.items() if k.startswith(kname_f)), None)
+                if traffic is not None:
+                    traffic_source = f"profiles/{rnd}/{args.workload}_hbm_traffic_pmc.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
+            except Exception:
+                traffic = None
     fwd_gbs = algo_bytes / t_fwd / 1e9
     bwd_gbs = algo_bytes / t_bwd / 1e9
 
-    # ---- secondary (N = 1 only): the same step on the same tokens STORED as bf16 (fp32 arithmetic and results; the
-    # token passes run on the bf16 matrix cores, csrc/ep_pool_mb.hip).  Not the headline: `value` above is fp32 storage.
+    # ---- secondary runs of the SAME step (never `value`): a fresh head + engine per run, the same timing protocol
+    def secondary(sN, sD, sQ, storage, steps, toks=None):
+        torch.manual_seed(0)
+        enc2 = Enc() if sD == D else None
+        if enc2 is None:
+            class Enc2(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.head = torch.nn.Linear(sD, Cc)
+            enc2 = Enc2()
+        probe_heads.build_probe_head(enc2, Namespace(cls_features="ep", ep_queries=sQ, d_out=1, nb_classes=Cc, num_heads=16,
+                                                     model="vit_base_patch16"))
+        h2 = enc2.head.to(dev).train()
+        eng2 = make_engine(h2, optimizer="lars", lr=lr, weight_decay=0.0)
+        if toks is None:
+            g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
+            toks = [torch.randn(B, sN, sD, device=dev, generator=g2) for _ in range(args.buffers)]
+        if storage == "bf16":
+            toks = [x.to(torch.bfloat16) for x in toks]
+        es = 2 if storage == "bf16" else 4
+        for i in range(min(10, args.warmup) or 1):
+            eng2.train_step(toks[i % args.buffers], ts[i % args.buffers])
+        eng2.flush(); eng2.read_stats()
+        barrier()
+        tb0 = time.perf_counter()
+        for i in range(steps):
+            eng2.train_step(toks[i % args.buffers], ts[i % args.buffers])
+        eng2.flush()
+        barrier()
+        el2 = time.perf_counter() - tb0
+        if world > 1:
+            t2 = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            el2 = float(t2.item())
+        l2 = eng2.read_stats()[0]
+        c2_, sc2 = h2[0].cls_token.detach(), h2[0].scale
+        tf2 = time_kernel(lambda i: F_.pool_forward(toks[i % args.buffers], c2_, sc2), args.kernel_iters)
+        v2 = B * world * steps / el2
+        return {"value": round(v2, 1), "unit": "images/s", "n_gpus": world, "steps": steps, "ms_per_step": round(el2 / steps * 1e3, 4),
+                "tokens": sN, "dim": sD, "queries": sQ, "batch_per_gpu": B, "token_storage": storage, "arithmetic": "f32",
+                "kernel": eng.lib.ep_pool_kernel_name_ex(B, sN, sD, sQ, 0, 1 if storage == "bf16" else 0).decode(),
+                "us_per_launch": round(tf2 * 1e6, 2), "algorithmic_bytes": B * sN * sD * es,
+                "frac": round(B * sN * sD * es / tf2 / 1e9 / HBM_PEAK_GBS, 4),
+                "step_frac": round(v2 / world * 2 * sN * sD * es / 1e9 / HBM_PEAK_GBS, 4),
+                "mean_loss_over_timed_steps": round(l2 / steps, 5)}
+
+    default_ep = args.head == "ep" and args.tokens == "f32" and args.workload == "c2"
+    # (N = 1 only) the same tokens STORED as bf16 (fp32 arithmetic and results; the token passes run on the bf16
+    # matrix cores, csrc/ep_pool_mb.hip)
     bf16_line = None
     if world == 1 and args.head == "ep" and args.tokens == "f32" and not args.no_bf16_secondary:
-        torch.manual_seed(0)
-        enc2 = Enc()
-        probe_heads.build_probe_head(enc2, Namespace(cls_features=args.head, ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
-                                                     model="capi_vitl14_in1k" if Nn == 256 else "vit_base_patch16"))
-        eng2 = make_engine(enc2.head.to(dev).train(), optimizer="lars", lr=lr, weight_decay=0.0)
-        xb = [x.to(torch.bfloat16) for x in xs]
-        k2 = max(10, min(args.steps, 50))
-        for i in range(5):
-            eng2.train_step(xb[i % args.buffers], ts[i % args.buffers])
-        eng2.flush(); eng2.read_stats()
-        torch.cuda.synchronize()
-        tb0 = time.perf_counter()
-        for i in range(k2):
-            eng2.train_step(xb[i % args.buffers], ts[i % args.buffers])
-        eng2.flush()
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - tb0
-        l2 = eng2.read_stats()[0]
-        tf2 = time_kernel(lambda i: F_.pool_forward(xb[i % args.buffers], cls, scale), args.kernel_iters)
-        bf16_line = {"value": round(B * k2 / el2, 1), "unit": "images/s", "steps": k2, "ms_per_step": round(el2 / k2 * 1e3, 4),
-                     "token_storage": "bf16", "arithmetic": "f32",
-                     "kernel": eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1).decode(),
-                     "us_per_launch": round(tf2 * 1e6, 2), "algorithmic_bytes": B * Nn * D * 2,
-                     "frac": round(B * Nn * D * 2 / tf2 / 1e9 / HBM_PEAK_GBS, 4),
-                     "mean_loss_over_timed_steps": round(l2 / k2, 5)}
-        del xb, eng2
+        bf16_line = secondary(Nn, D, Q, "bf16", max(10, min(args.steps, 50)), toks=xs)
+    # the north-star shape (ViT-B/16 tokens 197x768, BASELINE.json north_star) beside the configs[1] headline
+    ns_line = None
+    if default_ep and not args.no_north_star:
+        nsN, nsD, nsQ = WORKLOADS["ns"][:3]
+        ns_line = secondary(nsN, nsD, nsQ, "f32", args.steps)
+        ns_line["workload"] = WORKLOADS["ns"][4]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -401,15 +495,16 @@ def main():
                        "simpool": "SimPool-head train images/sec", "esimpool": "eSimPool-head train images/sec",
                        "cait": "CaiT-head train images/sec", "clip": "CLIP-head train images/sec",
                        "cbam": "CBAM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "step_ms_p10": pct(0.10), "step_ms_p50": pct(0.50), "step_ms_p90": pct(0.90),
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
                        "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B, "token_storage": args.tokens,
                        "global_batch": B * world, "optimizer": "lars", "token_buffers": args.buffers,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": kname_f, "achieved": round(fwd_gbs, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fwd_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes": algo_bytes,
+                         "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes": algo_bytes,
                          "bwd_kernel": {"kernel": kname_b, "achieved": round(bwd_gbs, 1),
                                         "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
                                         "us_per_launch": round(t_bwd * 1e6, 2)},
@@ -421,6 +516,8 @@ def main():
         }
         if bf16_line is not None:
             out["bf16_token_storage"] = bf16_line
+        if ns_line is not None:
+            out["north_star"] = ns_line
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port
             cb = max(8, min(128, B))

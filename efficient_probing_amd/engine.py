@@ -105,10 +105,12 @@ class ProbeHeadEngine:
         # Communication overlap (EP head, data parallel): the next step's first token pass needs the updated
         # cls_token only, so the step all-reduces + updates cls_token first and lets the large all-reduce of the
         # other gradients (and their update) run beside the next first token pass.  Same arithmetic, same order.
-        # None: on when world > 1, no gradient accumulation and no loss scaling (the inf-skip of a GradScaler
-        # needs all gradients before any update); "force": also with one rank (tests); env EP_OVERLAP_COMM=0: off.
+        # OPT-IN (overlap_comm=True or env EP_OVERLAP_COMM=1) until it has run on two real GPUs: the default data-parallel
+        # step is the plain single all-reduce of the flat gradient buffer.  When asked for it needs world > 1, no
+        # gradient accumulation and no loss scaling (the inf-skip of a GradScaler needs all gradients before any
+        # update); "force": also with one rank (tests).
         import os
-        want = overlap_comm if overlap_comm is not None else (os.environ.get("EP_OVERLAP_COMM", "1") != "0")
+        want = overlap_comm if overlap_comm is not None else (os.environ.get("EP_OVERLAP_COMM", "0") == "1")
         self._pipelined = bool(want) and self._supports_comm_overlap() and self.accum_iter == 1 \
             and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force")
         self._pending = None

@@ -27,7 +27,7 @@ sys.path.insert(0, HERE)
 REF = os.environ.get("EP_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 
-from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub,   # noqa: E402
+from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper,   # noqa: E402
                    COCA_CASES, COCA_INIT_DIMS, COCA_PARAM_NAMES, make_coca_inputs,
                    ABMILP_CASES, ABMILP_INIT_DIMS, ABMILP_PARAM_NAMES, ABMILP_SMALL, make_abmilp_inputs,
                    KNN_CASES, KNN_GRID, make_knn_inputs,
@@ -128,7 +128,7 @@ def run_case(case, optimizer_name="lars"):
     else:
         opt = torch.optim.SGD(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
     crit = torch.nn.CrossEntropyLoss()
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     names = ["cls_token", "v_weight", "fc_weight", "fc_bias"]
     plist = [head[0].cls_token, head[0].v.weight, head[2].weight, head[2].bias]
     for step in range(case.steps):
@@ -204,7 +204,7 @@ def run_coca_case(case):
     head.train()
     opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
     crit = torch.nn.CrossEntropyLoss()
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     small = ("gamma", "fc_bias")
     for step in range(case.steps):
         xb = inp["x_buf"] if step % 2 == 0 else inp["x_buf2"]
@@ -1041,7 +1041,7 @@ def run_abmilp_case(case):
     head.train()
     opt = LARS(head.parameters(), lr=0.0, weight_decay=case.weight_decay)
     crit = torch.nn.CrossEntropyLoss()
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     for step in range(case.steps):
         x = torch.from_numpy(inp["x_buf"] if step % 2 == 0 else inp["x_buf2"])
         t = torch.from_numpy(inp["targets"] if step % 2 == 0 else inp["targets2"])
@@ -1223,8 +1223,11 @@ def knn_fixture():
 def main():
     """``python make_golden.py`` regenerates everything; ``python make_golden.py aim [jepa ...]`` only the named families
     (their .npz files and their entry of host_fixtures.json)."""
-    only = set(sys.argv[1:])
+    only = {a.split(":")[0] for a in sys.argv[1:]}
+    # ``fam:case`` regenerates one case of a family and leaves the family's other committed files alone
+    only_cases = {tuple(a.split(":", 1)) for a in sys.argv[1:] if ":" in a}
     want = lambda fam: not only or fam in only
+    want_case = lambda fam, case: not any(f == fam for f, _ in only_cases) or (fam, case.name) in only_cases
     meta = {"torch": torch.__version__, "reference": REF, "cases": [c.name for c in CASES]}
 
     def dump(prefix, case, out):
@@ -1234,6 +1237,8 @@ def main():
 
     if want("ep"):
         for case in CASES:
+            if not want_case("ep", case):
+                continue
             out = run_case(case, "lars")
             if case.full:
                 sgd = run_case(case, "sgd")
@@ -1248,7 +1253,8 @@ def main():
                             ("dinovit", DINOVIT_CASES, run_dinovit_case)):
         if want(fam):
             for case in cases:
-                dump(fam, case, run(case))
+                if want_case(fam, case):
+                    dump(fam, case, run(case))
     hp = os.path.join(HERE, "host_fixtures.json")
     if only:
         with open(hp) as f:

@@ -1,0 +1,143 @@
+"""Parity of the headline kernels AT THE BATCH THE BENCH TIMES (B = 1024 per GPU, and 1025: one image more than a
+whole number of workgroup rounds).  At these sizes the persistent token-pass workgroups walk several images each
+(csrc/ep_pool.hip stream_plan caps the grid at 3 x CUs) and the weight-gradient side tasks of the second pass
+(csrc/ep_side.h) contract over 1024 / 1025 batch rows -- neither happens in the small golden fixtures.
+
+* token passes alone: against an fp64 evaluation of the formula on the GPU (no CPU oracle needed);
+* one full fused train iteration (forward, CE, backward with the side tasks, LARS), twice: against the op-for-op
+  torch-CPU port of the reference step (oracle/torch_port.py, pinned on the reference's goldens by
+  tests/test_oracle_golden.py::test_torch_port_matches_golden).
+
+Needs an MI355X (pytest -m gpu).  fp32 tolerances are written at the asserts."""
+import numpy as np
+import pytest
+import torch
+from argparse import Namespace
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [(1024, 256, 768, 8), (1025, 256, 768, 8), (1024, 197, 768, 8), (1025, 197, 768, 8)]
+IDS = ["c2_b1024", "c2_b1025", "ns_b1024", "ns_b1025"]
+
+
+def fp64_reference(x, cls, scale, dP, chunk=128):
+    """softmax((cls*scale) x^T) pooling and the cls gradient in float64, chunked over the batch."""
+    B = x.shape[0]
+    P = torch.empty(B, cls.shape[0], x.shape[2], dtype=torch.float64, device=x.device)
+    S = torch.empty(B, cls.shape[0], x.shape[1], dtype=torch.float64, device=x.device)
+    dcls = torch.zeros(cls.shape, dtype=torch.float64, device=x.device)
+    for b0 in range(0, B, chunk):
+        xb = x[b0:b0 + chunk].double()
+        s = torch.matmul((cls * scale).double(), xb.transpose(1, 2))
+        a = torch.softmax(s, dim=-1)
+        p = torch.matmul(a, xb)
+        dp = dP[b0:b0 + chunk].double()
+        delta = (dp * p).sum(-1, keepdim=True)
+        dA = torch.matmul(dp, xb.transpose(1, 2))
+        dcls += scale * torch.matmul(a * (dA - delta), xb).sum(0)
+        P[b0:b0 + chunk], S[b0:b0 + chunk] = p, s
+    return P, S, dcls
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_token_passes_at_bench_batch_vs_fp64(shape, storage):
+    from efficient_probing_amd import functional as F_, _native
+    B, Nn, D, Q = shape
+    lib = _native.load()
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    x = torch.randn(B, Nn, D, device=DEV, generator=gen)
+    if storage == "bf16":
+        x = x.to(torch.bfloat16)
+    cls = torch.randn(Q, D, device=DEV, generator=gen) * 0.7          # scores of order one: a non-trivial softmax
+    dP = torch.randn(B, Q, D, device=DEV, generator=gen)
+    scale = D ** -0.5
+    name = lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, 1 if storage == "bf16" else 0).decode()
+    assert "generic" not in name, name                               # the kernels the bench times, not the fallback
+    P, S, ML = F_.pool_forward(x, cls, scale)
+    Pref, Sref, dref = fp64_reference(x.float(), cls, scale, dP)
+    assert torch.allclose(S.double(), Sref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(P.double(), Pref, rtol=1e-5, atol=2e-6)
+    ML2 = ML.clone()
+    ML2[:, :, 2] = (dP.double() * Pref).sum(-1).float()
+    dcls = F_.pool_backward(x, S, ML2, dP, scale)
+    assert torch.allclose(dcls.double(), dref, rtol=1e-4, atol=2e-5 * float(dref.abs().max()))
+    # run to run: the same bits (no atomics on the path, fixed reduction order over the workgroups)
+    dcls2 = F_.pool_backward(x, S, ML2, dP, scale)
+    assert torch.equal(dcls, dcls2)
+
+
+def _heads(Nn, D, Q, Cc):
+    from efficient_probing_amd import probe_heads
+    from oracle import torch_port
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(D, Cc)
+    torch.manual_seed(0)
+    enc = Enc()
+    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc))
+    head = enc.head
+    port = torch_port.make_head(D, Q, Cc)
+    with torch.no_grad():
+        port[0].cls_token.copy_(head[0].cls_token)
+        port[0].v.weight.copy_(head[0].v.weight)
+        port[2].weight.copy_(head[2].weight)
+        port[2].bias.copy_(head[2].bias)
+    return head.to(DEV).train(), port.train()
+
+
+@pytest.mark.parametrize("shape", SHAPES[:2] + SHAPES[3:], ids=IDS[:2] + IDS[3:])
+def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape):
+    """Two full iterations at the bench configuration (lr = blr * B / 256 as main_linprobe.py:572-573) against the
+    torch-CPU port of the reference step: loss, every gradient (incl. the side-task weight gradients over 1024 / 1025
+    rows), the LARS momentum, the updated parameters and the BatchNorm running statistics."""
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    from oracle import torch_port
+    B, Nn, D, Q = shape
+    Cc = 1000
+    head, port = _heads(Nn, D, Q, Cc)
+    lr = 0.1 * B / 256
+    eng = ProbeHeadEngine(head, optimizer="lars", lr=lr, weight_decay=0.0)
+    pparams = list(port.parameters())                                   # v.weight, cls_token, fc.weight, fc.bias
+    order = [1, 0, 2, 3]                                                # engine order: cls_token, v.weight, fc.weight, fc.bias
+    mus = [torch.zeros_like(p) for p in pparams]
+    g = torch.Generator().manual_seed(77)
+    names = ["cls_token", "v.weight", "fc.weight", "fc.bias"]
+    for step in range(2):
+        x = torch.randn(B, Nn, D, generator=g)
+        t = torch.randint(0, Cc, (B,), generator=g)
+        xd, td = x.to(DEV), t.to(DEV)
+        # gradients first (phase 1 alone), then the update, so both are compared
+        eng.forward_backward(xd, td)
+        torch.cuda.synchronize()
+        grads = [p.grad.detach().cpu().clone() for p in eng.params_list]
+        eng.all_reduce_grads()
+        eng.optimizer_step(lr)
+        loss, top1, top5, bad = eng.read_stats()
+        want_loss = float(torch_port.train_step(port, mus, x, t, lr))
+        assert bad == 0
+        assert loss == pytest.approx(want_loss, rel=2e-5), step
+        for i, n in enumerate(names):
+            wp = pparams[order[i]]
+            wg = wp.grad.reshape(grads[i].shape)
+            gs = float(wg.abs().max())
+            np.testing.assert_allclose(grads[i].numpy(), wg.numpy(), rtol=1e-4, atol=2e-5 * gs, err_msg=f"step {step} grad {n}")
+            got = eng.params_list[i].detach().cpu().numpy()
+            np.testing.assert_allclose(got, wp.detach().reshape(got.shape).numpy(), rtol=1e-4, atol=3e-6,
+                                       err_msg=f"step {step} param {n}")
+            mu = eng.mu_views()[i].cpu().numpy()
+            wm = mus[order[i]].reshape(mu.shape).numpy()
+            # torch-CPU's fp32 norm error is one common factor on the momentum (tests/golden/cases.py:assert_mu_close)
+            from cases import assert_mu_close
+            assert_mu_close(mu, wm, err_msg=f"step {step} mu {n}")
+        np.testing.assert_allclose(head[1].running_mean.cpu().numpy(), port[1].running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(head[1].running_var.cpu().numpy(), port[1].running_var.numpy(), rtol=1e-5, atol=1e-6)
+    # top-1 / top-5 counters of the last step against the port's logits
+    port.eval()
+    with torch.no_grad():
+        want = port(x)
+    got = eng.eval_logits(xd).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-5)

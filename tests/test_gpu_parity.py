@@ -14,7 +14,7 @@ import pytest
 import torch
 from argparse import Namespace
 
-from cases import CASES, CASE_BY_NAME, STEP_LRS, make_inputs, view_tokens, sub
+from cases import CASES, CASE_BY_NAME, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol
 from oracle import ep_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -120,14 +120,14 @@ def test_module_forward_backward_golden(case):
     loss, stats = F_.cross_entropy_loss(logits, t)
     loss.backward()
     np.testing.assert_allclose(pooled.detach().cpu().numpy(), g["pooled"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], **post_bn_tol(case))
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], **post_bn_tol(case))
     assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-5)
     st = stats.cpu().numpy()
     assert st[1] * 100.0 / case.B == pytest.approx(float(g["acc1"]))
     assert st[2] * 100.0 / case.B == pytest.approx(float(g["acc5"]))
     assert st[3] == 0
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     got = {"cls_token": head[0].cls_token.grad, "v_weight": head[0].v.weight.grad,
            "fc_weight": head[2].weight.grad, "fc_bias": head[2].bias.grad}
     for n, gt in got.items():
@@ -147,7 +147,7 @@ def test_fused_engine_steps_golden(case, opt):
         pytest.skip("not recorded")
     head = build_head(case, inp)
     eng = ProbeHeadEngine(head, optimizer=opt, weight_decay=case.weight_decay)
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     names = ["cls_token", "v_weight", "fc_weight", "fc_bias"]
     for step in range(case.steps):
         xb = inp["x_buf"] if step % 2 == 0 else inp["x_buf2"]
@@ -161,21 +161,21 @@ def test_fused_engine_steps_golden(case, opt):
             a = p.detach().cpu().numpy()
             a = a if n in ("cls_token", "fc_bias") else keep(a)
             # later steps at lr 1.6 / 0.8 with B = 3..4 amplify fp32 rounding through BN's 1/sigma
-            np.testing.assert_allclose(a, g[f"{tag}_{n}"], rtol=1e-4, atol=3e-6 if step == 0 else 3e-5,
+            np.testing.assert_allclose(a, g[f"{tag}_{n}"], rtol=1e-4, atol=3e-6 if step == 0 or case.B >= 64 else 3e-5,
                                        err_msg=f"{tag} {n}")
         if opt == "lars":
             for n, mu in zip(names, eng.mu_views()):
                 a = mu.detach().cpu().numpy()
                 a = a if n in ("cls_token", "fc_bias") else keep(a)
                 want = g[f"{tag}_mu_{n}"]
-                # 5e-4: the golden trust ratio carries torch-CPU's fp32 norm error (see test_oracle_golden)
-                np.testing.assert_allclose(a, want, rtol=5e-4, atol=2e-5 * float(np.abs(want).max()), err_msg=f"mu {n}")
+                # the golden trust ratio carries torch-CPU's fp32 norm error as one common factor (cases.assert_mu_close)
+                assert_mu_close(a, want, err_msg=f"mu {n}")
         np.testing.assert_allclose(head[1].running_mean.cpu().numpy(), g[f"{tag}_running_mean"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(head[1].running_var.cpu().numpy(), g[f"{tag}_running_var"], rtol=1e-5, atol=1e-6)
         assert int(head[1].num_batches_tracked) == int(g[f"{tag}_nbt"])
     if opt == "lars":
         ev = eng.eval_logits(tokens(case, inp["x_buf"])).cpu().numpy()
-        np.testing.assert_allclose(ev, g["eval_logits"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(ev, g["eval_logits"], **(dict(rtol=2e-5, atol=2e-5) if case.B >= 64 else dict(rtol=2e-4, atol=2e-4)))
         head.eval()
         with torch.no_grad():
             ev2 = head(tokens(case, inp["x_buf"])).cpu().numpy()

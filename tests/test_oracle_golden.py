@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import CASES, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub
+from cases import CASES, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol
 from oracle import ep_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -35,13 +35,14 @@ def test_forward_and_grads(case):
     np.testing.assert_allclose(out["pooled"], g["pooled"], **FWD)
     np.testing.assert_allclose(O.ep_attention(x, st.cls_token), g["attn"], **FWD)
     np.testing.assert_allclose(cache["ep"]["attn"], g["attn"], **FWD)
-    np.testing.assert_allclose(out["z"], g["z"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(out["logits"], g["logits"], rtol=1e-4, atol=1e-5)
+    tol = dict(rtol=1e-4, atol=1e-5) if case.B < 64 else post_bn_tol(case)
+    np.testing.assert_allclose(out["z"], g["z"], **tol)
+    np.testing.assert_allclose(out["logits"], g["logits"], **tol)
     np.testing.assert_allclose(out["loss"], g["loss"], rtol=1e-5)
     a1, a5 = O.accuracy(out["logits"], inp["targets"])
     assert a1 == pytest.approx(float(g["acc1"])) and a5 == pytest.approx(float(g["acc5"]))
     gr = O.head_backward(st, cache)
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     for n in O.PARAM_ORDER:
         got = gr[n] if n in ("cls_token", "fc_bias") else keep(gr[n])
         want = g[f"grad_{n}"]
@@ -57,7 +58,7 @@ def test_optimizer_steps(case, opt):
     if f"{opt}1_loss" not in g:
         pytest.skip("optimizer variant not recorded for this case")
     st = state_from(case, inp)
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     for step in range(case.steps):
         xb = inp["x_buf"] if step % 2 == 0 else inp["x_buf2"]
         tg = inp["targets"] if step % 2 == 0 else inp["targets2"]
@@ -72,10 +73,9 @@ def test_optimizer_steps(case, opt):
             if opt == "lars":
                 mu = st.mu[n] if n in ("cls_token", "fc_bias") else keep(st.mu[n])
                 want = g[f"{tag}_mu_{n}"]
-                # torch's CPU float32 norm (naive per-lane accumulation over >1e6 elements) is
-                # itself off by up to ~1.5e-4 relative vs the exact norm; that error is a common
-                # factor on the LARS trust ratio and hence on mu, so mu is pinned to 5e-4 only.
-                np.testing.assert_allclose(mu, want, rtol=5e-4, atol=2e-5 * np.abs(want).max(), err_msg=f"{tag} mu {n}")
+                # torch's CPU float32 norm (naive per-lane accumulation over >1e6 elements) is itself off by
+                # 1.5e-4 .. 9e-4 relative to the exact norm: one common factor on the trust ratio and hence on mu
+                assert_mu_close(mu, want, err_msg=f"{tag} mu {n}")
         np.testing.assert_allclose(st.running_mean, g[f"{tag}_running_mean"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(st.running_var, g[f"{tag}_running_var"], rtol=1e-5, atol=1e-6)
         assert st.num_batches_tracked == int(g[f"{tag}_nbt"])
@@ -151,6 +151,6 @@ def test_torch_port_matches_golden(name):
     x = torch.from_numpy(view_tokens(case, inp["x_buf"]))
     loss = TP.train_step(head, mus, x, torch.from_numpy(inp["targets"]), STEP_LRS[0])
     assert float(loss) == pytest.approx(float(g["lars1_loss"]), rel=1e-6)
-    keep = (lambda a: a) if case.full else sub
+    keep = keeper(case)
     np.testing.assert_allclose(head[0].cls_token.detach().numpy(), g["lars1_cls_token"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(keep(head[2].weight.detach().numpy()), g["lars1_fc_weight"], rtol=1e-5, atol=1e-7)
