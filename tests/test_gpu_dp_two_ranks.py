@@ -37,14 +37,14 @@ def _data(rank, step):
     return x.to("cuda:0"), t.to("cuda:0")
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    eng = _build(overlap_comm=True)
-    assert eng.world == world and eng._pipelined
+    eng = _build(overlap_comm=overlap)            # None: the engine's default = the plain single all-reduce
+    assert eng.world == world and eng._pipelined == bool(overlap)
     for step in range(STEPS):
         x, t = _data(rank, step)
         eng.train_step(x, t, lr=LRS[step])
@@ -56,10 +56,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_pipelined_equals_simulation(tmp_path):
+@pytest.mark.parametrize("overlap", [None, True], ids=["default_single_allreduce", "opt_in_two_bucket_overlap"])
+def test_two_ranks_equal_simulation(tmp_path, overlap):
     import torch.multiprocessing as mp
-    world, port = 2, 29650 + (os.getpid() % 200)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    world, port = 2, 29650 + (os.getpid() % 200) + (300 if overlap else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     assert torch.equal(got[0]["p"], got[1]["p"]) and torch.equal(got[0]["mu"], got[1]["mu"])
     assert torch.equal(got[0]["rm"], got[1]["rm"])                       # sync_buffers: rank 0's running statistics
