@@ -101,8 +101,9 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape):
     head, port = _heads(Nn, D, Q, Cc)
     lr = 0.1 * B / 256
     eng = ProbeHeadEngine(head, optimizer="lars", lr=lr, weight_decay=0.0)
-    pparams = list(port.parameters())                                   # v.weight, cls_token, fc.weight, fc.bias
-    order = [1, 0, 2, 3]                                                # engine order: cls_token, v.weight, fc.weight, fc.bias
+    byname = dict(port.named_parameters())
+    pparams = [byname["0.cls_token"], byname["0.v.weight"], byname["2.weight"], byname["2.bias"]]   # the engine's order
+    order = [0, 1, 2, 3]
     mus = [torch.zeros_like(p) for p in pparams]
     g = torch.Generator().manual_seed(77)
     names = ["cls_token", "v.weight", "fc.weight", "fc.bias"]
