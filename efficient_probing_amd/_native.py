@@ -13,6 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
+EP_ABI_VERSION = 19        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
 
@@ -510,6 +511,12 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    # the step structs above are written for ONE ABI version (they have grown across versions): a stale, git-ignored
+    # .so that still exports every symbol would misread them silently
+    got = int(lib.ep_version())
+    if got != EP_ABI_VERSION:
+        raise NativeLibraryError(f"{LIB_PATH} reports ABI version {got}, the Python bindings are written for "
+                                 f"{EP_ABI_VERSION}: rebuild it (efficient_probing_amd/csrc/build.sh)")
     _lib = lib
     return lib
 

@@ -29,10 +29,14 @@ int cu_count() {
 // Fork/join events for the optional aux stream: a small per-thread pool created on first use and
 // reused (events carry no data; the library otherwise keeps no state).
 int get_events(hipEvent_t* out, int n) {
-  static thread_local hipEvent_t pool[4] = {nullptr, nullptr, nullptr, nullptr};
+  constexpr int MAX_DEV = 16;          // events belong to the device that was current when they were created
+  static thread_local hipEvent_t pool[MAX_DEV][4] = {};
+  int dev = 0;
+  EP_HIP(hipGetDevice(&dev));
+  EP_REQUIRE(dev >= 0 && dev < MAX_DEV && n <= 4, EP_E_ARG, "get_events: device %d / %d events not supported", dev, n);
   for (int i = 0; i < n; ++i) {
-    if (!pool[i]) EP_HIP(hipEventCreateWithFlags(&pool[i], hipEventDisableTiming));
-    out[i] = pool[i];
+    if (!pool[dev][i]) EP_HIP(hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming));
+    out[i] = pool[dev][i];
   }
   return 0;
 }

@@ -75,6 +75,9 @@ int attention_from_scores(const float* S, const float* ML, int rows, int N, floa
 
 // a_k / b_k: operand contiguous along K (true) or along its free dimension (false)
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
+// ep_gemm_x3.hip: the same contraction on the bf16 matrix cores (three-term operand split, fp32 accuracy); 16-byte
+// aligned operands only -- gemm() selects it
+void gemm_launch_x3(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
 
 size_t bn_workspace_bytes(int B, int Dp);
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,

@@ -391,11 +391,15 @@ __global__ __launch_bounds__(256) void ep_ce_kernel(const float* __restrict__ lo
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
   const float* row = logits + (int64_t)b * ldl;
-  const int tgt = (int)targets[b];
+  // a label outside [0, C) (an ignore_index, a wrong nb_classes) must not become an out-of-bounds read: the row is
+  // flagged (rowstat[3], which stops the training loop like a non-finite loss), contributes no loss and no gradient
+  const int64_t tgt64 = targets[b];
+  const bool tgt_ok = tgt64 >= 0 && tgt64 < (int64_t)C;
+  const int tgt = tgt_ok ? (int)tgt64 : 0;
   const float tv = row[tgt];
   float v[FAST ? CE_RPT : 1];
   float mx = -INFINITY;
-  int bad = 0, rank = 0;
+  int bad = tgt_ok ? 0 : 1, rank = 0;
   if (FAST) {
 #pragma unroll
     for (int r = 0; r < CE_RPT; ++r) {
@@ -431,9 +435,9 @@ __global__ __launch_bounds__(256) void ep_ce_kernel(const float* __restrict__ lo
   const float fr = wave_sum((float)rank);
   const float fb = wave_sum((float)bad);
   const float lse = mx + logf(se);
-  const float loss = lse - tv;
+  const float loss = tgt_ok ? lse - tv : 0.f;
   if (dlogits) {
-    const float g = grad_scale / (float)B, inv = 1.0f / se;
+    const float g = tgt_ok ? grad_scale / (float)B : 0.f, inv = 1.0f / se;
     float* drow = dlogits + (int64_t)b * ldl;
     if (FAST) {
 #pragma unroll

@@ -117,38 +117,96 @@ def _native_head(model):
     return head if (head is not None and is_native_head(head)) else None
 
 
+def _optimizer_spec(optimizer):
+    """(engine optimizer name, engine keyword arguments) of a torch / drop-in optimizer object (LARS / SGD / AdamW as
+    selected by reference main_linprobe.py:403-408)."""
+    g = optimizer.param_groups[0]
+    cls = type(optimizer).__name__.lower()
+    name = "lars" if "lars" in cls else ("adamw" if "adamw" in cls else "sgd")
+    kw = dict(lr=g.get("lr", 0.0), weight_decay=g.get("weight_decay", 0.0))
+    if name == "lars":
+        kw.update(momentum=g.get("momentum", 0.9), trust_coefficient=g.get("trust_coefficient", 0.001))
+    if name == "adamw":
+        kw.update(betas=tuple(g.get("betas", (0.9, 0.999))), adam_eps=g.get("eps", 1e-8))
+    return name, kw
+
+
+def _alias_optimizer_state(eng, optimizer, name):
+    """Keep ``optimizer.state_dict()`` interchangeable with what the reference saves and restores: the optimizer's
+    per-parameter state entries become VIEWS of the engine's flat state buffers (LARS: ``mu``, util/lars.py:32-35;
+    AdamW: ``exp_avg`` / ``exp_avg_sq`` / ``step`` as torch.optim.AdamW keeps them), and state already present in the
+    optimizer (a ``--resume`` ran ``optimizer.load_state_dict`` before the first step) is copied in first."""
+    if name == "lars":
+        for p, mu in zip(eng.params_list, eng.mu_views()):
+            st = optimizer.state[p]
+            if "mu" in st:
+                mu.copy_(st["mu"])                      # resumed from a checkpoint
+            st["mu"] = mu
+    elif name == "adamw":
+        views = [[b[o:o + p.numel()].view(p.shape) for p, o in zip(eng.params_list, eng.offsets)] for b in eng.state]
+        steps = []
+        for i, p in enumerate(eng.params_list):
+            st = optimizer.state[p]
+            if "exp_avg" in st and "exp_avg_sq" in st:
+                views[0][i].copy_(st["exp_avg"]); views[1][i].copy_(st["exp_avg_sq"])
+                steps.append(int(float(st.get("step", 0))))
+            st["exp_avg"], st["exp_avg_sq"] = views[0][i], views[1][i]
+            st["step"] = torch.tensor(float(steps[-1]) if steps else 0.0)
+        if steps:
+            if len(set(steps)) != 1:
+                raise RuntimeError(f"AdamW resume: the head's parameters carry different step counts {sorted(set(steps))}")
+            eng.opt_step = steps[0]                     # the bias correction continues where the checkpoint stopped
+
+        def _publish_step(opt):                         # state_dict() / checkpoint: the engine owns the step count
+            for p in eng.params_list:
+                opt.state[p]["step"] = torch.tensor(float(eng.opt_step))
+        optimizer.register_state_dict_pre_hook(_publish_step)
+
+
 def get_engine(model, optimizer=None, args=None):
-    """The fused engine attached to ``model`` (created on first use from the optimizer's
-    hyper-parameters; LARS / SGD / AdamW as selected by reference main_linprobe.py:403-408)."""
+    """The fused engine attached to ``model``.  The TRAINING engine is created the first time an optimizer is passed,
+    from that optimizer's class and hyper-parameters; a call without an optimizer before that (``evaluate()`` first)
+    gets a stateless evaluation engine that is replaced, not reused, when training starts.  A later call with another
+    optimizer class raises; hyper-parameters are re-read from the optimizer's first group on every call."""
     from .engine import make_engine
     m = model.module if hasattr(model, "module") else model
     eng = getattr(m, "_ep_engine", None)
+    if eng is not None and optimizer is not None:
+        name, kw = _optimizer_spec(optimizer)
+        if getattr(eng, "_eval_only", False):
+            eng = None                                  # built by evaluate() before training: never train on it
+        elif name != eng.optimizer_name:
+            raise RuntimeError(f"the fused engine of this model was built for {eng.optimizer_name}; got a "
+                               f"{type(optimizer).__name__} optimizer (build a new model / head for another optimizer)")
+        else:
+            eng.weight_decay = kw["weight_decay"]
+            if name == "lars":
+                eng.momentum, eng.trust_coefficient = kw["momentum"], kw["trust_coefficient"]
+            if name == "adamw":
+                eng.betas, eng.adam_eps = kw["betas"], kw["adam_eps"]
     if eng is None:
         head = _native_head(model)
         if head is None:
             return None
-        name, kw = "lars", {}
-        if optimizer is not None:
-            g = optimizer.param_groups[0]
-            cls = type(optimizer).__name__.lower()
-            name = "lars" if "lars" in cls else ("adamw" if "adamw" in cls else "sgd")
-            kw = dict(lr=g.get("lr", 0.0), weight_decay=g.get("weight_decay", 0.0))
-            if name == "lars":
-                kw.update(momentum=g.get("momentum", 0.9), trust_coefficient=g.get("trust_coefficient", 0.001))
-            if name == "adamw":
-                kw.update(betas=g.get("betas", (0.9, 0.999)), adam_eps=g.get("eps", 1e-8))
         accum = getattr(args, "accum_iter", 1) if args is not None else 1
-        eng = make_engine(head, optimizer=name, accum_iter=accum, **kw)
-        if optimizer is not None and name == "lars":
-            # keep optimizer.state_dict() interchangeable with the reference's (state[p]['mu']):
-            # the optimizer's momentum entries become views of the engine's flat buffer
-            for p, mu in zip(eng.params_list, eng.mu_views()):
-                st = optimizer.state[p]
-                if "mu" in st:
-                    mu.copy_(st["mu"])                      # resumed from a checkpoint
-                st["mu"] = mu
+        if optimizer is None:
+            eng = make_engine(head, optimizer="sgd", accum_iter=accum)     # no optimizer state: evaluation only
+            eng._eval_only = True
+        else:
+            name, kw = _optimizer_spec(optimizer)
+            eng = make_engine(head, optimizer=name, accum_iter=accum, **kw)
+            eng._eval_only = False
+            _alias_optimizer_state(eng, optimizer, name)
         m._ep_engine = eng
     return eng
+
+
+def _plain_cross_entropy(criterion) -> bool:
+    """What the fused step computes: mean cross-entropy over the batch, no class weights, no label smoothing
+    (reference main_linprobe.py:589)."""
+    return criterion is None or (type(criterion) is torch.nn.CrossEntropyLoss and criterion.weight is None
+                                 and criterion.label_smoothing == 0.0 and criterion.reduction == "mean"
+                                 and criterion.ignore_index == -100)
 
 
 def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
@@ -165,7 +223,10 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     accum_iter = getattr(args, "accum_iter", 1)
     amp = getattr(args, "amp", "none")
     n_iter = len(data_loader)
-    engine = get_engine(model, optimizer, args) if mixup_fn is None else None
+    # the fused step is plain CE + the optimizer: anything it would silently drop (mixup, gradient clipping, another
+    # criterion) takes the module path, which honours it
+    fusable = mixup_fn is None and not max_norm and _plain_cross_entropy(criterion)
+    engine = get_engine(model, optimizer, args) if fusable else None
     optimizer.zero_grad()
     pending = 0                                   # fused steps whose statistics are still on the GPU
 

@@ -99,6 +99,21 @@ def shards_of_rank(meta: dict, world: int, rank: int) -> List[dict]:
     return [s for s in meta["shards"] if s["index"] % world == rank]
 
 
+def steps_per_epoch(meta: dict, world: int, batch_size: int, per_shard: bool = False) -> int:
+    """Batches EVERY rank yields per epoch: the minimum over the ranks of what each one's shards hold, computed from
+    ``meta.json`` alone (no collective).  Whole shards are dealt round-robin, so ranks can own different image counts;
+    every engine step ends in a blocking all-reduce of the flat gradients, so all ranks must run the same number of
+    steps or the longer one hangs there.  The reference gets equal lengths from ``DistributedSampler`` (it pads by
+    wrap-around, main_linprobe.py:286-287); here the surplus of the larger ranks is dropped, like ``drop_last``.
+    ``per_shard``: batches never span shards (the streaming loader)."""
+    counts = []
+    for r in range(world):
+        mine = shards_of_rank(meta, world, r)
+        counts.append(sum(s["images"] // batch_size for s in mine) if per_shard
+                      else sum(s["images"] for s in mine) // batch_size)
+    return min(counts) if counts else 0
+
+
 def open_shard(store_dir: str, meta: dict, shard: dict) -> Tuple[np.memmap, np.ndarray]:
     tok = np.memmap(os.path.join(store_dir, f"tokens-{shard['index']:05d}.bin"),
                     dtype=np.float32 if meta.get("dtype", "float32") == "float32" else np.int16, mode="r",
@@ -116,6 +131,7 @@ class ResidentTokenStore:
         meta = load_meta(store_dir)
         mine = shards_of_rank(meta, world, rank)
         n = sum(s["images"] for s in mine)
+        self.meta, self.world = meta, world
         self.N, self.D, self.seed, self.rank = meta["num_tokens"], meta["dim"], seed, rank
         self.dtype = meta.get("dtype", "float32")
         tdt = torch.float32 if self.dtype == "float32" else torch.bfloat16
@@ -129,11 +145,20 @@ class ResidentTokenStore:
         self.num_images = n
         self.labels = torch.from_numpy(np.concatenate(labels) if labels else np.zeros(0, np.int64)).to(device)
 
+    def num_batches(self, batch_size: int, drop_last: bool = True) -> int:
+        """Batches per epoch.  Data parallel (world > 1): the same number on every rank (``steps_per_epoch``)."""
+        if self.world > 1:
+            return steps_per_epoch(self.meta, self.world, batch_size)
+        return self.num_images // batch_size if drop_last else -(-self.num_images // batch_size)
+
     def batches(self, batch_size: int, epoch: int = 0, shuffle: bool = True, drop_last: bool = True):
         g = torch.Generator(device="cpu").manual_seed(self.seed * 1000003 + epoch * 101 + self.rank)
         order = torch.randperm(self.num_images, generator=g) if shuffle else torch.arange(self.num_images)
         order = order.to(dtype=torch.int32, device=self.tokens.device)
-        stop = self.num_images - (self.num_images % batch_size if drop_last else 0)
+        if self.world > 1:                 # equal step counts on all ranks: each step all-reduces the gradients
+            stop = self.num_batches(batch_size) * batch_size
+        else:
+            stop = self.num_images - (self.num_images % batch_size if drop_last else 0)
         for lo in range(0, stop, batch_size):
             idx = order[lo:lo + batch_size].contiguous()
             yield self.tokens, idx, self.labels[idx.long()]
@@ -146,6 +171,8 @@ class StreamingTokenLoader:
         self.dir, self.device, self.B = store_dir, device, batch_size
         self.meta = load_meta(store_dir)
         self.shards = shards_of_rank(self.meta, world, rank)
+        # data parallel: every rank stops after the same number of batches (see steps_per_epoch)
+        self.limit = steps_per_epoch(self.meta, world, batch_size, per_shard=True) if world > 1 else None
         self.stream = torch.cuda.Stream(device=device)
         N, D = self.meta["num_tokens"], self.meta["dim"]
         self.dtype = self.meta.get("dtype", "float32")
@@ -154,7 +181,8 @@ class StreamingTokenLoader:
         self.dev = [torch.empty((batch_size, N, D), dtype=tdt, device=device) for _ in range(2)]
 
     def __len__(self):
-        return sum(s["images"] // self.B for s in self.shards)
+        n = sum(s["images"] // self.B for s in self.shards)
+        return n if self.limit is None else min(n, self.limit)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         k = 0
@@ -162,9 +190,14 @@ class StreamingTokenLoader:
         copied = [None, None]     # H2D-complete events per buffer (host staging may be rewritten after them)
         consumed = [None, None]   # main-stream events: the consumer's kernels on a device buffer are enqueued before them
         main = torch.cuda.current_stream(self.device)
+        total = len(self)
         for s in self.shards:
+            if k >= total:
+                break
             tok, lab = open_shard(self.dir, self.meta, s)
             for lo in range(0, s["images"] - self.B + 1, self.B):
+                if k >= total:
+                    break
                 buf = k & 1
                 if copied[buf] is not None:
                     copied[buf].synchronize()                     # previous H2D out of this staging buffer is done

@@ -135,3 +135,104 @@ def test_evaluate_matches_oracle():
     assert stats["acc1"] == pytest.approx(np.mean([a[0] for a in accs]))
     assert stats["acc5"] == pytest.approx(np.mean([a[1] for a in accs]))
     assert stats["preds"].shape == (2 * case.B,)
+
+
+def _adamw_run(case, inp, epochs, resume_after=None, tmp_path=None):
+    """`epochs` epochs of the fused path under torch.optim.AdamW; with `resume_after`, the run is cut after that many
+    epochs, saved with checkpoint.save_model, and continued in a FRESH model / optimizer through checkpoint.load_model."""
+    from efficient_probing_amd import engine_finetune as EF, checkpoint as CK
+    from efficient_probing_amd.util.misc import NativeScalerWithGradNormCount
+    args = Namespace(**{**vars(ARGS), "epochs": epochs + 1, "output_dir": str(tmp_path) if tmp_path else "", "suffix": "t",
+                        "resume": "", "start_epoch": 0})
+
+    def fresh():
+        m = make_model(case, inp)
+        return m, torch.optim.AdamW(m.head.parameters(), lr=0.0, weight_decay=0.05, betas=(0.9, 0.95))
+    model, opt = fresh()
+    loader = loader_of(case, inp, 3)
+    for ep in range(epochs):
+        if resume_after is not None and ep == resume_after:
+            path = CK.save_model(args, ep - 1, model, model.head, opt, NativeScalerWithGradNormCount(), {})
+            model, opt = fresh()
+            args.resume = str(path)
+            CK.load_model(args, model, opt, NativeScalerWithGradNormCount())
+            assert args.start_epoch == ep
+        EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), loader, opt, torch.device(DEV), ep,
+                           NativeScalerWithGradNormCount(), args=args)
+    return model, opt
+
+
+def test_adamw_save_and_resume_continues_the_trajectory(tmp_path):
+    """with AdamW the fused path kept exp_avg / exp_avg_sq / step only inside the engine, so a --resume
+    restarted the moments and the bias correction.  Now optimizer.state holds views of the engine's buffers (and the
+    step), so the checkpoint carries them and a resumed run equals the uninterrupted one bit for bit."""
+    case = Case("aw", B=16, N=24, D=128, Q=4, C=12, seed=4)
+    inp = make_inputs(case)
+    m_full, o_full = _adamw_run(case, inp, epochs=3)
+    m_res, o_res = _adamw_run(case, inp, epochs=3, resume_after=2, tmp_path=tmp_path)
+    for (n1, p1), (n2, p2) in zip(m_full.head.named_parameters(), m_res.head.named_parameters()):
+        assert torch.equal(p1, p2), n1
+    sd = o_res.state_dict()["state"]
+    assert len(sd) == 4 and all({"step", "exp_avg", "exp_avg_sq"} <= set(st) for st in sd.values())
+    assert all(float(st["step"]) == 9.0 for st in sd.values())                 # 3 epochs x 3 steps
+    for a, b in zip(o_full.state_dict()["state"].values(), sd.values()):
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+    # and the moments are what torch's own AdamW computes from the same gradients (one step, module path)
+    from efficient_probing_amd import functional as F_
+    m_t = make_model(case, inp)
+    o_t = torch.optim.AdamW(m_t.head.parameters(), lr=0.01, weight_decay=0.05, betas=(0.9, 0.95))
+    x, t = torch.from_numpy(inp["x_buf"]).to(DEV), torch.from_numpy(inp["targets"]).to(DEV)
+    F_.cross_entropy_loss(m_t.head(x), t)[0].backward()
+    o_t.step()
+    from efficient_probing_amd.engine import make_engine
+    m_e = make_model(case, inp)
+    eng = make_engine(m_e.head, optimizer="adamw", lr=0.01, weight_decay=0.05, betas=(0.9, 0.95))
+    eng.train_step(x, t)
+    for p_t, p_e in zip(m_t.head.parameters(), m_e.head.parameters()):
+        np.testing.assert_allclose(p_e.detach().cpu().numpy(), p_t.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_evaluate_before_training_does_not_fix_the_optimizer():
+    """evaluate() used to create (and cache) a LARS engine with weight_decay 0; a later train_one_epoch with
+    SGD / another weight decay silently reused it."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd.util.misc import NativeScalerWithGradNormCount
+    case = Case("evtr", B=16, N=24, D=128, Q=4, C=12, seed=6)
+    inp = make_inputs(case)
+    loader = loader_of(case, inp, 2)
+
+    def train(evaluate_first):
+        model = make_model(case, inp)
+        if evaluate_first:
+            EF.evaluate(loader, model, torch.device(DEV))
+            assert EF.get_engine(model)._eval_only
+        opt = torch.optim.SGD(model.head.parameters(), lr=0.0, weight_decay=0.01)
+        EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), loader, opt, torch.device(DEV), 1,
+                           NativeScalerWithGradNormCount(), args=ARGS)
+        eng = EF.get_engine(model)
+        assert eng.optimizer_name == "sgd" and eng.weight_decay == 0.01 and not eng._eval_only
+        return model
+    a, b = train(False), train(True)
+    for p, q in zip(a.head.parameters(), b.head.parameters()):
+        assert torch.equal(p, q)
+    # another optimizer class on the same model is an error, not a silent reuse
+    from efficient_probing_amd.util.lars import LARS
+    with pytest.raises(RuntimeError, match="built for sgd"):
+        EF.get_engine(a, LARS(a.head.parameters(), lr=0.1))
+
+
+def test_clipping_and_other_criteria_take_the_module_path():
+    """The fused step computes plain mean cross-entropy and does not clip: max_norm, label smoothing or mixup must
+    not be dropped silently -- those calls run the reference's module loop."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd.util.lars import LARS
+    from efficient_probing_amd.util.misc import NativeScalerWithGradNormCount
+    case = Case("clip", B=16, N=24, D=128, Q=4, C=12, seed=7)
+    inp = make_inputs(case)
+    loader = loader_of(case, inp, 2)
+    for kw, crit in ((dict(max_norm=0.5), torch.nn.CrossEntropyLoss()), (dict(), torch.nn.CrossEntropyLoss(label_smoothing=0.1))):
+        model = make_model(case, inp)
+        opt = LARS(model.head.parameters(), lr=0.0)
+        EF.train_one_epoch(model, crit, loader, opt, torch.device(DEV), 1, NativeScalerWithGradNormCount(), args=ARGS, **kw)
+        assert getattr(model, "_ep_engine", None) is None
+    assert EF._plain_cross_entropy(torch.nn.CrossEntropyLoss()) and not EF._plain_cross_entropy(torch.nn.MSELoss())

@@ -405,3 +405,24 @@ def test_online_softmax_under_adversarial_score_order(shape):
     ref = torch.matmul(Aref * (dA - delta[..., None]), x.double()).sum(0)
     assert torch.isfinite(dcls).all()
     np.testing.assert_allclose(dcls.cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=5e-5 * float(ref.abs().max()))
+
+
+def test_label_outside_the_class_range_is_flagged_not_read():
+    """ep_ce_kernel read row[target] unchecked.  A label of -1 (an ignore_index) or >= C now marks the row as
+    bad (stats[3], which stops the training loop), and that row contributes no loss and no gradient."""
+    from efficient_probing_amd import functional as F_
+    torch.manual_seed(3)
+    logits = torch.randn(6, 10, device=DEV, requires_grad=True)
+    good = torch.tensor([1, 2, 3, 4, 5, 6], device=DEV)
+    for badval in (-1, 10, 1 << 40):
+        t = good.clone(); t[2] = badval
+        lg = logits.detach().clone().requires_grad_(True)
+        loss, stats = F_.cross_entropy_loss(lg, t)
+        loss.backward()
+        st = stats.cpu().numpy()
+        assert st[3] == 1                                        # one flagged row
+        assert torch.isfinite(loss) and torch.isfinite(lg.grad).all()
+        assert float(lg.grad[2].abs().max()) == 0.0              # no gradient from the flagged row
+        keep = [0, 1, 3, 4, 5]
+        ref = torch.nn.functional.cross_entropy(logits.detach()[keep], good[keep], reduction="sum") / 6
+        assert float(loss) == pytest.approx(float(ref), rel=1e-5)

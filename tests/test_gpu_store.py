@@ -71,6 +71,11 @@ def test_resident_store_training_equals_gathered_batches(tmp_path):
     s0 = TS.ResidentTokenStore(str(tmp_path), DEV, world=2, rank=0)
     s1 = TS.ResidentTokenStore(str(tmp_path), DEV, world=2, rank=1)
     assert s0.num_images + s1.num_images == 100 and s0.num_images == 60
+    # ... and run the same number of steps per epoch although they own 60 / 40 images
+    assert len(list(s0.batches(16))) == len(list(s1.batches(16))) == 2 == TS.steps_per_epoch(TS.load_meta(str(tmp_path)), 2, 16)
+    l0 = TS.StreamingTokenLoader(str(tmp_path), DEV, batch_size=16, world=2, rank=0)
+    l1 = TS.StreamingTokenLoader(str(tmp_path), DEV, batch_size=16, world=2, rank=1)
+    assert len(l0) == len(l1) == 2 and sum(1 for _ in l0) == sum(1 for _ in l1) == 2
 
 
 def test_streaming_loader_delivers_the_store(tmp_path):

@@ -26,8 +26,20 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ep_version() >= 2
+    # one ABI version everywhere: the header, the library and the ctypes structs (load() raises on a stale .so)
+    abi = int(re.search(r"#define\s+EP_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.ep_version() == abi == _native.EP_ABI_VERSION
     assert isinstance(_native.last_error(), str)
+
+
+def test_stale_library_is_rejected(monkeypatch):
+    """a git-ignored .so of another ABI version still exports every symbol and would misread the step
+    structs; load() must refuse it."""
+    from efficient_probing_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "EP_ABI_VERSION", _native.EP_ABI_VERSION + 1)
+    with pytest.raises(_native.NativeLibraryError, match="ABI version"):
+        _native.load()
 
 
 def test_param_layout_matches_parameters_order():

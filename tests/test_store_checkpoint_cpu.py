@@ -50,6 +50,35 @@ def test_token_store_roundtrip_and_rank_partition(tmp_path):
         TS.load_meta(str(tmp_path / "bad"))
 
 
+def test_uneven_shards_give_every_rank_the_same_number_of_steps(tmp_path):
+    """Whole shards are dealt round-robin, so two ranks can own 60 / 40 images; each engine step ends in a blocking
+    all-reduce, so both must run the same number of steps (the reference: DistributedSampler, main_linprobe.py:286-287)."""
+    from efficient_probing_amd import token_store as TS
+    rng = np.random.default_rng(2)
+    w = TS.TokenStoreWriter(str(tmp_path), num_tokens=3, dim=8, shard_images=40)
+    w.add(rng.standard_normal((100, 3, 8), dtype=np.float32), rng.integers(0, 10, 100))     # shards of 40, 40, 20
+    meta = w.close()
+    own = [sum(s["images"] for s in TS.shards_of_rank(meta, 2, r)) for r in (0, 1)]
+    assert own == [60, 40]
+    assert TS.steps_per_epoch(meta, 2, 16) == 2                       # min(60 // 16, 40 // 16)
+    assert TS.steps_per_epoch(meta, 2, 16, per_shard=True) == 2       # rank 0: 40//16 + 20//16 = 3, rank 1: 2
+    assert TS.steps_per_epoch(meta, 1, 16) == 6
+    assert TS.steps_per_epoch(meta, 3, 16) == 1                       # 40, 40, 20 images
+    for B in (7, 16, 20, 33):
+        counts = []
+        for r in (0, 1):
+            st = TS.ResidentTokenStore(str(tmp_path), "cpu", world=2, rank=r)
+            got = list(st.batches(B, epoch=1))
+            counts.append(len(got))
+            assert len(got) == st.num_batches(B)
+            for tokens, idx, tgt in got:
+                assert idx.numel() == B and int(idx.max()) < st.num_images
+        assert counts[0] == counts[1] == min(60 // B, 40 // B)
+    # one rank: the whole store, drop_last as before
+    st = TS.ResidentTokenStore(str(tmp_path), "cpu")
+    assert len(list(st.batches(16))) == 6 and st.num_batches(16, drop_last=False) == 7
+
+
 def test_reads_reference_npz_dump(tmp_path):
     """tools/dump_tokens.py:95-98 writes tokens/images/names into one .npz."""
     from efficient_probing_amd import token_store as TS
