@@ -256,7 +256,36 @@ class ProbeHeadEngine:
             self.optimizer_step(lr)
 
     @torch.no_grad()
-    def eval_logits(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def eval_logits_fp16_autocast(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Evaluation logits with the roundings of the reference's evaluation mode.  The reference ALWAYS evaluates
+        under ``torch.cuda.amp.autocast()`` (engine_finetune.py:131: fp16 on the GPU): every Linear / matmul takes its
+        operands rounded to fp16, accumulates in fp32 and returns fp16; softmax, BatchNorm statistics and the loss stay
+        fp32.  Here the same kernels run on operands rounded to fp16 at those points (tokens, scaled queries, both weight
+        matrices; pooled projection, BatchNorm output and logits rounded to fp16 on the way out), so a head trained by
+        the reference scores like it does there.  Two roundings cannot be placed identically because the kernels pool
+        before they project: the reference rounds the (B, Q, N) scores and the per-token values V to fp16; both are
+        below the fp16 resolution of the result (see tests/test_gpu_eval_precision.py for the measured distance)."""
+        if type(self) is not ProbeHeadEngine:
+            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
+        self.flush()
+        r16 = lambda t: t.to(torch.float16).to(torch.float32)
+        xv, _ = F_.as_token_view(x)
+        if image_index is not None:
+            xv = xv[image_index.long()]
+        x16 = r16(xv)                                                        # k = x under autocast (ep.py:38,42)
+        q16 = r16(self.pool.cls_token.detach()[0] * self.pool.scale)          # q = cls_token * scale, then the matmul cast
+        P, _, _ = F_.pool_forward(x16, q16, 1.0)
+        y16 = r16(F_.project_forward(P, r16(self.pool.v.weight.detach())))   # self.v under autocast, attn @ v
+        z16 = r16(F_.bn_forward_eval(y16, self.bn.running_mean, self.bn.running_var, self.bn.eps))
+        return r16(F_.linear_forward(z16, r16(self.fc.weight.detach()), r16(self.fc.bias.detach())))
+
+    @torch.no_grad()
+    def eval_logits(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None,
+                    precision: str = "fp32") -> torch.Tensor:
+        if precision == "fp16_autocast":
+            return self.eval_logits_fp16_autocast(x, image_index)
+        if precision != "fp32":
+            raise ValueError("precision must be 'fp32' or 'fp16_autocast'")
         self.flush()
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape

@@ -292,7 +292,12 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
 
 @torch.no_grad()
 def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = False, cls_features: str = "cls",
-             return_block: Optional[int] = None, token_fn: Optional[Callable] = None):
+             return_block: Optional[int] = None, token_fn: Optional[Callable] = None, precision: str = "fp32"):
+    """``precision``: "fp32" (default: the kernels' own arithmetic) or "fp16_autocast" -- the reference's evaluation
+    mode (it always evaluates under ``torch.cuda.amp.autocast()``, engine_finetune.py:131), reproduced on the fused
+    path by ``ProbeHeadEngine.eval_logits_fp16_autocast`` and on the module path by torch's autocast itself."""
+    if precision not in ("fp32", "fp16_autocast"):
+        raise ValueError("precision must be 'fp32' or 'fp16_autocast'")
     model.eval()
     metric_logger = MetricLogger()
     engine = get_engine(model)
@@ -302,9 +307,11 @@ def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = Fal
     for batch in metric_logger.log_every(data_loader, 10, "Test:"):
         images, target = batch[0].to(device, non_blocking=True), batch[-1].to(device, non_blocking=True)
         if engine is not None and (images.dim() == 3 or token_fn is not None):
-            output = engine.eval_logits(images if images.dim() == 3 else token_fn(images))
+            output = engine.eval_logits(images if images.dim() == 3 else token_fn(images), precision=precision)
         else:
-            output = model(images).float()
+            with torch.autocast("cuda", enabled=(precision == "fp16_autocast" and images.is_cuda), dtype=torch.float16):
+                output = model(images)
+            output = output.float()
         loss = torch.nn.functional.cross_entropy(output, target)
         acc1, acc5 = accuracy(output, target)
         n = images.shape[0]

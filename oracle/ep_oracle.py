@@ -342,6 +342,26 @@ def head_forward_eval(st: HeadState, x):
     return linear_forward(z, st.fc_weight, st.fc_bias)
 
 
+def head_forward_eval_fp16_autocast(st: HeadState, x):
+    """The reference's evaluation forward as it actually runs: ``with torch.cuda.amp.autocast():`` wraps the model call
+    in evaluate() (engine_finetune.py:131), i.e. fp16 autocast.  Autocast's op lists: Linear / matmul take fp16
+    operands and return fp16 (fp32 accumulation inside), softmax runs in fp32 (and returns fp32), batch_norm takes the
+    fp16 input, computes in fp32 and returns fp16.  Restated on the reference's own association (project every token,
+    then pool -- ep.py:35-45).  Pinned on ``eval_logits_fp16_autocast`` of the golden fixtures."""
+    r16 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+    x = np.asarray(x, dtype=F32)
+    B, N, C = x.shape
+    Q, dq = st.num_queries, (C // st.d_out) // st.num_queries
+    q = (st.cls_token[0] * F32(ep_scale(C))).astype(F32)                    # ep.py:37,39 (fp32 mul: not an autocast op)
+    x16, w16 = r16(x), r16(st.v_weight)
+    v = r16(x16.reshape(B * N, C) @ w16.T).reshape(B, N, Q, dq).transpose(0, 2, 1, 3)        # ep.py:40 self.v -> fp16
+    s = r16(np.matmul(r16(q)[None], x16.transpose(0, 2, 1)))                # ep.py:42 q @ k^T -> fp16
+    a = _softmax_lastdim(s)                                                 # ep.py:43 softmax: fp32
+    pooled = r16(np.matmul(r16(a)[:, :, None, :], v)).reshape(B, C // st.d_out)                # ep.py:44 attn @ v -> fp16
+    z = r16(bn_forward_eval(pooled, st.running_mean, st.running_var))       # probe_heads.py:110: fp32 math, fp16 out
+    return r16(linear_forward(z, r16(st.fc_weight), r16(st.fc_bias)))       # probe_heads.py:76 Linear -> fp16
+
+
 def head_train_step(st: HeadState, x, targets, lr: float, weight_decay: float = 0.0,
                     optimizer: str = "lars", momentum: float = 0.9,
                     trust_coefficient: float = 0.001):

@@ -173,6 +173,11 @@ def run_case(case, optimizer_name="lars"):
         with torch.no_grad():
             x = torch.from_numpy(view_tokens(case, inp["x_buf"]))
             out["eval_logits"] = head(x).numpy()
+            # the reference evaluates under torch.cuda.amp.autocast() (engine_finetune.py:131: fp16); the CPU autocast
+            # of the same modules places the same roundings (Linear / matmul operands and results fp16, softmax and
+            # BatchNorm statistics fp32)
+            with torch.autocast("cpu", dtype=torch.float16):
+                out["eval_logits_fp16_autocast"] = head(x).float().numpy()
     return out
 
 

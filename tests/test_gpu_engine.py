@@ -135,6 +135,14 @@ def test_evaluate_matches_oracle():
     assert stats["acc1"] == pytest.approx(np.mean([a[0] for a in accs]))
     assert stats["acc5"] == pytest.approx(np.mean([a[1] for a in accs]))
     assert stats["preds"].shape == (2 * case.B,)
+    # the reference's evaluation precision (fp16 autocast, engine_finetune.py:131) through the same call: the fused path
+    # (engine emulation) and the module path (torch autocast around the native modules) agree to fp16 resolution, and
+    # sit within fp16 resolution of the fp32 evaluation
+    s16 = EF.evaluate(loader, model, torch.device(DEV), precision="fp16_autocast")
+    assert s16["loss"] == pytest.approx(stats["loss"], rel=2e-3)
+    assert abs(s16["acc1"] - stats["acc1"]) <= 100.0 / case.B + 1e-9
+    with pytest.raises(ValueError):
+        EF.evaluate(loader, model, torch.device(DEV), precision="bf16")
 
 
 def _adamw_run(case, inp, epochs, resume_after=None, tmp_path=None):

@@ -180,6 +180,14 @@ def test_fused_engine_steps_golden(case, opt):
         with torch.no_grad():
             ev2 = head(tokens(case, inp["x_buf"])).cpu().numpy()
         np.testing.assert_allclose(ev2, ev, rtol=1e-6, atol=1e-6)
+        if "eval_logits_fp16_autocast" in g.files:
+            # the reference's own evaluation mode (fp16 autocast, engine_finetune.py:131) through the precision switch:
+            # an fp16 result, pinned to a few fp16 ulps of the logits' scale; the fp32 evaluation above sits further away
+            want = g["eval_logits_fp16_autocast"]
+            ev16 = eng.eval_logits(tokens(case, inp["x_buf"]), precision="fp16_autocast").cpu().numpy()
+            ulp = 2.0 ** -11 * float(np.abs(want).max())
+            np.testing.assert_allclose(ev16, want, rtol=0, atol=6 * ulp)
+            assert (ev16.argmax(1) != want.argmax(1)).sum() <= max(1, case.B // 32)      # near-ties at an untrained head
 
 
 ADHOC = [dict(B=16, N=50, D=256, Q=8, C=33), dict(B=6, N=37, D=2048, Q=8, C=20), dict(B=5, N=20, D=4096, Q=4, C=12)]

@@ -82,6 +82,14 @@ def test_optimizer_steps(case, opt):
     if opt == "lars":
         ev = O.head_forward_eval(st, view_tokens(case, inp["x_buf"]))
         np.testing.assert_allclose(ev, g["eval_logits"], rtol=2e-4, atol=2e-4)
+        if "eval_logits_fp16_autocast" in g.files:
+            # the reference's evaluation mode (fp16 autocast, engine_finetune.py:131): an fp16 result is pinned to a few
+            # fp16 ulps of the logits' scale (summation order inside the fp32-accumulating matmuls differs)
+            ev16 = O.head_forward_eval_fp16_autocast(st, view_tokens(case, inp["x_buf"]))
+            want = g["eval_logits_fp16_autocast"]
+            np.testing.assert_allclose(ev16, want, rtol=0, atol=4 * 2.0 ** -11 * float(np.abs(want).max()))
+            # and it is a different thing from the fp32 evaluation: the switch matters at this resolution
+            assert float(np.abs(want - g["eval_logits"]).max()) > 1e-6
 
 
 def test_lr_schedule_table():
