@@ -483,10 +483,12 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   const bool ws_ok = use_ws && vec && !force_bm && p.K >= 256 && (!p.side || (use_ws & 2));
   static int use_dma = -1;
   if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
-  // default: the three-term bf16 split on the bf16 matrix cores (ep_gemm_x3.hip; fp32 accuracy at 3/8 of the f32 matrix
-  // time); EP_GEMM_X3=0 keeps the v_mfma_f32_16x16x4_f32 kernel (the independent implementation the tests compare with)
+  // EP_GEMM_X3=1 (experiment, off by default): the three-term bf16 split on the bf16 matrix cores (ep_gemm_x3.hip).
+  // Measured on MI355X (tools/exp_gemm.sh): no faster than the f32 kernel on the 1024-row head contractions (19.5 vs
+  // 20.4 us: the in-register split costs the vector issue what the matrix pipe saves) and its truncation error is
+  // one-sided, which the batch-cancelling gradients of the CaiT head see (tests/test_gpu_cait.py).
   static int use_x3 = -1;
-  if (use_x3 < 0) { const char* e = getenv("EP_GEMM_X3"); use_x3 = e ? atoi(e) : 1; }
+  if (use_x3 < 0) { const char* e = getenv("EP_GEMM_X3"); use_x3 = e ? atoi(e) : 0; }
   if (use_dma && use_x3 && vec && !force_bm) gemm_launch_x3(a_k, b_k, p, batch, st);
   else if (use_dma && vec && !force_bm) gemm_launch_dma(a_k, b_k, p, batch, st);
   else if (ws_ok) gemm_launch_ws(a_k, b_k, p, batch, st);

@@ -205,9 +205,9 @@ __global__ __launch_bounds__(512) void ep_gemm_x3_kernel(GemmParams p) {
   {                                                                                \
     x3_dma_wait<2 * (NST - 3 >= 0 ? NST - 3 : 0)>();                               \
     x3_barrier();                                                                  \
-    issue((IT) + NST - 1);                                                         \
+    if (p.ablate != 2) issue((IT) + NST - 1);                                      \
     read_frags(((IT) + 1) % NST, fa[(F) ^ 1], fb[(F) ^ 1]);                        \
-    multiply(fa[F], fb[F]);                                                        \
+    if (p.ablate != 1) multiply(fa[F], fb[F]);                                     \
     if (ktail && (IT) + 1 == nk - 1) { __builtin_amdgcn_s_waitcnt(0xc07f); zero_tail(((IT) + 1) * BK, fa[(F) ^ 1], fb[(F) ^ 1]); } \
   }
   int it = 0;
@@ -251,11 +251,14 @@ static void x3_launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
 // flight.  Larger grids run two workgroups per CU on 4-stage rings (64 KiB each).
 void gemm_launch_x3(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   dim3 grid((p.N + BN - 1) / BN, (p.M + 63) / 64, batch);
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("EP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+  GemmParams pa = p; pa.ablate = ablate;
   static int force_nst = -1;
   if (force_nst < 0) { const char* e = getenv("EP_GEMM_X3_NST"); force_nst = e ? atoi(e) : 0; }
   const long tiles = (long)grid.x * grid.y * grid.z;
   const bool deep = force_nst ? force_nst == 8 : tiles <= (long)cu_count();
-#define EP_GEMM_LAUNCH(AK, BK_) { if (deep) x3_launch_one<AK, BK_, 8>(p, grid, st); else x3_launch_one<AK, BK_, 4>(p, grid, st); }
+#define EP_GEMM_LAUNCH(AK, BK_) { if (deep) x3_launch_one<AK, BK_, 8>(pa, grid, st); else x3_launch_one<AK, BK_, 4>(pa, grid, st); }
   if (a_k && b_k) EP_GEMM_LAUNCH(true, true)
   else if (a_k && !b_k) EP_GEMM_LAUNCH(true, false)
   else if (!a_k && b_k) EP_GEMM_LAUNCH(false, true)

@@ -44,6 +44,7 @@ struct GemmParams {
   int accumulate;
   int side;                         // 1: runs on the aux stream beside a token pass (kernel choice hint)
   float* skws; size_t skws_floats;  // optional scratch for a split of K (few output tiles, very long K): >= 2 M N floats
+  int ablate;                       // diagnostic only (EP_GEMM_ABLATE): 1 operand ring only (no arithmetic), 2 arithmetic only
 };
 
 // Work appended to the launch of the second token pass (ep_side.h: run_side_task)

@@ -379,7 +379,9 @@ class AbmilpHeadEngine(ProbeHeadEngine):
     def forward_backward(self, x, targets, image_index=None):
         super().forward_backward(self._tokens(x, image_index), targets, None)
 
-    def eval_logits(self, x, image_index=None):
+    def eval_logits(self, x, image_index=None, precision="fp32"):
+        if precision != "fp32":
+            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
         return super().eval_logits(self._tokens(x, image_index), None)
 
     def _call_train(self, s, ws) -> int:
@@ -704,7 +706,9 @@ class DolgHeadEngine(ProbeHeadEngine):
     def forward_backward(self, x, targets, image_index=None):
         super().forward_backward(self._tokens(x, image_index), targets, None)
 
-    def eval_logits(self, x, image_index=None):
+    def eval_logits(self, x, image_index=None, precision="fp32"):
+        if precision != "fp32":
+            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
         return super().eval_logits(self._tokens(x, image_index), None)
 
     def sync_buffers(self):
@@ -870,7 +874,9 @@ class LinearProbeEngine(ProbeHeadEngine):
         f = self._features(x, image_index)
         super().forward_backward(f.view(f.shape[0], 1, f.shape[1]), targets, None)
 
-    def eval_logits(self, x, image_index=None):
+    def eval_logits(self, x, image_index=None, precision="fp32"):
+        if precision != "fp32":
+            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
         f = self._features(x, image_index)
         return super().eval_logits(f.view(f.shape[0], 1, f.shape[1]), None)
 
