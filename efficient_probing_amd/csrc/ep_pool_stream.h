@@ -9,6 +9,9 @@ namespace ep {
 #ifndef EP_STREAM_NSLOT_CAP
 #define EP_STREAM_NSLOT_CAP 8
 #endif
+#ifndef EP_STREAM_ABLATE
+#define EP_STREAM_ABLATE 0        // diagnostic builds of the forward pass: 1 ring only (no arithmetic), 3 no pooling FMAs
+#endif
 #ifndef EP_DMA_AUX
 #define EP_DMA_AUX 2              // cache-policy bits of the LDS-DMA loads (2 = nt: streamed once)
 #endif

@@ -79,18 +79,32 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // lane-local partial dot products of TB token rows with QW query rows (packed FMAs)
 template <int QW, int KP>
 __device__ __forceinline__ void partial_scores(const f4 (&w)[QW][KP], const f4 (&xv)[TB][KP], float (&part)[QW][TB]) {
+  // k-outer: the QW*TB dot products advance together, so consecutive v_pk_fma_f32 are independent (a dependent pair
+  // needs a wait state between them)
+  f2 s[QW][TB];
 #pragma unroll
   for (int j = 0; j < QW; ++j)
 #pragma unroll
-    for (int t = 0; t < TB; ++t) {
-      f2 s = {0.f, 0.f};
+    for (int t = 0; t < TB; ++t) s[j][t] = w[j][0].xy * xv[t][0].xy;
 #pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        s = fma2(w[j][k].xy, xv[t][k].xy, s);
-        s = fma2(w[j][k].zw, xv[t][k].zw, s);
-      }
-      part[j][t] = s.x + s.y;
-    }
+  for (int j = 0; j < QW; ++j)
+#pragma unroll
+    for (int t = 0; t < TB; ++t) s[j][t] = fma2(w[j][0].zw, xv[t][0].zw, s[j][t]);
+#pragma unroll
+  for (int k = 1; k < KP; ++k) {
+#pragma unroll
+    for (int j = 0; j < QW; ++j)
+#pragma unroll
+      for (int t = 0; t < TB; ++t) s[j][t] = fma2(w[j][k].xy, xv[t][k].xy, s[j][t]);
+#pragma unroll
+    for (int j = 0; j < QW; ++j)
+#pragma unroll
+      for (int t = 0; t < TB; ++t) s[j][t] = fma2(w[j][k].zw, xv[t][k].zw, s[j][t]);
+  }
+#pragma unroll
+  for (int j = 0; j < QW; ++j)
+#pragma unroll
+    for (int t = 0; t < TB; ++t) part[j][t] = s[j][t].x + s[j][t].y;
 }
 
 // butterfly reduction: on return u[q] holds, in every lane of row t (lanes 16t..16t+15), the
@@ -226,34 +240,45 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 
   f4 acc[QW][KP];
   float m[QW], mL[QW], lsum[QW], c2[QW];
-  int cimg = 0, ctile = 0, cslot = 0;
-  for (int i = 0; i < n_items; ++i) {
-    // ---- wait for item i, free the slot of item i-1, refill it ---------------------------
-    // Outstanding VMEM ops of this wave, oldest first: DMA of items i..pi-1 (KD each), then the
-    // S / P stores of the previous iteration.  Requiring <= (pi-1-i)*KD outstanding retires
-    // item i (and, harmlessly early, a few ops of item i+1 in place of the stores).
+  int cslot = 0, i = 0;
+  // wait for item i, free the slot of item i-1, refill it.  Outstanding VMEM ops of this wave, oldest first: DMA of
+  // items i..pi-1 (KD each), then the S / P stores of the previous iteration.  Requiring <= (pi-1-i)*KD outstanding
+  // retires item i (and, harmlessly early, a few ops of item i+1 in place of the stores).
+  auto ring_step = [&]() {
     const int ahead = pi - 1 - i;
     if (ahead == NSLOT - 2) wait_vmcnt_imm<(NSLOT - 2) * KD>();
     else wait_vmcnt(ahead * KD);
     ring_barrier();
     produce();
+  };
+  if (q0 >= Q || EP_STREAM_ABLATE == 1) {
+    // a wave without a query (Q < QW * NW) only keeps the ring turning
+    for (; i < n_items; ++i) ring_step();
+    return;
+  }
+  // Loop shape (it decides what the register allocator does with the 24 accumulator registers): image-outer /
+  // tile-inner, so the accumulators are initialised in front of the tile loop and stored behind it -- plain
+  // loop-carried values, no conditional re-initialisation inside the loop; and the rest of a mini-batch is written out
+  // on BOTH sides of the rare max-rescale branch, so each side updates the accumulators in place.  The flat item loop
+  // with `if (first tile) acc = 0`, `if (rescale) acc *= f` and `if (last tile) store` made hipcc copy all accumulators
+  // twice per tile (27 v_mov_b64 of ~300 instructions).
+  for (int cimg = 0; cimg < n_img; ++cimg) {
     const int b = wg + cimg * G;
-    const int n0 = ctile * TT;
-    const int nvalid = (N - n0) < TT ? (N - n0) : TT;
-    const char* tile = ring + cslot * slot_bytes;
-    const float* small = reinterpret_cast<const float*>(small_base + (cslot * NW + w) * 256);
-    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
-    if (ctile == 0) {
-      if (p.cls_bstride != 0 && cimg != 0) { load_cls(b); sum_cls(); }   // per-image query override (rare path)
+    if (p.cls_bstride != 0 && cimg != 0) { load_cls(b); sum_cls(); }   // per-image query override (rare path)
 #pragma unroll
-      for (int j = 0; j < QW; ++j) {
-        m[j] = -INFINITY; mL[j] = -INFINITY; lsum[j] = 0.f; c2[j] = 0.f;
+    for (int j = 0; j < QW; ++j) {
+      m[j] = -INFINITY; mL[j] = -INFINITY; lsum[j] = 0.f; c2[j] = 0.f;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) acc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int k = 0; k < KP; ++k) acc[j][k] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    // ---- compute: TT/TB butterfly mini-batches per tile ------------------------------------
-    if (p.ablate != 1 && q0 < Q) {
+    for (int ctile = 0; ctile < tiles_per_img; ++ctile, ++i) {
+      ring_step();
+      const int n0 = ctile * TT;
+      const int nvalid = (N - n0) < TT ? (N - n0) : TT;
+      const char* tile = ring + cslot * slot_bytes;
+      const float* small = reinterpret_cast<const float*>(small_base + (cslot * NW + w) * 256);
+      cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+      // ---- compute: TT/TB butterfly mini-batches per tile ------------------------------------
 #pragma unroll
       for (int t0 = 0; t0 < TT; t0 += TB) {
         if (t0 >= nvalid) break;
@@ -278,6 +303,25 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           ue[j] = rowvalid ? u[j] : -INFINITY;
           need |= ue[j] > m[j] + LAZY_MAX_THR;
         }
+        // weights, raw scores out, pooling: the part of the mini-batch behind the rescale decision
+        auto finish = [&]() {
+          float pr[QW];
+#pragma unroll
+          for (int j = 0; j < QW; ++j) {
+            pr[j] = __builtin_amdgcn_exp2f(fmaf(ue[j], LOG2E, -mL[j]));      // invalid rows: exp2(-inf) = 0
+            lsum[j] += pr[j];
+          }
+          if ((lane & 15) == 0 && rowvalid) {                                // raw scores for backward / attention maps
+#pragma unroll
+            for (int j = 0; j < QW; ++j)
+              if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + t0 + row)] = u[j];
+          }
+          if (LN) {
+#pragma unroll
+            for (int j = 0; j < QW; ++j) { pr[j] *= trstd; c2[j] = fmaf(pr[j], tmean, c2[j]); }   // weights a * rstd
+          }
+          if (EP_STREAM_ABLATE != 3) accumulate_rows<QW, KP>(pr, xv, acc);
+        };
         if (__builtin_amdgcn_ballot_w64(need) != 0ull) {     // wave-uniform, rare
 #pragma unroll
           for (int j = 0; j < QW; ++j) {
@@ -290,51 +334,32 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 #pragma unroll
             for (int k = 0; k < KP; ++k) acc[j][k] *= f;
           }
+          finish();
+        } else {
+          finish();
         }
-        float pr[QW];
-#pragma unroll
-        for (int j = 0; j < QW; ++j) {
-          pr[j] = __builtin_amdgcn_exp2f(fmaf(ue[j], LOG2E, -mL[j]));      // invalid rows: exp2(-inf) = 0
-          lsum[j] += pr[j];
-        }
-        // raw scores for backward / attention maps
-        if ((lane & 15) == 0 && rowvalid) {
-#pragma unroll
-          for (int j = 0; j < QW; ++j)
-            if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + t0 + row)] = u[j];
-        }
-        if (LN) {
-#pragma unroll
-          for (int j = 0; j < QW; ++j) { pr[j] *= trstd; c2[j] = fmaf(pr[j], tmean, c2[j]); }   // weights a * rstd
-        }
-        if (p.ablate != 3) accumulate_rows<QW, KP>(pr, xv, acc);
       }
     }
     // ---- image epilogue -------------------------------------------------------------------
-    if (ctile == tiles_per_img - 1) {
 #pragma unroll
-      for (int j = 0; j < QW; ++j) {
-        const float l = readlane_f(lsum[j], 0) + readlane_f(lsum[j], 16) +
-                        readlane_f(lsum[j], 32) + readlane_f(lsum[j], 48);
-        const float inv = 1.0f / l;
-        const float shift = LN ? (readlane_f(c2[j], 0) + readlane_f(c2[j], 16) + readlane_f(c2[j], 32) +
-                                  readlane_f(c2[j], 48)) * inv : 0.f;
-        if (q0 + j < Q) {
-          float* Pq = p.P + ((int64_t)b * Q + q0 + j) * D;
+    for (int j = 0; j < QW; ++j) {
+      const float l = readlane_f(lsum[j], 0) + readlane_f(lsum[j], 16) +
+                      readlane_f(lsum[j], 32) + readlane_f(lsum[j], 48);
+      const float inv = 1.0f / l;
+      const float shift = LN ? (readlane_f(c2[j], 0) + readlane_f(c2[j], 16) + readlane_f(c2[j], 32) +
+                                readlane_f(c2[j], 48)) * inv : 0.f;
+      if (q0 + j < Q) {
+        float* Pq = p.P + ((int64_t)b * Q + q0 + j) * D;
 #pragma unroll
-          for (int k = 0; k < KP; ++k) {
-            const int c = lane + 64 * k;
-            if (c < nchunk) *reinterpret_cast<f4*>(Pq + 4 * c) = acc[j][k] * inv - shift;
-          }
-          if (lane == 0) {
-            const f4 rec = {m[j], l, 0.f, 0.f};
-            *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + q0 + j) * 4) = rec;
-          }
+        for (int k = 0; k < KP; ++k) {
+          const int c = lane + 64 * k;
+          if (c < nchunk) *reinterpret_cast<f4*>(Pq + 4 * c) = acc[j][k] * inv - shift;
+        }
+        if (lane == 0) {
+          const f4 rec = {m[j], l, 0.f, 0.f};
+          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + q0 + j) * 4) = rec;
         }
       }
-      ctile = 0; ++cimg;
-    } else {
-      ++ctile;
     }
   }
 }
