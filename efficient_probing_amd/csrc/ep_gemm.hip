@@ -483,10 +483,8 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   const bool ws_ok = use_ws && vec && !force_bm && p.K >= 256 && (!p.side || (use_ws & 2));
   static int use_dma = -1;
   if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
-  // EP_GEMM_X3=1 (experiment, off by default): the three-term bf16 split on the bf16 matrix cores (ep_gemm_x3.hip).
-  // Measured on MI355X (tools/exp_gemm.sh): no faster than the f32 kernel on the 1024-row head contractions (19.5 vs
-  // 20.4 us: the in-register split costs the vector issue what the matrix pipe saves) and its truncation error is
-  // one-sided, which the batch-cancelling gradients of the CaiT head see (tests/test_gpu_cait.py).
+  // EP_GEMM_X3=1 (experiment, off by default): the three-term bf16 split on the bf16 matrix cores (ep_gemm_x3.hip: fp32
+  // accuracy, but no faster on MI355X -- its header says why)
   static int use_x3 = -1;
   if (use_x3 < 0) { const char* e = getenv("EP_GEMM_X3"); use_x3 = e ? atoi(e) : 0; }
   if (use_dma && use_x3 && vec && !force_bm) gemm_launch_x3(a_k, b_k, p, batch, st);
