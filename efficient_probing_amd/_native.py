@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
-EP_ABI_VERSION = 19        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
+EP_ABI_VERSION = 20        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
 
@@ -325,6 +325,9 @@ SIGNATURES = {
     "ep_linear_forward": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_int, c_void]),
     "ep_linear_backward": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                    c_int, c_void]),
+    "ep_planes_elems": (c_size, [c_int, c_int]),
+    "ep_planes_split": (c_int, [c_f32p, c_int, c_int, c_i64, c_void, c_void, c_void]),
+    "ep_matmul_planes": (c_int, [c_f32p, c_i64, c_void, c_int, c_int, c_f32p, c_int, c_int, c_f32p, c_i64, c_void]),
     "ep_cross_entropy": (c_int, [c_f32p, c_int, c_void, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p, c_void]),
     "ep_optim_workspace_bytes": (c_size, [c_i64, c_int]),
     "ep_lars_step": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, C.POINTER(EPSegment), c_int, c_float, c_float,

@@ -30,10 +30,10 @@ int cu_count() {
 // reused (events carry no data; the library otherwise keeps no state).
 int get_events(hipEvent_t* out, int n) {
   constexpr int MAX_DEV = 16;          // events belong to the device that was current when they were created
-  static thread_local hipEvent_t pool[MAX_DEV][4] = {};
+  static thread_local hipEvent_t pool[MAX_DEV][6] = {};
   int dev = 0;
   EP_HIP(hipGetDevice(&dev));
-  EP_REQUIRE(dev >= 0 && dev < MAX_DEV && n <= 4, EP_E_ARG, "get_events: device %d / %d events not supported", dev, n);
+  EP_REQUIRE(dev >= 0 && dev < MAX_DEV && n <= 6, EP_E_ARG, "get_events: device %d / %d events not supported", dev, n);
   for (int i = 0; i < n; ++i) {
     if (!pool[dev][i]) EP_HIP(hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming));
     out[i] = pool[dev][i];
@@ -54,6 +54,7 @@ int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, in
 
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
+  uint16_t *plWv, *plWvT, *plWc, *plWcT;       // bf16 planes of the two weight matrices, both orientations (ep_planes.hip)
   void* pool_ws; size_t pool_ws_bytes;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
@@ -90,8 +91,54 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   const int64_t total = ep_head_param_offsets(&d, offs);
   w.opt_ws_bytes = optim_workspace_bytes(total, 4);
   w.opt_ws = take(w.opt_ws_bytes / sizeof(float));
+  auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
+  w.plWv = take16(planes_elems(Dp, d.D)); w.plWvT = take16(planes_elems(d.D, Dp));
+  w.plWc = take16(planes_elems(d.C, Dp)); w.plWcT = take16(planes_elems(Dp, d.C));
   w.total = off;
   return w;
+}
+
+// EXPERIMENT, off by default (EP_GEMM_PLANES=1): the four critical-path contractions of a train step against pre-split
+// weight planes (ep_planes.hip).  Needs the per-query slice width to be a multiple of the MFMA K (32) for the dP
+// contraction.  Measured on MI355X at 1024 x 256 x 768: the logits / dz kernels alone are faster than the f32 kernel
+// (17.1 / 20.3 us against 20.4 / 25.3 us), the whole step is not (0.490 against 0.467 ms: the split launch, the
+// half-empty 96-column tiles of the per-query projection and the 3-K-tile dP contraction eat the gain).
+static bool head_planes_ok(const ep_head_dims& d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : 0; }
+  const int Dp = d.D / d.d_out;
+  return on && (Dp / d.Q) % 32 == 0 && d.D % 4 == 0 && Dp % 4 == 0;
+}
+static int head_planes_split(const ep_head_dims& d, const HeadWs& w, const float* Wv, const float* Wc, hipStream_t st) {
+  const int Dp = d.D / d.d_out;
+  PlaneSpec sp[2] = {{Wv, Dp, d.D, d.D, w.plWv, w.plWvT}, {Wc, d.C, Dp, Dp, w.plWc, w.plWcT}};
+  return planes_split(sp, 2, st);
+}
+static GemmParams planes_gemm(const float* A, int64_t lda, int64_t sAz, const uint16_t* pl, int rowsW, int Kw, int64_t sBpz,
+                              float* C, int64_t ldc, int64_t sCz, int M, int N, int K, const float* bias) {
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.sAz = sAz; g.C = C; g.ldc = ldc; g.sCz = sCz; g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.bias = bias;
+  g.Bpl = pl; g.ldbp = (int64_t)round_up((size_t)Kw, 32); g.pl_term = (int64_t)rowsW * g.ldbp; g.sBpz = sBpz;
+  return g;
+}
+// y[b, q Dq + c] = P[b, q, :] . Wv[q Dq + c, :]
+static int project_forward_pl(const HeadWs& w, const ep_head_dims& d, hipStream_t st) {
+  const int Dp = d.D / d.d_out, Dq = Dp / d.Q;
+  const int64_t ld = (int64_t)round_up((size_t)d.D, 32);
+  return gemm_planes(planes_gemm(w.P, (int64_t)d.Q * d.D, d.D, w.plWv, Dp, d.D, (int64_t)Dq * ld, w.y, Dp, Dq, d.B, Dq, d.D, nullptr), d.Q, st);
+}
+// dP[b, q, :] = dy[b, q Dq : (q+1) Dq] . Wv[q Dq : (q+1) Dq, :]   (planes of Wv^T, contraction offset q Dq)
+static int project_backward_dP_pl(const HeadWs& w, const ep_head_dims& d, hipStream_t st) {
+  const int Dp = d.D / d.d_out, Dq = Dp / d.Q;
+  return gemm_planes(planes_gemm(w.dy, Dp, Dq, w.plWvT, d.D, Dp, Dq, w.dP, (int64_t)d.Q * d.D, d.D, d.B, d.D, Dq, nullptr), d.Q, st);
+}
+static int linear_forward_pl(const HeadWs& w, const ep_head_dims& d, const float* bc, hipStream_t st) {
+  const int Dp = d.D / d.d_out;
+  return gemm_planes(planes_gemm(w.z, Dp, 0, w.plWc, d.C, Dp, 0, w.logits, w.ldl, 0, d.B, d.C, Dp, bc), 1, st);
+}
+static int linear_backward_dz_pl(const HeadWs& w, const ep_head_dims& d, hipStream_t st) {
+  const int Dp = d.D / d.d_out;
+  return gemm_planes(planes_gemm(w.dlogits, w.ldl, 0, w.plWcT, Dp, d.C, 0, w.dz, Dp, 0, d.B, Dp, d.C, nullptr), 1, st);
 }
 
 static int check_dims(const ep_head_dims& d) {
@@ -317,6 +364,22 @@ int ep_linear_backward(const float* dlogits, int ldl, const float* z, const floa
   return linear_backward(dlogits, ldl, z, Wc, B, Dp, C, dz, dWc, dbc, accumulate, (hipStream_t)stream);
 }
 
+size_t ep_planes_elems(int rows, int K) { return rows > 0 && K > 0 ? planes_elems(rows, K) : 0; }
+int ep_planes_split(const float* W, int R, int K, int64_t ldw, uint16_t* planes_n, uint16_t* planes_t, ep_stream_t stream) {
+  EP_REQUIRE(W && R > 0 && K > 0 && ldw >= K && (planes_n || planes_t), EP_E_ARG, "ep_planes_split: bad argument");
+  PlaneSpec sp{W, R, K, ldw, planes_n, planes_t};
+  return planes_split(&sp, 1, (hipStream_t)stream);
+}
+int ep_matmul_planes(const float* A, int64_t lda, const uint16_t* planes, int rows_w, int K, const float* bias, int M,
+                     int N, float* C, int64_t ldc, ep_stream_t stream) {
+  EP_REQUIRE(A && planes && C && M > 0 && N > 0 && K > 0 && N <= rows_w && lda >= K && ldc >= N, EP_E_ARG,
+             "ep_matmul_planes: bad argument");
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.bias = bias;
+  g.Bpl = planes; g.ldbp = (int64_t)round_up((size_t)K, 32); g.pl_term = (int64_t)rows_w * g.ldbp;
+  return gemm_planes(g, 1, (hipStream_t)stream);
+}
+
 int ep_cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
                      float* row_stats, float* dlogits, float* stats, ep_stream_t stream) {
   EP_REQUIRE(logits && targets && B > 0 && C > 0 && ldl >= C, EP_E_ARG, "ep_cross_entropy: bad argument");
@@ -389,12 +452,37 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   }
   PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale, s->x_dtype);
   p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
+  // Weight planes of THIS step (ep_planes.hip).  With the whole step in one call and an aux stream the split runs BESIDE
+  // the first token pass (it needs the weights only, the pass the queries only): fork before the pass is enqueued, join
+  // in front of the first contraction.  Split phases (data-parallel overlap): the large update of the previous step
+  // lands between phase 4 and phase 8, so the split runs in phase 8 on the main stream.
+  const bool pl = head_planes_ok(d) && (s->phases & (1 | 8));
+  hipEvent_t pev[2] = {nullptr, nullptr};
+  bool split_done = false;
+  if (pl && (s->phases & 1) && s->aux_stream && (hipStream_t)s->aux_stream != st) {
+    hipStream_t ax = (hipStream_t)s->aux_stream;
+    hipEvent_t evs[6];
+    EP_TRY(get_events(evs, 6));
+    pev[0] = evs[4]; pev[1] = evs[5];               // (events 0..2 are the fork / join of the weight-gradient side path)
+    EP_HIP(hipEventRecord(pev[0], st));              // after the previous optimizer update
+    EP_HIP(hipStreamWaitEvent(ax, pev[0], 0));
+    EP_TRY(head_planes_split(d, w, Wv, Wc, ax));
+    EP_HIP(hipEventRecord(pev[1], ax));
+    split_done = true;
+  }
   if (s->phases & (1 | 4)) EP_TRY(pool_forward(p, st));      // first token pass: depends on cls_token only
   if (s->phases & (1 | 8)) {
-    EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
+    if (pl) {
+      if (split_done) EP_HIP(hipStreamWaitEvent(st, pev[1], 0));
+      else EP_TRY(head_planes_split(d, w, Wv, Wc, st));
+      EP_TRY(project_forward_pl(w, d, st));
+    } else {
+      EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
+    }
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));
-    EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
+    if (pl) EP_TRY(linear_forward_pl(w, d, bc, st));
+    else EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
     EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
     // The weight gradients dWc / dbc / dWv and the statistics feed nothing before the optimizer.
     // Preferred: they ride in the launch of the second token pass as extra workgroups, which the
@@ -405,9 +493,15 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     const GemmParams gWv = dwv_gemm(w.dy, w.P, d.B, d.D, Dp, d.Q, s->grads + offs[1], s->accumulate);
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
     if (pool_backward_takes_side(p) && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
-      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
+      if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
+      else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
-      EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+      if (pl) {
+        EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
+        EP_TRY(project_backward_dP_pl(w, d, st));
+      } else {
+        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+      }
       SideTasks sd{};
       side_add_gemm(sd, gWc, 1);
       side_add_gemm(sd, gWv, d.Q);
@@ -427,7 +521,8 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
       EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
                              s->accumulate, side));
-      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
+      if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
+      else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       if (side != st) {
         EP_HIP(hipEventRecord(ev[1], st));
@@ -435,7 +530,12 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       }
       EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
                               s->accumulate, side));
-      EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+      if (pl) {
+        EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
+        EP_TRY(project_backward_dP_pl(w, d, st));
+      } else {
+        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+      }
       EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st));
       if (side != st) {
         EP_HIP(hipEventRecord(ev[2], side));

@@ -483,12 +483,7 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   const bool ws_ok = use_ws && vec && !force_bm && p.K >= 256 && (!p.side || (use_ws & 2));
   static int use_dma = -1;
   if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
-  // EP_GEMM_X3=1 (experiment, off by default): the three-term bf16 split on the bf16 matrix cores (ep_gemm_x3.hip: fp32
-  // accuracy, but no faster on MI355X -- its header says why)
-  static int use_x3 = -1;
-  if (use_x3 < 0) { const char* e = getenv("EP_GEMM_X3"); use_x3 = e ? atoi(e) : 0; }
-  if (use_dma && use_x3 && vec && !force_bm) gemm_launch_x3(a_k, b_k, p, batch, st);
-  else if (use_dma && vec && !force_bm) gemm_launch_dma(a_k, b_k, p, batch, st);
+  if (use_dma && vec && !force_bm) gemm_launch_dma(a_k, b_k, p, batch, st);
   else if (ws_ok) gemm_launch_ws(a_k, b_k, p, batch, st);
   else if (small) gemm_launch<32>(a_k, b_k, vec, p, batch, st);
   else gemm_launch<64>(a_k, b_k, vec, p, batch, st);

@@ -44,8 +44,22 @@ struct GemmParams {
   int accumulate;
   int side;                         // 1: runs on the aux stream beside a token pass (kernel choice hint)
   float* skws; size_t skws_floats;  // optional scratch for a split of K (few output tiles, very long K): >= 2 M N floats
-  int ablate;                       // diagnostic only (EP_GEMM_ABLATE): 1 operand ring only (no arithmetic), 2 arithmetic only
+  int ablate;                       // diagnostic only
+  // ep_planes.hip: the B operand as pre-split bf16 planes (weights; see planes_split) -- [term][row][ldbp], K contiguous
+  const uint16_t* Bpl; int64_t pl_term, ldbp, sBpz;   // plane base, term stride, row stride, batch offset (elements)
 };
+
+// a row-major weight matrix W (R x K, leading dimension ldw) and where its planes go (ep_planes.hip); either may be null
+struct PlaneSpec {
+  const float* W; int R, K; int64_t ldw;
+  uint16_t* pn;                     // planes of W   : 3 * R * round_up(K, 32) elements
+  uint16_t* pt;                     // planes of W^T : 3 * K * round_up(R, 32) elements
+};
+size_t planes_elems(int rows, int K);               // elements (uint16) of the planes of a rows x K matrix
+int planes_split(const PlaneSpec* specs, int n, hipStream_t st);
+bool gemm_planes_ok(const GemmParams& p);
+// C[z] (+)= alpha * A[z] W[z]^T (+ bias): A fp32 with K contiguous (lda), W given as planes (Bpl ...); fp32 accuracy
+int gemm_planes(const GemmParams& p, int batch, hipStream_t st);
 
 // Work appended to the launch of the second token pass (ep_side.h: run_side_task)
 struct SideTasks {
@@ -76,9 +90,6 @@ int attention_from_scores(const float* S, const float* ML, int rows, int N, floa
 
 // a_k / b_k: operand contiguous along K (true) or along its free dimension (false)
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
-// ep_gemm_x3.hip: the same contraction on the bf16 matrix cores (three-term operand split, fp32 accuracy); 16-byte
-// aligned operands only -- gemm() selects it
-void gemm_launch_x3(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
 
 size_t bn_workspace_bytes(int B, int Dp);
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,

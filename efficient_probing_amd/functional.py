@@ -195,6 +195,32 @@ def linear_forward(z, Wc, bc) -> torch.Tensor:
     return buf[:, :C_]
 
 
+def planes_split(W: torch.Tensor, natural: bool = True, transposed: bool = False):
+    """bf16 planes (three exact terms per element, csrc/ep_planes.hip) of a row-major fp32 matrix W (R, K) and / or of
+    its transpose: int16 tensors for ``matmul_planes``."""
+    lib = N.load()
+    W = _f32c(W, "W")
+    R, K = W.shape
+    pn = torch.empty(lib.ep_planes_elems(R, K), device=W.device, dtype=torch.int16) if natural else None
+    pt = torch.empty(lib.ep_planes_elems(K, R), device=W.device, dtype=torch.int16) if transposed else None
+    N.check(lib.ep_planes_split(W.data_ptr(), R, K, K, _ptr(pn), _ptr(pt), N.current_stream_ptr(W.device)), "ep_planes_split")
+    return pn, pt
+
+
+def matmul_planes(A: torch.Tensor, planes: torch.Tensor, rows_w: int, bias: Optional[torch.Tensor] = None,
+                  n_out: Optional[int] = None) -> torch.Tensor:
+    """A (M, K) fp32 times the transpose of the (rows_w, K) matrix whose planes are given -> (M, n_out or rows_w)."""
+    lib = N.load()
+    A = _f32c(A, "A")
+    M, K = A.shape
+    n = rows_w if n_out is None else n_out
+    ldc = padded_ld(n)
+    buf = torch.empty((M, ldc), device=A.device, dtype=torch.float32)
+    N.check(lib.ep_matmul_planes(A.data_ptr(), K, planes.data_ptr(), rows_w, K, _ptr(bias), M, n, buf.data_ptr(), ldc,
+                                 N.current_stream_ptr(A.device)), "ep_matmul_planes")
+    return buf[:, :n]
+
+
 def _padded_rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """(B, C) tensor -> storage with a leading dimension that is a multiple of 4 and zero pad."""
     B, C_ = t.shape

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 19
+#define EP_ABI_VERSION 20
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -152,6 +152,25 @@ int ep_linear_forward(const float* z, const float* Wc, const float* bc, int B, i
 int ep_linear_backward(const float* dlogits, int ldl, const float* z, const float* Wc, int B,
                        int Dp, int C, float* dz, float* dWc, float* dbc, int accumulate,
                        ep_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pre-split weights ("planes") for the bf16 matrix cores at fp32 accuracy (csrc/ep_planes.hip).
+ * The fused train step splits the head's two weight matrices once per step and runs its four
+ * critical-path contractions (reference poolings/ep.py:40, probe_heads.py:76 and their autograd)
+ * against the planes; these three entry points expose the same kernels.
+ *   ep_planes_elems : 16-bit elements of the planes of a rows x K matrix (3 terms, K padded to 32)
+ *   ep_planes_split : W (R x K, row-major, leading dimension ldw) -> planes of W (`planes_n`,
+ *                     ep_planes_elems(R, K) elements) and / or of W^T (`planes_t`,
+ *                     ep_planes_elems(K, R) elements); either may be null; 16-byte aligned
+ *   ep_matmul_planes: C (M x N, ldc) = A (M x K fp32, lda % 4 == 0, 16-byte aligned) times the
+ *                     TRANSPOSE of the rows_w x K matrix whose planes are given (N <= rows_w),
+ *                     + bias[n] when bias != null.  Same result as the fp32 contraction up to
+ *                     summation order (every product is exact; terms below 2^-24 are dropped). */
+size_t ep_planes_elems(int rows, int K);
+int ep_planes_split(const float* W, int R, int K, int64_t ldw, uint16_t* planes_n, uint16_t* planes_t,
+                    ep_stream_t stream);
+int ep_matmul_planes(const float* A, int64_t lda, const uint16_t* planes, int rows_w, int K,
+                     const float* bias, int M, int N, float* C, int64_t ldc, ep_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * CrossEntropyLoss() mean reduction + timm accuracy counts -- reference
