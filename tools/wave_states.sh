@@ -7,7 +7,7 @@ set -uo pipefail
 tag="$1"; shift
 out="gpurun_out/waves_$tag"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="${EP_PROF_STEPS:---steps 20 --warmup 5} --no-cpu-baseline --no-bf16-secondary --kernel-iters 5 $*"
+args="${EP_PROF_STEPS:---steps 20 --warmup 5} --no-cpu-baseline --no-bf16-secondary --no-north-star --kernel-iters 5 $*"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d "$out/pmc" -- python3 bench.py $args > /dev/null 2> "$out/pmc.log"
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
