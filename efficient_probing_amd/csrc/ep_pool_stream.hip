@@ -265,6 +265,9 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   for (int cimg = 0; cimg < n_img; ++cimg) {
     const int b = wg + cimg * G;
     if (p.cls_bstride != 0 && cimg != 0) { load_cls(b); sum_cls(); }   // per-image query override (rare path)
+    float* Srow[QW];                                 // where this lane's row of a mini-batch stores its raw scores
+#pragma unroll
+    for (int j = 0; j < QW; ++j) Srow[j] = p.S + ((int64_t)b * Q + (q0 + j < Q ? q0 + j : q0)) * N + (lane >> 4);
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
       m[j] = -INFINITY; mL[j] = -INFINITY; lsum[j] = 0.f; c2[j] = 0.f;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           if ((lane & 15) == 0 && rowvalid) {                                // raw scores for backward / attention maps
 #pragma unroll
             for (int j = 0; j < QW; ++j)
-              if (q0 + j < Q) p.S[((int64_t)b * Q + q0 + j) * N + (unsigned)(n0 + t0 + row)] = u[j];
+              if (q0 + j < Q) Srow[j][n0 + t0] = u[j];
           }
           if (LN) {
 #pragma unroll
@@ -433,34 +436,42 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
     int sq = q0 + lane / TT; sq = sq < Q ? sq : Q - 1;             // tile:   S[b, sq, n0 + lane % TT]
     const int st = lane % TT;
     int pi = 0, pimg = 0, pidx = 0, pslot = 0;
+    // per-image bases of the producer (recomputed when it moves to the next image, not per ring item)
+    const char* pimg_x = nullptr; const char* pimg_dP = nullptr; const float* pimg_ML = nullptr;
+    const float* pimg_S = nullptr; const float* pimg_ts = nullptr;
+    auto producer_image = [&]() {
+      const int b = (wg + pimg * G) < p.B ? (wg + pimg * G) : wg;
+      pimg_x = xbytes + EP_IMG_OFF(p, b) * ES;
+      pimg_dP = reinterpret_cast<const char*>(p.dP + (int64_t)b * Q * D);
+      pimg_ML = p.ML + ((int64_t)b * Q + hq) * 4 + (lane & 3);
+      pimg_S = p.S + ((int64_t)b * Q + sq) * N;
+      if (LN) pimg_ts = p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2;
+    };
+    producer_image();
     auto produce = [&]() {
       if (pi < n_items) {
-        const int b = wg + pimg * G;
         char* small = small_base + (pslot * NW + w) * 256;
         char* slot = ring + pslot * slot_bytes;
         if (pidx < H) {                                   // header: rows of dP[b]
           const int r0 = pidx * HR;
           const int rows = (Q - r0) < HR ? (Q - r0) : HR;
-          const char* src = reinterpret_cast<const char*>(p.dP + ((int64_t)b * Q + r0) * D);
-          dma_rows<NW, KDMA>(src, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
-          const float* ms = p.ML + ((int64_t)b * Q + hq) * 4 + (lane & 3);
-          __builtin_amdgcn_global_load_lds((gptr_t)ms, (lds_ptr_t)small, 4, 0, 0);
+          dma_rows<NW, KDMA>(pimg_dP + (int64_t)r0 * hrowbytes, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
+          __builtin_amdgcn_global_load_lds((gptr_t)pimg_ML, (lds_ptr_t)small, 4, 0, 0);
         } else {
           const int n0 = (pidx - H) * TT;
           const int rows = (N - n0) < TT ? (N - n0) : TT;
-          const char* src = xbytes + (EP_IMG_OFF(p, b) + (int64_t)n0 * D) * ES;
-          dma_rows<NW, KDMA>(src, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
+          dma_rows<NW, KDMA>(pimg_x + (int64_t)n0 * rowbytes, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
           int nn = n0 + st; nn = nn < N ? nn : N - 1;
-          const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;
+          const float* ss = pimg_S + nn;
           if (LN && lane >= QW * TT) {              // lanes behind the scores fetch the {mean, rstd} pairs of the tile
             int e = n0 * 2 + (lane - QW * TT); e = e < 2 * N ? e : 2 * N - 1;
-            ss = p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2 + e;
+            ss = pimg_ts + e;
           }
           __builtin_amdgcn_global_load_lds((gptr_t)ss, (lds_ptr_t)small, 4, 0, 0);
         }
         ++pi;
         pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
-        if (++pidx == items_per_img) { pidx = 0; ++pimg; }
+        if (++pidx == items_per_img) { pidx = 0; ++pimg; producer_image(); }
       }
     };
 #pragma unroll
