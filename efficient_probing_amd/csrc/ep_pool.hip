@@ -394,6 +394,7 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
     return stream_launch(false, c, p, st);
   }
   const size_t lds = (size_t)(p.N + 8) * sizeof(float);
+  EP_REQUIRE(lds <= 64 * 1024, EP_E_UNSUPPORTED, "generic pooling kernel: N = %d tokens per image exceed its LDS row buffer (max 16376)", p.N);
   if (p.x_bf16) hipLaunchKernelGGL(ep_pool_fwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(ep_pool_fwd_generic_kernel<false>, dim3(p.B), dim3(256), lds, st, p);
   EP_LAUNCH_CHECK("ep_pool_fwd_generic_kernel");
@@ -433,6 +434,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     nparts = c.grid;
   } else {
     const size_t lds = (size_t)(p.N + 8) * sizeof(float);
+    EP_REQUIRE(lds <= 64 * 1024, EP_E_UNSUPPORTED, "generic pooling kernel: N = %d tokens per image exceed its LDS row buffer (max 16376)", p.N);
     if (p.x_bf16) hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<false>, dim3(p.B), dim3(256), lds, st, p);
     EP_LAUNCH_CHECK("ep_pool_bwd_generic_kernel");
@@ -451,6 +453,7 @@ int pool_backward_per_image(const PoolParams& p0, float* dq, hipStream_t st) {
   if (!force_generic() && imgqf_supported(p)) return imgqf_backward(p, dq, st);
   p.Gpart = dq;
   const size_t lds = (size_t)(p.N + 8) * sizeof(float);
+  EP_REQUIRE(lds <= 64 * 1024, EP_E_UNSUPPORTED, "generic pooling kernel: N = %d tokens per image exceed its LDS row buffer (max 16376)", p.N);
   if (p.x_bf16) hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(ep_pool_bwd_generic_kernel<false>, dim3(p.B), dim3(256), lds, st, p);
   if (p.scale != 1.0f) {
