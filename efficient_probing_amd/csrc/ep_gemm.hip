@@ -117,24 +117,16 @@ __global__ __launch_bounds__(512) void ep_gemm_ws_kernel(GemmParams p) {
     }
     ws_barrier();
   }
+  {
+    f4v blk[MI * 2]; int rb[MI * 2], cb[MI * 2];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 32 + ni * 16 + i16;
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + mi * 16 + kk * 4 + r;
-        if (row < p.M) {
-          float* c = C + (int64_t)row * p.ldc + col;
-          float v = p.alpha * acc[mi][ni][r] + bv;
-          if (p.accumulate) v += *c;
-          *c = v;
-        }
+      for (int ni = 0; ni < 2; ++ni) {
+        blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * 32 + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
       }
-    }
+    store_acc_blocks<MI * 2>(p, C, z, rb, cb, blk, kk, i16);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -175,12 +167,21 @@ __global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams 
   const int w = wall & 3;
   const int wm = w >> 1, wn = w & 1;
   const int i16 = lane & 15, kk = lane >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  // npers > 1 (host: N % 64 == 0, K % 32 == 0): the workgroup walks npers consecutive N-tiles of its row block through ONE
+  // ring -- the K-tiles of N-tile t+1 follow those of N-tile t without a drain, so the ~5 us a launch-sized pipeline spends
+  // filling and emptying is paid once per workgroup instead of once per 64x64 tile (contractions with a short K and many
+  // tiles: dP = dy_q Wv_q with K = 96)
+  const int npers = p.npers > 1 ? p.npers : 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int nt0 = blockIdx.x * npers;
+  const int my_nt = (ntn - nt0) < npers ? (ntn - nt0) : npers;
+  const int m0 = blockIdx.y * 64, n0 = nt0 * BN;
   const int z = blockIdx.z;
   const float* A = p.A + (int64_t)z * p.sAz;
   const float* B = p.B + (int64_t)z * p.sBz;
   float* C = p.C + (int64_t)z * p.sCz;
   const int nk = (p.K + BK - 1) / BK;
+  const int total = my_nt * nk;                      // ring steps of this workgroup
 
   // ---- DMA source offsets (elements) of this lane's two pieces per operand, for a full K-tile at k0 = 0 ----
   // piece pc = w + 4 jj covers LDS positions pc*64 + lane
@@ -211,9 +212,12 @@ __global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams 
   kstepA = A_K ? BK : (int64_t)BK * p.lda;
   kstepB = B_K ? BK : (int64_t)BK * p.ldb;
   const bool ktail = (p.K % BK) != 0;
-  auto issue = [&](int t) {                          // DMA K-tile t (clamped to the last one) into stage t % NST
-    const int tt = t < nk ? t : nk - 1;
-    char* st = lds + (t % NST) * STB;
+  const int64_t ntstepB = B_K ? (int64_t)BN * p.ldb : (int64_t)BN;   // one N-tile further along B
+  int is_t = 0, is_kt = 0, is_nt = 0, is_stage = 0;   // the issuing wave's position in the (N-tile, K-tile) sequence
+  auto issue = [&](int) {                            // DMA the next tile of the sequence (clamped to the last one) into the next stage
+    const int tt = is_kt;
+    char* st = lds + is_stage * STB;
+    const int64_t nb = is_nt * ntstepB;
     if (ktail && tt == nk - 1) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -227,8 +231,13 @@ __global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams 
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         __builtin_amdgcn_global_load_lds((gptr_t)(A + srcA[jj] + tt * kstepA), (lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(B + srcB[jj] + tt * kstepB), (lds_ptr_t)(st + OPB + (w + 4 * jj) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(B + srcB[jj] + nb + tt * kstepB), (lds_ptr_t)(st + OPB + (w + 4 * jj) * 1024), 16, 0, 0);
       }
+    }
+    is_stage = (is_stage + 1 == NST) ? 0 : is_stage + 1;
+    if (is_t < total - 1) {                          // past the end: the last tile again (keeps the vmcnt arithmetic uniform)
+      ++is_t;
+      if (++is_kt == nk) { is_kt = 0; ++is_nt; }
     }
   };
 
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams 
     for (int t = 0; t < NST - 1; ++t) issue(t);
     dma_wait<4 * (NST - 2)>();
     ws_barrier();                                    // tile 0 landed
-    for (int it = 0; it < nk; ++it) {
+    for (int it = 0; it < total; ++it) {
       dma_wait<4 * (NST - 3 >= 0 ? NST - 3 : 0)>();  // tile it+1 landed (this wave's pieces)
       ws_barrier();                                  // ... everyone's; the matrix waves hold tile `it` in registers
       issue(it + NST - 1);                           // refill the stage tile it-1 lived in
@@ -351,37 +360,36 @@ __global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams 
     __builtin_amdgcn_sched_barrier(0);                                             \
     if (ktail && (IT) + 1 == nk - 1) { __builtin_amdgcn_s_waitcnt(0xc07f); zero_tail(((IT) + 1) * BK, fa[(F) ^ 1], fb[(F) ^ 1]); } \
   }
+  auto store_tile = [&](int ncol0) {
+    f4v blk[4]; int rb[4], cb[4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * 32 + mi * 16; cb[mi * 2 + ni] = ncol0 + wn * 32 + ni * 16;
+        acc[mi][ni] = f4v{0.f, 0.f, 0.f, 0.f};
+      }
+    store_acc_blocks<4>(p, C, z, rb, cb, blk, kk, i16);
+  };
+  int ckt = 0, cn0 = n0;                             // K-tile inside the current N-tile, its first column
+  auto tile_end = [&]() {
+    if (++ckt == nk) { ckt = 0; store_tile(cn0); cn0 += BN; }
+  };
   int it = 0;
-  for (; it + 1 < nk; it += 2) {
+  for (; it + 1 < total; it += 2) {
     EP_DMA_STEP(it, 0)
+    tile_end();
     EP_DMA_STEP(it + 1, 1)
+    tile_end();
   }
-  if (it < nk) EP_DMA_STEP(it, 0)
+  if (it < total) { EP_DMA_STEP(it, 0) tile_end(); }
 #undef EP_DMA_STEP
   if (!WS) dma_wait<0>();                            // redundant prefetches past the last tile: drain before exit
-
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 32 + ni * 16 + i16;
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + mi * 16 + kk * 4 + r;
-        if (row < p.M) {
-          float* c = C + (int64_t)row * p.ldc + col;
-          float v = p.alpha * acc[mi][ni][r] + bv;
-          if (p.accumulate) v += *c;
-          *c = v;
-        }
-      }
-    }
 }
 
 static void gemm_launch_dma(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
-  dim3 grid((p.N + BN - 1) / BN, (p.M + 63) / 64, batch);
+  const int npers = p.npers > 1 ? p.npers : 1;
+  dim3 grid(((p.N + BN - 1) / BN + npers - 1) / npers, (p.M + 63) / 64, batch);
   // 4 ring stages (64 KiB: two workgroups per CU on large grids), wave-specialised: measured fastest of
   // {3, 4, 5 stages} x {specialised, symmetric} on both the 256-tile head contractions and the 65536-row AbMILP ones
 #define EP_GEMM_LAUNCH(AK, BK_) hipLaunchKernelGGL((ep_gemm_dma_kernel<AK, BK_, 4, true>), grid, dim3(512), 0, st, p)
@@ -483,7 +491,22 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   const bool ws_ok = use_ws && vec && !force_bm && p.K >= 256 && (!p.side || (use_ws & 2));
   static int use_dma = -1;
   if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
-  if (use_dma && vec && !force_bm) gemm_launch_dma(a_k, b_k, p, batch, st);
+  if (use_dma && vec && !force_bm) {
+    // short K and many tiles: every workgroup walks several N-tiles through one ring (see the kernel) -- as many as still
+    // leave one workgroup per CU.  dP = dy_q Wv_q at 1024 x 768, Q = 8 (K = 96, 1536 tiles): 22.7 us with one tile per
+    // workgroup, 20.8 / 19.6 / 19.1 us with 2 / 3 / 6.  EP_GEMM_NPERS: 1 = off, n > 1 = at most n.
+    GemmParams q = p;
+    static int npers_env = -1;
+    if (npers_env < 0) { const char* e = getenv("EP_GEMM_NPERS"); npers_env = e ? atoi(e) : 0; }
+    const int ntn = (p.N + BN - 1) / BN, nk = (p.K + BK - 1) / BK;
+    if (p.N % BN == 0 && p.K % BK == 0 && nk <= 8 && ntn > 1 && tiles64 >= 4L * cu_count()) {
+      int np = npers_env > 0 ? npers_env : ntn;
+      if (np > ntn) np = ntn;
+      while (np > 1 && (ntn % np != 0 || tiles64 / np < cu_count())) --np;
+      q.npers = np;
+    }
+    gemm_launch_dma(a_k, b_k, q, batch, st);
+  }
   else if (ws_ok) gemm_launch_ws(a_k, b_k, p, batch, st);
   else if (small) gemm_launch<32>(a_k, b_k, vec, p, batch, st);
   else gemm_launch<64>(a_k, b_k, vec, p, batch, st);

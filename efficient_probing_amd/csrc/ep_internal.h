@@ -45,6 +45,7 @@ struct GemmParams {
   int side;                         // 1: runs on the aux stream beside a token pass (kernel choice hint)
   float* skws; size_t skws_floats;  // optional scratch for a split of K (few output tiles, very long K): >= 2 M N floats
   int ablate;                       // diagnostic only
+  int npers;                        // LDS-DMA kernel: N-tiles one workgroup walks (0 / 1: one; set by gemm())
   // ep_planes.hip: the B operand as pre-split bf16 planes (weights; see planes_split) -- [term][row][ldbp], K contiguous
   const uint16_t* Bpl; int64_t pl_term, ldbp, sBpz;   // plane base, term stride, row stride, batch offset (elements)
 };

@@ -299,21 +299,11 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   if (it < nk) EP_PL_STEP(it, 0)
 #undef EP_PL_STEP
 
+  {
+    int rb[2], cb[2];
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
-    const int col = n0 + wn * 32 + bi * 16 + i16;
-    if (col >= p.N) continue;
-    const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * 16 + kk * 4 + r;
-      if (row < p.M) {
-        float* c = C + (int64_t)row * p.ldc + col;
-        float v = p.alpha * acc[bi][r] + bv;
-        if (p.accumulate) v += *c;
-        *c = v;
-      }
-    }
+    for (int bi = 0; bi < 2; ++bi) { rb[bi] = m0 + wm * 16; cb[bi] = n0 + wn * 32 + bi * 16; }
+    store_acc_blocks<2>(p, C, z, rb, cb, acc, kk, i16);
   }
 }
 

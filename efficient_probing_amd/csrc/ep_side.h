@@ -14,6 +14,51 @@ constexpr int LDK = BK + 2;    // K-layout row stride (floats)
 constexpr int LDT = BM + 16;   // T-layout row stride (floats)
 
 
+// ---- epilogue of a 16x16x4-MFMA tile ---------------------------------------------------------
+// Block b of the NB accumulator blocks of a wave covers rows rowb[b] + 4 kk + r (r = 0..3) and column colb[b] + i16.
+// Everything that LOADS (bias, the old values when accumulating) is issued first and waited for once; then the stores go
+// out back to back.  With a conditional load in front of every store (`if (accumulate) v += *c; *c = v;`) the compiler
+// has to wait vmcnt(0) at each join -- vmcnt counts loads and stores in order, so every store waited for the round trip
+// of the one before it: 16 serialised write latencies at the end of every tile.
+template <int NB>
+__device__ __forceinline__ void store_acc_blocks(const GemmParams& p, float* __restrict__ C, int z, const int (&rowb)[NB],
+                                                 const int (&colb)[NB], const f4v (&acc)[NB], int kk, int i16) {
+  // loads are unconditional (addresses clamped into the matrix) and every value is finished in straight-line code, so
+  // the one wait for them sits in front of the first store and the guarded stores themselves wait for nothing
+  float v[NB][4];
+  bool cok[NB];
+  int64_t off[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = colb[b] + i16;
+    cok[b] = col < p.N;
+    const int colc = cok[b] ? col : p.N - 1;
+    const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + colc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rowb[b] + kk * 4 + r;
+      off[b][r] = (int64_t)(row < p.M ? row : p.M - 1) * p.ldc + colc;
+      v[b][r] = p.alpha * acc[b][r] + bv;
+    }
+  }
+  if (p.accumulate) {
+    float old[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) old[b][r] = C[off[b][r]];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[b][r] += old[b][r];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (cok[b] && rowb[b] + kk * 4 + r < p.M) C[off[b][r]] = v[b][r];
+}
+
 // ---- global -> register tile loads ---------------------------------------------------------
 // K layout: 64 rows x 32 k ; thread handles float4 (row = idx/8, kq = idx%8), idx = tid + 256 r
 template <bool VEC, int RT>
@@ -179,24 +224,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, i
   }
 #undef EP_GEMM_STEP
   // epilogue: D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + r
+  {
+    f4v blk[MI * 2]; int rb[MI * 2], cb[MI * 2];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 32 + ni * 16 + i16;
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[(int64_t)z * p.sBiasz + col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * (16 * MI) + mi * 16 + kk * 4 + r;
-        if (row < p.M) {
-          float* c = C + (int64_t)row * p.ldc + col;
-          float v = p.alpha * acc[mi][ni][r] + bv;
-          if (p.accumulate) v += *c;
-          *c = v;
-        }
+      for (int ni = 0; ni < 2; ++ni) {
+        blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
       }
-    }
+    store_acc_blocks<MI * 2>(p, C, z, rb, cb, blk, kk, i16);
+  }
 }
 
 
