@@ -163,9 +163,12 @@ __global__ __launch_bounds__(1024) void ep_bn_bwd_fused_kernel(const float* __re
     s1 += g[i];
     s2 = fmaf(g[i], zz[i], s2);
   }
+  float rs = rstd[ok ? col : 0];
   const float m1 = bnf_reduce(s1, sm, tx, wv) / (float)B;
   const float m2 = bnf_reduce(s2, sm, tx, wv) / (float)B;
-  const float rs = ok ? rstd[col] : 0.f;
+  // rs is pinned in a register HERE: a load result first used inside the guarded blocks below makes the compiler wait
+  // vmcnt(0) in each of them -- i.e. for the round trip of the previous store (vmcnt counts loads and stores in order)
+  asm volatile("" : "+v"(rs));
 #pragma unroll
   for (int i = 0; i < BNF_RPT; ++i) {
     const int b = ty + 64 * i;
