@@ -496,11 +496,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
       else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
+      // the softmax-correction rows dy_q . y_q: inside the second pass where its kernel can (one launch less)
+      const bool in_pass = pool_backward_takes_delta(p, Dp);
+      if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
       if (pl) {
-        EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
+        if (!in_pass) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));
       } else {
-        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, in_pass ? nullptr : w.ML, 0, st));
       }
       SideTasks sd{};
       side_add_gemm(sd, gWc, 1);

@@ -26,6 +26,10 @@ struct PoolParams {
   const float* sbias;    // fwd: added to the score before the softmax (the stored S includes it)   (B,Q,N)
   const float* dabias;   // bwd: added to dA = dP . v_n                                               (B,Q,N)
   float* dSout;          // bwd: the score gradients dS                                               (B,Q,N)
+  // bwd, vector-ALU streaming kernel only: the softmax-correction term delta[b,q] = sum_c dyv[b, q Dv/Q + c] yv[b, q Dv/Q + c]
+  // (= dP[b,q] . P[b,q]) computed by the pass itself from one extra ring item per image instead of being read from
+  // ML[b,q,2] (saves the ep_delta_kernel launch in front of the pass); null: read ML
+  const float* dyv; const float* yv; int Dv;
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
   int kdma;              // 16-byte DMA instructions per wave per ring item
@@ -82,6 +86,7 @@ int pool_forward(const PoolParams& p, hipStream_t st);
 // `side` (optional): extra work to run inside the launch; honoured only when pool_backward_takes_side(p)
 int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st, const SideTasks* side = nullptr);
 bool pool_backward_takes_side(const PoolParams& p);
+bool pool_backward_takes_delta(const PoolParams& p, int Dv);   // ... and compute the delta rows itself (dyv / yv / Dv)
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
 int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);

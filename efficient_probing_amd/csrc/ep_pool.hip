@@ -410,6 +410,18 @@ bool pool_backward_takes_side(const PoolParams& p) {
   return c.ok && c.nw == 4;
 }
 
+// The same kernel can compute the softmax-correction rows itself (PoolParams.dyv / yv / Dv): one ring item per image
+// holds dy[b] | y[b] (Dv floats each, 1-KiB pieces), every wave reduces the slices of its queries.
+bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
+  static int allow = -1;
+  if (allow < 0) { const char* e = getenv("EP_POOL_DELTA"); allow = e ? atoi(e) : 1; }
+  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+  if (!c.ok || !stream_takes(p) || Dv <= 0 || Dv % (4 * p.Q) != 0) return false;
+  const size_t slot = (size_t)stream_tt(c.qw, c.kp, c.nw) * p.D * 4;
+  return 2 * (((size_t)Dv * 4 + 1023) / 1024) * 1024 <= slot;
+}
+
 int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side) {
   PoolParams p = p0;
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);

@@ -406,7 +406,12 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const int npiece = slot_bytes >> 10;
   const int tiles_per_img = (N + TT - 1) / TT;
   const int H = (Q + HR - 1) / HR;
-  const int items_per_img = H + tiles_per_img;
+  const int HD = p.dyv ? 1 : 0;                     // one more header item: the rows dy[b], y[b] the delta terms come from
+  const int H2 = H + HD;
+  const int items_per_img = H2 + tiles_per_img;
+  const int dv_row = p.Dv * 4;                      // bytes of a dy / y row
+  const int dv_rp = (dv_row + 1023) >> 10;          // 1-KiB ring pieces per row: dy at piece 0, y at piece dv_rp
+  const int dvq = HD ? p.Dv / Q : 0;                // value channels per query
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * items_per_img;
   const int q0 = w * QW;
@@ -439,6 +444,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
     // per-image bases of the producer (recomputed when it moves to the next image, not per ring item)
     const char* pimg_x = nullptr; const char* pimg_dP = nullptr; const float* pimg_ML = nullptr;
     const float* pimg_S = nullptr; const float* pimg_ts = nullptr;
+    const char* pimg_dy = nullptr; const char* pimg_y = nullptr;
     auto producer_image = [&]() {
       const int b = (wg + pimg * G) < p.B ? (wg + pimg * G) : wg;
       pimg_x = xbytes + EP_IMG_OFF(p, b) * ES;
@@ -446,6 +452,10 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       pimg_ML = p.ML + ((int64_t)b * Q + hq) * 4 + (lane & 3);
       pimg_S = p.S + ((int64_t)b * Q + sq) * N;
       if (LN) pimg_ts = p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2;
+      if (HD) {
+        pimg_dy = reinterpret_cast<const char*>(p.dyv + (int64_t)b * p.Dv);
+        pimg_y = reinterpret_cast<const char*>(p.yv + (int64_t)b * p.Dv);
+      }
     };
     producer_image();
     auto produce = [&]() {
@@ -457,8 +467,19 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           const int rows = (Q - r0) < HR ? (Q - r0) : HR;
           dma_rows<NW, KDMA>(pimg_dP + (int64_t)r0 * hrowbytes, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
           __builtin_amdgcn_global_load_lds((gptr_t)pimg_ML, (lds_ptr_t)small, 4, 0, 0);
+        } else if (pidx < H2) {                           // delta item: dy[b] | y[b] (same instruction count as every item)
+#pragma unroll
+          for (int j = 0; j < KDMA; ++j) {
+            int pc = w + NW * j;
+            pc = pc < 2 * dv_rp ? pc : 2 * dv_rp - 1;
+            const bool second = pc >= dv_rp;
+            unsigned off = (unsigned)(second ? pc - dv_rp : pc) * 1024u + lane16;
+            off = off < (unsigned)(dv_row - 16) ? off : (unsigned)(dv_row - 16);
+            __builtin_amdgcn_global_load_lds((gptr_t)((second ? pimg_y : pimg_dy) + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, 0);
+          }
+          __builtin_amdgcn_global_load_lds((gptr_t)pimg_ML, (lds_ptr_t)small, 4, 0, 0);
         } else {
-          const int n0 = (pidx - H) * TT;
+          const int n0 = (pidx - H2) * TT;
           const int rows = (N - n0) < TT ? (N - n0) : TT;
           dma_rows<NW, KDMA>(pimg_x + (int64_t)n0 * rowbytes, (unsigned)(rows * rowbytes - 16), slot, npiece, w, lane16);
           int nn = n0 + st; nn = nn < N ? nn : N - 1;
@@ -521,8 +542,21 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
             gsum[j] = wave_sum(t);
           }
         }
+      } else if (cidx < H2) {
+        // delta item: dl = dy[b, q-slice] . y[b, q-slice] for this wave's queries (overrides the ML[.,.,2] picked up above)
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+          const int q = q0 + j < Q ? q0 + j : Q - 1;
+          float t = 0.f;
+          for (int c = 4 * lane; c < dvq; c += 256) {
+            const f4 a = *reinterpret_cast<const f4*>(tile + (q * dvq + c) * 4);
+            const f4 b = *reinterpret_cast<const f4*>(tile + dv_rp * 1024 + (q * dvq + c) * 4);
+            t += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+          }
+          dl[j] = wave_sum(t);
+        }
       } else {
-        const int n0 = (cidx - H) * TT;
+        const int n0 = (cidx - H2) * TT;
         const int nvalid = q0 < Q ? ((N - n0) < TT ? (N - n0) : TT) : 0;   // waves without a query skip
 #pragma unroll
         for (int t0 = 0; t0 < TT; t0 += TB) {
