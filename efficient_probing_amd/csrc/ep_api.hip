@@ -470,6 +470,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     EP_HIP(hipEventRecord(pev[1], ax));
     split_done = true;
   }
+  DeferredReduce red{};                                       // last stage of the dcls reduction, finished by the optimizer
   if (s->phases & (1 | 4)) EP_TRY(pool_forward(p, st));      // first token pass: depends on cls_token only
   if (s->phases & (1 | 8)) {
     if (pl) {
@@ -512,7 +513,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
       sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;
       sd.total += sd.n_colsum + sd.n_stats;
-      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, &sd));
+      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, &sd, (s->phases & 2) ? &red : nullptr));
     } else {
       hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
       hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -559,7 +560,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
                       use, nuse, s->lr, s->weight_decay,
                       s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,
-                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st));
+                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red));
   }
   return 0;
 }

@@ -84,7 +84,15 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q);
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16 = 0);
 int pool_forward(const PoolParams& p, hipStream_t st);
 // `side` (optional): extra work to run inside the launch; honoured only when pool_backward_takes_side(p)
-int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st, const SideTasks* side = nullptr);
+// The last stage of a two-stage partial reduction, handed to the optimizer instead of being launched: element j of
+// out[0..n) = (accumulate ? out[j] : 0) + scale * sum_{r < 16} stage[r n + j], summed in ep_reduce_partials_kernel's order.
+struct DeferredReduce {
+  const float* stage;               // null: nothing deferred (the reduction ran in full)
+  float* out; int n; float scale; int accumulate;
+};
+// `defer` (optional): leave the final 16 -> 1 stage of the dcls reduction to optim_step (same call, same stream)
+int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t st, const SideTasks* side = nullptr,
+                  DeferredReduce* defer = nullptr);
 bool pool_backward_takes_side(const PoolParams& p);
 bool pool_backward_takes_delta(const PoolParams& p, int Dv);   // ... and compute the delta rows itself (dyv / yv / Dv)
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
@@ -125,12 +133,12 @@ void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch);
 // run the side tasks as stand-alone launches on `st` (kernel families that cannot carry them)
 int side_run_standalone(const SideTasks& sd, hipStream_t st);
 int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
-                    hipStream_t st);
+                    hipStream_t st, DeferredReduce* defer = nullptr);
 
 size_t optim_workspace_bytes(int64_t total, int nseg);
 int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,
                int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
-               hipStream_t st);
+               hipStream_t st, const DeferredReduce* red = nullptr);   // red: finish that reduction into g first (g is written)
 
 }  // namespace ep

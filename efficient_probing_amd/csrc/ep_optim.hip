@@ -31,6 +31,9 @@ struct OptParams {
   float* partial;                     // [nchunks][4]
   int nchunks;
   int32_t* found_inf; float* grad_norm;
+  // deferred last stage of a partial reduction (DeferredReduce): g[red_off .. red_off + red_n) is produced HERE, by the
+  // norms kernel, from 16 stage rows -- and written back to g for the update kernel and for readers of the gradients
+  const float* red_stage; float* gw; int64_t red_off; int red_n; float red_scale; int red_accumulate;
 };
 
 __device__ __forceinline__ int seg_of_chunk(const OptSegs& s, int chunk) {
@@ -67,7 +70,22 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
     const int64_t i = base + e;
     if (i + 3 < end) {
       const f4 pv = *reinterpret_cast<const f4*>(o.p + i);
-      const f4 gv = *reinterpret_cast<const f4*>(o.g + i);
+      f4 gv;
+      if (o.red_stage && i >= o.red_off && i < o.red_off + o.red_n) {     // offsets and lengths are multiples of 4
+        const float* sp = o.red_stage + (i - o.red_off);
+        f4 t[4];
+#pragma unroll
+        for (int py = 0; py < 4; ++py) {                                    // ep_reduce_partials_kernel's order, 16 rows
+          const f4 s0 = *reinterpret_cast<const f4*>(sp + (int64_t)py * o.red_n) + *reinterpret_cast<const f4*>(sp + (int64_t)(py + 8) * o.red_n);
+          const f4 s1 = *reinterpret_cast<const f4*>(sp + (int64_t)(py + 4) * o.red_n) + *reinterpret_cast<const f4*>(sp + (int64_t)(py + 12) * o.red_n);
+          t[py] = s0 + s1;
+        }
+        gv = ((t[0] + t[1]) + (t[2] + t[3])) * o.red_scale;
+        if (o.red_accumulate) gv += *reinterpret_cast<const f4*>(o.g + i);
+        *reinterpret_cast<f4*>(o.gw + i) = gv;
+      } else {
+        gv = *reinterpret_cast<const f4*>(o.g + i);
+      }
       acc1(pv.x, gv.x); acc1(pv.y, gv.y); acc1(pv.z, gv.z); acc1(pv.w, gv.w);
     } else {
       for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
@@ -173,7 +191,7 @@ size_t optim_workspace_bytes(int64_t total, int nseg) {
 int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,
                int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
-               hipStream_t st) {
+               hipStream_t st, const DeferredReduce* red) {
   EP_REQUIRE(p && g && found_inf && ws, EP_E_ARG, "optimizer: null pointer");
   EP_REQUIRE(mode != 0 || s0, EP_E_ARG, "LARS needs the momentum buffer");
   EP_REQUIRE(mode != 2 || (s0 && s1), EP_E_ARG, "AdamW needs exp_avg and exp_avg_sq");
@@ -191,6 +209,19 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
     o.bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   }
   o.partial = (float*)ws; o.nchunks = nchunks; o.found_inf = found_inf; o.grad_norm = grad_norm;
+  if (red && red->stage) {
+    // the range must lie inside ONE segment on a float4 boundary, whole float4s (the norms kernel's vector path)
+    const int64_t off = red->out - g;
+    bool inside = false;
+    for (int k = 0; k < nseg; ++k)
+      inside |= off >= segs[k].offset && off + red->n <= segs[k].offset + segs[k].numel && (off - segs[k].offset) % 4 == 0;
+    if (inside && off >= 0 && off % 4 == 0 && red->n % 4 == 0 && aligned16(red->stage) && aligned16(g)) {
+      o.red_stage = red->stage; o.gw = const_cast<float*>(g); o.red_off = off; o.red_n = red->n;
+      o.red_scale = red->scale; o.red_accumulate = red->accumulate;
+    } else {
+      EP_TRY(reduce_partials(red->stage, 16, red->n, red->scale, red->accumulate, red->out, nullptr, st));
+    }
+  }
   hipLaunchKernelGGL(ep_opt_norms_kernel, dim3(nchunks), dim3(256), 0, st, o, S);
   EP_LAUNCH_CHECK("ep_opt_norms_kernel");
   hipLaunchKernelGGL(ep_opt_update_kernel, dim3(nchunks), dim3(256), 0, st, o, S);

@@ -422,7 +422,8 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
   return 2 * (((size_t)Dv * 4 + 1023) / 1024) * 1024 <= slot;
 }
 
-int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side) {
+int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side,
+                  DeferredReduce* defer) {
   PoolParams p = p0;
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   int nparts;
@@ -452,7 +453,7 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     EP_LAUNCH_CHECK("ep_pool_bwd_generic_kernel");
     nparts = p.B;
   }
-  return reduce_partials(p.Gpart, nparts, p.Q * p.D, p.scale, accumulate, dcls, p.Gpart + (int64_t)nparts * p.Q * p.D, st);
+  return reduce_partials(p.Gpart, nparts, p.Q * p.D, p.scale, accumulate, dcls, p.Gpart + (int64_t)nparts * p.Q * p.D, st, defer);
 }
 
 // The generic kernel writes one (Q,D) partial PER IMAGE: with per-image query rows those partials are the result.
@@ -479,11 +480,13 @@ int pool_backward_per_image(const PoolParams& p0, float* dq, hipStream_t st) {
 // out[n] (+)= scale * sum_i parts[i][n] in two deterministic stages for many parts:
 // nparts -> 16 group sums (`stage`, 16*n floats) -> out
 int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
-                    hipStream_t st) {
+                    hipStream_t st, DeferredReduce* defer) {
   const int gx = (n / 4 + 63) / 64;
+  if (defer) defer->stage = nullptr;
   if (nparts > 32) {
     hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 16), dim3(256), 0, st, parts, nparts, n, 1.0f, 0, stage);
-    hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, stage, 16, n, scale, accumulate, out);
+    if (defer && n % 4 == 0) { *defer = DeferredReduce{stage, out, n, scale, accumulate}; }
+    else hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, stage, 16, n, scale, accumulate, out);
   } else {
     hipLaunchKernelGGL(ep_reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, parts, nparts, n, scale, accumulate, out);
   }
