@@ -102,9 +102,28 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
   __shared__ float sm[4];
   const int chunk = blockIdx.x;
   const int k = seg_of_chunk(segs, chunk);
+  const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
+  const int64_t end = segs.off[k] + segs.numel[k];
   // global non-finite flag and gradient norm (fixed order over all chunks)
   float bad = 0.f, gg = 0.f;
   for (int c = threadIdx.x; c < o.nchunks; c += 256) { bad += o.partial[(int64_t)c * 4 + 3]; gg += o.partial[(int64_t)c * 4 + 2]; }
+  // this thread's elements are fetched NOW (behind the first partial loads: vmcnt retires in order): the block sums and
+  // the second chain of partial loads below run while they are in flight, instead of in front of them
+  constexpr int NV = OPT_CHUNK / 1024;
+  f4 pvr[NV], gvr[NV], avr[NV], bvr[NV];
+  // branch-free (a conditional load makes the compiler wait for everything in flight at the join): unused state buffers
+  // alias the parameters, float4 groups past the segment end re-read its first one
+  const float* s0p = o.mode != 1 ? o.s0 : o.p;
+  const float* s1p = o.mode == 2 ? o.s1 : o.p;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int64_t i = base + threadIdx.x * 4 + 1024 * v;
+    const int64_t ic = (i + 3 < end) ? i : base;
+    pvr[v] = *reinterpret_cast<const f4*>(o.p + ic);
+    gvr[v] = *reinterpret_cast<const f4*>(o.g + ic);
+    avr[v] = *reinterpret_cast<const f4*>(s0p + ic);
+    bvr[v] = *reinterpret_cast<const f4*>(s1p + ic);
+  }
   bad = block_sum(bad, sm);
   gg = block_sum(gg, sm);
   if (chunk == 0 && threadIdx.x == 0) {
@@ -122,10 +141,8 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
     const float pn = sqrtf(pp), un = sqrtf(uu);
     q = (pn > 0.f && un > 0.f) ? o.tc * pn / un : 1.0f;  // util/lars.py:26-29
   }
-  const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
-  const int64_t end = segs.off[k] + segs.numel[k];
   const bool decay = (o.mode == 0) ? (segs.trust[k] != 0) : (o.mode == 1);
-  auto upd1 = [&](int64_t i, float pv, float graw, float& s0v, float& s1v) -> float {
+  auto upd1 = [&](float pv, float graw, float& s0v, float& s1v) -> float {
     const float gv = graw * o.inv_scale;
     if (o.mode == 0) {                                   // LARS (util/lars.py:21-37)
       float dp = decay ? fmaf(o.wd, pv, gv) : gv;
@@ -143,24 +160,22 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
       return pw - (o.lr / o.bc1) * (s0v / denom);        // bc1 = 1 - beta1^t
     }
   };
-  for (int e = threadIdx.x * 4; e < OPT_CHUNK; e += 1024) {
-    const int64_t i = base + e;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int64_t i = base + threadIdx.x * 4 + 1024 * v;
     if (i + 3 < end) {
-      f4 pv = *reinterpret_cast<const f4*>(o.p + i);
-      const f4 gv = *reinterpret_cast<const f4*>(o.g + i);
-      f4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
-      if (o.mode != 1) av = *reinterpret_cast<const f4*>(o.s0 + i);
-      if (o.mode == 2) bv = *reinterpret_cast<const f4*>(o.s1 + i);
-      float a[4] = {av.x, av.y, av.z, av.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
-      pv.x = upd1(i, pv.x, gv.x, a[0], b[0]); pv.y = upd1(i + 1, pv.y, gv.y, a[1], b[1]);
-      pv.z = upd1(i + 2, pv.z, gv.z, a[2], b[2]); pv.w = upd1(i + 3, pv.w, gv.w, a[3], b[3]);
+      f4 pv = pvr[v];
+      const f4 gv = gvr[v];
+      float a[4] = {avr[v].x, avr[v].y, avr[v].z, avr[v].w}, b[4] = {bvr[v].x, bvr[v].y, bvr[v].z, bvr[v].w};
+      pv.x = upd1(pv.x, gv.x, a[0], b[0]); pv.y = upd1(pv.y, gv.y, a[1], b[1]);
+      pv.z = upd1(pv.z, gv.z, a[2], b[2]); pv.w = upd1(pv.w, gv.w, a[3], b[3]);
       *reinterpret_cast<f4*>(o.p + i) = pv;
       if (o.mode != 1) *reinterpret_cast<f4*>(o.s0 + i) = f4{a[0], a[1], a[2], a[3]};
       if (o.mode == 2) *reinterpret_cast<f4*>(o.s1 + i) = f4{b[0], b[1], b[2], b[3]};
     } else {
       for (int64_t t = i; t < end && t < i + 4; ++t) {
         float a = o.mode != 1 ? o.s0[t] : 0.f, b = o.mode == 2 ? o.s1[t] : 0.f;
-        o.p[t] = upd1(t, o.p[t], o.g[t], a, b);
+        o.p[t] = upd1(o.p[t], o.g[t], a, b);
         if (o.mode != 1) o.s0[t] = a;
         if (o.mode == 2) o.s1[t] = b;
       }
