@@ -40,6 +40,15 @@ __global__ __launch_bounds__(256) void ep_reduce_partials_kernel(const float* __
   f4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
   if (j < n) {
     int i = i0 + py;
+    // eight loads in flight per trip (a two-load trip is one memory round trip per pair); the order of the additions
+    // into s0 / s1 is the one of the two-load loop below, which finishes the rest
+    for (; i + 28 < i1; i += 32) {
+      f4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f4*>(part + (int64_t)(i + 4 * u) * n + j);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { s0 += a[u]; s1 += a[u + 1]; }
+    }
     for (; i + 4 < i1; i += 8) {
       s0 += *reinterpret_cast<const f4*>(part + (int64_t)i * n + j);
       s1 += *reinterpret_cast<const f4*>(part + (int64_t)(i + 4) * n + j);

@@ -117,9 +117,13 @@ __global__ __launch_bounds__(1024) void ep_bn_fused_kernel(const float* __restri
   float v[BNF_RPT];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < BNF_RPT; ++i) {
+  for (int i = 0; i < BNF_RPT; ++i) {                  // branch-free loads (clamped address): all in flight together
     const int b = ty + 64 * i;
-    v[i] = (ok && b < B) ? y[(int64_t)b * Dp + col] : 0.f;
+    v[i] = y[(int64_t)(b < B ? b : B - 1) * Dp + (ok ? col : 0)];
+  }
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    v[i] = (ok && ty + 64 * i < B) ? v[i] : 0.f;
     s += v[i];
   }
   const float mu = bnf_reduce(s, sm, tx, wv) / (float)B;
@@ -157,9 +161,14 @@ __global__ __launch_bounds__(1024) void ep_bn_bwd_fused_kernel(const float* __re
 #pragma unroll
   for (int i = 0; i < BNF_RPT; ++i) {
     const int b = ty + 64 * i;
-    const bool in = ok && b < B;
-    g[i] = in ? dz[(int64_t)b * Dp + col] : 0.f;
-    zz[i] = in ? z[(int64_t)b * Dp + col] : 0.f;
+    const int64_t at = (int64_t)(b < B ? b : B - 1) * Dp + (ok ? col : 0);   // branch-free loads, all in flight together
+    g[i] = dz[at]; zz[i] = z[at];
+  }
+#pragma unroll
+  for (int i = 0; i < BNF_RPT; ++i) {
+    const bool in = ok && ty + 64 * i < B;
+    g[i] = in ? g[i] : 0.f;
+    zz[i] = in ? zz[i] : 0.f;
     s1 += g[i];
     s2 = fmaf(g[i], zz[i], s2);
   }
