@@ -66,26 +66,40 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
     pp = fmaf(pv, pv, pp); uu = fmaf(u, u, uu); gg = fmaf(gv, gv, gg);
     bad += (fabsf(gv) <= 3.4028234664e38f) ? 0.f : 1.f;
   };
+  // a chunk of the deferred reduction's range (optim_step: the range is a float4-aligned part of ONE segment, so a chunk
+  // is inside it or outside): its gradients are summed here from the 16 stage rows, in ep_reduce_partials_kernel's order
+  const bool redchunk = o.red_stage && base >= o.red_off && base < o.red_off + o.red_n;
+  if (redchunk) {
+    const int64_t rend = (o.red_off + o.red_n) < end ? (o.red_off + o.red_n) : end;
+#pragma unroll
+    for (int v = 0; v < OPT_CHUNK / 1024; ++v) {                  // straight-line loads (clamped), guarded uses
+      const int64_t i = base + threadIdx.x * 4 + 1024 * v;
+      const bool in = i + 3 < rend;
+      const int64_t ic = in ? i : base;
+      const float* sp = o.red_stage + (ic - o.red_off);
+      f4 r[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) r[u] = *reinterpret_cast<const f4*>(sp + (int64_t)u * o.red_n);
+      const f4 pv = *reinterpret_cast<const f4*>(o.p + ic);
+      const f4 old = *reinterpret_cast<const f4*>(o.g + ic);
+      f4 t[4];
+#pragma unroll
+      for (int py = 0; py < 4; ++py) t[py] = (r[py] + r[py + 8]) + (r[py + 4] + r[py + 12]);
+      f4 gv = ((t[0] + t[1]) + (t[2] + t[3])) * o.red_scale;
+      if (o.red_accumulate) gv += old;
+      if (in) {
+        *reinterpret_cast<f4*>(o.gw + i) = gv;
+        acc1(pv.x, gv.x); acc1(pv.y, gv.y); acc1(pv.z, gv.z); acc1(pv.w, gv.w);
+      } else if (i < end) {                                        // elements of the segment behind the range
+        for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
+      }
+    }
+  } else
   for (int e = threadIdx.x * 4; e < OPT_CHUNK; e += 1024) {     // segment offsets are multiples of 4
     const int64_t i = base + e;
     if (i + 3 < end) {
       const f4 pv = *reinterpret_cast<const f4*>(o.p + i);
-      f4 gv;
-      if (o.red_stage && i >= o.red_off && i < o.red_off + o.red_n) {     // offsets and lengths are multiples of 4
-        const float* sp = o.red_stage + (i - o.red_off);
-        f4 t[4];
-#pragma unroll
-        for (int py = 0; py < 4; ++py) {                                    // ep_reduce_partials_kernel's order, 16 rows
-          const f4 s0 = *reinterpret_cast<const f4*>(sp + (int64_t)py * o.red_n) + *reinterpret_cast<const f4*>(sp + (int64_t)(py + 8) * o.red_n);
-          const f4 s1 = *reinterpret_cast<const f4*>(sp + (int64_t)(py + 4) * o.red_n) + *reinterpret_cast<const f4*>(sp + (int64_t)(py + 12) * o.red_n);
-          t[py] = s0 + s1;
-        }
-        gv = ((t[0] + t[1]) + (t[2] + t[3])) * o.red_scale;
-        if (o.red_accumulate) gv += *reinterpret_cast<const f4*>(o.g + i);
-        *reinterpret_cast<f4*>(o.gw + i) = gv;
-      } else {
-        gv = *reinterpret_cast<const f4*>(o.g + i);
-      }
+      const f4 gv = *reinterpret_cast<const f4*>(o.g + i);
       acc1(pv.x, gv.x); acc1(pv.y, gv.y); acc1(pv.z, gv.z); acc1(pv.w, gv.w);
     } else {
       for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
@@ -225,11 +239,11 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
   }
   o.partial = (float*)ws; o.nchunks = nchunks; o.found_inf = found_inf; o.grad_norm = grad_norm;
   if (red && red->stage) {
-    // the range must lie inside ONE segment on a float4 boundary, whole float4s (the norms kernel's vector path)
+    // the range must be one whole segment of whole float4s (the norms kernel decides per chunk)
     const int64_t off = red->out - g;
     bool inside = false;
     for (int k = 0; k < nseg; ++k)
-      inside |= off >= segs[k].offset && off + red->n <= segs[k].offset + segs[k].numel && (off - segs[k].offset) % 4 == 0;
+      inside |= off == segs[k].offset && red->n == segs[k].numel;     // the range IS a segment: chunks are inside it or outside
     if (inside && off >= 0 && off % 4 == 0 && red->n % 4 == 0 && aligned16(red->stage) && aligned16(g)) {
       o.red_stage = red->stage; o.gw = const_cast<float*>(g); o.red_off = off; o.red_n = red->n;
       o.red_scale = red->scale; o.red_accumulate = red->accumulate;

@@ -245,11 +245,32 @@ class ProbeHeadEngine:
         self._optimizer_call(lr, 0, 1)                                       # cls_token: the next step can start
         self._pending = (w2, lr, self.opt_step)
 
+    def _one_call_step(self) -> bool:
+        """One rank, no gradient accumulation: nothing happens between backward and update, so the step is ONE library
+        call (phases = 3) -- which also lets the library hand the last stage of the cls_token gradient reduction to the
+        optimizer's first kernel (one launch less).  Same arithmetic as the two calls."""
+        return type(self) is ProbeHeadEngine and self.world == 1 and self.accum_iter == 1 and self._micro == 0
+
+    def _train_step_one_call(self, x, targets, lr, image_index) -> None:
+        self.flush()
+        xv, bstride = F_.as_token_view(x)
+        _, Nn, D = xv.shape
+        iptr, B = F_._index_arg(image_index, xv)
+        ws = self._workspace(B, Nn)
+        targets = targets.to(device=self.device, dtype=torch.int64)
+        self.opt_step += 1
+        s = self._step_struct(xv, bstride, targets, 3, False, lr)
+        s.image_index = iptr
+        N.check(self._call_train(s, ws), "head train step")
+        self._micro = 0
+
     def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None,
                    image_index: Optional[torch.Tensor] = None) -> None:
         """One full iteration (accum_iter == 1): forward/backward, gradient all-reduce, update."""
         if self._pipelined:
             return self._train_step_pipelined(x, targets, lr, image_index)
+        if self._one_call_step():
+            return self._train_step_one_call(x, targets, lr, image_index)
         self.forward_backward(x, targets, image_index)
         if self._micro >= self.accum_iter:
             self.all_reduce_grads()
