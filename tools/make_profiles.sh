@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $args > /dev/null 2> "$out/pmc_fetch.log"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py $args > /dev/null 2> "$out/pmc_write.log"
 python3 tools/prof_summary.py "$out/trace" > "$out/kernel_stats_summary.txt"
+python3 tools/step_timeline.py "$out/trace" ${EP_PROF_TIMELINE_STEP:-60} > "$out/step_timeline.txt" 2>/dev/null
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
