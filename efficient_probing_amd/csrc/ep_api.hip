@@ -222,7 +222,13 @@ int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, i
 void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch) {
   const int i = sd.n_gemm++;
   sd.g[i] = g;
+  // tile height: 64 rows where they divide (dWc: 1000 x 768), 32 where 64 would leave a third of the tiles half empty
+  // (dWv: 96 rows per query).  Same-box A/B of the whole step (EP_SIDE_BM, diagnostics): this mix 0.4465 ms, all 32-row
+  // tiles 0.4535 ms, all 64-row tiles 0.459 ms.
+  static int force_bm = -1;
+  if (force_bm < 0) { const char* e = getenv("EP_SIDE_BM"); force_bm = e ? atoi(e) : 0; }
   sd.bm[i] = (g.M % 64 == 0 || g.M >= 256) ? 64 : 32;
+  if (force_bm == 32 || force_bm == 64) sd.bm[i] = force_bm;
   sd.gx[i] = (g.N + 63) / 64; sd.gy[i] = (g.M + sd.bm[i] - 1) / sd.bm[i]; sd.gz[i] = batch;
   sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
 }
