@@ -341,7 +341,9 @@ static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 // vector-ALU kernel), and the backward at D = 1152, where the other two kernels run short of LDS / registers
 static bool use_mm(const PoolParams& p, bool bwd) {
   if (needs_generic(p)) return false;
-  if (p.tokstat || p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
+  static int ln_mm = -1;                 // LayerNorm-of-tokens mode on the all-matrix-core kernel (EP_POOL_LN_MM=0: vector-ALU kernel)
+  if (ln_mm < 0) { const char* e = getenv("EP_POOL_LN_MM"); ln_mm = e ? atoi(e) : 1; }
+  if ((p.tokstat && !ln_mm) || p.x_bf16 || !mm_supported(p.D, p.Q, p.cls_bstride)) return false;
   if (pool_mode() == 3) return true;
   if (pool_mode() != 0) return false;
   return p.Q > 8 || (bwd && p.D == 1152 && p.Q >= 5);

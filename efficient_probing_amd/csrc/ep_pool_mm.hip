@@ -41,13 +41,13 @@ struct MmCfg {
   static constexpr int KDMA = NG;                    // 1 KiB DMA pieces per wave per tile
   static constexpr int SPART = MM_NW * 272 * 4;      // partial score blocks (padded: conflict-free gather)
   static constexpr int SMALL = 2048;                 // per slot (backward): S tile (16 q x 16 t floats) + ML rows (64 x 16 B)
+  static constexpr int TS = 256;                     // per slot (LayerNorm-of-tokens mode): {mean, rstd} of the 16 tokens
   static constexpr int LDS_TOTAL = 160 * 1024;
-  static constexpr int nslot(bool bwd) {
-    int ns = (LDS_TOTAL - SPART) / (SLOT + (bwd ? SMALL : 0));
+  static constexpr int nslot(bool bwd, bool ln) {
+    int ns = (LDS_TOTAL - SPART) / (SLOT + (bwd ? SMALL : 0) + (ln ? TS : 0));
     return ns > 4 ? 4 : ns;
   }
-  static constexpr int NSLOT_F = nslot(false), NSLOT_B = nslot(true);
-  static constexpr bool VALID = NSLOT_F >= 2 && NSLOT_B >= 2;
+  static constexpr bool VALID = nslot(false, true) >= 2 && nslot(true, true) >= 2;
 };
 
 __device__ __forceinline__ void mm_wait_vmcnt(int n) {
@@ -159,13 +159,18 @@ __device__ __forceinline__ void mm_pool(const char* tile, int plane, int w, cons
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int NG>
+// LN: LayerNorm-of-tokens mode (PoolParams.tokstat): the pass pools xhat = (x - mean) rstd without materialising it --
+// scores rstd (q.x - mean sum(q)), pooling weights a rstd, one scalar per query (sum_n a rstd mean) taken off at the end;
+// the {mean, rstd} pairs of a tile ride in the ring as one more 4-byte-per-lane DMA piece per wave.
+template <int NG, bool LN>
 __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParams p) {
   using C = MmCfg<NG>;
-  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT_F, KDMA = C::KDMA;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::nslot(false, LN), KDMA = C::KDMA;
+  constexpr int KD = KDMA + (LN ? 1 : 0);
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* ring = lds;
   char* spart = lds + NSLOT * SLOT;
+  char* tsbase = spart + C::SPART;                  // LN: [NSLOT][256 B]
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
@@ -191,20 +196,36 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
   const int plane = kk * ROWB + 16 * ((j >> 2) ^ kk) + 4 * (j & 3);
   unsigned soff[NG];
   mm_source_offsets<NG>(w, lane, soff);
+  float wsum_j = 0.f;                                // LN: sum over D of the scaled query j
+  if (LN) {
+    if (j < Q)
+      for (int c = kk; c < D / 4; c += 4) {
+        const f4 v = *reinterpret_cast<const f4*>(p.cls + (int64_t)j * D + 4 * c) * p.scale;
+        wsum_j += (v.x + v.y) + (v.z + v.w);
+      }
+    wsum_j = q4_sum(wsum_j);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
   const char* psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, wg));
+  const float* pts = LN ? p.tokstat + (int64_t)(p.index ? p.index[wg] : wg) * N * 2 : nullptr;
   auto produce = [&]() {
     if (pi < n_items) {
       const int left = N - ptile * MM_TT;
       const unsigned limit = (unsigned)((left < MM_TT ? left : MM_TT) * ROWB - 16);
       mm_dma_tile<NG>(psrc, limit, ring + pslot * SLOT, w, soff);
+      if (LN) {                                      // every wave copies the same 128 bytes: keeps the counted waits uniform
+        int e = ptile * MM_TT * 2 + (lane & 31); e = e < 2 * N ? e : 2 * N - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pts + e), (lds_ptr_t)(tsbase + pslot * C::TS), 4, 0, 0);
+      }
       ++pi;
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
       if (++ptile == tiles_per_img) {
         ptile = 0; ++pimg;
-        psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+        const int bn = (wg + pimg * G) < p.B ? (wg + pimg * G) : wg;
+        psrc = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, bn));
+        if (LN) pts = p.tokstat + (int64_t)(p.index ? p.index[bn] : bn) * N * 2;
       } else {
         psrc += SLOT;
       }
@@ -215,19 +236,21 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
 
   f4 acc[NG];
   float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;     // per lane: running max / partial sum of query j
+  float c2 = 0.f;                                          // LN: partial of sum_n a rstd mean
   int cimg = 0, ctile = 0, cslot = 0;
   for (int i = 0; i < n_items; ++i) {
     const int ahead = pi - 1 - i;
-    if (ahead == NSLOT - 2) mm_wait_vmcnt_imm<(NSLOT - 2) * KDMA>();
-    else mm_wait_vmcnt(ahead * KDMA);
+    if (ahead == NSLOT - 2) mm_wait_vmcnt_imm<(NSLOT - 2) * KD>();
+    else mm_wait_vmcnt(ahead * KD);
     mm_barrier();                                   // tile i landed everywhere; slot of tile i-1 is free
     const int b = wg + cimg * G;
     const int n0 = ctile * MM_TT;
     const int nvalid = (N - n0) < MM_TT ? (N - n0) : MM_TT;
     const char* tile = ring + cslot * SLOT;
+    const float* tstat = reinterpret_cast<const float*>(tsbase + cslot * C::TS);
     cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
     if (ctile == 0) {
-      m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
+      m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f; c2 = 0.f;
 #pragma unroll
       for (int blk = 0; blk < NG; ++blk) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -235,6 +258,14 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
     mm_barrier();                                   // all partial score blocks are in the scratch
     float sc[4], ue[4];
     mm_gather(spart, j, kk, sc);
+    float tm[4], tr[4];
+    if (LN) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        tm[s] = tstat[2 * (4 * s + kk)]; tr[s] = tstat[2 * (4 * s + kk) + 1];
+        sc[s] = tr[s] * (sc[s] - tm[s] * wsum_j);                             // q . xhat
+      }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -245,7 +276,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
       const float mn = fmaxf(m_j, q4_max(mx));
       const float f = __builtin_amdgcn_exp2f((m_j - mn) * MM_LOG2E);           // m = -inf -> 0
       m_j = mn; mL_j = mn * MM_LOG2E;
-      lsum *= f;
+      lsum *= f; c2 *= f;
 #pragma unroll
       for (int blk = 0; blk < NG; ++blk) acc[blk] *= f;                       // my column is query j
     }
@@ -254,6 +285,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
     for (int s = 0; s < 4; ++s) {
       wgt[s] = __builtin_amdgcn_exp2f(fmaf(ue[s], MM_LOG2E, -mL_j));          // invalid tokens: 0
       lsum += wgt[s];
+      if (LN) { wgt[s] *= tr[s]; c2 = fmaf(wgt[s], tm[s], c2); }              // pooling weights a rstd
     }
     if (w == 0 && j < Q) {                          // every wave holds the same scores: one writes them
 #pragma unroll
@@ -264,10 +296,11 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
     if (ctile == tiles_per_img - 1) {
       const float l = q4_sum(lsum);
       const float inv = 1.0f / l;
+      const float shift = LN ? q4_sum(c2) * inv : 0.f;                        // sum_n A rstd_n mean_n
       if (j < Q) {
         float* Pq = p.P + ((int64_t)b * Q + j) * D + 16 * NG * w + 4 * kk;      // rows i = 4*kk + r of each block
 #pragma unroll
-        for (int blk = 0; blk < NG; ++blk) *reinterpret_cast<f4*>(Pq + 16 * blk) = acc[blk] * inv;
+        for (int blk = 0; blk < NG; ++blk) *reinterpret_cast<f4*>(Pq + 16 * blk) = acc[blk] * inv - shift;
         if (w == 0 && kk == 0) {
           const f4 rec = {m_j, l, 0.f, 0.f};
           *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + j) * 4) = rec;
@@ -286,15 +319,16 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
 // benign duplicates that keep the counted waits uniform): header -> ML[b, q, 0:4] rows, token
 // tile -> S[b, q, n0:n0+16] (lane = query*4 + quarter).
 // ---------------------------------------------------------------------------------------
-template <int NG>
+template <int NG, bool LN>
 __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParams p) {
   using C = MmCfg<NG>;
-  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT_B, KDMA = C::KDMA;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::nslot(true, LN), KDMA = C::KDMA;
   constexpr int KD = KDMA + 1;
+  constexpr int SMALLB = C::SMALL + (LN ? C::TS : 0);   // per slot: S tile | ML rows | LN: {mean, rstd} of the tile
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* ring = lds;
   char* spart = lds + NSLOT * SLOT;
-  char* small_base = spart + C::SPART;                  // [NSLOT][1280 B]
+  char* small_base = spart + C::SPART;                  // [NSLOT][SMALLB]
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
@@ -306,6 +340,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
   const int j = lane & 15, kk = lane >> 4;
 
   f4 gacc[NG];
+  float c3 = 0.f;                                       // LN: partial of sum_b sum_n dS rstd mean
 #pragma unroll
   for (int blk = 0; blk < NG; ++blk) gacc[blk] = f4{0.f, 0.f, 0.f, 0.f};
 
@@ -325,7 +360,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
       if (pi < n_items) {
         const int b = wg + pimg * G;
         char* slot = ring + pslot * SLOT;
-        char* small = small_base + pslot * C::SMALL;
+        char* small = small_base + pslot * SMALLB;
         if (pidx == 0) {
           const char* src = reinterpret_cast<const char*>(p.dP + (int64_t)b * Q * D);
           const int rows = Q < MM_TT ? Q : MM_TT;
@@ -340,7 +375,13 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
           mm_dma_tile<NG>(src, (unsigned)(rows * ROWB - 16), slot, w, soff);
           int nn = n0 + (se & 15); nn = nn < N ? nn : N - 1;
           const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;
-          __builtin_amdgcn_global_load_lds((gptr_t)ss, (lds_ptr_t)(small + 256 * (w & 3)), 4, 0, 0);
+          char* sdst = small + 256 * (w & 3);
+          if (LN && w >= 4) {                         // waves 4-7 (duplicates of 0-3 otherwise) fetch the tile's {mean, rstd}
+            int e = n0 * 2 + (lane & 31); e = e < 2 * N ? e : 2 * N - 1;
+            ss = p.tokstat + (int64_t)(p.index ? p.index[b] : b) * N * 2 + e;
+            sdst = small + C::SMALL;
+          }
+          __builtin_amdgcn_global_load_lds((gptr_t)ss, (lds_ptr_t)sdst, 4, 0, 0);
         }
         ++pi;
         pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
@@ -352,6 +393,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
 
     float bq[NG][4];
     float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
+    float gsum_j = 0.f;                                 // LN: sum over D of dP[b, j]
     int cidx = 0, cslot = 0;
     for (int i = 0; i < n_items; ++i) {
       const int ahead = pi - 1 - i;
@@ -359,7 +401,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
       else mm_wait_vmcnt(ahead * KD);
       mm_barrier();
       const char* tile = ring + cslot * SLOT;
-      const char* small = small_base + cslot * C::SMALL;
+      const char* small = small_base + cslot * SMALLB;
       cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
       if (cidx == 0) {
         produce();
@@ -371,6 +413,20 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
         }
         const f4 rec = *reinterpret_cast<const f4*>(small + 1024 + 16 * (j < Q ? j : Q - 1));
         mL_j = rec.x * MM_LOG2E; il_j = 1.0f / rec.y; dl_j = rec.z;
+        if (LN) {
+          // sum of the whole dP row: slice sums of the 8 waves through the score scratch (free between two token items:
+          // the barrier at the top of this item is behind every wave's gather of the previous one)
+          float gs = 0.f;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) gs += (bq[g][0] + bq[g][1]) + (bq[g][2] + bq[g][3]);
+          gs = q4_sum(gs);
+          float* sp = reinterpret_cast<float*>(spart);
+          if (kk == 0) sp[w * 16 + j] = gs;
+          mm_barrier();
+          gsum_j = 0.f;
+#pragma unroll
+          for (int ws = 0; ws < MM_NW; ++ws) gsum_j += sp[ws * 16 + j];
+        }
       } else {
         const int n0 = (cidx - 1) * MM_TT;
         const int nvalid = (N - n0) < MM_TT ? (N - n0) : MM_TT;
@@ -379,36 +435,44 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
         float u[4], wgt[4];
         mm_gather(spart, j, kk, u);
         const int jq = j < Q ? j : Q - 1;
+        const float* tstat = reinterpret_cast<const float*>(small + C::SMALL);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+          float tmv = 0.f, trv = 1.f;
+          if (LN) {
+            tmv = tstat[2 * (4 * s + kk)]; trv = tstat[2 * (4 * s + kk) + 1];
+            u[s] = trv * (u[s] - tmv * gsum_j);                                                   // dA = dP . xhat
+          }
           const float sv = *reinterpret_cast<const float*>(small + 4 * (16 * jq + 4 * s + kk));   // S[b, j, n0 + 4s + kk]
           const float a = __builtin_amdgcn_exp2f(fmaf(sv, MM_LOG2E, -mL_j)) * il_j;
           wgt[s] = ((4 * s + kk) < nvalid && j < Q) ? a * (u[s] - dl_j) : 0.f;
+          if (LN) { wgt[s] *= trv; c3 = fmaf(wgt[s], tmv, c3); }                                  // dS rstd: sum dS xhat
         }
         mm_pool<NG>(tile, plane, w, wgt, gacc);
       }
       if (++cidx == items_per_img) cidx = 0;
     }
   }
+  const float gshift = LN ? q4_sum(c3) : 0.f;           // (every wave saw the same weights: no cross-wave term)
   if (j < Q) {
     float* Gq = p.Gpart + ((int64_t)wg * Q + j) * D + 16 * NG * w + 4 * kk;
 #pragma unroll
-    for (int blk = 0; blk < NG; ++blk) *reinterpret_cast<f4*>(Gq + 16 * blk) = gacc[blk];
+    for (int blk = 0; blk < NG; ++blk) *reinterpret_cast<f4*>(Gq + 16 * blk) = gacc[blk] - gshift;
   }
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NG>
+template <int NG, bool LN>
 static int mm_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   using C = MmCfg<NG>;
   if constexpr (!C::VALID) {
     set_error("no matrix-core pooling kernel for D=%d", 128 * NG);
     return EP_E_UNSUPPORTED;
   } else {
-    const size_t lds = bwd ? (size_t)C::NSLOT_B * (C::SLOT + C::SMALL) + C::SPART
-                           : (size_t)C::NSLOT_F * C::SLOT + C::SPART;
-    auto kf = ep_pool_mm_fwd_kernel<NG>;
-    auto kb = ep_pool_mm_bwd_kernel<NG>;
+    const size_t lds = bwd ? (size_t)C::nslot(true, LN) * (C::SLOT + C::SMALL + (LN ? C::TS : 0)) + C::SPART
+                           : (size_t)C::nslot(false, LN) * (C::SLOT + (LN ? C::TS : 0)) + C::SPART;
+    auto kf = ep_pool_mm_fwd_kernel<NG, LN>;
+    auto kb = ep_pool_mm_bwd_kernel<NG, LN>;
     const void* fn = bwd ? (const void*)kb : (const void*)kf;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
@@ -423,16 +487,21 @@ bool mm_supported(int D, int Q, int64_t cls_bstride) {
   return D % 128 == 0 && D >= 256 && D <= 1152 && Q >= 1 && Q <= 16 && cls_bstride == 0;
 }
 
+template <int NG>
+static int mm_launch_ln(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  return p.tokstat ? mm_launch_one<NG, true>(bwd, p, grid, st) : mm_launch_one<NG, false>(bwd, p, grid, st);
+}
+
 int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   switch (p.D / 128) {
-    case 2: return mm_launch_one<2>(bwd, p, grid, st);
-    case 3: return mm_launch_one<3>(bwd, p, grid, st);
-    case 4: return mm_launch_one<4>(bwd, p, grid, st);
-    case 5: return mm_launch_one<5>(bwd, p, grid, st);
-    case 6: return mm_launch_one<6>(bwd, p, grid, st);
-    case 7: return mm_launch_one<7>(bwd, p, grid, st);
-    case 8: return mm_launch_one<8>(bwd, p, grid, st);
-    case 9: return mm_launch_one<9>(bwd, p, grid, st);
+    case 2: return mm_launch_ln<2>(bwd, p, grid, st);
+    case 3: return mm_launch_ln<3>(bwd, p, grid, st);
+    case 4: return mm_launch_ln<4>(bwd, p, grid, st);
+    case 5: return mm_launch_ln<5>(bwd, p, grid, st);
+    case 6: return mm_launch_ln<6>(bwd, p, grid, st);
+    case 7: return mm_launch_ln<7>(bwd, p, grid, st);
+    case 8: return mm_launch_ln<8>(bwd, p, grid, st);
+    case 9: return mm_launch_ln<9>(bwd, p, grid, st);
   }
   set_error("no matrix-core pooling kernel for D=%d", p.D);
   return EP_E_UNSUPPORTED;

@@ -101,6 +101,9 @@ class ProbeHeadEngine:
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self._ws = None
         self._ws_key = None
+        import os as _os
+        if _os.environ.get("EP_AUX_STREAM", "1") == "0":     # diagnostics: everything on one stream
+            overlap = False
         self.aux_stream = torch.cuda.Stream(device=dev) if overlap else None
         # Communication overlap (EP head, data parallel): the next step's first token pass needs the updated
         # cls_token only, so the step all-reduces + updates cls_token first and lets the large all-reduce of the

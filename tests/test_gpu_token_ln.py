@@ -8,7 +8,9 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 SHAPES = [(6, 17, 64, 4), (5, 50, 256, 8), (9, 197, 768, 8), (300, 33, 384, 1), (7, 196, 1024, 8), (4, 256, 1152, 8),
-          (4, 30, 200, 5), (3, 20, 4096, 8), (5, 64, 768, 16)]
+          (4, 30, 200, 5), (3, 20, 4096, 8), (5, 64, 768, 16),
+          # more than 8 queries: LayerNorm-of-tokens mode of the all-matrix-core kernel (ragged last tile, several images per workgroup)
+          (5, 50, 768, 16), (3, 45, 1152, 16), (3, 37, 512, 12), (300, 21, 256, 9)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
