@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
       f4 t[4];
 #pragma unroll
       for (int py = 0; py < 4; ++py) t[py] = (r[py] + r[py + 8]) + (r[py + 4] + r[py + 12]);
-      f4 gv = ((t[0] + t[1]) + (t[2] + t[3])) * o.red_scale;
-      if (o.red_accumulate) gv += old;
+      const f4 ts = (t[0] + t[1]) + (t[2] + t[3]);
+      f4 gv = ts * o.red_scale;
+      if (o.red_accumulate)                 // one rounding, as in ep_reduce_partials_kernel
+        gv = f4{fmaf(ts.x, o.red_scale, old.x), fmaf(ts.y, o.red_scale, old.y), fmaf(ts.z, o.red_scale, old.z), fmaf(ts.w, o.red_scale, old.w)};
       if (in) {
         *reinterpret_cast<f4*>(o.gw + i) = gv;
         acc1(pv.x, gv.x); acc1(pv.y, gv.y); acc1(pv.z, gv.z); acc1(pv.w, gv.w);

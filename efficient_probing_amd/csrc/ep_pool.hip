@@ -58,9 +58,15 @@ __global__ __launch_bounds__(256) void ep_reduce_partials_kernel(const float* __
   sm[py][cx] = s0 + s1;
   __syncthreads();
   if (py == 0 && j < n) {
-    f4 s = ((sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx])) * alpha;
+    const f4 t = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
     float* o = out + (int64_t)g * n + j;
-    if (accumulate) s += *reinterpret_cast<const f4*>(o);
+    f4 s;
+    if (accumulate) {                       // ONE rounding, spelled out: ep_opt_norms_kernel's deferred stage does the same
+      const f4 old = *reinterpret_cast<const f4*>(o);
+      s = f4{fmaf(t.x, alpha, old.x), fmaf(t.y, alpha, old.y), fmaf(t.z, alpha, old.z), fmaf(t.w, alpha, old.w)};
+    } else {
+      s = t * alpha;
+    }
     *reinterpret_cast<f4*>(o) = s;
   }
 }

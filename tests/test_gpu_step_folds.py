@@ -110,3 +110,30 @@ def test_fold_on_and_off_agree(knob):
     a, b = outs
     assert np.allclose(a["loss"], b["loss"], rtol=2e-6)
     assert torch.allclose(a["p"], b["p"], rtol=2e-4, atol=2e-6)
+
+
+def test_one_call_step_with_gradient_accumulation_is_bit_equal():
+    """phases = 3 with accumulate = 1 (second micro-batch of an accum_iter = 2 step, driven through the C ABI struct the
+    engine builds): the deferred reduction stage then ADDS to the gradient of the first micro-batch inside the norms kernel."""
+    from efficient_probing_amd import functional as F_, _native as N
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    e1 = ProbeHeadEngine(make_head(seed=2), optimizer="lars", lr=0.3, weight_decay=1e-4, accum_iter=2)
+    e2 = ProbeHeadEngine(make_head(seed=2), optimizer="lars", lr=0.3, weight_decay=1e-4, accum_iter=2)
+    g = torch.Generator().manual_seed(11)
+    xa = torch.randn(1024, 40, 768, generator=g).to(DEV); ta = torch.randint(0, 1000, (1024,), generator=g).to(DEV)
+    xb = torch.randn(1024, 40, 768, generator=g).to(DEV); tb = torch.randint(0, 1000, (1024,), generator=g).to(DEV)
+    for e in (e1, e2):
+        e.forward_backward(xa, ta)                                   # micro-batch 1: gradients only
+    # micro-batch 2 on e1: backward (accumulating) + optimizer in ONE call
+    xv, bstride = F_.as_token_view(xb)
+    ws = e1._workspace(xv.shape[0], xv.shape[1])
+    e1.opt_step += 1
+    s = e1._step_struct(xv, bstride, tb.to(torch.int64), 3, True, None)
+    N.check(e1._call_train(s, ws), "one-call accumulate step")
+    e1._micro = 0
+    # ... and the engine's own two-call form on e2
+    e2.train_step(xb, tb)
+    assert e2._micro == 0 and e2.opt_step == e1.opt_step == 1
+    assert torch.equal(e1.flat_g, e2.flat_g)
+    assert torch.equal(e1.flat_p, e2.flat_p)
+    assert torch.equal(e1.state[0], e2.state[0])
