@@ -338,7 +338,9 @@ static bool use_mf(const PoolParams& p, bool bwd) {
   if (needs_generic(p)) return false;
   if (p.tokstat || p.x_bf16 || pool_mode() != 0 || !mf_supported(p.D, p.Q, p.cls_bstride)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
-  if (c.ok && (p.Q <= 4 || stream_waves_per_cu(c.qw, c.kp, c.nw) == 12)) return false;   // vector-ALU kernel wins
+  static int force_mf = -1;
+  if (force_mf < 0) { const char* e = getenv("EP_POOL_MF_FORCE"); force_mf = e ? atoi(e) : 0; }
+  if (!force_mf && c.ok && (p.Q <= 4 || stream_waves_per_cu(c.qw, c.kp, c.nw) == 12)) return false;   // vector-ALU kernel wins
   return true;
 }
 static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
