@@ -9,7 +9,7 @@ Nn = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 B, D, Q = 1024, 768, 8
 dev = "cuda:0"
 xs = [torch.randn(B, Nn, D, device=dev) for _ in range(3)]
-cls = torch.randn(Q, D, device=dev) * 0.5
+cls = torch.randn(Q, D, device=dev) * float(os.environ.get("CLS_STD", 0.5))   # query scale: how peaked the softmax is
 dP = torch.randn(B, Q, D, device=dev)
 for i in range(it):
     P, S, ML = F_.pool_forward(xs[i % 3], cls, D ** -0.5)
