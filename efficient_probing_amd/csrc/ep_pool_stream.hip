@@ -109,15 +109,43 @@ __device__ __forceinline__ void partial_scores(const f4 (&w)[QW][KP], const f4 (
 
 // butterfly reduction: on return u[q] holds, in every lane of row t (lanes 16t..16t+15), the
 // 64-lane sum of part[q][t].
+// sum over the 16 lanes of a row for TWO values at once, as v_add_f32 with the DPP modifier on its first source: one
+// instruction per value and level.  (From `v += dpp(v)` on two values hipcc makes two v_mov_b32_dpp + one v_pk_add_f32
+// per level: 12 vector instructions instead of 8.)  A DPP source written by the previous vector instruction needs two
+// wait states: the other value's add and one s_nop provide them.
+__device__ __forceinline__ void row16_sum2(float& a, float& b) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(a), "+v"(b));
+}
+
 template <int QW>
 __device__ __forceinline__ void butterfly(const float (&part)[QW][TB], float (&u)[QW]) {
+  float f[QW];
 #pragma unroll
   for (int q = 0; q < QW; ++q) {
     // fold32(a,b): lanes<32 <- a, lanes>=32 <- b.  fold16(r0,r1): rows <- [r0.lo, r1.lo, r0.hi, r1.hi]
     // rows [t0,t1,t2,t3]  <=  r0 = fold32(t0,t2), r1 = fold32(t1,t3)
     const float r0 = fold32(part[q][0], part[q][2]);
     const float r1 = fold32(part[q][1], part[q][3]);
-    u[q] = row16_sum(fold16(r0, r1));
+    f[q] = fold16(r0, r1);
+  }
+  if constexpr (QW == 2) {
+    row16_sum2(f[0], f[1]);
+    u[0] = f[0]; u[1] = f[1];
+  } else {
+#pragma unroll
+    for (int q = 0; q < QW; ++q) u[q] = row16_sum(f[q]);
   }
 }
 
