@@ -529,66 +529,83 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
     f4 gq[QW][KP];                  // dP rows of this wave's queries for the current image
     float mLq[QW], il[QW], dl[QW];  // row max * log2e, 1/l, delta of this wave's queries
     float gsum[QW];                 // LN: sum over D of the dP row
-    int cidx = 0, cslot = 0;
+    int cslot = 0, i = 0;
     constexpr int KD = KDMA + 1;
-    for (int i = 0; i < n_items; ++i) {
+    const char* tile = nullptr;
+    const float* small = nullptr;
+    // wait for item i, free the slot of item i-1, refill it (see the forward pass)
+    auto ring_step = [&]() {
       const int ahead = pi - 1 - i;
       if (ahead == NSLOT - 2) wait_vmcnt_imm<(NSLOT - 2) * KD>();
       else wait_vmcnt(ahead * KD);
       ring_barrier();
       produce();
-      const char* tile = ring + cslot * slot_bytes;
-      const float* small = reinterpret_cast<const float*>(small_base + (cslot * NW + w) * 256);
+      tile = ring + cslot * slot_bytes;
+      small = reinterpret_cast<const float*>(small_base + (cslot * NW + w) * 256);
       cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
-      if (cidx < H) {
-        // header item: pick up the dP rows of my queries that live in this item
-#pragma unroll
-        for (int j = 0; j < QW; ++j) {
-          const int q = q0 + j;
-          if (q < Q && q / HR == cidx) {
-            const int r = q % HR;
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-              f4 v = *reinterpret_cast<const f4*>(tile + r * hrowbytes + hoff[k]);
-              if (lane + 64 * k >= nchunk) v = f4{0.f, 0.f, 0.f, 0.f};
-              gq[j][k] = v;
-            }
-          } else if (q >= Q && cidx == 0) {
-#pragma unroll
-            for (int k = 0; k < KP; ++k) gq[j][k] = f4{0.f, 0.f, 0.f, 0.f};
-          }
-          mLq[j] = small[4 * j + 0] * LOG2E;
-          il[j] = 1.0f / small[4 * j + 1];
-          dl[j] = small[4 * j + 2];
-        }
-        if (LN && cidx == H - 1) {
+    };
+    if (q0 >= Q) {
+      // a wave without a query (Q < QW * NW) only keeps the ring turning; its accumulators stay zero and are not stored
+      for (; i < n_items; ++i) ring_step();
+    } else
+    // Loop shape as in the forward pass: image-outer, the header items, then the token tiles in a loop of their own whose
+    // body updates the accumulators unconditionally and in place.  The flat item loop (header / delta / tile chosen per
+    // item, tile work skipped for query-less waves) made hipcc copy all 24 accumulator registers in front of every tile.
+    for (int cimg = 0; cimg < n_img; ++cimg) {
+      for (int cidx = 0; cidx < H2; ++cidx, ++i) {
+        ring_step();
+        if (cidx < H) {
+          // header item: pick up the dP rows of my queries that live in this item
 #pragma unroll
           for (int j = 0; j < QW; ++j) {
+            const int q = q0 + j;
+            if (q < Q && q / HR == cidx) {
+              const int r = q % HR;
+#pragma unroll
+              for (int k = 0; k < KP; ++k) {
+                f4 v = *reinterpret_cast<const f4*>(tile + r * hrowbytes + hoff[k]);
+                if (lane + 64 * k >= nchunk) v = f4{0.f, 0.f, 0.f, 0.f};
+                gq[j][k] = v;
+              }
+            } else if (q >= Q && cidx == 0) {
+#pragma unroll
+              for (int k = 0; k < KP; ++k) gq[j][k] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+            mLq[j] = small[4 * j + 0] * LOG2E;
+            il[j] = 1.0f / small[4 * j + 1];
+            dl[j] = small[4 * j + 2];
+          }
+          if (LN && cidx == H - 1) {
+#pragma unroll
+            for (int j = 0; j < QW; ++j) {
+              float t = 0.f;
+#pragma unroll
+              for (int k = 0; k < KP; ++k) t += (gq[j][k].x + gq[j][k].y) + (gq[j][k].z + gq[j][k].w);
+              gsum[j] = wave_sum(t);
+            }
+          }
+        } else {
+          // delta item: dl = dy[b, q-slice] . y[b, q-slice] for this wave's queries (overrides the ML[.,.,2] picked up above)
+#pragma unroll
+          for (int j = 0; j < QW; ++j) {
+            const int q = q0 + j < Q ? q0 + j : Q - 1;
             float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < KP; ++k) t += (gq[j][k].x + gq[j][k].y) + (gq[j][k].z + gq[j][k].w);
-            gsum[j] = wave_sum(t);
+            for (int c = 4 * lane; c < dvq; c += 256) {
+              const f4 a = *reinterpret_cast<const f4*>(tile + (q * dvq + c) * 4);
+              const f4 b = *reinterpret_cast<const f4*>(tile + dv_rp * 1024 + (q * dvq + c) * 4);
+              t += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+            }
+            dl[j] = wave_sum(t);
           }
         }
-      } else if (cidx < H2) {
-        // delta item: dl = dy[b, q-slice] . y[b, q-slice] for this wave's queries (overrides the ML[.,.,2] picked up above)
-#pragma unroll
-        for (int j = 0; j < QW; ++j) {
-          const int q = q0 + j < Q ? q0 + j : Q - 1;
-          float t = 0.f;
-          for (int c = 4 * lane; c < dvq; c += 256) {
-            const f4 a = *reinterpret_cast<const f4*>(tile + (q * dvq + c) * 4);
-            const f4 b = *reinterpret_cast<const f4*>(tile + dv_rp * 1024 + (q * dvq + c) * 4);
-            t += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
-          }
-          dl[j] = wave_sum(t);
-        }
-      } else {
-        const int n0 = (cidx - H2) * TT;
-        const int nvalid = q0 < Q ? ((N - n0) < TT ? (N - n0) : TT) : 0;   // waves without a query skip
+      }
+      for (int ctile = 0; ctile < tiles_per_img; ++ctile, ++i) {
+        ring_step();
+        const int n0 = ctile * TT;
+        const int nvalid = (N - n0) < TT ? (N - n0) : TT;      // >= 1
 #pragma unroll
         for (int t0 = 0; t0 < TT; t0 += TB) {
-          if (t0 >= nvalid) break;
+          if (t0 > 0 && t0 >= nvalid) break;                    // (TT > TB only: later mini-batches of a ragged tile)
           f4 xv[TB][KP];
           load_rows<QW, KP, BF16>(tile + t0 * rowbytes, rowbytes, coff, xv);
           float part[QW][TB];
@@ -614,7 +631,6 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
           accumulate_rows<QW, KP>(wgt, xv, gacc);
         }
       }
-      if (++cidx == items_per_img) cidx = 0;
     }
   }
   // per-workgroup partial of sum_b sum_n dS x  (reduced + scaled by ep_reduce_partials)
