@@ -362,13 +362,21 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
             const float f = __builtin_amdgcn_exp2f((m[j] - mn) * LOG2E);   // m = -inf -> 0
             m[j] = mn; mL[j] = mn * LOG2E;
             lsum[j] *= f; c2[j] *= f;
+            // in place, by hand: with `acc[j][k] *= f` here hipcc renames the accumulators across this rare branch and
+            // copies them back at the loop latch of EVERY tile (10 vector moves) -- or, with the rest of the mini-batch
+            // written once behind the branch, twice per tile.  The volatile asm pins them to their registers; the rest of
+            // the mini-batch then follows once, and the kernel needs 128 instead of 162 registers.
+            const f2 ff = {f, f};
 #pragma unroll
-            for (int k = 0; k < KP; ++k) acc[j][k] *= f;
+            for (int k = 0; k < KP; ++k) {
+              f2 lo = acc[j][k].xy, hi = acc[j][k].zw;
+              asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(lo) : "v"(ff));
+              asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(hi) : "v"(ff));
+              acc[j][k].xy = lo; acc[j][k].zw = hi;
+            }
           }
-          finish();
-        } else {
-          finish();
         }
+        finish();
       }
     }
     // ---- image epilogue -------------------------------------------------------------------
