@@ -230,6 +230,9 @@ void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch) {
   sd.bm[i] = (g.M % 64 == 0 || g.M >= 256) ? 64 : 32;
   if (force_bm == 32 || force_bm == 64) sd.bm[i] = force_bm;
   sd.gx[i] = (g.N + 63) / 64; sd.gy[i] = (g.M + sd.bm[i] - 1) / sd.bm[i]; sd.gz[i] = batch;
+  static int xcd = -1;
+  if (xcd < 0) { const char* e = getenv("EP_SIDE_XCD"); xcd = e ? atoi(e) : 1; }
+  sd.xcd_order = xcd;
   sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
 }
 

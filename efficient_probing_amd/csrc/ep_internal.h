@@ -75,6 +75,7 @@ struct SideTasks {
   const float* rowstat; float* stats; int rs_B, n_stats;
   int total;                        // number of extra workgroups
   int first_block;                  // set by the launcher: side workgroups occupy blocks [first_block, first_block + total)
+  int xcd_order;                    // 1: tiles of a contraction are handed out XCD by XCD (run_side_task)
 };
 
 // element offset of image b of the batch inside the token buffer
