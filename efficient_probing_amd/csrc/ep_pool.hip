@@ -462,6 +462,9 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));
   } else if (c.ok && !force_generic() && !needs_generic(p) && stream_takes(p)) {
+    static int bwd_grid = -1;           // diagnostics: pooling workgroups of the SECOND pass only (e.g. 2 per CU, the third slot left to the side work)
+    if (bwd_grid < 0) { const char* e = getenv("EP_POOL_BWD_GRID"); bwd_grid = e ? atoi(e) : 0; }
+    if (bwd_grid > 0 && side && side->total > 0) c.grid = bwd_grid < p.B ? bwd_grid : p.B;
     EP_TRY(stream_launch(true, c, p, st, side));
     nparts = c.grid;
   } else {

@@ -175,25 +175,32 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, i
   auto compute = [&](int buf) {
     const float* As = lds[buf][0];
     const float* Bs = lds[buf][1];
+    // ALL fragments of the K-tile are read up front (8 k-steps x (MI + 2) values per lane), the matrix instructions
+    // follow with counted waits: read just in front of their use (2 reads, wait, 4 MFMAs, 2 reads, wait, ...) the matrix
+    // pipe sat idle for an LDS round trip in front of every group of four -- the weight-gradient side work of the
+    // second token pass took 65 us on an otherwise EMPTY chip for 27 us of matrix time.
+    float af[BK / 4][MI], bf[BK / 4][2];
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      float af[MI], bf[2];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row = wm * (16 * MI) + mi * 16 + i16;
-        af[mi] = A_K ? As[row * LDK + 4 * s + kk] : As[(4 * s + kk) * LDT + row];
+        af[s][mi] = A_K ? As[row * LDK + 4 * s + kk] : As[(4 * s + kk) * LDT + row];
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int col = wn * 32 + ni * 16 + i16;
-        bf[ni] = B_K ? Bs[col * LDK + 4 * s + kk] : Bs[(4 * s + kk) * LDT + col];
+        bf[s][ni] = B_K ? Bs[col * LDK + 4 * s + kk] : Bs[(4 * s + kk) * LDT + col];
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);               // (the scheduler would sink the reads back in front of their uses)
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-    }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][mi], bf[s][ni], acc[mi][ni], 0, 0, 0);
   };
 
   const int nk = (p.K + BK - 1) / BK;
