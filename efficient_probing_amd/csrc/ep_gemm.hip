@@ -387,6 +387,134 @@ __global__ __launch_bounds__(WS ? 512 : 256) void ep_gemm_dma_kernel(GemmParams 
   if (!WS) dma_wait<0>();                            // redundant prefetches past the last tile: drain before exit
 }
 
+// ---------------------------------------------------------------------------------------------
+// 32 x 96 tiles for K/K-layout contractions whose N is a multiple of 96 but not of 64 -- the per-query value projection
+// y_q = P_q Wv_q^T (N = Dp / Q = 96 at 256x768, Q = 8): 64x64 tiles leave every second tile half empty (a quarter of the
+// matrix time).  Same ring, swizzle, k-mapping and wave specialisation as ep_gemm_dma_kernel<true, true, 4, true>; a stage
+// holds a 32-row A image (4 KiB) and a 96-row B image (12 KiB) = the same 16 one-KiB DMA pieces, four per loader wave;
+// matrix wave (wm, wn) owns 16 rows x 48 columns = 1 x 3 MFMA blocks.  K % 32 == 0, N % 96 == 0 (host-checked).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void ep_gemm_kk96_kernel(GemmParams p) {
+  constexpr int NST = 4;
+  constexpr int STB = 16 * 1024;                     // bytes per ring stage: A image 4 KiB | B image 12 KiB
+  constexpr int AIMG = 4 * 1024;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wall >= 4;
+  const int w = wall & 3;
+  const int wm = w >> 1, wn = w & 1;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 96;
+  const int z = blockIdx.z;
+  const float* A = p.A + (int64_t)z * p.sAz;
+  const float* B = p.B + (int64_t)z * p.sBz;
+  float* C = p.C + (int64_t)z * p.sCz;
+  const int nk = p.K / BK;
+
+  if (loader) {
+    // piece pc = w + 4 jj of the stage: positions pc*64 + lane -> image row r = pos >> 3 (A rows 0..31, then B rows 0..95),
+    // slot q = pos & 7 holding k-chunk q ^ ((r >> 1) & 7) of that row
+    const float* src[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int pos = (w + 4 * jj) * 64 + lane;
+      int r = pos >> 3;
+      const int q = pos & 7;
+      const bool isA = r < 32;
+      if (!isA) r -= 32;
+      const int kq = q ^ ((r >> 1) & 7);
+      if (isA) { int row = m0 + r; row = row < p.M ? row : p.M - 1; src[jj] = A + (int64_t)row * p.lda + 4 * kq; }
+      else src[jj] = B + (int64_t)(n0 + r) * p.ldb + 4 * kq;
+    }
+    auto issue = [&](int t) {
+      const int tt = t < nk ? t : nk - 1;            // past the end: the last tile again (uniform vmcnt arithmetic)
+      char* st = lds + (t % NST) * STB;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[jj] + tt * BK), (lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t);
+    dma_wait<4 * (NST - 2)>();
+    ws_barrier();                                    // tile 0 landed
+    for (int it = 0; it < nk; ++it) {
+      dma_wait<4 * (NST - 3)>();                     // tile it+1 landed (this wave's pieces)
+      ws_barrier();                                  // ... everyone's; the matrix waves hold tile `it` in registers
+      issue(it + NST - 1);
+    }
+    dma_wait<0>();
+    return;
+  }
+
+  int fragA[2], fragB[3][2];
+  {
+    const int r = wm * 16 + i16;
+    fragA[0] = r * 128 + 16 * ((0 + kk) ^ ((r >> 1) & 7));
+    fragA[1] = r * 128 + 16 * ((4 + kk) ^ ((r >> 1) & 7));
+  }
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) {
+    const int r = wn * 48 + bi * 16 + i16;
+    fragB[bi][0] = AIMG + r * 128 + 16 * ((0 + kk) ^ ((r >> 1) & 7));
+    fragB[bi][1] = AIMG + r * 128 + 16 * ((4 + kk) ^ ((r >> 1) & 7));
+  }
+  f4v fa[2][2], fb[2][3][2];                         // [set][g], [set][block][g]
+  auto read_frags = [&](int stage, f4v (&xa)[2], f4v (&xb)[3][2]) {
+    const char* sb = lds + stage * STB;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      xa[g] = *reinterpret_cast<const f4v*>(sb + fragA[g]);
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) xb[bi][g] = *reinterpret_cast<const f4v*>(sb + fragB[bi][g]);
+    }
+  };
+  f4v acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) acc[b] = f4v{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const f4v (&xa)[2], const f4v (&xb)[3][2]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int bi = 0; bi < 3; ++bi)
+          acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g][j], xb[bi][g][j], acc[bi], 0, 0, 0);
+  };
+  ws_barrier();                                      // tile 0 landed
+  read_frags(0, fa[0], fb[0]);
+#define EP_KK96_STEP(IT, F)                                      \
+  {                                                              \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          \
+    ws_barrier();                                                \
+    read_frags(((IT) + 1) % NST, fa[(F) ^ 1], fb[(F) ^ 1]);      \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    multiply(fa[F], fb[F]);                                      \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  }
+  int it = 0;
+  for (; it + 1 < nk; it += 2) {
+    EP_KK96_STEP(it, 0)
+    EP_KK96_STEP(it + 1, 1)
+  }
+  if (it < nk) EP_KK96_STEP(it, 0)
+#undef EP_KK96_STEP
+  int rb[3], cb[3];
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) { rb[bi] = m0 + wm * 16; cb[bi] = n0 + wn * 48 + bi * 16; }
+  store_acc_blocks<3>(p, C, z, rb, cb, acc, kk, i16);
+}
+
+static bool gemm_kk96_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_KK96"); on = e ? atoi(e) : 1; }
+  if (!on || !a_k || !b_k || p.N % 96 != 0 || p.N % 64 == 0 || p.K % BK != 0 || p.K < BK || p.M < 1) return false;
+  // worth it where the 64x64 tiling wastes tiles and the 32-row grid still fills the chip
+  const long tiles = (long)(p.N / 96) * ((p.M + 31) / 32) * batch;
+  return tiles >= cu_count();
+}
+
 static void gemm_launch_dma(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   const int npers = p.npers > 1 ? p.npers : 1;
   dim3 grid(((p.N + BN - 1) / BN + npers - 1) / npers, (p.M + 63) / 64, batch);
@@ -491,7 +619,9 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   const bool ws_ok = use_ws && vec && !force_bm && p.K >= 256 && (!p.side || (use_ws & 2));
   static int use_dma = -1;
   if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
-  if (use_dma && vec && !force_bm) {
+  if (use_dma && vec && !force_bm && gemm_kk96_ok(a_k, b_k, p, batch)) {
+    hipLaunchKernelGGL(ep_gemm_kk96_kernel, dim3(p.N / 96, (p.M + 31) / 32, batch), dim3(512), 0, st, p);
+  } else if (use_dma && vec && !force_bm) {
     // short K and many tiles: every workgroup walks several N-tiles through one ring (see the kernel) -- as many as still
     // leave one workgroup per CU.  dP = dy_q Wv_q at 1024 x 768, Q = 8 (K = 96, 1536 tiles): 22.7 us with one tile per
     // workgroup, 20.8 / 19.6 / 19.1 us with 2 / 3 / 6.  EP_GEMM_NPERS: 1 = off, n > 1 = at most n.

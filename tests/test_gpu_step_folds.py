@@ -137,3 +137,19 @@ def test_one_call_step_with_gradient_accumulation_is_bit_equal():
     assert torch.equal(e1.flat_g, e2.flat_g)
     assert torch.equal(e1.flat_p, e2.flat_p)
     assert torch.equal(e1.state[0], e2.state[0])
+
+
+@pytest.mark.parametrize("B", [1024, 1025, 2048 + 7])
+def test_value_projection_on_32x96_tiles_vs_fp64(B):
+    """y_q = P_q Wv_q^T with N = 96 columns per query: the 32 x 96-tile kernel (csrc/ep_gemm.hip: ep_gemm_kk96_kernel),
+    which engages from 256 tiles on (B >= 1024 at Q = 8), against fp64; ragged last row tile included."""
+    from efficient_probing_amd import functional as F_
+    D, Q = 768, 8
+    g = torch.Generator(device=DEV).manual_seed(4)
+    P = torch.randn(B, Q, D, device=DEV, generator=g)
+    Wv = torch.randn(D, D, device=DEV, generator=g) * 0.05
+    y = F_.project_forward(P, Wv)
+    Dq = D // Q
+    ref = torch.einsum("bqd,qcd->bqc", P.double(), Wv.double().view(Q, Dq, D)).reshape(B, D)
+    err = (y.double() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item() + 1e-6, err          # K = 768 fp32 products
