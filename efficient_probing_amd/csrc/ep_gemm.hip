@@ -506,6 +506,165 @@ __global__ __launch_bounds__(512) void ep_gemm_kk96_kernel(GemmParams p) {
   store_acc_blocks<3>(p, C, z, rb, cb, acc, kk, i16);
 }
 
+// The same 32 x 96 tiling with the B operand in T layout (k-rows of N contiguous columns): dz = dlogits Wc at
+// 1024 x 768 is 16 x 12 = 192 tiles of 64 x 64 on 256 CUs, and 32 x 8 = 256 tiles of 32 x 96.  B image: 32 k-rows of 96
+// floats (24 chunks of 16 B, chunk c of k-row k in slot c ^ 4((k >> 2) & 1): the T-layout swizzle of the 64-column
+// kernel; rows are 96 words apart, k-rows 4 apart still alias modulo 64 banks, so the same two-group argument holds).
+// K tail (K % 32 != 0; K % 4 == 0): sources clamped, out-of-range k zeroed in registers on the last tile.
+__global__ __launch_bounds__(512) void ep_gemm_kt96_kernel(GemmParams p) {
+  constexpr int NST = 4;
+  constexpr int STB = 16 * 1024;
+  constexpr int AIMG = 4 * 1024;
+  constexpr int ROWB = 96 * 4;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wall >= 4;
+  const int w = wall & 3;
+  const int wm = w >> 1, wn = w & 1;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 96;
+  const int z = blockIdx.z;
+  const float* A = p.A + (int64_t)z * p.sAz;
+  const float* B = p.B + (int64_t)z * p.sBz;
+  float* C = p.C + (int64_t)z * p.sCz;
+  const int nk = (p.K + BK - 1) / BK;
+  const bool ktail = (p.K % BK) != 0;
+
+  if (loader) {
+    auto src_of = [&](int jj, int k0) -> const float* {
+      const int pos = (w + 4 * jj) * 64 + lane;
+      if (pos < 256) {                                 // A image, K layout: row r, slot q holds k-chunk q ^ ((r >> 1) & 7)
+        const int r = pos >> 3, q = pos & 7;
+        const int kq = q ^ ((r >> 1) & 7);
+        int row = m0 + r; row = row < p.M ? row : p.M - 1;
+        int k = k0 + 4 * kq; k = k < p.K ? k : 0;
+        return A + (int64_t)row * p.lda + k;
+      }
+      const int pb = pos - 256;                        // B image, T layout: k-row k, slot q holds column chunk q ^ 4((k >> 2) & 1)
+      const int k = pb / 24, q = pb - 24 * k;
+      const int c = q ^ (4 * ((k >> 2) & 1));
+      int kr = k0 + k; kr = kr < p.K ? kr : p.K - 1;
+      return B + (int64_t)kr * p.ldb + n0 + 4 * c;
+    };
+    const float* src[4];
+    int64_t step[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      src[jj] = src_of(jj, 0);
+      step[jj] = ((w + 4 * jj) * 64 + lane) < 256 ? (int64_t)BK : (int64_t)BK * p.ldb;
+    }
+    auto issue = [&](int t) {
+      const int tt = t < nk ? t : nk - 1;
+      char* st = lds + (t % NST) * STB;
+      if (ktail && tt == nk - 1) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          __builtin_amdgcn_global_load_lds((gptr_t)src_of(jj, tt * BK), (lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src[jj] + tt * step[jj]), (lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t);
+    dma_wait<4 * (NST - 2)>();
+    ws_barrier();
+    for (int it = 0; it < nk; ++it) {
+      dma_wait<4 * (NST - 3)>();
+      ws_barrier();
+      issue(it + NST - 1);
+    }
+    dma_wait<0>();
+    return;
+  }
+
+  int fragA[2], fragB[3];
+  {
+    const int r = wm * 16 + i16;
+    fragA[0] = r * 128 + 16 * ((0 + kk) ^ ((r >> 1) & 7));
+    fragA[1] = r * 128 + 16 * ((4 + kk) ^ ((r >> 1) & 7));
+  }
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) {
+    const int r = wn * 48 + bi * 16 + i16;             // column inside the tile
+    fragB[bi] = AIMG + 4 * kk * ROWB + 16 * ((r >> 2) ^ (4 * (kk & 1))) + 4 * (r & 3);
+  }
+  f4v fa[2][2], fb[2][3][2];
+  auto read_frags = [&](int stage, f4v (&xa)[2], f4v (&xb)[3][2]) {
+    const char* sb = lds + stage * STB;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      xa[g] = *reinterpret_cast<const f4v*>(sb + fragA[g]);
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xb[bi][g][j] = *reinterpret_cast<const float*>(sb + fragB[bi] + (16 * g + j) * ROWB);
+    }
+  };
+  auto zero_tail = [&](int k0, f4v (&xa)[2], f4v (&xb)[3][2]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool out = k0 + 16 * g + 4 * kk + j >= p.K;
+        xa[g][j] = out ? 0.f : xa[g][j];
+#pragma unroll
+        for (int bi = 0; bi < 3; ++bi) xb[bi][g][j] = out ? 0.f : xb[bi][g][j];
+      }
+  };
+  f4v acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) acc[b] = f4v{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const f4v (&xa)[2], const f4v (&xb)[3][2]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int bi = 0; bi < 3; ++bi)
+          acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g][j], xb[bi][g][j], acc[bi], 0, 0, 0);
+  };
+  ws_barrier();
+  read_frags(0, fa[0], fb[0]);
+  if (ktail && nk == 1) { __builtin_amdgcn_s_waitcnt(0xc07f); zero_tail(0, fa[0], fb[0]); }
+#define EP_KT96_STEP(IT, F)                                      \
+  {                                                              \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          \
+    ws_barrier();                                                \
+    read_frags(((IT) + 1) % NST, fa[(F) ^ 1], fb[(F) ^ 1]);      \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    multiply(fa[F], fb[F]);                                      \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    if (ktail && (IT) + 1 == nk - 1) { __builtin_amdgcn_s_waitcnt(0xc07f); zero_tail(((IT) + 1) * BK, fa[(F) ^ 1], fb[(F) ^ 1]); } \
+  }
+  int it = 0;
+  for (; it + 1 < nk; it += 2) {
+    EP_KT96_STEP(it, 0)
+    EP_KT96_STEP(it + 1, 1)
+  }
+  if (it < nk) EP_KT96_STEP(it, 0)
+#undef EP_KT96_STEP
+  int rb[3], cb[3];
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) { rb[bi] = m0 + wm * 16; cb[bi] = n0 + wn * 48 + bi * 16; }
+  store_acc_blocks<3>(p, C, z, rb, cb, acc, kk, i16);
+}
+
+// K/T layout on 32 x 96 tiles: where the 64 x 64 grid is a partial round of the chip and the 32 x 96 grid a whole one
+static bool gemm_kt96_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_KT96"); on = e ? atoi(e) : 1; }
+  if (!on || !a_k || b_k || p.N % 96 != 0 || p.K < BK || p.K % 4 != 0 || p.M < 1 || p.npers > 1) return false;
+  const long cus = cu_count();
+  const long t64 = (long)((p.N + 63) / 64) * ((p.M + 63) / 64) * batch;
+  const long t96 = (long)(p.N / 96) * ((p.M + 31) / 32) * batch;
+  // one partial round of 64 x 64 tiles against whole rounds of the smaller ones (same matrix work per round)
+  return t64 < cus && t96 % cus == 0 && (p.K + BK - 1) / BK >= 8;
+}
+
 static bool gemm_kk96_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_KK96"); on = e ? atoi(e) : 1; }
@@ -621,6 +780,8 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
   if (use_dma && vec && !force_bm && gemm_kk96_ok(a_k, b_k, p, batch)) {
     hipLaunchKernelGGL(ep_gemm_kk96_kernel, dim3(p.N / 96, (p.M + 31) / 32, batch), dim3(512), 0, st, p);
+  } else if (use_dma && vec && !force_bm && gemm_kt96_ok(a_k, b_k, p, batch)) {
+    hipLaunchKernelGGL(ep_gemm_kt96_kernel, dim3(p.N / 96, (p.M + 31) / 32, batch), dim3(512), 0, st, p);
   } else if (use_dma && vec && !force_bm) {
     // short K and many tiles: every workgroup walks several N-tiles through one ring (see the kernel) -- as many as still
     // leave one workgroup per CU.  dP = dy_q Wv_q at 1024 x 768, Q = 8 (K = 96, 1536 tiles): 22.7 us with one tile per

@@ -153,3 +153,20 @@ def test_value_projection_on_32x96_tiles_vs_fp64(B):
     ref = torch.einsum("bqd,qcd->bqc", P.double(), Wv.double().view(Q, Dq, D)).reshape(B, D)
     err = (y.double() - ref).abs().max().item()
     assert err <= 3e-6 * ref.abs().max().item() + 1e-6, err          # K = 768 fp32 products
+
+
+@pytest.mark.parametrize("B,C", [(1024, 1000), (1024, 1024), (1024, 44)])
+def test_dz_on_32x96_tiles_vs_fp64(B, C):
+    """dz = dlogits Wc (K = classes: 1000 has a K tail of 8; 44 is shorter than 8 K-tiles and stays on the 64 x 64
+    kernel) on the K/T-layout 32 x 96-tile kernel (csrc/ep_gemm.hip: ep_gemm_kt96_kernel) against fp64."""
+    from efficient_probing_amd import functional as F_
+    D = 768
+    g = torch.Generator(device=DEV).manual_seed(8)
+    dl = torch.randn(B, C, device=DEV, generator=g)
+    z = torch.randn(B, D, device=DEV, generator=g)
+    Wc = torch.randn(C, D, device=DEV, generator=g) * 0.05
+    out = F_.linear_backward(dl, z, Wc, True, None, None, False)
+    dz = out[0] if isinstance(out, (tuple, list)) else out
+    ref = dl.double() @ Wc.double()
+    err = (dz.double() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item() + 1e-6, err
