@@ -86,9 +86,30 @@ def spawn_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll all ranks: the first one that dies takes the others with it (they would otherwise sit in the rendezvous or in an
+    # all-reduce until the collective's timeout); children never outlive this process
+    import time
     rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            for pr in list(live):
+                code = pr.poll()
+                if code is not None:
+                    live.remove(pr)
+                    rc = max(rc, abs(code))
+            if live and rc == 0:
+                time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
     return rc
 
 

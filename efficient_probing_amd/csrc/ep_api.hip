@@ -61,6 +61,17 @@ struct HeadWs {
   size_t total;
 };
 
+// EXPERIMENT, off by default (EP_GEMM_PLANES=1): the four critical-path contractions of a train step against pre-split
+// weight planes (ep_planes.hip).  Needs the per-query slice width to be a multiple of the MFMA K (32) for the dP
+// contraction.  Measured on MI355X at 1024 x 256 x 768: the logits / dz kernels alone are faster than the f32 kernel
+// (17.1 / 20.3 us against 20.4 / 25.3 us), the whole step is not (0.490 against 0.467 ms: the split launch, the
+// half-empty 96-column tiles of the per-query projection and the 3-K-tile dP contraction eat the gain).
+static bool head_planes_ok(const ep_head_dims& d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : 0; }
+  const int Dp = d.D / d.d_out;
+  return on && (Dp / d.Q) % 32 == 0 && d.D % 4 == 0 && Dp % 4 == 0;
+}
 static HeadWs carve(const ep_head_dims& d, void* base) {
   HeadWs w{};
   const int Dp = d.D / d.d_out;
@@ -91,24 +102,15 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   const int64_t total = ep_head_param_offsets(&d, offs);
   w.opt_ws_bytes = optim_workspace_bytes(total, 4);
   w.opt_ws = take(w.opt_ws_bytes / sizeof(float));
-  auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
-  w.plWv = take16(planes_elems(Dp, d.D)); w.plWvT = take16(planes_elems(d.D, Dp));
-  w.plWc = take16(planes_elems(d.C, Dp)); w.plWcT = take16(planes_elems(Dp, d.C));
+  if (head_planes_ok(d)) {            // the bf16 weight planes exist only when the (opt-in) planes contractions will run
+    auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
+    w.plWv = take16(planes_elems(Dp, d.D)); w.plWvT = take16(planes_elems(d.D, Dp));
+    w.plWc = take16(planes_elems(d.C, Dp)); w.plWcT = take16(planes_elems(Dp, d.C));
+  }
   w.total = off;
   return w;
 }
 
-// EXPERIMENT, off by default (EP_GEMM_PLANES=1): the four critical-path contractions of a train step against pre-split
-// weight planes (ep_planes.hip).  Needs the per-query slice width to be a multiple of the MFMA K (32) for the dP
-// contraction.  Measured on MI355X at 1024 x 256 x 768: the logits / dz kernels alone are faster than the f32 kernel
-// (17.1 / 20.3 us against 20.4 / 25.3 us), the whole step is not (0.490 against 0.467 ms: the split launch, the
-// half-empty 96-column tiles of the per-query projection and the 3-K-tile dP contraction eat the gain).
-static bool head_planes_ok(const ep_head_dims& d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : 0; }
-  const int Dp = d.D / d.d_out;
-  return on && (Dp / d.Q) % 32 == 0 && d.D % 4 == 0 && Dp % 4 == 0;
-}
 static int head_planes_split(const ep_head_dims& d, const HeadWs& w, const float* Wv, const float* Wc, hipStream_t st) {
   const int Dp = d.D / d.d_out;
   PlaneSpec sp[2] = {{Wv, Dp, d.D, d.D, w.plWv, w.plWvT}, {Wc, d.C, Dp, Dp, w.plWc, w.plWcT}};

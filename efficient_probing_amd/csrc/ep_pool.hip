@@ -437,7 +437,11 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
   if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (!c.ok || !stream_takes(p) || Dv <= 0 || Dv % (4 * p.Q) != 0) return false;
-  const size_t slot = (size_t)stream_tt(c.qw, c.kp, c.nw) * p.D * 4;
+  // ring slot of the kernel that will run = (tokens per tile) * D * (bytes per stored element).  A bf16 tile holds TWICE
+  // the tokens (ep_pool_stream.hip: TT = Cfg::TT * (BF16 ? 2 : 1)) at half the bytes each, so the slot is
+  // stream_tt * D * 4 bytes for both storage types (tests/test_gpu_step_folds.py: bf16 at D = 192 / 640)
+  const size_t tt = (size_t)stream_tt(c.qw, c.kp, c.nw) * (p.x_bf16 ? 2 : 1);
+  const size_t slot = tt * p.D * (p.x_bf16 ? 2 : 4);
   return 2 * (((size_t)Dv * 4 + 1023) / 1024) * 1024 <= slot;
 }
 

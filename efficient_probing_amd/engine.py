@@ -288,7 +288,7 @@ class ProbeHeadEngine:
         matrices; pooled projection, BatchNorm output and logits rounded to fp16 on the way out), so a head trained by
         the reference scores like it does there.  Two roundings cannot be placed identically because the kernels pool
         before they project: the reference rounds the (B, Q, N) scores and the per-token values V to fp16; both are
-        below the fp16 resolution of the result (see tests/test_gpu_eval_precision.py for the measured distance)."""
+        below the fp16 resolution of the result (tests/test_gpu_parity.py::test_fused_engine_steps_golden pins the distance on the fp16-autocast goldens)."""
         if type(self) is not ProbeHeadEngine:
             raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
         self.flush()

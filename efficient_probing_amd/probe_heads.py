@@ -16,13 +16,12 @@ Invariants kept from the reference (published numbers depend on them):
 
 Native on MI355X: ``ep``, ``coca``, ``abmilp``, ``siglip``, ``cae``, ``jepa``, ``aim``, ``simpool``, ``esimpool``, ``cait``,
 ``clip``, ``dolg``, ``cbam`` and ``dinovit`` -- all fourteen names (pooling, BatchNorm1d and the classifier run in the HIP kernels
-of libep_hip.so).  ``_reference_pooling(name)`` is a factory for the reference's own PyTorch module (needs the reference
-repository importable, ``poolings.*`` on sys.path) and ``register_pooling`` plugs in any other; such modules run as stock
-PyTorch-ROCm modules behind the native BatchNorm.
+of libep_hip.so).  ``register_pooling`` plugs in any other factory (``tools/reference_poolings.py`` builds factories for the
+reference's own PyTorch modules when its repository is importable -- a development aid kept OUTSIDE this package); such
+modules run as stock PyTorch-ROCm modules behind the native BatchNorm.
 """
 from __future__ import annotations
 
-import importlib
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -84,49 +83,6 @@ def _batchnorm(width: int) -> nn.Module:
 PoolingFactory = Callable[[int, object, nn.Module], nn.Module]
 ClassifierFactory = Optional[Callable[[int, object], nn.Linear]]
 
-# how the reference builds the pooling modules we do not (yet) run natively:
-# name -> (module path, class name, kwargs(dim, args, model))
-_REFERENCE_SPECS = {
-    "abmilp": ("poolings.abmilp", "ABMILPHead",
-               lambda dim, a, m: dict(dim=dim, self_attention_apply_to=a.abmilp_sa, activation=a.abmilp_act,
-                                      depth=a.abmilp_depth, cond=a.abmilp_cond, content=a.abmilp_content,
-                                      num_patches=m.patch_embed.num_patches)),
-    "simpool": ("poolings.simpool", "SimPool",
-                lambda dim, a, m: dict(dim=dim, num_heads=1, qkv_bias=False, qk_scale=None, gamma=None,
-                                       use_beta=False)),
-    "esimpool": ("poolings.simpool", "SimPool_nolinears",
-                 lambda dim, a, m: dict(dim=dim, num_heads=12, qk_scale=None, gamma=None, use_beta=False)),
-    "clip": ("poolings.clip.attention_pool2d", "AttentionPool2d",
-             lambda dim, a, m: dict(in_features=dim, feat_size=16 if a.model == "capi_vitl14_in1k" else 14)),
-    "siglip": ("poolings.clip.attention_pool", "AttentionPoolLatent", lambda dim, a, m: dict(in_features=dim)),
-    "aim": ("poolings.aim", "AttentionPoolingClassifier", lambda dim, a, m: dict(dim=dim, num_heads=a.num_heads)),
-    "cbam": ("poolings.cbam", "CbamPooling", lambda dim, a, m: dict(channels=dim, spatial_kernel_size=7)),
-    "coca": ("poolings.coca_pytorch", "CrossAttention", lambda dim, a, m: dict(dim=dim)),
-    "cait": ("poolings.other_pool", "CAPooling", lambda dim, a, m: dict(embed_dim=dim)),
-    "dinovit": ("poolings.other_pool", "DinoViTBlockPooling", lambda dim, a, m: dict(d_model=dim)),
-    "jepa": ("poolings.jepa.attentive_pooler", "AttentivePooler",
-             lambda dim, a, m: dict(embed_dim=dim, num_heads=a.num_heads)),
-    "dolg": ("poolings.dolg.dolg", "SpatialAttention2d",
-             lambda dim, a, m: dict(in_c=dim, s3_dim=dim, with_aspp=False)),
-    "cae": ("poolings.cae_att", "CAEAttentiveBlock", lambda dim, a, m: dict(dim=dim)),
-}
-
-
-def _reference_pooling(name: str) -> PoolingFactory:
-    mod_name, cls_name, kwargs = _REFERENCE_SPECS[name]
-
-    def make(dim, args, model):
-        try:
-            cls = getattr(importlib.import_module(mod_name), cls_name)
-        except Exception as e:  # the reference repo is not on sys.path
-            raise NotImplementedError(
-                f"--cls_features {name}: no native MI355X kernel yet and the reference module "
-                f"{mod_name}.{cls_name} is not importable ({e}); put the reference repository on sys.path or "
-                f"register a factory with efficient_probing_amd.probe_heads.register_pooling().") from e
-        return cls(**kwargs(dim, args, model))
-    return make
-
-
 def _make_ep(dim, args, model):
     return EfficientProbing(dim=dim, num_queries=args.ep_queries, d_out=args.d_out)
 
@@ -135,9 +91,7 @@ def _make_ep_classifier(dim, args):
     return Linear(dim // args.d_out, args.nb_classes, bias=True)
 
 
-POOLINGS: Dict[str, Tuple[PoolingFactory, ClassifierFactory]] = {
-    name: (_reference_pooling(name), None) for name in _REFERENCE_SPECS
-}
+POOLINGS: Dict[str, Tuple[PoolingFactory, ClassifierFactory]] = {}
 POOLINGS["ep"] = (_make_ep, _make_ep_classifier)
 POOLINGS["abmilp"] = (lambda dim, args, model: ABMILPHead(       # native (reference probe_heads.py:42-51)
     dim=dim, self_attention_apply_to=args.abmilp_sa, activation=args.abmilp_act, depth=args.abmilp_depth,

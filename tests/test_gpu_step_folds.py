@@ -80,16 +80,18 @@ sys.path.insert(0, os.getcwd())
 from argparse import Namespace
 from efficient_probing_amd import probe_heads
 from efficient_probing_amd.engine import ProbeHeadEngine
+D = int(os.environ.get("EP_TEST_D", "768")); BF16 = os.environ.get("EP_TEST_BF16", "0") == "1"
 class Enc(torch.nn.Module):
     def __init__(self):
-        super().__init__(); self.head = torch.nn.Linear(768, 1000)
+        super().__init__(); self.head = torch.nn.Linear(D, 1000)
 torch.manual_seed(0); enc = Enc()
 probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=8, d_out=1, nb_classes=1000))
 eng = ProbeHeadEngine(enc.head.to("cuda:0").train(), optimizer="lars", lr=0.4, weight_decay=1e-4)
 g = torch.Generator().manual_seed(5)
 losses = []
 for s in range(3):
-    x = torch.randn(1024, 50, 768, generator=g).to("cuda:0"); t = torch.randint(0, 1000, (1024,), generator=g).to("cuda:0")
+    x = torch.randn(1024, 50, D, generator=g).to("cuda:0"); t = torch.randint(0, 1000, (1024,), generator=g).to("cuda:0")
+    if BF16: x = x.to(torch.bfloat16)
     eng.train_step(x, t); losses.append(eng.read_stats()[0])
 torch.save({"loss": losses, "p": eng.flat_p.cpu()}, sys.argv[1])
 '''
@@ -105,6 +107,26 @@ def test_fold_on_and_off_agree(knob):
             env.pop(knob, None)
             if val is not None:
                 env[knob] = val
+            subprocess.run([sys.executable, "-c", CODE, f.name], check=True, env=env, cwd=ROOT)
+            outs.append(torch.load(f.name))
+    a, b = outs
+    assert np.allclose(a["loss"], b["loss"], rtol=2e-6)
+    assert torch.allclose(a["p"], b["p"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("D", [192, 640])
+def test_delta_fold_with_bf16_tokens_and_narrow_rows(D):
+    """bf16-STORED tokens at D % 256 != 0: the in-pass delta item (dy | y in 1-KiB pieces) must fit the ring
+    slot of the bf16 instantiation (twice the tokens per tile at half the bytes: the same slot bytes as fp32).  Shapes the
+    bf16 matrix-core kernels do not take, so the vector-ALU streaming kernel runs; fold on against ep_delta_kernel."""
+    outs = []
+    for val in (None, "0"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ)
+            env.pop("EP_POOL_DELTA", None)
+            env.update({"EP_TEST_D": str(D), "EP_TEST_BF16": "1"})
+            if val is not None:
+                env["EP_POOL_DELTA"] = val
             subprocess.run([sys.executable, "-c", CODE, f.name], check=True, env=env, cwd=ROOT)
             outs.append(torch.load(f.name))
     a, b = outs

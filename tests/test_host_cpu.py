@@ -119,14 +119,16 @@ def test_registry_surface():
     own = enc.head
     probe_heads.build_probe_head(enc, _args(cls_features="cls"))
     assert len(enc.head) == 2 and enc.head[1] is own
-    # every registry name is native; the reference's own module stays available as an explicit factory and fails loudly
-    # when the reference repository is not on sys.path
+    # every registry name is native and the product package holds no hook that imports the reference's modules; the
+    # development aid tools/reference_poolings.py fails loudly when the reference repository is not on sys.path
     assert all(probe_heads.POOLINGS[n][0] is not None for n in ATTENTIVE_POOLINGS)
     enc = StubEncoder(64, 10)
     probe_heads.build_probe_head(enc, _args(cls_features="dinovit"))
     assert probe_heads.is_native_dinovit_head(enc.head) and probe_heads.is_native_head(enc.head)
+    assert not hasattr(probe_heads, "_reference_pooling") and "importlib" not in vars(probe_heads)
+    from tools.reference_poolings import reference_pooling
     with pytest.raises(NotImplementedError, match="register_pooling"):
-        probe_heads._reference_pooling("dinovit")(64, _args(cls_features="dinovit"), enc)
+        reference_pooling("dinovit")(64, _args(cls_features="dinovit"), enc)
     # ... another implementation can be plugged in; it keeps the encoder's classifier
     native = probe_heads.POOLINGS["dinovit"]
     probe_heads.register_pooling("dinovit", lambda dim, a, m: torch.nn.Identity())

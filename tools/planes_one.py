@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One planes contraction launched back to back (GPU box; run under rocprofv3).  usage: planes_one.py {y|logits|dz|dP} [iters]"""
+"""One planes contraction launched back to back (GPU box; run under rocprofv3).  usage: planes_one.py {logits|dz|split} [iters]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
