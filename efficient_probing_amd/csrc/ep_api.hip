@@ -54,6 +54,8 @@ int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, in
 
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
+  float* ypart;                                // in-pass value projection: IP_YPARTS K-quarter partials of y (ep_inpass.h)
+  int *ycnt, *dcnt, *iperr; int nrb;           // arrival counters per 32-image row block (zero between steps), give-up count
   uint16_t *plWv, *plWvT, *plWc, *plWcT;       // bf16 planes of the two weight matrices, both orientations (ep_planes.hip)
   void* pool_ws; size_t pool_ws_bytes;
   void* opt_ws; size_t opt_ws_bytes;
@@ -96,6 +98,11 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   w.dz = take(B * Dp);
   w.dy = take(B * Dp);
   w.dP = take(B * d.Q * d.D);
+  w.ypart = take((size_t)IP_YPARTS * B * Dp);
+  w.nrb = (d.B + 31) / 32;
+  w.ycnt = reinterpret_cast<int*>(take(2 * (size_t)w.nrb + 4));
+  w.dcnt = w.ycnt ? w.ycnt + w.nrb : nullptr;
+  w.iperr = w.ycnt ? w.ycnt + 2 * w.nrb : nullptr;
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.Q);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
   int64_t offs[4];
@@ -442,6 +449,13 @@ size_t ep_head_workspace_bytes(const ep_head_dims* dims) {
   return carve(*dims, nullptr).total;
 }
 
+int64_t ep_head_workspace_flag_offset(const ep_head_dims* dims) {
+  if (!dims || check_dims(*dims) != 0) return -1;
+  char* base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // carve() only does address arithmetic on a non-null base
+  const HeadWs w = carve(*dims, base);
+  return reinterpret_cast<char*>(w.iperr) - base;
+}
+
 int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream_t stream) {
   EP_REQUIRE(s && ws, EP_E_ARG, "ep_head_train_step: null pointer");
   const ep_head_dims& d = s->dims;
@@ -482,15 +496,30 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     split_done = true;
   }
   DeferredReduce red{};                                       // last stage of the dcls reduction, finished by the optimizer
+  // In-pass contractions (ep_inpass.h): y inside the first pass -- only when the whole forward/backward is this call: in
+  // the split schedule (phases 4 / 8) the large update of the previous step lands BETWEEN the first pass and the
+  // projection, so the pass must not read Wv -- and dP inside the second pass.
+  const int ipmask = (s->phases & (1 | 4 | 8)) && !pl ? pool_inpass_mask(p, Dp) : 0;
+  const bool ip_y = (ipmask & 1) && (s->phases & 1) && bn_takes_parts(d.B);
+  if (ipmask) {
+    p.ip_err = w.iperr;
+    p.ip_zero = w.dcnt; p.ip_nzero = w.nrb;                   // the first pass clears the second pass's counters
+    if (ip_y) { p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; }
+  }
   if (s->phases & (1 | 4)) EP_TRY(pool_forward(p, st));      // first token pass: depends on cls_token only
+  p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
     if (pl) {
       if (split_done) EP_HIP(hipStreamWaitEvent(st, pev[1], 0));
       else EP_TRY(head_planes_split(d, w, Wv, Wc, st));
       EP_TRY(project_forward_pl(w, d, st));
-    } else {
+    } else if (!ip_y) {
       EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
     }
+    if (ip_y)   // the K-quarter partials of the in-pass projection are summed by the BatchNorm kernel (which also writes y)
+      EP_TRY(bn_forward_train(w.ypart, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
+                              s->num_batches_tracked, w.bnpart, st, IP_YPARTS, (int64_t)d.B * Dp, w.y));
+    else
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));
     if (pl) EP_TRY(linear_forward_pl(w, d, bc, st));
@@ -504,6 +533,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     const GemmParams gWc = dwc_gemm(w.dlogits, w.ldl, w.z, d.B, Dp, d.C, s->grads + offs[2], s->accumulate);
     const GemmParams gWv = dwv_gemm(w.dy, w.P, d.B, d.D, Dp, d.Q, s->grads + offs[1], s->accumulate);
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
+    if (ipmask) { p.ip_zero = w.ycnt; p.ip_nzero = w.nrb; }            // the second pass clears the first pass's counters
     if (pool_backward_takes_side(p) && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
       if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
       else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
@@ -511,11 +541,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       // the softmax-correction rows dy_q . y_q: inside the second pass where its kernel can (one launch less)
       const bool in_pass = pool_backward_takes_delta(p, Dp);
       if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
+      const bool ip_dp = (ipmask & 2) != 0;
+      if (ip_dp) { p.ip_dy = w.dy; p.ip_Wv = Wv; p.ip_dcnt = w.dcnt; }   // dP rows by the pooling workgroups themselves
       if (pl) {
         if (!in_pass) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));
       } else {
-        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, in_pass ? nullptr : w.ML, 0, st));
+        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, ip_dp ? nullptr : w.dP, nullptr,
+                                in_pass ? nullptr : w.ML, 0, st));
       }
       SideTasks sd{};
       side_add_gemm(sd, gWc, 1);

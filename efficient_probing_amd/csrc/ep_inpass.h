@@ -1,0 +1,202 @@
+// In-pass contractions of the fused EP step (gfx950): the two projections around the BatchNorm/classifier chain are
+// computed INSIDE the token passes by the pooling workgroups themselves, so that they cost the step (almost) no time of
+// their own -- the matrix pipe is idle while the passes stream, and HBM is idle while the contractions run:
+//
+//   first pass  : y[b, q Dq + c] = P[b, q, :] . Wv[q Dq + c, :]   (reference poolings/ep.py:40 after pool-then-project)
+//                 as four K-quarter partials, by workgroups that have finished their images while the others stream;
+//   second pass : dP[b, q, :] = dy[b, q-slice] Wv[q-slice, :]      (autograd of the same line)
+//                 by every pooling workgroup in front of its own stream (no contraction launch before the pass).
+//
+// Work unit: images are grouped into row blocks of 32; a row block needs 32 tasks = 8 queries x 4 quarters (K quarters
+// for y, column quarters for dP), and image b of the batch names task b: (row block b / 32, query (b % 32) / 4,
+// quarter b % 4).  Hand-off between workgroups: one arrival counter per row block in global memory, zero at launch,
+// bumped once per wave (release fence, relaxed agent-scope add); a consumer polls it from one lane with s_sleep and
+// fences (acquire) once it reads the target -- the barrier-counter recipe of MI355X_MICROARCH.md, per row block instead
+// of per grid.  A consumer only ever waits for workgroups that are resident (dispatch is in block order and the
+// producers of a row block have block indices no higher than 31 above the consumer's), and every wait is bounded
+// (PoolParams.ip_err counts give-ups; tests assert it stays zero).
+//
+// Shapes: Q = 8, D = 256 KT (KT = 1..3), d_out = 1, B % 32 == 0, pooling grid % 32 == 0 (host-checked: ep_pool.hip).
+#pragma once
+#include "ep_common.h"
+#include "ep_internal.h"
+#include "ep_side.h"
+
+namespace ep {
+
+constexpr int IP_WAVES = 4;                      // waves per workgroup of the kernels that carry these tasks
+constexpr int IP_TARGET = 32 * IP_WAVES;         // arrivals that complete a row block
+constexpr int IP_SPIN_LIMIT = 1 << 21;           // x ~0.3 us per poll: gives up after ~0.5 s instead of hanging the GPU
+
+// this wave's global stores so far become visible device-wide, then one arrival
+__device__ __forceinline__ void ip_arrive(int* cnt) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane_id() == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// whole workgroup: returns once *cnt >= target (polled by one lane), with an acquire fence in every wave
+__device__ __forceinline__ void ip_wait(int* cnt, int target, int* err) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > IP_SPIN_LIMIT) { if (err) atomicAdd(err, 1); break; }
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// LDS bytes the tasks need (the token ring of the pass is idle while they run)
+constexpr size_t ip_dp_lds_bytes(int kt) {
+  return (size_t)(32 * (((32 * kt + 29) / 64) * 64 + 34) + 32 * kt * (64 + 16)) * sizeof(float);
+}
+constexpr size_t ip_y_lds_bytes(int kt) { return (size_t)2 * (32 + 32 * kt) * (BK + 2) * sizeof(float); }
+
+// ---- second pass: dP rows of one (row block, query, column quarter) --------------------------------------------
+// A = dy[32 rows, q-slice of DQ = 32 KT columns] (K layout), B = Wv[q-slice rows, column quarter of 64 KT] (T layout: k-rows
+// of contiguous output columns).  Everything is fetched up front (KT + 2 KT KT float4 per thread), one round trip; the
+// A image stays in LDS, the KT 64-column B tiles pass through one LDS buffer.  Exact fp32 (v_mfma_f32_16x16x4_f32).
+template <int KT>
+__device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds_raw) {
+  constexpr int DQ = 32 * KT, D = 256 * KT, Q = 8, CW = 64 * KT;
+  constexpr int SA = ((DQ + 29) / 64) * 64 + 34;      // A row stride in floats, == 34 (mod 64): conflict-free fragment reads
+  constexpr int SB = 64 + 16;                         // B k-row stride
+  float* As = reinterpret_cast<float*>(lds_raw);      // [32][SA]
+  float* Bs = As + 32 * SA;                           // [DQ][SB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = wave_id_uniform();
+  const int wm = w >> 1, wn = w & 1, i16 = lane & 15, kk = lane >> 4;
+  const int rb = b >> 5, r = b & 31, q = r >> 2, ch = r & 3;
+  const int row0 = rb * 32;
+  const float* A = p.ip_dy + (int64_t)row0 * D + q * DQ;
+  const float* W = p.ip_Wv + (int64_t)q * DQ * D + ch * CW;
+  float* C = const_cast<float*>(p.dP) + ((int64_t)row0 * Q + q) * D + ch * CW;
+
+  f4v ra[KT], rw[KT][2 * KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    const int idx = tid + 256 * i;
+    ra[i] = *reinterpret_cast<const f4v*>(A + (int64_t)(idx / (DQ / 4)) * D + 4 * (idx % (DQ / 4)));
+  }
+#pragma unroll
+  for (int nt = 0; nt < KT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 2 * KT; ++i) {
+      const int idx = tid + 256 * i;
+      rw[nt][i] = *reinterpret_cast<const f4v*>(W + (int64_t)(idx >> 4) * D + nt * 64 + 4 * (idx & 15));
+    }
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    const int idx = tid + 256 * i;
+    float* d = As + (idx / (DQ / 4)) * SA + 4 * (idx % (DQ / 4));
+    *reinterpret_cast<f2*>(d) = f2{ra[i].x, ra[i].y};
+    *reinterpret_cast<f2*>(d + 2) = f2{ra[i].z, ra[i].w};
+  }
+#pragma unroll
+  for (int nt = 0; nt < KT; ++nt) {
+    if (nt > 0) __syncthreads();                       // every wave is done reading the previous B tile
+#pragma unroll
+    for (int i = 0; i < 2 * KT; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<f4v*>(Bs + (idx >> 4) * SB + 4 * (idx & 15)) = rw[nt][i];
+    }
+    __syncthreads();
+    f4v acc[2] = {f4v{0.f, 0.f, 0.f, 0.f}, f4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float af[8], bf[8][2];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int k = 32 * kt + 4 * s + kk;
+        af[s] = As[(wm * 16 + i16) * SA + k];
+        bf[s][0] = Bs[k * SB + wn * 32 + i16];
+        bf[s][1] = Bs[k * SB + wn * 32 + 16 + i16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s][1], acc[1], 0, 0, 0);
+      }
+    }
+    // D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        C[(int64_t)(wm * 16 + kk * 4 + rr) * Q * D + nt * 64 + wn * 32 + ni * 16 + i16] = acc[ni][rr];
+  }
+  __syncthreads();                                     // LDS free for the next task / the token ring
+}
+
+// ---- first pass: one K quarter of y for (row block, query) -------------------------------------------------------
+// A = P[32 rows, q, K quarter of 64 KT] (K layout, row stride Q D), B = Wv[q-slice rows (32 KT outputs), K quarter]
+// (K layout).  Output 32 x 32 KT into the partial buffer of that quarter; wave (wm, wn) owns 16 rows x 16 KT columns.
+// All 2 KT K-tiles are fetched up front (2 KT (1 + KT) float4 per thread), then pass through a double LDS buffer.
+template <int KT>
+__device__ __forceinline__ void ip_y_task(const PoolParams& p, int b, char* lds_raw) {
+  constexpr int DQ = 32 * KT, D = 256 * KT, Q = 8, NKT = 2 * KT;
+  constexpr int LDK2 = BK + 2;
+  constexpr int STAGE = (32 + DQ) * LDK2;             // floats per stage: A image then B image
+  float* stage = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = wave_id_uniform();
+  const int wm = w >> 1, wn = w & 1, i16 = lane & 15, kk = lane >> 4;
+  const int rb = b >> 5, r = b & 31, q = r >> 2, ks = r & 3;
+  const int row0 = rb * 32;
+  const float* A = p.P + ((int64_t)row0 * Q + q) * D + ks * (64 * KT);
+  const float* W = p.ip_WvF + (int64_t)q * DQ * D + ks * (64 * KT);
+  float* C = p.ip_ypart + ((int64_t)ks * p.B + row0) * D + q * DQ;
+
+  f4v ra[NKT], rw[NKT][KT];
+  const int lrow = tid >> 3, lc = 4 * (tid & 7);
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    ra[t] = *reinterpret_cast<const f4v*>(A + (int64_t)lrow * Q * D + 32 * t + lc);
+#pragma unroll
+    for (int i = 0; i < KT; ++i) rw[t][i] = *reinterpret_cast<const f4v*>(W + (int64_t)(lrow + 32 * i) * D + 32 * t + lc);
+  }
+  auto lstore = [&](int t) {
+    float* sa = stage + (t & 1) * STAGE;
+    float* d = sa + lrow * LDK2 + lc;
+    *reinterpret_cast<f2*>(d) = f2{ra[t].x, ra[t].y};
+    *reinterpret_cast<f2*>(d + 2) = f2{ra[t].z, ra[t].w};
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      float* e = sa + (32 + lrow + 32 * i) * LDK2 + lc;
+      *reinterpret_cast<f2*>(e) = f2{rw[t][i].x, rw[t][i].y};
+      *reinterpret_cast<f2*>(e + 2) = f2{rw[t][i].z, rw[t][i].w};
+    }
+  };
+  f4v acc[KT];
+#pragma unroll
+  for (int bi = 0; bi < KT; ++bi) acc[bi] = f4v{0.f, 0.f, 0.f, 0.f};
+  lstore(0);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (t + 1 < NKT) lstore(t + 1);                    // the other buffer: everyone left it before the last barrier
+    const float* sa = stage + (t & 1) * STAGE;
+    const float* sb = sa + 32 * LDK2;
+    float af[8], bf[8][KT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      af[s] = sa[(wm * 16 + i16) * LDK2 + 4 * s + kk];
+#pragma unroll
+      for (int bi = 0; bi < KT; ++bi) bf[s][bi] = sb[(wn * 16 * KT + bi * 16 + i16) * LDK2 + 4 * s + kk];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int bi = 0; bi < KT; ++bi) acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s][bi], acc[bi], 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int bi = 0; bi < KT; ++bi)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      C[(int64_t)(wm * 16 + kk * 4 + rr) * D + wn * 16 * KT + bi * 16 + i16] = acc[bi][rr];
+}
+
+}  // namespace ep

@@ -30,6 +30,17 @@ struct PoolParams {
   // (= dP[b,q] . P[b,q]) computed by the pass itself from one extra ring item per image instead of being read from
   // ML[b,q,2] (saves the ep_delta_kernel launch in front of the pass); null: read ML
   const float* dyv; const float* yv; int Dv;
+  // ---- in-pass contractions of the fused EP step (ep_inpass.h; 4-wave vector-ALU streaming kernels, Q = 8, D = 256 KP,
+  // d_out = 1, B and the pooling grid multiples of 32).  Image b owns "task b" of its 32-image row block: one of the
+  // 8 queries x 4 column (K) quarters.  Counters: one int per row block, ZERO at launch, 4 wave arrivals per task.
+  // second pass: dP[b, q, :] = dy[b, q-slice] Wv[q-slice, :] is produced by the pooling workgroups themselves before they
+  // stream (no ep_gemm launch in front of the pass): ip_dy (B, D), ip_Wv (D, D), the result goes to the buffer `dP` points at
+  const float* ip_dy; const float* ip_Wv; int* ip_dcnt;
+  // first pass: y = P_q Wv_q^T as four K-quarter partials ip_ypart[ks][b][:] by the workgroups that have finished their
+  // images (the matrix pipe is idle under the pass); BatchNorm sums the partials in fixed order
+  const float* ip_WvF; float* ip_ypart; int* ip_ycnt;
+  int* ip_zero; int ip_nzero;   // counters this launch clears for the OTHER pass (first instructions of workgroup 0)
+  int* ip_err;           // bumped when a bounded flag wait gives up (never in a correct run; tests read it)
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
   int kdma;              // 16-byte DMA instructions per wave per ring item
@@ -96,6 +107,10 @@ int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t 
                   DeferredReduce* defer = nullptr);
 bool pool_backward_takes_side(const PoolParams& p);
 bool pool_backward_takes_delta(const PoolParams& p, int Dv);   // ... and compute the delta rows itself (dyv / yv / Dv)
+// In-pass contractions (ep_inpass.h) possible for this shape on BOTH passes?  bit 0: y inside the first pass, bit 1: dP
+// inside the second (EP_INPASS=<mask> switches them, default 3).  Dv = width of the projection (must equal D).
+int pool_inpass_mask(const PoolParams& p, int Dv);
+constexpr int IP_YPARTS = 4;                                   // K quarters of the in-pass value projection
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
 int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
@@ -107,8 +122,12 @@ int attention_from_scores(const float* S, const float* ML, int rows, int N, floa
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
 
 size_t bn_workspace_bytes(int B, int Dp);
+// nparts > 1 (one-launch kernel only, B <= 1024): y is given as nparts partial matrices `pstride` floats apart, summed in
+// fixed order ((p0 + p1) + (p2 + p3)); the sum is also written to y_out (may be null)
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
-                     float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st);
+                     float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st, int nparts = 1,
+                     int64_t pstride = 0, float* y_out = nullptr);
+bool bn_takes_parts(int B);
 int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean, const float* rvar, float* z,
                     hipStream_t st);
 int bn_backward(const float* dz, const float* z, const float* rstd, int B, int Dp, float* dy, float* partial,

@@ -445,6 +445,24 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
   return 2 * (((size_t)Dv * 4 + 1023) / 1024) * 1024 <= slot;
 }
 
+// In-pass contractions (ep_inpass.h): both passes on the 4-wave / 2-queries-per-wave streaming kernel, Q = 8, D = 256 kp,
+// projection width = D, whole row blocks of 32 images, pooling grid a multiple of 32 (a row block's producers then sit in
+// one aligned group of 32 workgroups).
+int pool_inpass_mask(const PoolParams& p, int Dv) {
+  static int want = -1;
+  if (want < 0) { const char* e = getenv("EP_INPASS"); want = e ? atoi(e) : 3; }
+  if (!want || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) ||
+      use_mm(p, false) || use_mf(p, false) || force_generic() || !stream_takes(p)) return 0;
+  const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+  if (!c.ok || c.nw != 4 || c.qw != 2 || c.kp > 3 || p.Q != 8 || p.D != 256 * c.kp || Dv != p.D || p.B % 32 != 0 ||
+      c.grid % 32 != 0 || p.cls_bstride != 0)
+    return 0;
+  static int bwd_grid = -1;           // (diagnostic grid override of the second pass, see pool_backward)
+  if (bwd_grid < 0) { const char* e = getenv("EP_POOL_BWD_GRID"); bwd_grid = e ? atoi(e) : 0; }
+  if (bwd_grid > 0 && bwd_grid % 32 != 0) return 0;
+  return want & 3;
+}
+
 int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side,
                   DeferredReduce* defer) {
   PoolParams p = p0;

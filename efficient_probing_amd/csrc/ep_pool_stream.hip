@@ -24,6 +24,7 @@
 #include "ep_internal.h"
 #include "ep_pool_stream.h"
 #include "ep_side.h"
+#include "ep_inpass.h"
 
 namespace ep {
 
@@ -200,6 +201,12 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   const int wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;     // images b = wg + j*G
   const int n_items = n_img * tiles_per_img;
+  // in-pass contractions (ep_inpass.h): this launch clears the arrival counters of the OTHER pass
+  constexpr bool IPOK = (NW == 4 && QW == 2 && KP <= 3 && !LN);
+  if constexpr (IPOK) {
+    if (wg == 0 && p.ip_zero)
+      for (int t = threadIdx.x; t < p.ip_nzero; t += NW * 64) p.ip_zero[t] = 0;
+  }
   if (n_items <= 0) return;
   const int q0 = w * QW;
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -400,6 +407,33 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         }
       }
     }
+    if constexpr (IPOK) {
+      if (p.ip_ycnt) ip_arrive(p.ip_ycnt + (b >> 5));       // this wave's P rows of image b are out
+    }
+  }
+  // ---- in-pass value projection (ep_inpass.h): this workgroup has streamed all its images; while the others still
+  // stream it runs projection tasks on the idle matrix pipe.  Rounds: R = ceil(B / G); the `nfull` workgroups that own an
+  // image of the last round are busy until the end of the pass, so the tasks of their EARLIER images are dealt to the
+  // workgroups that are done one round sooner ("helpers"); a workgroup runs the tasks of the images it finished last.
+  if constexpr (IPOK) {
+    if (p.ip_ycnt) {
+      __syncthreads();                                       // every wave has left the token ring
+      const int R = (p.B + G - 1) / G;
+      const int nfull = p.B - (R - 1) * G;                   // workgroups with R images (== G when B % G == 0)
+      const int nh = G - nfull;                              // helpers: done one round before the end of the pass
+      const bool owner_last = wg < nfull;
+      int ntask;
+      if (owner_last) ntask = nh == 0 ? R : 1;               // no helpers: all of its images' tasks, at the end
+      else ntask = (R - 1) + ((R - 1) * nfull - (wg - nfull) + nh - 1) / nh;
+      for (int i = 0; i < ntask; ++i) {                      // ONE copy of the task body in the kernel
+        int b;
+        if (owner_last) b = nh == 0 ? wg + i * G : wg + (R - 1) * G;
+        else if (i < R - 1) b = wg + i * G;
+        else { const int e = (wg - nfull) + (i - (R - 1)) * nh; b = (e % nfull) + (e / nfull) * G; }
+        ip_wait(p.ip_ycnt + (b >> 5), IP_TARGET, p.ip_err);
+        ip_y_task<KP>(p, b, ring);
+      }
+    }
   }
 }
 
@@ -433,6 +467,21 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   }
   const int lane = lane_id();
   const int w = wave_id_uniform();
+  // ---- in-pass contractions (ep_inpass.h): clear the first pass's counters; produce the dP rows of this workgroup's
+  // images' tasks, publish them, and wait for the row blocks of its own images before the stream (whose header items
+  // read dP) starts.  The producers of a row block sit in the consumer's own aligned group of 32 workgroups.
+  constexpr bool IPOK = (NW == 4 && QW == 2 && KP <= 3 && !LN);
+  if constexpr (IPOK) {
+    if (wg == 0 && p.ip_zero)
+      for (int t = threadIdx.x; t < p.ip_nzero; t += NW * 64) p.ip_zero[t] = 0;
+    if (p.ip_dy) {
+      for (int b = wg; b < p.B; b += G) {
+        ip_dp_task<KP>(p, b, ring);
+        ip_arrive(p.ip_dcnt + (b >> 5));
+      }
+      for (int b = wg; b < p.B; b += G) ip_wait(p.ip_dcnt + (b >> 5), IP_TARGET, p.ip_err);
+    }
+  }
   const int D = DFIX ? DFIX : p.D;
   const int N = p.N, Q = p.Q;
   const int rowbytes = D * ES;                      // token rows
@@ -664,6 +713,10 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   const int D = p.D;
   const size_t slot = (size_t)Cfg::TT * D * 4;          // bf16: twice the tokens, half the bytes each
   size_t lds = (bwd || LN) ? (size_t)Cfg::NSLOT_B * (slot + (size_t)NW * 256) : (size_t)Cfg::NSLOT_F * slot;
+  if constexpr (NW == 4 && QW == 2 && KP <= 3 && !LN) {     // in-pass tasks reuse the ring's LDS
+    if (bwd && p.ip_dy && lds < ip_dp_lds_bytes(KP)) lds = ip_dp_lds_bytes(KP);
+    if (!bwd && p.ip_ycnt && lds < ip_y_lds_bytes(KP)) lds = ip_y_lds_bytes(KP);
+  }
   SideTasks sd{};
   if (bwd && side && side->total > 0) {
     if (NW != 4) { set_error("side tasks need 4-wave workgroups"); return EP_E_UNSUPPORTED; }

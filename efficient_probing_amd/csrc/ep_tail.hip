@@ -106,20 +106,44 @@ __device__ __forceinline__ float bnf_reduce(float v, float (*sm)[16], int tx, in
   return t;
 }
 
+// PARTS: y arrives as four partial matrices `pstride` floats apart (the K quarters of the in-pass value projection,
+// ep_inpass.h), summed here as (p0 + p1) + (p2 + p3); the sum is written to y_out for the second token pass.
+template <bool PARTS>
 __global__ __launch_bounds__(1024) void ep_bn_fused_kernel(const float* __restrict__ y, int B, int Dp, float eps, float momentum,
                                                          float* __restrict__ z, float* __restrict__ rstd_out,
                                                          float* __restrict__ rmean, float* __restrict__ rvar,
-                                                         int64_t* __restrict__ nbt) {
+                                                         int64_t* __restrict__ nbt, int64_t pstride,
+                                                         float* __restrict__ y_out) {
   __shared__ float sm[16][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, wv = threadIdx.x >> 6;
   const int col = blockIdx.x * 16 + tx;
   const bool ok = col < Dp;
   float v[BNF_RPT];
   float s = 0.f;
+  if constexpr (PARTS) {
+    float pq[BNF_RPT][4];
 #pragma unroll
-  for (int i = 0; i < BNF_RPT; ++i) {                  // branch-free loads (clamped address): all in flight together
-    const int b = ty + 64 * i;
-    v[i] = y[(int64_t)(b < B ? b : B - 1) * Dp + (ok ? col : 0)];
+    for (int i = 0; i < BNF_RPT; ++i) {                // branch-free loads (clamped address): all in flight together
+      const int b = ty + 64 * i;
+      const int64_t at = (int64_t)(b < B ? b : B - 1) * Dp + (ok ? col : 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pq[i][k] = y[(int64_t)k * pstride + at];
+    }
+#pragma unroll
+    for (int i = 0; i < BNF_RPT; ++i) v[i] = (pq[i][0] + pq[i][1]) + (pq[i][2] + pq[i][3]);
+    if (y_out) {
+#pragma unroll
+      for (int i = 0; i < BNF_RPT; ++i) {
+        const int b = ty + 64 * i;
+        if (ok && b < B) y_out[(int64_t)b * Dp + col] = v[i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < BNF_RPT; ++i) {                  // branch-free loads (clamped address): all in flight together
+      const int b = ty + 64 * i;
+      v[i] = y[(int64_t)(b < B ? b : B - 1) * Dp + (ok ? col : 0)];
+    }
   }
 #pragma unroll
   for (int i = 0; i < BNF_RPT; ++i) {
@@ -497,11 +521,19 @@ static bool bn_fused(int B) {
 }
 size_t bn_workspace_bytes(int B, int Dp) { (void)B; return round_up((size_t)RS_MAX * 2 * Dp * sizeof(float), 256); }
 
+bool bn_takes_parts(int B) { return bn_fused(B); }
+
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
-                     float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st) {
+                     float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st, int nparts, int64_t pstride,
+                     float* y_out) {
+  EP_REQUIRE(nparts == 1 || (nparts == 4 && bn_fused(B)), EP_E_UNSUPPORTED, "BatchNorm over partial sums: 4 parts, B <= %d", 64 * BNF_RPT);
   if (bn_fused(B)) {
-    hipLaunchKernelGGL(ep_bn_fused_kernel, dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean, rvar,
-                       nbt);
+    if (nparts == 4)
+      hipLaunchKernelGGL(ep_bn_fused_kernel<true>, dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean,
+                         rvar, nbt, pstride, y_out);
+    else
+      hipLaunchKernelGGL(ep_bn_fused_kernel<false>, dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean,
+                         rvar, nbt, (int64_t)0, nullptr);
     EP_LAUNCH_CHECK("ep_bn_fused_kernel");
     return 0;
   }

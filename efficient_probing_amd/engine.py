@@ -142,7 +142,8 @@ class ProbeHeadEngine:
             nbytes = self._ws_bytes()
             if nbytes == 0:
                 raise RuntimeError(f"head workspace query: {N.last_error()}")
-            self._ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+            # zero-filled: the step keeps arrival counters in it that it leaves at zero (include/ep_hip.h, ABI v21)
+            self._ws = torch.zeros(nbytes, device=self.device, dtype=torch.uint8)
             self._ws_key = key
         return self._ws
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 20
+#define EP_ABI_VERSION 21
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -227,7 +227,11 @@ int ep_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
  * the total element count).
  * phases: 1 = forward+loss+backward into `grads` (accumulating if accumulate != 0);
  *         2 = optimizer only; 3 = both.  Between 1 and 2 the caller may all-reduce `grads`
- *         (the single RCCL all-reduce per step that replaces DDP, main_linprobe.py:581-583).  */
+ *         (the single RCCL all-reduce per step that replaces DDP, main_linprobe.py:581-583).
+ * Workspace contract (ABI v21): `ws` must be ZERO-FILLED by the caller before its first use (hipMemset once after the
+ * allocation) and must not be written by the caller between steps.  It holds the arrival counters of the in-pass
+ * contractions (csrc/ep_inpass.h: the value projection and its dP gradient computed inside the two token passes), which
+ * every step leaves at zero again.  A workspace may serve another (B, N) of the same byte size after being zero-filled. */
 typedef struct ep_head_dims {
   int32_t B, N, D, Q, d_out, C;
 } ep_head_dims;
@@ -264,6 +268,9 @@ typedef struct ep_head_step {
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);
 size_t ep_head_workspace_bytes(const ep_head_dims* dims);
+/* byte offset inside `ws` of an int32 that counts bounded flag waits of the in-pass contractions that gave up (always 0
+ * in a correct run; a diagnostic for tests).  -1: bad dims. */
+int64_t ep_head_workspace_flag_offset(const ep_head_dims* dims);
 int ep_head_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 /* eval forward: logits (B, ldl) from tokens using running statistics
  * (reference engine_finetune.py:106-166 inner forward).                                    */
