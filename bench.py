@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-secondary", action="store_true", help="skip the bf16-token-storage line of the default EP run")
     ap.add_argument("--no-north-star", action="store_true", help="skip the north-star-shape (197x768) object of the default EP run")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 20-step secondaries of the other BASELINE configurations (c1, c3, c4, c5)")
+    ap.add_argument("--no-through-engine", action="store_true",
+                    help="skip the train_one_epoch() secondary (the same workload through the reference's loop surface)")
+    ap.add_argument("--engine-steps", type=int, default=200, help="iterations of the train_one_epoch() secondary")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher check without a GPU: spawn / join the ranks (gloo), all-reduce a flat buffer of the "
                          "gradient's size once and print the rank count -- no kernels, no throughput")
@@ -322,6 +326,7 @@ def main():
         xs = [x.to(torch.bfloat16) for x in xs]
     esize = 2 if args.tokens == "bf16" else 4
     ts = [torch.randint(0, Cc, (B,), device=dev, generator=gen) for _ in range(args.buffers)]
+    ts_all = ts
 
     def barrier():
         if world > 1:
@@ -343,6 +348,8 @@ def main():
     # of (a ~6 us hole per mark in the kernel timeline), so the marks sit every `mark_every` steps and a sample is the
     # mean step time of one such window
     me = max(1, args.mark_every)
+    if args.steps // me < 5:                               # the spread comes from at least five windows
+        me = max(1, args.steps // 5)
     nwin = args.steps // me
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(nwin + 1)]
     t0 = time.perf_counter()
@@ -446,6 +453,30 @@ def main():
                                           dP.data_ptr(), dcls.data_ptr(), 0, ws.data_ptr(), ws_bytes, stream), "bwd")
     t_bwd = time_kernel(run_bwd, args.kernel_iters)
 
+    # ---- the two token-pass launches INSIDE the step (they carry the in-pass contractions and the weight-gradient side
+    # work): event-bracketed by the library in a few untimed, instrumented steps (ep_debug_set_pass_events)
+    in_step = None
+    if args.head == "ep":
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for e in evs:
+            e.record()                                       # (creates the underlying hipEvent_t)
+        torch.cuda.synchronize()
+        fw, bw = [], []
+        try:
+            eng.lib.ep_debug_set_pass_events(*[e.cuda_event for e in evs])
+            for i in range(12):
+                eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+                torch.cuda.synchronize()
+                if i >= 2:
+                    fw.append(evs[0].elapsed_time(evs[1]) * 1e3); bw.append(evs[2].elapsed_time(evs[3]) * 1e3)
+        finally:
+            eng.lib.ep_debug_set_pass_events(None, None, None, None)
+        eng.flush(); eng.read_stats()
+        fw.sort(); bw.sort()
+        in_step = {"fwd_us": round(fw[len(fw) // 2], 2), "bwd_us": round(bw[len(bw) // 2], 2), "samples": len(fw),
+                   "method": "hipEvents recorded by the library around the two pass launches of 10 untimed steps (median); "
+                             "an event drains the queue, so each figure includes the ~2 us fill of an empty chip"}
+
     algo_bytes = B * Nn * D * esize                           # one streaming read of the stored tokens
     dt = 1 if args.tokens == "bf16" else 0
     kname_f = "ep_imgqf_kernel (forward)" if rowq else "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (forward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 0, dt).decode()
@@ -453,7 +484,7 @@ def main():
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic, traffic_source = None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"{args.workload}_hbm_traffic_pmc.json")
         if traffic is None and os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
             try:
@@ -467,17 +498,18 @@ def main():
     bwd_gbs = algo_bytes / t_bwd / 1e9
 
     # ---- secondary runs of the SAME step (never `value`): a fresh head + engine per run, the same timing protocol
-    def secondary(sN, sD, sQ, storage, steps, toks=None):
+    def secondary(sN, sD, sQ, storage, steps, toks=None, sC=None):
+        sC = sC or Cc
         torch.manual_seed(0)
-        enc2 = Enc() if sD == D else None
-        if enc2 is None:
-            class Enc2(torch.nn.Module):
-                def __init__(self):
-                    super().__init__()
-                    self.head = torch.nn.Linear(sD, Cc)
-            enc2 = Enc2()
-        probe_heads.build_probe_head(enc2, Namespace(cls_features="ep", ep_queries=sQ, d_out=1, nb_classes=Cc, num_heads=16,
+
+        class Enc2(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.head = torch.nn.Linear(sD, sC)
+        enc2 = Enc2()
+        probe_heads.build_probe_head(enc2, Namespace(cls_features="ep", ep_queries=sQ, d_out=1, nb_classes=sC, num_heads=16,
                                                      model="vit_base_patch16"))
+        ts = [t % sC for t in ts_all]
         h2 = enc2.head.to(dev).train()
         eng2 = make_engine(h2, optimizer="lars", lr=lr, weight_decay=0.0)
         if toks is None:
@@ -525,9 +557,72 @@ def main():
         ns_line = secondary(nsN, nsD, nsQ, "f32", args.steps)
         ns_line["workload"] = WORKLOADS["ns"][4]
 
+    # every other BASELINE configuration as a short secondary of the same step (never `value`)
+    configs = None
+    if default_ep and not args.no_configs:
+        configs = {}
+        for name in ("c1", "c3", "c4", "c5"):
+            cN, cD, cQ, cC, cdesc = WORKLOADS[name]
+            torch.cuda.empty_cache()
+            line = secondary(cN, cD, cQ, "f32", 20, sC=cC)
+            line["workload"] = cdesc
+            line["classes"] = cC
+            configs[name] = line
+        torch.cuda.empty_cache()
+    # the same workload through the reference's loop surface (engine_finetune.train_one_epoch, reference
+    # engine_finetune.py:22-103): a resident token store, adjust_learning_rate every iteration, meters every 20
+    through = None
+    if default_ep and world == 1 and not args.no_through_engine:
+        import contextlib
+        from efficient_probing_amd import engine_finetune as EF
+        from efficient_probing_amd.token_store import ResidentTokenStore
+        from efficient_probing_amd.util.lars import LARS
+        torch.manual_seed(0)
+        enc3 = Enc()
+        probe_heads.build_probe_head(enc3, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
+                                                     model="vit_base_patch16"))
+        enc3.to(dev)
+        store = ResidentTokenStore.from_tensors(torch.cat(xs, 0), torch.cat(ts, 0))
+        n_it = args.engine_steps
+
+        class Epochs:                                        # `n_it` iterations: the store's epochs back to back
+            def __len__(self):
+                return n_it
+
+            def __iter__(self):
+                k, ep = 0, 0
+                while k < n_it:
+                    for bt in store.batches(B, epoch=ep):
+                        if k == n_it:
+                            return
+                        k += 1
+                        yield bt
+                    ep += 1
+        opt3 = LARS(enc3.head.parameters(), lr=lr, weight_decay=0.0)
+        a3 = Namespace(lr=lr, min_lr=0.0, warmup_epochs=10, epochs=90, accum_iter=1, amp="none")
+        crit = torch.nn.CrossEntropyLoss()
+        with contextlib.redirect_stdout(sys.stderr):
+            n_it = 60
+            EF.train_one_epoch(enc3, crit, Epochs(), opt3, dev, 20, None, args=a3)      # spin-up + warm-up, untimed
+            n_it = args.engine_steps
+            barrier()
+            tq0 = time.perf_counter()
+            st3 = EF.train_one_epoch(enc3, crit, Epochs(), opt3, dev, 21, None, args=a3)
+            barrier()
+            el3 = time.perf_counter() - tq0
+        through = {"value": round(B * n_it / el3, 1), "unit": "images/s", "steps": n_it, "ms_per_step": round(el3 / n_it * 1e3, 4),
+                   "surface": "efficient_probing_amd.engine_finetune.train_one_epoch over ResidentTokenStore batches "
+                              "(image_index into HBM-resident tokens), LARS, lr_sched.adjust_learning_rate per iteration, "
+                              "meters read back every 20 iterations",
+                   "mean_loss": round(float(st3.get("loss", float("nan"))), 5)}
+        del store
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
+        if through is not None:
+            through["vs_train_step"] = round(through["value"] / value, 4)
         out = {
             "metric": {"ep": "EP-head train images/sec", "coca": "CoCa-head train images/sec",
                        "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec",
@@ -554,6 +649,16 @@ def main():
                       "step_ms_device": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}},
             "eval_forward": {"value": round(B / eval_s, 1), "unit": "images/s per GPU", "ms_per_batch": round(eval_s * 1e3, 4)},
         }
+        if in_step is not None:
+            # the stand-alone figures above price the pass kernels alone; these are the same launches inside the step
+            in_step["fwd_frac"] = round(algo_bytes / (in_step["fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            in_step["bwd_frac"] = round(algo_bytes / (in_step["bwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            in_step["between_and_after_us"] = round(ms_per_step * 1e3 - in_step["fwd_us"] - in_step["bwd_us"], 2)
+            out["roofline"]["in_step"] = in_step
+        if configs is not None:
+            out["configs"] = configs
+        if through is not None:
+            out["train_one_epoch"] = through
         if bf16_line is not None:
             out["bf16_token_storage"] = bf16_line
         if ns_line is not None:

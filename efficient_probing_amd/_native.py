@@ -339,6 +339,7 @@ SIGNATURES = {
     "ep_head_param_offsets": (c_i64, [C.POINTER(EPHeadDims), C.POINTER(c_i64)]),
     "ep_head_workspace_bytes": (c_size, [C.POINTER(EPHeadDims)]),
     "ep_head_workspace_flag_offset": (C.c_int64, [C.POINTER(EPHeadDims)]),
+    "ep_debug_set_pass_events": (c_int, [c_void, c_void, c_void, c_void]),
     "ep_head_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),
     "ep_head_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p,
                                      c_float, c_f32p, c_int, c_void, c_size, c_void]),

@@ -8,6 +8,9 @@
 namespace ep {
 
 static thread_local char g_err[512] = "";
+// diagnostics (ep_debug_set_pass_events): events recorded around the two token passes of the next EP head train steps
+static thread_local hipEvent_t g_pass_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+static inline void mark_pass(int i, hipStream_t st) { if (g_pass_ev[i]) (void)hipEventRecord(g_pass_ev[i], st); }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -262,6 +265,11 @@ int ep_version(void) { return EP_ABI_VERSION; }
 const char* ep_last_error_string(void) { return g_err; }
 int ep_device_cu_count(void) { return cu_count(); }
 int ep_debug_force_generic_pool(int on) { return debug_force_generic(on); }
+int ep_debug_set_pass_events(void* fwd_begin, void* fwd_end, void* bwd_begin, void* bwd_end) {
+  g_pass_ev[0] = (hipEvent_t)fwd_begin; g_pass_ev[1] = (hipEvent_t)fwd_end;
+  g_pass_ev[2] = (hipEvent_t)bwd_begin; g_pass_ev[3] = (hipEvent_t)bwd_end;
+  return 0;
+}
 
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q) { return pool_workspace_bytes(B, N, D, Q); }
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward) { return pool_kernel_family(B, N, D, Q, backward); }
@@ -506,7 +514,11 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     p.ip_zero = w.dcnt; p.ip_nzero = w.nrb;                   // the first pass clears the second pass's counters
     if (ip_y) { p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; }
   }
-  if (s->phases & (1 | 4)) EP_TRY(pool_forward(p, st));      // first token pass: depends on cls_token only
+  if (s->phases & (1 | 4)) {                                  // first token pass: depends on cls_token only
+    mark_pass(0, st);
+    EP_TRY(pool_forward(p, st));
+    mark_pass(1, st);
+  }
   p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
     if (pl) {
@@ -557,7 +569,9 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
       sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;
       sd.total += sd.n_colsum + sd.n_stats;
+      mark_pass(2, st);
       EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, &sd, (s->phases & 2) ? &red : nullptr));
+      mark_pass(3, st);
     } else {
       hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
       hipEvent_t ev[3] = {nullptr, nullptr, nullptr};

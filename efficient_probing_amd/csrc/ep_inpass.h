@@ -9,12 +9,16 @@
 //
 // Work unit: images are grouped into row blocks of 32; a row block needs 32 tasks = 8 queries x 4 quarters (K quarters
 // for y, column quarters for dP), and image b of the batch names task b: (row block b / 32, query (b % 32) / 4,
-// quarter b % 4).  Hand-off between workgroups: one arrival counter per row block in global memory, zero at launch,
-// bumped once per wave (release fence, relaxed agent-scope add); a consumer polls it from one lane with s_sleep and
-// fences (acquire) once it reads the target -- the barrier-counter recipe of MI355X_MICROARCH.md, per row block instead
-// of per grid.  A consumer only ever waits for workgroups that are resident (dispatch is in block order and the
-// producers of a row block have block indices no higher than 31 above the consumer's), and every wait is bounded
-// (PoolParams.ip_err counts give-ups; tests assert it stays zero).
+// quarter b % 4).  Hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md
+// Guideline 16): the handed-off rows are stored WRITE-THROUGH (16-byte `sc1` buffer stores, every 128-byte line written
+// whole by one instruction), every storing wave drains its stores (s_waitcnt vmcnt(0)) and adds for itself to the row
+// block's arrival counter (agent-scope atomic; zero at launch); a consumer polls the counter from one lane (sc1 load +
+// s_sleep), passes a workgroup barrier and then reads the rows with `sc1` buffer loads (first pass) or, where the
+// reader is the LDS-DMA ring, behind ONE agent-scope acquire per workgroup (second pass).  No release fences: one
+// `buffer_wbl2` per wave and image measured +220 us per pass (4096 L2 write-backs).  A consumer only ever waits for
+// workgroups that are resident (dispatch is in block order and the producers of a row block have block indices no
+// higher than 31 above the consumer's), and every wait is bounded (PoolParams.ip_err counts give-ups; tests assert it
+// stays zero).
 //
 // Shapes: Q = 8, D = 256 KT (KT = 1..3), d_out = 1, B % 32 == 0, pooling grid % 32 == 0 (host-checked: ep_pool.hip).
 #pragma once
@@ -28,12 +32,28 @@ constexpr int IP_WAVES = 4;                      // waves per workgroup of the k
 constexpr int IP_TARGET = 32 * IP_WAVES;         // arrivals that complete a row block
 constexpr int IP_SPIN_LIMIT = 1 << 21;           // x ~0.3 us per poll: gives up after ~0.5 s instead of hanging the GPU
 
-// this wave's global stores so far become visible device-wide, then one arrival
+// raw buffer view of a handed-off matrix: 16-byte loads / stores with the sc1 bit (aux 16) that the compiler still
+// tracks in its vmcnt bookkeeping (inline-asm stores would not be)
+constexpr int IP_SC1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ip_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+}
+__device__ __forceinline__ void ip_store16_wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f4v v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, IP_SC1);
+}
+__device__ __forceinline__ f4v ip_load16_coherent(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, IP_SC1);
+}
+
+// this wave's write-through stores have left the CU (drain), then ONE arrival for the wave
 __device__ __forceinline__ void ip_arrive(int* cnt) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane_id() == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// whole workgroup: returns once *cnt >= target (polled by one lane), with an acquire fence in every wave
+// whole workgroup: returns once *cnt >= target, polled by one lane; the barrier stands between the poll and every load
+// of the handed-off rows.  ACQUIRE: additionally ONE agent-scope acquire (this CU's L1) completed in front of the
+// barrier, for readers that are not sc1 loads to registers (the LDS-DMA ring).
+template <bool ACQUIRE>
 __device__ __forceinline__ void ip_wait(int* cnt, int target, int* err) {
   if (threadIdx.x == 0) {
     int spins = 0;
@@ -41,14 +61,17 @@ __device__ __forceinline__ void ip_wait(int* cnt, int target, int* err) {
       if (++spins > IP_SPIN_LIMIT) { if (err) atomicAdd(err, 1); break; }
       __builtin_amdgcn_s_sleep(16);
     }
+    if (ACQUIRE) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the invalidate has completed before the barrier opens
+    }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // LDS bytes the tasks need (the token ring of the pass is idle while they run)
-constexpr size_t ip_dp_lds_bytes(int kt) {
-  return (size_t)(32 * (((32 * kt + 29) / 64) * 64 + 34) + 32 * kt * (64 + 16)) * sizeof(float);
+constexpr size_t ip_dp_lds_bytes(int kt) {      // A image + one B tile (>= the 32 x 68 output staging tile that reuses it)
+  return (size_t)(32 * (((32 * kt + 29) / 64) * 64 + 34) + (32 * kt * (64 + 16) > 32 * 68 ? 32 * kt * (64 + 16) : 32 * 68)) * sizeof(float);
 }
 constexpr size_t ip_y_lds_bytes(int kt) { return (size_t)2 * (32 + 32 * kt) * (BK + 2) * sizeof(float); }
 
@@ -70,7 +93,10 @@ __device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds
   const int row0 = rb * 32;
   const float* A = p.ip_dy + (int64_t)row0 * D + q * DQ;
   const float* W = p.ip_Wv + (int64_t)q * DQ * D + ch * CW;
-  float* C = const_cast<float*>(p.dP) + ((int64_t)row0 * Q + q) * D + ch * CW;
+  constexpr int SC = 64 + 4;                          // row stride of the output staging tile (it reuses the B buffer)
+  float* Cs = Bs;
+  const __amdgpu_buffer_rsrc_t rC = ip_rsrc(p.dP, (size_t)p.B * Q * D * sizeof(float));
+  const unsigned c_off = (unsigned)((((int64_t)row0 * Q + q) * D + ch * CW) * sizeof(float));
 
   f4v ra[KT], rw[KT][2 * KT];
 #pragma unroll
@@ -94,7 +120,7 @@ __device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds
   }
 #pragma unroll
   for (int nt = 0; nt < KT; ++nt) {
-    if (nt > 0) __syncthreads();                       // every wave is done reading the previous B tile
+    if (nt > 0) __syncthreads();                       // every wave is done reading the previous output tile
 #pragma unroll
     for (int i = 0; i < 2 * KT; ++i) {
       const int idx = tid + 256 * i;
@@ -119,12 +145,20 @@ __device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s][1], acc[1], 0, 0, 0);
       }
     }
-    // D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + r
+    // The rows are handed to other workgroups inside this launch: 16-byte write-through stores, every 128-byte line whole
+    // in one instruction -- so the tile goes through LDS once (D layout of 16x16x4: column = lane & 15, row = 4 (lane >> 4) + r)
+    __syncthreads();                                   // every wave is done reading the B tile
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        C[(int64_t)(wm * 16 + kk * 4 + rr) * Q * D + nt * 64 + wn * 32 + ni * 16 + i16] = acc[ni][rr];
+      for (int rr = 0; rr < 4; ++rr) Cs[(wm * 16 + kk * 4 + rr) * SC + wn * 32 + ni * 16 + i16] = acc[ni][rr];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, c4 = idx & 15;
+      const f4v v = *reinterpret_cast<const f4v*>(Cs + row * SC + 4 * c4);
+      ip_store16_wt(rC, c_off + (unsigned)(((int64_t)row * Q * D + nt * 64 + 4 * c4) * sizeof(float)), v);
+    }
   }
   __syncthreads();                                     // LDS free for the next task / the token ring
 }
@@ -144,7 +178,8 @@ __device__ __forceinline__ void ip_y_task(const PoolParams& p, int b, char* lds_
   const int wm = w >> 1, wn = w & 1, i16 = lane & 15, kk = lane >> 4;
   const int rb = b >> 5, r = b & 31, q = r >> 2, ks = r & 3;
   const int row0 = rb * 32;
-  const float* A = p.P + ((int64_t)row0 * Q + q) * D + ks * (64 * KT);
+  const __amdgpu_buffer_rsrc_t rP = ip_rsrc(p.P, (size_t)p.B * Q * D * sizeof(float));   // rows handed over in this launch
+  const unsigned a_off = (unsigned)((((int64_t)row0 * Q + q) * D + ks * (64 * KT)) * sizeof(float));
   const float* W = p.ip_WvF + (int64_t)q * DQ * D + ks * (64 * KT);
   float* C = p.ip_ypart + ((int64_t)ks * p.B + row0) * D + q * DQ;
 
@@ -152,7 +187,7 @@ __device__ __forceinline__ void ip_y_task(const PoolParams& p, int b, char* lds_
   const int lrow = tid >> 3, lc = 4 * (tid & 7);
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
-    ra[t] = *reinterpret_cast<const f4v*>(A + (int64_t)lrow * Q * D + 32 * t + lc);
+    ra[t] = ip_load16_coherent(rP, a_off + (unsigned)(((int64_t)lrow * Q * D + 32 * t + lc) * sizeof(float)));
 #pragma unroll
     for (int i = 0; i < KT; ++i) rw[t][i] = *reinterpret_cast<const f4v*>(W + (int64_t)(lrow + 32 * i) * D + 32 * t + lc);
   }

@@ -455,7 +455,7 @@ int pool_inpass_mask(const PoolParams& p, int Dv) {
       use_mm(p, false) || use_mf(p, false) || force_generic() || !stream_takes(p)) return 0;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (!c.ok || c.nw != 4 || c.qw != 2 || c.kp > 3 || p.Q != 8 || p.D != 256 * c.kp || Dv != p.D || p.B % 32 != 0 ||
-      c.grid % 32 != 0 || p.cls_bstride != 0)
+      c.grid % 32 != 0 || p.cls_bstride != 0 || (int64_t)p.B * p.Q * p.D * 4 >= (int64_t)0x7fffffff)   // (32-bit buffer offsets)
     return 0;
   static int bwd_grid = -1;           // (diagnostic grid override of the second pass, see pool_backward)
   if (bwd_grid < 0) { const char* e = getenv("EP_POOL_BWD_GRID"); bwd_grid = e ? atoi(e) : 0; }

@@ -396,10 +396,26 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
                                 readlane_f(c2[j], 48)) * inv : 0.f;
       if (q0 + j < Q) {
         float* Pq = p.P + ((int64_t)b * Q + q0 + j) * D;
+        bool handed = false;
+        if constexpr (IPOK) handed = p.ip_ycnt != nullptr;
+        if (handed) {
+          // these rows are read by other workgroups inside this launch (ep_inpass.h): write-through 16-byte stores
+          if constexpr (IPOK) {
+            const __amdgpu_buffer_rsrc_t rP = ip_rsrc(p.P, (size_t)p.B * Q * D * sizeof(float));
+            const unsigned off = (unsigned)(((int64_t)b * Q + q0 + j) * D * sizeof(float));
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+              const int c = lane + 64 * k;
+              const f4 v = acc[j][k] * inv - shift;
+              if (c < nchunk) ip_store16_wt(rP, off + 16u * (unsigned)c, f4v{v.x, v.y, v.z, v.w});
+            }
+          }
+        } else {
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
           const int c = lane + 64 * k;
           if (c < nchunk) *reinterpret_cast<f4*>(Pq + 4 * c) = acc[j][k] * inv - shift;
+        }
         }
         if (lane == 0) {
           const f4 rec = {m[j], l, 0.f, 0.f};
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         if (owner_last) b = nh == 0 ? wg + i * G : wg + (R - 1) * G;
         else if (i < R - 1) b = wg + i * G;
         else { const int e = (wg - nfull) + (i - (R - 1)) * nh; b = (e % nfull) + (e / nfull) * G; }
-        ip_wait(p.ip_ycnt + (b >> 5), IP_TARGET, p.ip_err);
+        ip_wait<false>(p.ip_ycnt + (b >> 5), IP_TARGET, p.ip_err);   // the task reads P with sc1 loads
         ip_y_task<KP>(p, b, ring);
       }
     }
@@ -479,7 +495,11 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         ip_dp_task<KP>(p, b, ring);
         ip_arrive(p.ip_dcnt + (b >> 5));
       }
-      for (int b = wg; b < p.B; b += G) ip_wait(p.ip_dcnt + (b >> 5), IP_TARGET, p.ip_err);
+      // the dP rows are read by the LDS-DMA ring: ONE acquire per workgroup, behind its last poll
+      for (int b = wg; b < p.B; b += G) {
+        if (b + G < p.B) ip_wait<false>(p.ip_dcnt + (b >> 5), IP_TARGET, p.ip_err);
+        else ip_wait<true>(p.ip_dcnt + (b >> 5), IP_TARGET, p.ip_err);
+      }
     }
   }
   const int D = DFIX ? DFIX : p.D;

@@ -214,7 +214,9 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
                     max_norm: float = 0, mixup_fn=None, log_writer=None, args=None,
                     token_fn: Optional[Callable] = None):
     """``token_fn(samples) -> (B, N, D) tokens`` (the frozen encoder) enables the fused path for image
-    loaders; loaders that already yield 3-D token tensors take it directly."""
+    loaders; loaders that already yield 3-D token tensors take it directly.  A loader may also yield
+    ``(store_tensor, image_index, targets)`` (``token_store.ResidentTokenStore.loader``): the batch is then read in
+    place from the HBM-resident store through ``image_index`` -- no gather copy."""
     model.train(True)
     metric_logger = MetricLogger()
     metric_logger.add_meter("lr", SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -240,18 +242,24 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         metric_logger.meters["acc1"].update(top1 * 100.0 / (bsz * n_steps), n_steps)
         metric_logger.meters["acc5"].update(top5 * 100.0 / (bsz * n_steps), n_steps)
 
-    for step, (samples, targets) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+    for step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+        samples, targets = batch[0], batch[-1]
+        image_index = batch[1] if len(batch) == 3 else None          # (store, index, targets): resident token store
         if step % accum_iter == 0:
             lr = lr_sched.adjust_learning_rate(optimizer, step / n_iter + epoch, args)
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
         fused = engine is not None and (samples.dim() == 3 or token_fn is not None)
+        if image_index is not None and not fused:
+            raise RuntimeError("(store, image_index, targets) batches need the fused engine path (a native head, plain "
+                               "cross-entropy, no mixup / gradient clipping)")
         if fused:
             tokens = samples if samples.dim() == 3 else token_fn(samples)
             if accum_iter == 1:        # one call: lets a data-parallel EP step overlap its large all-reduce
-                engine.train_step(tokens.detach(), targets, lr=max(g["lr"] for g in optimizer.param_groups))
+                engine.train_step(tokens.detach(), targets, lr=max(g["lr"] for g in optimizer.param_groups),
+                                  image_index=image_index)
             else:
-                engine.forward_backward(tokens.detach(), targets)
+                engine.forward_backward(tokens.detach(), targets, image_index)
                 if (step + 1) % accum_iter == 0:
                     engine.all_reduce_grads()
                     engine.optimizer_step(lr=max(g["lr"] for g in optimizer.param_groups))
@@ -306,15 +314,18 @@ def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = Fal
     all_t, all_p = [], []
     for batch in metric_logger.log_every(data_loader, 10, "Test:"):
         images, target = batch[0].to(device, non_blocking=True), batch[-1].to(device, non_blocking=True)
+        index = batch[1] if len(batch) == 3 else None                # (store, image_index, targets): resident token store
+        if index is not None and engine is None:
+            raise RuntimeError("(store, image_index, targets) batches need a native head (the fused engine path)")
         if engine is not None and (images.dim() == 3 or token_fn is not None):
-            output = engine.eval_logits(images if images.dim() == 3 else token_fn(images), precision=precision)
+            output = engine.eval_logits(images if images.dim() == 3 else token_fn(images), image_index=index, precision=precision)
         else:
             with torch.autocast("cuda", enabled=(precision == "fp16_autocast" and images.is_cuda), dtype=torch.float16):
                 output = model(images)
             output = output.float()
         loss = torch.nn.functional.cross_entropy(output, target)
         acc1, acc5 = accuracy(output, target)
-        n = images.shape[0]
+        n = target.shape[0]
         metric_logger.update(loss=loss.item())
         metric_logger.meters["acc1"].update(acc1.item(), n=n)
         metric_logger.meters["acc5"].update(acc5.item(), n=n)

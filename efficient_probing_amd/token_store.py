@@ -145,6 +145,23 @@ class ResidentTokenStore:
         self.num_images = n
         self.labels = torch.from_numpy(np.concatenate(labels) if labels else np.zeros(0, np.int64)).to(device)
 
+    @classmethod
+    def from_tensors(cls, tokens: torch.Tensor, labels: torch.Tensor, seed: int = 0) -> "ResidentTokenStore":
+        """A resident store around tokens that are already in HBM (synthetic benchmarks, tokens produced by a live encoder
+        pass): ``tokens`` (n, N, D) fp32 / bf16 on the GPU, ``labels`` (n,) int64.  One rank's view (world = 1)."""
+        self = cls.__new__(cls)
+        n, N, D = tokens.shape
+        self.meta, self.world, self.N, self.D, self.seed, self.rank = {"num_tokens": N, "dim": D}, 1, N, D, seed, 0
+        self.dtype = "float32" if tokens.dtype == torch.float32 else "bfloat16"
+        self.tokens, self.num_images = tokens, n
+        self.labels = labels.to(device=tokens.device, dtype=torch.int64)
+        return self
+
+    def loader(self, batch_size: int, epoch: int = 0, shuffle: bool = True, drop_last: bool = True) -> "StoreEpoch":
+        """One epoch as a sized iterable of ``(store_tensor, image_index, targets)`` -- what
+        ``engine_finetune.train_one_epoch`` / ``evaluate`` take in place of a DataLoader (they need ``len()``)."""
+        return StoreEpoch(self, batch_size, epoch, shuffle, drop_last)
+
     def num_batches(self, batch_size: int, drop_last: bool = True) -> int:
         """Batches per epoch.  Data parallel (world > 1): the same number on every rank (``steps_per_epoch``)."""
         if self.world > 1:
@@ -162,6 +179,19 @@ class ResidentTokenStore:
         for lo in range(0, stop, batch_size):
             idx = order[lo:lo + batch_size].contiguous()
             yield self.tokens, idx, self.labels[idx.long()]
+
+
+class StoreEpoch:
+    """``len()`` + iteration over one epoch of a ResidentTokenStore (see ``ResidentTokenStore.loader``)."""
+
+    def __init__(self, store: ResidentTokenStore, batch_size: int, epoch: int, shuffle: bool, drop_last: bool):
+        self.store, self.batch_size, self.epoch, self.shuffle, self.drop_last = store, batch_size, epoch, shuffle, drop_last
+
+    def __len__(self) -> int:
+        return self.store.num_batches(self.batch_size, self.drop_last)
+
+    def __iter__(self):
+        return self.store.batches(self.batch_size, self.epoch, self.shuffle, self.drop_last)
 
 
 class StreamingTokenLoader:

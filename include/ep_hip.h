@@ -56,6 +56,11 @@ int ep_device_cu_count(void);
  * vector-ALU streaming kernel, else generic), 1 = generic only, 2 = no matrix-core kernel.
  * Returns the old value. */
 int ep_debug_force_generic_pool(int mode);
+/* measurement hook (bench.py `roofline.in_step`): four caller-owned hipEvent_t handles that the calling thread's next
+ * ep_head_train_step calls record on their stream in front of / behind the first token pass and in front of / behind the
+ * second one (the launches that carry the in-pass contractions and the weight-gradient side work); NULLs switch it off.
+ * An event is a marker the queue drains in front of: use it in untimed, instrumented steps only. */
+int ep_debug_set_pass_events(void* fwd_begin, void* fwd_end, void* bwd_begin, void* bwd_end);
 
 /* ------------------------------------------------------------------------------------------
  * EP attentive pooling, forward.   Replaces reference poolings/ep.py:35-44 (scores q.k^T,
