@@ -103,9 +103,10 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   w.dP = take(B * d.Q * d.D);
   w.ypart = take((size_t)IP_YPARTS * B * Dp);
   w.nrb = (d.B + 31) / 32;
-  w.ycnt = reinterpret_cast<int*>(take(2 * (size_t)w.nrb + 4));
-  w.dcnt = w.ycnt ? w.ycnt + w.nrb : nullptr;
-  w.iperr = w.ycnt ? w.ycnt + 2 * w.nrb : nullptr;
+  // one counter per 128-byte line (IP_CNT_STRIDE ints apart): ycnt | dcnt | give-up count
+  w.ycnt = reinterpret_cast<int*>(take(2 * (size_t)w.nrb * 32 + 32));
+  w.dcnt = w.ycnt ? w.ycnt + (size_t)w.nrb * 32 : nullptr;
+  w.iperr = w.ycnt ? w.ycnt + 2 * (size_t)w.nrb * 32 : nullptr;
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.Q);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
   int64_t offs[4];
@@ -511,7 +512,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   const bool ip_y = (ipmask & 1) && (s->phases & 1) && bn_takes_parts(d.B);
   if (ipmask) {
     p.ip_err = w.iperr;
-    p.ip_zero = w.dcnt; p.ip_nzero = w.nrb;                   // the first pass clears the second pass's counters
+    p.ip_zero = w.dcnt; p.ip_nzero = w.nrb * 32;                   // the first pass clears the second pass's counters
     if (ip_y) { p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; }
   }
   if (s->phases & (1 | 4)) {                                  // first token pass: depends on cls_token only
@@ -545,7 +546,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     const GemmParams gWc = dwc_gemm(w.dlogits, w.ldl, w.z, d.B, Dp, d.C, s->grads + offs[2], s->accumulate);
     const GemmParams gWv = dwv_gemm(w.dy, w.P, d.B, d.D, Dp, d.Q, s->grads + offs[1], s->accumulate);
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-    if (ipmask) { p.ip_zero = w.ycnt; p.ip_nzero = w.nrb; }            // the second pass clears the first pass's counters
+    if (ipmask) { p.ip_zero = w.ycnt; p.ip_nzero = w.nrb * 32; }            // the second pass clears the first pass's counters
     if (pool_backward_takes_side(p) && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
       if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
       else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));

@@ -30,7 +30,11 @@ namespace ep {
 
 constexpr int IP_WAVES = 4;                      // waves per workgroup of the kernels that carry these tasks
 constexpr int IP_TARGET = 32 * IP_WAVES;         // arrivals that complete a row block
-constexpr int IP_SPIN_LIMIT = 1 << 21;           // x ~0.3 us per poll: gives up after ~0.5 s instead of hanging the GPU
+constexpr int IP_SPIN_LIMIT = 1 << 19;           // x ~1.3 us per poll: gives up after ~0.7 s instead of hanging the GPU
+// One counter per 128-byte line, polled about once a microsecond.  With the 32 counters of a 1024-image batch on ONE line
+// and 0.3 us polls, the few hundred polling workgroups of a pass (sc1 loads: every poll crosses the fabric to the line's
+// home) cut the token stream of everybody else to 40 % (measured with EP_IP_STAMP: 2.2 TB/s while pollers were active).
+constexpr int IP_CNT_STRIDE = 32;                // ints between the counters of consecutive row blocks
 
 // raw buffer view of a handed-off matrix: 16-byte loads / stores with the sc1 bit (aux 16) that the compiler still
 // tracks in its vmcnt bookkeeping (inline-asm stores would not be)
@@ -59,7 +63,7 @@ __device__ __forceinline__ void ip_wait(int* cnt, int target, int* err) {
     int spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > IP_SPIN_LIMIT) { if (err) atomicAdd(err, 1); break; }
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(32);
     }
     if (ACQUIRE) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -208,6 +208,10 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       for (int t = threadIdx.x; t < p.ip_nzero; t += NW * 64) p.ip_zero[t] = 0;
   }
   if (n_items <= 0) return;
+  auto stamp = [&](int k) {                                  // diagnostic only (EP_IP_STAMP): 100 MHz timeline per workgroup
+    if constexpr (IPOK) { if (p.dbg && threadIdx.x == 0) p.dbg[(int64_t)wg * 8 + k] = __builtin_amdgcn_s_memrealtime(); }
+  };
+  stamp(0);
   const int q0 = w * QW;
   const unsigned lane16 = (unsigned)lane * 16u;
   // byte offset of this lane's 16-byte chunk k inside a token row; lanes past the end of the row
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       }
     }
     if constexpr (IPOK) {
-      if (p.ip_ycnt) ip_arrive(p.ip_ycnt + (b >> 5));       // this wave's P rows of image b are out
+      if (p.ip_ycnt) ip_arrive(p.ip_ycnt + (b >> 5) * IP_CNT_STRIDE);       // this wave's P rows of image b are out
     }
   }
   // ---- in-pass value projection (ep_inpass.h): this workgroup has streamed all its images; while the others still
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   if constexpr (IPOK) {
     if (p.ip_ycnt) {
       __syncthreads();                                       // every wave has left the token ring
+      stamp(1);
       const int R = (p.B + G - 1) / G;
       const int nfull = p.B - (R - 1) * G;                   // workgroups with R images (== G when B % G == 0)
       const int nh = G - nfull;                              // helpers: done one round before the end of the pass
@@ -446,9 +451,12 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         if (owner_last) b = nh == 0 ? wg + i * G : wg + (R - 1) * G;
         else if (i < R - 1) b = wg + i * G;
         else { const int e = (wg - nfull) + (i - (R - 1)) * nh; b = (e % nfull) + (e / nfull) * G; }
-        ip_wait<false>(p.ip_ycnt + (b >> 5), IP_TARGET, p.ip_err);   // the task reads P with sc1 loads
-        ip_y_task<KP>(p, b, ring);
+        ip_wait<false>(p.ip_ycnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);   // the task reads P with sc1 loads
+        if (i == 0) stamp(2);
+        if (!(p.ablate & 1)) ip_y_task<KP>(p, b, ring);
+        if (i == 0) stamp(3);
       }
+      stamp(4);
     }
   }
 }
@@ -490,16 +498,23 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   if constexpr (IPOK) {
     if (wg == 0 && p.ip_zero)
       for (int t = threadIdx.x; t < p.ip_nzero; t += NW * 64) p.ip_zero[t] = 0;
+    auto stamp = [&](int k) {                              // diagnostic only (EP_IP_STAMP)
+      if (p.dbg && threadIdx.x == 0) p.dbg[(int64_t)wg * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
     if (p.ip_dy) {
+      stamp(0);
       for (int b = wg; b < p.B; b += G) {
-        ip_dp_task<KP>(p, b, ring);
-        ip_arrive(p.ip_dcnt + (b >> 5));
+        if (!(p.ablate & 1)) ip_dp_task<KP>(p, b, ring);
+        if (b == wg) stamp(1);
+        ip_arrive(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE);
       }
+      stamp(2);
       // the dP rows are read by the LDS-DMA ring: ONE acquire per workgroup, behind its last poll
       for (int b = wg; b < p.B; b += G) {
-        if (b + G < p.B) ip_wait<false>(p.ip_dcnt + (b >> 5), IP_TARGET, p.ip_err);
-        else ip_wait<true>(p.ip_dcnt + (b >> 5), IP_TARGET, p.ip_err);
+        if (b + G < p.B) ip_wait<false>(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
+        else ip_wait<true>(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
       }
+      stamp(3);
     }
   }
   const int D = DFIX ? DFIX : p.D;
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       }
     }
   }
+  if constexpr (IPOK) { if (p.dbg && p.ip_dy && threadIdx.x == 0) p.dbg[(int64_t)wg * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
   // per-workgroup partial of sum_b sum_n dS x  (reduced + scaled by ep_reduce_partials)
 #pragma unroll
   for (int j = 0; j < QW; ++j)
@@ -751,6 +767,40 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   auto kf = ep_pool_fwd_kernel<QW, KP, NW, DFIX, BF16, LN>;
   auto kb = ep_pool_bwd_kernel<QW, KP, NW, DFIX, BF16, LN>;
   const void* fn = bwd ? (const void*)kb : (const void*)kf;
+  // diagnostic only (EP_IP_STAMP=1): per-workgroup timeline of the in-pass tasks, printed to stderr (synchronises!)
+  static int stampmode = -1;
+  if (stampmode < 0) { const char* e = getenv("EP_IP_STAMP"); stampmode = e ? atoi(e) : 0; }
+  const bool stamped = stampmode && ((bwd && p.ip_dy) || (!bwd && p.ip_ycnt)) && grid <= 4096;
+  if (stamped) {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, 4096 * 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), st);
+    PoolParams q = p;
+    q.dbg = dbg;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (bwd) hipLaunchKernelGGL(kb, dim3(grid + sd.total), dim3(NW * 64), lds, st, q, sd);
+    else hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, st, q);
+    (void)hipStreamSynchronize(st);
+    static unsigned long long host[4096 * 8];
+    (void)hipMemcpy(host, dbg, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    static int printed[2] = {0, 0};
+    if (printed[bwd ? 1 : 0]++ % 20 == 10) {
+      unsigned long long t0 = ~0ull;
+      for (int g = 0; g < grid; ++g) if (host[g * 8] && host[g * 8] < t0) t0 = host[g * 8];
+      fprintf(stderr, "[EP_IP_STAMP] %s grid %d: mean us since the first workgroup started, per third of the grid\n", bwd ? "bwd" : "fwd", grid);
+      for (int part = 0; part < 3; ++part) {
+        const int g0 = grid * part / 3, g1 = grid * (part + 1) / 3;
+        double m[6] = {0}, mx[6] = {0}; int cnt[6] = {0};
+        for (int g = g0; g < g1; ++g)
+          for (int k = 0; k < 5; ++k)
+            if (host[g * 8 + k]) { const double us = (double)(host[g * 8 + k] - t0) / 100.0; m[k] += us; if (us > mx[k]) mx[k] = us; ++cnt[k]; }
+        fprintf(stderr, "   wg %4d..%4d:", g0, g1 - 1);
+        for (int k = 0; k < 5; ++k) fprintf(stderr, "  s%d %7.1f (max %7.1f)", k, cnt[k] ? m[k] / cnt[k] : -1.0, mx[k]);
+        fprintf(stderr, "\n");
+      }
+    }
+    return 0;
+  }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
   if (bwd) hipLaunchKernelGGL(kb, dim3(grid + sd.total), dim3(NW * 64), lds, st, p, sd);

@@ -247,3 +247,33 @@ def test_clipping_and_other_criteria_take_the_module_path():
         EF.train_one_epoch(model, crit, loader, opt, torch.device(DEV), 1, NativeScalerWithGradNormCount(), args=ARGS, **kw)
         assert getattr(model, "_ep_engine", None) is None
     assert EF._plain_cross_entropy(torch.nn.CrossEntropyLoss()) and not EF._plain_cross_entropy(torch.nn.MSELoss())
+
+
+def test_store_batches_through_train_one_epoch_and_evaluate():
+    """``(store, image_index, targets)`` batches of a resident token store (token_store.ResidentTokenStore.loader) go
+    through train_one_epoch / evaluate in place and give what the same images give as gathered token tensors."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd.token_store import ResidentTokenStore
+    from efficient_probing_amd.util.lars import LARS
+    case = Case("store", B=16, N=40, D=256, Q=8, C=20, seed=7)
+    inp = make_inputs(case)
+    tokens = torch.from_numpy(np.concatenate([inp["x_buf"], inp["x_buf2"]], 0)).to(DEV)      # 2 B images
+    labels = torch.from_numpy(np.concatenate([inp["targets"], inp["targets2"]], 0)).to(DEV)
+    store = ResidentTokenStore.from_tensors(tokens, labels, seed=3)
+    assert len(store.loader(case.B)) == 2
+    outs = []
+    for use_store in (True, False):
+        model = make_model(case, inp)
+        opt = LARS(model.head.parameters(), lr=0.0, weight_decay=1e-4)
+        loader = store.loader(case.B, epoch=1)
+        if not use_store:                         # the same batches, gathered into dense token tensors
+            loader = [(tok[idx.long()].contiguous(), tgt) for tok, idx, tgt in loader]
+        stats = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), loader, opt, torch.device(DEV), 1, None, args=ARGS)
+        ev = EF.evaluate(store.loader(case.B, shuffle=False) if use_store else
+                         [(tok[idx.long()].contiguous(), tgt) for tok, idx, tgt in store.loader(case.B, shuffle=False)],
+                         model, torch.device(DEV))
+        outs.append((stats, ev, torch.cat([p.detach().flatten() for p in model.head.parameters()]).cpu()))
+    (s1, e1, p1), (s2, e2, p2) = outs
+    assert s1["loss"] == pytest.approx(s2["loss"], rel=1e-6)
+    assert torch.equal(p1, p2)                    # same kernels on the same images: bit-equal parameters
+    assert e1["acc1"] == e2["acc1"] and e1["loss"] == pytest.approx(e2["loss"], rel=1e-6)
