@@ -58,7 +58,8 @@ int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, in
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
   float* ypart;                                // in-pass value projection: IP_YPARTS K-quarter partials of y (ep_inpass.h)
-  int *ycnt, *dcnt, *iperr; int nrb;           // arrival counters per 32-image row block (zero between steps), give-up count
+  int *ycnt, *dcnt, *tick, *iperr; int nrb;    // arrival counters per 32-image row block and the image ticket counter
+                                               // (each on a 128-byte line of its own, zero between steps), give-up count
   uint16_t *plWv, *plWvT, *plWc, *plWcT;       // bf16 planes of the two weight matrices, both orientations (ep_planes.hip)
   void* pool_ws; size_t pool_ws_bytes;
   void* opt_ws; size_t opt_ws_bytes;
@@ -103,10 +104,11 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   w.dP = take(B * d.Q * d.D);
   w.ypart = take((size_t)IP_YPARTS * B * Dp);
   w.nrb = (d.B + 31) / 32;
-  // one counter per 128-byte line (IP_CNT_STRIDE ints apart): ycnt | dcnt | give-up count
-  w.ycnt = reinterpret_cast<int*>(take(2 * (size_t)w.nrb * 32 + 32));
+  // one counter per 128-byte line (IP_CNT_STRIDE ints apart): ycnt | dcnt | ticket | give-up count
+  w.ycnt = reinterpret_cast<int*>(take(2 * (size_t)w.nrb * 32 + 64));
   w.dcnt = w.ycnt ? w.ycnt + (size_t)w.nrb * 32 : nullptr;
-  w.iperr = w.ycnt ? w.ycnt + 2 * (size_t)w.nrb * 32 : nullptr;
+  w.tick = w.ycnt ? w.ycnt + 2 * (size_t)w.nrb * 32 : nullptr;
+  w.iperr = w.ycnt ? w.ycnt + 2 * (size_t)w.nrb * 32 + 32 : nullptr;
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.Q);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
   int64_t offs[4];
@@ -512,7 +514,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   const bool ip_y = (ipmask & 1) && (s->phases & 1) && bn_takes_parts(d.B);
   if (ipmask) {
     p.ip_err = w.iperr;
-    p.ip_zero = w.dcnt; p.ip_nzero = w.nrb * 32;                   // the first pass clears the second pass's counters
+    p.ip_zero = w.dcnt; p.ip_nzero = w.nrb * 32 + 32;                   // the first pass clears the second pass's counters
     if (ip_y) { p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; }
   }
   if (s->phases & (1 | 4)) {                                  // first token pass: depends on cls_token only
@@ -556,6 +558,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
       const bool ip_dp = (ipmask & 2) != 0;
       if (ip_dp) { p.ip_dy = w.dy; p.ip_Wv = Wv; p.ip_dcnt = w.dcnt; }   // dP rows by the pooling workgroups themselves
+      if ((ipmask & 4) && in_pass) p.tick = w.tick;                      // ... in the ticketed form (ep_pool_bwd2.hip)
       if (pl) {
         if (!in_pass) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));

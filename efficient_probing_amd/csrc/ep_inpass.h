@@ -84,7 +84,8 @@ constexpr size_t ip_y_lds_bytes(int kt) { return (size_t)2 * (32 + 32 * kt) * (B
 // of contiguous output columns).  Everything is fetched up front (KT + 2 KT KT float4 per thread), one round trip; the
 // A image stays in LDS, the KT 64-column B tiles pass through one LDS buffer.  Exact fp32 (v_mfma_f32_16x16x4_f32).
 template <int KT>
-__device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds_raw) {
+__device__ __forceinline__ void ip_dp_task_body(const float* __restrict__ dy, const float* __restrict__ Wv, float* dP, int nB, int b,
+                                               char* lds_raw) {
   constexpr int DQ = 32 * KT, D = 256 * KT, Q = 8, CW = 64 * KT;
   constexpr int SA = ((DQ + 29) / 64) * 64 + 34;      // A row stride in floats, == 34 (mod 64): conflict-free fragment reads
   constexpr int SB = 64 + 16;                         // B k-row stride
@@ -95,11 +96,11 @@ __device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds
   const int wm = w >> 1, wn = w & 1, i16 = lane & 15, kk = lane >> 4;
   const int rb = b >> 5, r = b & 31, q = r >> 2, ch = r & 3;
   const int row0 = rb * 32;
-  const float* A = p.ip_dy + (int64_t)row0 * D + q * DQ;
-  const float* W = p.ip_Wv + (int64_t)q * DQ * D + ch * CW;
+  const float* A = dy + (int64_t)row0 * D + q * DQ;
+  const float* W = Wv + (int64_t)q * DQ * D + ch * CW;
   constexpr int SC = 64 + 4;                          // row stride of the output staging tile (it reuses the B buffer)
   float* Cs = Bs;
-  const __amdgpu_buffer_rsrc_t rC = ip_rsrc(p.dP, (size_t)p.B * Q * D * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rC = ip_rsrc(dP, (size_t)nB * Q * D * sizeof(float));
   const unsigned c_off = (unsigned)((((int64_t)row0 * Q + q) * D + ch * CW) * sizeof(float));
 
   f4v ra[KT], rw[KT][2 * KT];
@@ -165,6 +166,18 @@ __device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds
     }
   }
   __syncthreads();                                     // LDS free for the next task / the token ring
+}
+
+template <int KT>
+__device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds_raw) {
+  ip_dp_task_body<KT>(p.ip_dy, p.ip_Wv, const_cast<float*>(p.dP), p.B, b, lds_raw);
+}
+// the same as a CALL: inside the ticketed second pass the task sits in the middle of the token loop, and inlined there its
+// ~90 staging registers pushed the loop's own values into scratch (64 spilled registers); as a function the caller only
+// saves what is live across the (rare) call
+template <int KT>
+__device__ __attribute__((noinline)) void ip_dp_task_call(const float* dy, const float* Wv, float* dP, int nB, int b, char* lds_raw) {
+  ip_dp_task_body<KT>(dy, Wv, dP, nB, b, lds_raw);
 }
 
 // ---- first pass: one K quarter of y for (row block, query) -------------------------------------------------------

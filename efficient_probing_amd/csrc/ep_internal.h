@@ -40,6 +40,9 @@ struct PoolParams {
   // images (the matrix pipe is idle under the pass); BatchNorm sums the partials in fixed order
   const float* ip_WvF; float* ip_ypart; int* ip_ycnt;
   int* ip_zero; int ip_nzero;   // counters this launch clears for the OTHER pass (first instructions of workgroup 0)
+  // ticketed second pass (ep_pool_bwd2.hip): images are handed out by a device-wide counter (zero at launch); workgroups
+  // with index < tick_base stream image `index` first, a ticket t names image tick_base + t
+  int* tick; int tick_base;
   int* ip_err;           // bumped when a bounded flag wait gives up (never in a correct run; tests read it)
   int nslot;             // ring depth
   int slot_bytes;        // TT*D*4
@@ -110,6 +113,8 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv);   // ... and comput
 // In-pass contractions (ep_inpass.h) possible for this shape on BOTH passes?  bit 0: y inside the first pass, bit 1: dP
 // inside the second (EP_INPASS=<mask> switches them, default 3).  Dv = width of the projection (must equal D).
 int pool_inpass_mask(const PoolParams& p, int Dv);
+// bit 2 of that mask: the ticketed second pass (ep_pool_bwd2.hip: dP and the weight-gradient side tasks under the stream)
+int bwd2_launch(const PoolParams& p, int grid, int first, hipStream_t st, const SideTasks* side);
 constexpr int IP_YPARTS = 4;                                   // K quarters of the in-pass value projection
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
 int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);

@@ -460,7 +460,12 @@ int pool_inpass_mask(const PoolParams& p, int Dv) {
   static int bwd_grid = -1;           // (diagnostic grid override of the second pass, see pool_backward)
   if (bwd_grid < 0) { const char* e = getenv("EP_POOL_BWD_GRID"); bwd_grid = e ? atoi(e) : 0; }
   if (bwd_grid > 0 && bwd_grid % 32 != 0) return 0;
-  return want & 3;
+  int m = want & 3;
+  // ticketed second pass: at least 20 token tiles per image (its task point and the row-block check sit inside an image)
+  // and at least 64 pooling workgroups (a row block's 32 tickets are then drawn by workgroups that never wait on it)
+  const int tt = stream_tt(c.qw, c.kp, c.nw) * (p.x_bf16 ? 2 : 1);
+  if ((want & 4) && (p.N + tt - 1) / tt >= 20 && c.grid >= 64) m |= 4 | 2;
+  return m;
 }
 
 int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side,
@@ -483,6 +488,15 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     const int grid = mf_grid(p.B);
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));
+  } else if (p.tick) {
+    // ticketed form (ep_pool_bwd2.hip): one gradient partial per IMAGE; `first` pooling workgroups in front of the side tasks
+    static int first_env = -1;
+    if (first_env < 0) { const char* e = getenv("EP_BWD2_FIRST"); first_env = e ? atoi(e) : 0; }
+    int first = (side && side->total > 0) ? (c.grid * 2 / 3) / 32 * 32 : c.grid;
+    if (first_env > 0) first = first_env < c.grid ? first_env : c.grid;
+    p.tick_base = first;
+    EP_TRY(bwd2_launch(p, c.grid, first, st, side));
+    nparts = p.B;
   } else if (c.ok && !force_generic() && !needs_generic(p) && stream_takes(p)) {
     static int bwd_grid = -1;           // diagnostics: pooling workgroups of the SECOND pass only (e.g. 2 per CU, the third slot left to the side work)
     if (bwd_grid < 0) { const char* e = getenv("EP_POOL_BWD_GRID"); bwd_grid = e ? atoi(e) : 0; }
