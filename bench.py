@@ -319,6 +319,8 @@ def main():
     head = enc.head.to(dev).train()
     lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
     eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0)
+    if hasattr(eng, "defer_update"):
+        eng.defer_update = True          # (the loop below calls flush() before it stops the clock, as train_one_epoch does)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     xs = [torch.randn(B, Nn, D, device=dev, generator=gen) for _ in range(args.buffers)]
@@ -512,6 +514,8 @@ def main():
         ts = [t % sC for t in ts_all]
         h2 = enc2.head.to(dev).train()
         eng2 = make_engine(h2, optimizer="lars", lr=lr, weight_decay=0.0)
+        if hasattr(eng2, "defer_update"):
+            eng2.defer_update = True
         if toks is None:
             g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
             toks = [torch.randn(B, sN, sD, device=dev, generator=g2) for _ in range(args.buffers)]

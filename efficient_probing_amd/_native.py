@@ -54,6 +54,7 @@ class EPHeadStep(C.Structure):
         ("phases", C.c_int32),
         ("aux_stream", C.c_void_p),
         ("opt_first_segment", C.c_int32), ("opt_num_segments", C.c_int32),
+        ("defer_event", C.c_void_p),
     ]
 
 

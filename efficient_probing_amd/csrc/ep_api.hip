@@ -517,11 +517,16 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     p.ip_zero = w.dcnt; p.ip_nzero = w.nrb * 32 + 32;                   // the first pass clears the second pass's counters
     if (ip_y) { p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; }
   }
+  // a deferred large update of the previous step (phases bit 5): v.weight / fc.* are first read behind the first token
+  // pass -- unless that pass computes the projection itself
+  const bool wait_defer = (s->phases & 32) && s->defer_event;
+  if (wait_defer && ip_y) EP_HIP(hipStreamWaitEvent(st, (hipEvent_t)s->defer_event, 0));
   if (s->phases & (1 | 4)) {                                  // first token pass: depends on cls_token only
     mark_pass(0, st);
     EP_TRY(pool_forward(p, st));
     mark_pass(1, st);
   }
+  if (wait_defer && !ip_y) EP_HIP(hipStreamWaitEvent(st, (hipEvent_t)s->defer_event, 0));
   p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
     if (pl) {
@@ -619,6 +624,22 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
                "optimizer segment range [%d, +%d) outside the four tensors", s->opt_first_segment, s->opt_num_segments);
     const ep_segment* use = (s->optimizer == 0 || sub) ? segs + (sub ? s->opt_first_segment : 0) : nullptr;
     const int nuse = (s->optimizer == 0 || sub) ? (sub ? s->opt_num_segments : 4) : 0;
+    hipStream_t ax = (hipStream_t)s->aux_stream;
+    if ((s->phases & 16) && s->defer_event && ax && ax != st && !sub) {
+      // deferred large update: cls_token here (one launch; it also finishes the cls_token gradient reduction), the three
+      // large tensors on the aux stream beside whatever the caller enqueues next on `stream`
+      EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total, segs, 1, s->lr,
+                        s->weight_decay, s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps,
+                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red));
+      hipEvent_t evs[6];
+      EP_TRY(get_events(evs, 6));
+      EP_HIP(hipEventRecord(evs[3], st));                      // the gradients are complete on `stream` here
+      EP_HIP(hipStreamWaitEvent(ax, evs[3], 0));
+      EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total, segs + 1, 3, s->lr,
+                        s->weight_decay, s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps,
+                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, ax, nullptr));
+      EP_HIP(hipEventRecord((hipEvent_t)s->defer_event, ax));
+    } else
     EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
                       use, nuse, s->lr, s->weight_decay,
                       s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,

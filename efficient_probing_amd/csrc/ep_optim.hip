@@ -42,19 +42,20 @@ __device__ __forceinline__ int seg_of_chunk(const OptSegs& s, int chunk) {
   return k;
 }
 
-__device__ __forceinline__ float block_sum(float v, float* sm) {
+// sum over the 256 threads of a GROUP (a whole 256-thread workgroup, or one quarter of the 1024-thread small-segment
+// kernel: `tid` is the index inside the group, `sm` the group's four floats); every thread of the workgroup must call it
+__device__ __forceinline__ float block_sum(float v, float* sm, int tid) {
   v = wave_sum(v);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) sm[w] = v;
   __syncthreads();
   float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
   __syncthreads();
   return r;
 }
 
-__global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs segs) {
-  __shared__ float sm[4];
-  const int chunk = blockIdx.x;
+// norms of one chunk: the body of ep_opt_norms_kernel.  Returns the four partial sums in every thread of the group.
+__device__ __forceinline__ f4 chunk_norms(const OptParams& o, const OptSegs& segs, int chunk, int tid, float* sm) {
   const int k = seg_of_chunk(segs, chunk);
   const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
   const int64_t end = segs.off[k] + segs.numel[k];
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
     const int64_t rend = (o.red_off + o.red_n) < end ? (o.red_off + o.red_n) : end;
 #pragma unroll
     for (int v = 0; v < OPT_CHUNK / 1024; ++v) {                  // straight-line loads (clamped), guarded uses
-      const int64_t i = base + threadIdx.x * 4 + 1024 * v;
+      const int64_t i = base + tid * 4 + 1024 * v;
       const bool in = i + 3 < rend;
       const int64_t ic = in ? i : base;
       const float* sp = o.red_stage + (ic - o.red_off);
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
       if (o.red_accumulate)                 // one rounding, as in ep_reduce_partials_kernel
         gv = f4{fmaf(ts.x, o.red_scale, old.x), fmaf(ts.y, o.red_scale, old.y), fmaf(ts.z, o.red_scale, old.z), fmaf(ts.w, o.red_scale, old.w)};
       if (in) {
-        *reinterpret_cast<f4*>(o.gw + i) = gv;
+        if (o.gw) *reinterpret_cast<f4*>(o.gw + i) = gv;        // (null: a shadow group of the small-segment kernel)
         acc1(pv.x, gv.x); acc1(pv.y, gv.y); acc1(pv.z, gv.z); acc1(pv.w, gv.w);
       } else if (i < end) {                                        // elements of the segment behind the range
         for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
       }
     }
   } else
-  for (int e = threadIdx.x * 4; e < OPT_CHUNK; e += 1024) {     // segment offsets are multiples of 4
+  for (int e = tid * 4; e < OPT_CHUNK; e += 1024) {     // segment offsets are multiples of 4
     const int64_t i = base + e;
     if (i + 3 < end) {
       const f4 pv = *reinterpret_cast<const f4*>(o.p + i);
@@ -107,22 +108,26 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
       for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
     }
   }
-  pp = block_sum(pp, sm); uu = block_sum(uu, sm); gg = block_sum(gg, sm); bad = block_sum(bad, sm);
-  if (threadIdx.x == 0) {
-    float* out = o.partial + (int64_t)chunk * 4;
-    out[0] = pp; out[1] = uu; out[2] = gg; out[3] = bad;
-  }
+  pp = block_sum(pp, sm, tid); uu = block_sum(uu, sm, tid); gg = block_sum(gg, sm, tid); bad = block_sum(bad, sm, tid);
+  return f4{pp, uu, gg, bad};
 }
 
-__global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs segs) {
+__global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs segs) {
   __shared__ float sm[4];
-  const int chunk = blockIdx.x;
+  const f4 r = chunk_norms(o, segs, blockIdx.x, threadIdx.x, sm);
+  if (threadIdx.x == 0) *reinterpret_cast<f4*>(o.partial + (int64_t)blockIdx.x * 4) = r;
+}
+
+// update of one chunk: the body of ep_opt_update_kernel.  `partial`: the per-chunk sums (global memory, or the LDS copy of
+// the small-segment kernel).
+__device__ __forceinline__ void chunk_update(const OptParams& o, const OptSegs& segs, int chunk, int tid, float* sm,
+                                             const float* partial, bool active) {
   const int k = seg_of_chunk(segs, chunk);
   const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
   const int64_t end = segs.off[k] + segs.numel[k];
   // global non-finite flag and gradient norm (fixed order over all chunks)
   float bad = 0.f, gg = 0.f;
-  for (int c = threadIdx.x; c < o.nchunks; c += 256) { bad += o.partial[(int64_t)c * 4 + 3]; gg += o.partial[(int64_t)c * 4 + 2]; }
+  for (int c = tid; c < o.nchunks; c += 256) { bad += partial[(int64_t)c * 4 + 3]; gg += partial[(int64_t)c * 4 + 2]; }
   // this thread's elements are fetched NOW (behind the first partial loads: vmcnt retires in order): the block sums and
   // the second chain of partial loads below run while they are in flight, instead of in front of them
   constexpr int NV = OPT_CHUNK / 1024;
@@ -133,27 +138,27 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
   const float* s1p = o.mode == 2 ? o.s1 : o.p;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int64_t i = base + threadIdx.x * 4 + 1024 * v;
+    const int64_t i = base + tid * 4 + 1024 * v;
     const int64_t ic = (i + 3 < end) ? i : base;
     pvr[v] = *reinterpret_cast<const f4*>(o.p + ic);
     gvr[v] = *reinterpret_cast<const f4*>(o.g + ic);
     avr[v] = *reinterpret_cast<const f4*>(s0p + ic);
     bvr[v] = *reinterpret_cast<const f4*>(s1p + ic);
   }
-  bad = block_sum(bad, sm);
-  gg = block_sum(gg, sm);
-  if (chunk == 0 && threadIdx.x == 0) {
+  bad = block_sum(bad, sm, tid);
+  gg = block_sum(gg, sm, tid);
+  if (active && chunk == 0 && tid == 0) {
     *o.found_inf = bad > 0.f ? 1 : 0;
     if (o.grad_norm) *o.grad_norm = sqrtf(gg);
   }
-  if (bad > 0.f) return;                                 // GradScaler.step: skip the update
+  const bool skip = bad > 0.f || !active;                // GradScaler.step: skip the update (block sums stay uniform)
   float q = 1.0f;
   if (o.mode == 0 && segs.trust[k]) {
     float pp = 0.f, uu = 0.f;
-    for (int c = segs.first_chunk[k] + threadIdx.x; c < segs.first_chunk[k + 1]; c += 256) {
-      pp += o.partial[(int64_t)c * 4 + 0]; uu += o.partial[(int64_t)c * 4 + 1];
+    for (int c = segs.first_chunk[k] + tid; c < segs.first_chunk[k + 1]; c += 256) {
+      pp += partial[(int64_t)c * 4 + 0]; uu += partial[(int64_t)c * 4 + 1];
     }
-    pp = block_sum(pp, sm); uu = block_sum(uu, sm);
+    pp = block_sum(pp, sm, tid); uu = block_sum(uu, sm, tid);
     const float pn = sqrtf(pp), un = sqrtf(uu);
     q = (pn > 0.f && un > 0.f) ? o.tc * pn / un : 1.0f;  // util/lars.py:26-29
   }
@@ -176,9 +181,10 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
       return pw - (o.lr / o.bc1) * (s0v / denom);        // bc1 = 1 - beta1^t
     }
   };
+  if (skip) return;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int64_t i = base + threadIdx.x * 4 + 1024 * v;
+    const int64_t i = base + tid * 4 + 1024 * v;
     if (i + 3 < end) {
       f4 pv = pvr[v];
       const f4 gv = gvr[v];
@@ -198,6 +204,32 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
     }
   }
 }
+
+__global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs segs) {
+  __shared__ float sm[4];
+  chunk_update(o, segs, blockIdx.x, threadIdx.x, sm, o.partial, true);
+}
+
+// One SMALL range of segments (at most OPT_SMALL_CHUNKS chunks: the cls_token of the EP head is 6144 elements = 2 chunks)
+// in ONE launch of one workgroup: group g of 256 threads runs chunk g's norms body, the partials go through LDS, the same
+// group then runs chunk g's update body.  Every sum is taken exactly as the two-launch path takes it (bit-equal results);
+// what goes away is one launch boundary and the round trip of the partials through memory -- the deferred-update step
+// (ep_head_train_step, phases bit 4) has only this in front of the next step's first token pass.
+constexpr int OPT_SMALL_CHUNKS = 4;
+__global__ __launch_bounds__(256 * OPT_SMALL_CHUNKS) void ep_opt_small_kernel(OptParams o, OptSegs segs) {
+  __shared__ float sm[OPT_SMALL_CHUNKS][4];
+  __shared__ __attribute__((aligned(16))) float part[OPT_SMALL_CHUNKS * 4];
+  const int g = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const bool active = g < o.nchunks;
+  const int chunk = active ? g : o.nchunks - 1;          // idle groups shadow the last chunk (barriers stay uniform), write nothing
+  OptParams on = o;
+  if (!active) on.gw = nullptr;
+  const f4 r = chunk_norms(on, segs, chunk, tid, sm[g]);
+  if (active && tid == 0) *reinterpret_cast<f4*>(part + 4 * g) = r;
+  __syncthreads();
+  chunk_update(o, segs, chunk, tid, sm[g], part, active);
+}
+
 
 static int build_segs(const ep_segment* segs, int nseg, int64_t total, OptSegs& out, int& nchunks) {
   EP_REQUIRE(nseg >= 1 && nseg <= OPT_MAX_SEG, EP_E_ARG, "optimizer: 1..%d segments supported, got %d", OPT_MAX_SEG, nseg);
@@ -252,6 +284,14 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
     } else {
       EP_TRY(reduce_partials(red->stage, 16, red->n, red->scale, red->accumulate, red->out, nullptr, st));
     }
+  }
+  static int small_on = -1;
+  if (small_on < 0) { const char* e = getenv("EP_OPT_SMALL"); small_on = e ? atoi(e) : 0; }   // off: 17 us in one workgroup against 7 + 8 us for the two launches (same latency chain)
+  if (small_on && nseg == 1 && nchunks <= OPT_SMALL_CHUNKS) {
+    // one small tensor (the cls_token of a split / deferred update): norms and update in ONE launch, same sums
+    hipLaunchKernelGGL(ep_opt_small_kernel, dim3(1), dim3(256 * OPT_SMALL_CHUNKS), 0, st, o, S);
+    EP_LAUNCH_CHECK("ep_opt_small_kernel");
+    return 0;
   }
   hipLaunchKernelGGL(ep_opt_norms_kernel, dim3(nchunks), dim3(256), 0, st, o, S);
   EP_LAUNCH_CHECK("ep_opt_norms_kernel");

@@ -450,7 +450,7 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
 // one aligned group of 32 workgroups).
 int pool_inpass_mask(const PoolParams& p, int Dv) {
   static int want = -1;
-  if (want < 0) { const char* e = getenv("EP_INPASS"); want = e ? atoi(e) : 0; }   // (default off until it wins: see DESIGN section 4)
+  if (want < 0) { const char* e = getenv("EP_INPASS"); want = e ? atoi(e) : 2; }   // default: dP inside the second pass
   if (!want || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) ||
       use_mm(p, false) || use_mf(p, false) || force_generic() || !stream_takes(p)) return 0;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);

@@ -29,6 +29,7 @@
 #include "ep_stream_dev.h"
 #include "ep_side.h"
 #include "ep_inpass.h"
+#include "ep_sidetask.h"
 
 namespace ep {
 

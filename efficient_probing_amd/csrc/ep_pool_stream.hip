@@ -25,6 +25,7 @@
 #include "ep_pool_stream.h"
 #include "ep_side.h"
 #include "ep_inpass.h"
+#include "ep_sidetask.h"
 #include "ep_stream_dev.h"
 
 namespace ep {
@@ -359,17 +360,24 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
     };
     if (p.ip_dy) {
       stamp(0);
-      for (int b = wg; b < p.B; b += G) {
+      // Tasks: image b names task b.  A workgroup runs the task of its FIRST image itself; the tasks of later-round
+      // images go to the workgroups that stream the fewest images (the last ones of the grid, which the SIMDs serve last
+      // anyway: wave arbitration is oldest-first), so the workgroups with the most images start streaming first.
+      const int R = (p.B + G - 1) / G;
+      const int nfull = p.B - (R - 1) * G;                   // workgroups with R images
+      const int nh = G - nfull;                              // helpers
+      int first = 1;
+      auto run = [&](int b) {
         if (!(p.ablate & 1)) ip_dp_task<KP>(p, b, ring);
-        if (b == wg) stamp(1);
+        if (first) { stamp(1); first = 0; }
         ip_arrive(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE);
-      }
+      };
+      run(wg);
+      if (nh == 0) { for (int b = wg + G; b < p.B; b += G) run(b); }
+      else if (wg >= nfull)                                  // later-round image G + e goes to helper G - 1 - (e % nh)
+        for (int e = G - 1 - wg; e < p.B - G; e += nh) run(G + e);
       stamp(2);
-      // the dP rows are read by the LDS-DMA ring: ONE acquire per workgroup, behind its last poll
-      for (int b = wg; b < p.B; b += G) {
-        if (b + G < p.B) ip_wait<false>(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
-        else ip_wait<true>(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
-      }
+      for (int b = wg; b < p.B; b += G) ip_wait<false>(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
       stamp(3);
     }
   }
@@ -441,7 +449,9 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
         if (pidx < H) {                                   // header: rows of dP[b]
           const int r0 = pidx * HR;
           const int rows = (Q - r0) < HR ? (Q - r0) : HR;
-          dma_rows<NW, KDMA>(pimg_dP + (int64_t)r0 * hrowbytes, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
+          // (rows written inside this launch by the in-pass dP tasks are read with sc1: no acquire needed, ep_inpass.h)
+          if (IPOK && p.ip_dy) dma_rows<NW, KDMA, IP_SC1>(pimg_dP + (int64_t)r0 * hrowbytes, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
+          else dma_rows<NW, KDMA>(pimg_dP + (int64_t)r0 * hrowbytes, (unsigned)(rows * hrowbytes - 16), slot, npiece, w, lane16);
           __builtin_amdgcn_global_load_lds((gptr_t)pimg_ML, (lds_ptr_t)small, 4, 0, 0);
         } else if (pidx < H2) {                           // delta item: dy[b] | y[b] (same instruction count as every item)
 #pragma unroll

@@ -117,6 +117,13 @@ class ProbeHeadEngine:
         self._pipelined = bool(want) and self._supports_comm_overlap() and self.accum_iter == 1 \
             and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force")
         self._pending = None
+        # Deferred large update (one rank): the step updates cls_token, then v.weight / fc.* on the aux stream BESIDE the
+        # next step's first token pass (which reads cls_token only).  Off by default -- between a train_step() and the
+        # next flush() the three large tensors may still be in flight, so only callers that flush() before they read
+        # parameters switch it on: engine_finetune.train_one_epoch does for its loop, bench.py does.
+        self.defer_update = False
+        self._defer_event = None
+        self._deferred = False
         if broadcast_from_rank0 and self.world > 1:
             dist.broadcast(self.flat_p, src=0, group=self.group)     # what DDP does at wrap time
             self.sync_buffers()
@@ -219,6 +226,9 @@ class ProbeHeadEngine:
     def flush(self) -> None:
         """Complete the deferred half of a pipelined step: wait for the large gradient all-reduce and update the
         tensors it covers.  Called automatically before anything that reads those parameters."""
+        if self._deferred:                                    # the current stream waits for the aux-stream update; the host does not
+            self._defer_event.wait(torch.cuda.current_stream(self.device))
+            self._deferred = False
         if self._pending is not None:
             work, lr, step = self._pending
             self._pending = None
@@ -255,7 +265,16 @@ class ProbeHeadEngine:
         optimizer's first kernel (one launch less).  Same arithmetic as the two calls."""
         return type(self) is ProbeHeadEngine and self.world == 1 and self.accum_iter == 1 and self._micro == 0
 
+    def _can_defer(self) -> bool:
+        import os
+        # EP_DEFER_OPT=1 to use it: measured SLOWER on MI355X / ROCm 7.2 (0.452 against 0.433 ms per step at 256x768) -- a
+        # dependency between two HIP streams costs 8-12 us of idle queue on each side (DESIGN section 4, round 3)
+        return (self.defer_update and self.aux_stream is not None and self.loss_scale == 1.0
+                and os.environ.get("EP_DEFER_OPT", "0") == "1")
+
     def _train_step_one_call(self, x, targets, lr, image_index) -> None:
+        if self._can_defer():
+            return self._train_step_deferred(x, targets, lr, image_index)
         self.flush()
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
@@ -266,6 +285,29 @@ class ProbeHeadEngine:
         s = self._step_struct(xv, bstride, targets, 3, False, lr)
         s.image_index = iptr
         N.check(self._call_train(s, ws), "head train step")
+        self._micro = 0
+
+    def _train_step_deferred(self, x, targets, lr, image_index) -> None:
+        """The one-call step with the deferred large update (include/ep_hip.h, phases bits 4 / 5): no flush() in front of
+        it -- the library itself makes the stream wait for the previous step's large update behind the first token pass."""
+        if self._pending is not None:
+            self.flush()
+        if self._defer_event is None:
+            self._defer_event = torch.cuda.Event()
+            self._defer_event.record(torch.cuda.current_stream(self.device))     # (creates the underlying hipEvent_t)
+        xv, bstride = F_.as_token_view(x)
+        _, Nn, D = xv.shape
+        iptr, B = F_._index_arg(image_index, xv)
+        if self._deferred and self._ws_key != (B, Nn):
+            self.flush()                                      # the update in flight still uses the old workspace
+        ws = self._workspace(B, Nn)
+        targets = targets.to(device=self.device, dtype=torch.int64)
+        self.opt_step += 1
+        s = self._step_struct(xv, bstride, targets, 3 | 16 | (32 if self._deferred else 0), False, lr)
+        s.image_index = iptr
+        s.defer_event = self._defer_event.cuda_event
+        N.check(self._call_train(s, ws), "head train step (deferred update)")
+        self._deferred = True
         self._micro = 0
 
     def train_step(self, x: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None,

@@ -229,6 +229,10 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     # criterion) takes the module path, which honours it
     fusable = mixup_fn is None and not max_norm and _plain_cross_entropy(criterion)
     engine = get_engine(model, optimizer, args) if fusable else None
+    if engine is not None and hasattr(engine, "defer_update"):
+        # inside this loop nothing reads the head's parameters between two steps: let the large update of a step run
+        # beside the next step's first token pass (flushed below, before anything can read them)
+        engine.defer_update = True
     optimizer.zero_grad()
     pending = 0                                   # fused steps whose statistics are still on the GPU
 
@@ -292,7 +296,9 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             log_writer.add_scalar("lr", metric_logger.meters["lr"].value, epoch_1000x)
     eng = getattr(model.module if hasattr(model, "module") else model, "_ep_engine", None)
     if eng is not None:
-        eng.flush()                       # a pipelined data-parallel step defers its large update by half a step
+        eng.flush()                       # a pipelined / deferred step leaves its large update half a step behind
+        if hasattr(eng, "defer_update"):
+            eng.defer_update = False
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     return {k: m.global_avg for k, m in metric_logger.meters.items()}

@@ -269,6 +269,15 @@ typedef struct ep_head_step {
    * all-reduce of the remaining gradients run beside it (see engine.ProbeHeadEngine).  found_inf /
    * grad_norm then cover the updated tensors only. */
   int32_t opt_first_segment, opt_num_segments;
+  /* Deferred large update (ABI v21).  phases bit 4 (16), with phases bit 1 (2) and an aux_stream: the optimizer updates
+   * cls_token on `stream` (one launch), then v.weight / fc.weight / fc.bias on aux_stream, and records the caller-owned
+   * event `defer_event` (a hipEvent_t) there instead of joining -- the next step's first token pass needs nothing but
+   * cls_token, so it starts right behind the small update while the large one runs beside it.  phases bit 5 (32) on a
+   * LATER call: make `stream` wait for defer_event in front of the first read of those three tensors (behind the first
+   * token pass).  A caller that reads the parameters itself waits on the event first (engine.ProbeHeadEngine.flush()).
+   * Same arithmetic and order per tensor as the undeferred step; found_inf / grad_norm then cover the tensors of the call
+   * that wrote them last (use it without loss scaling only). */
+  void* defer_event;
 } ep_head_step;
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);
