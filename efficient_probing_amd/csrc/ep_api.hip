@@ -512,10 +512,17 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   // projection, so the pass must not read Wv -- and dP inside the second pass.
   const int ipmask = (s->phases & (1 | 4 | 8)) && !pl ? pool_inpass_mask(p, Dp) : 0;
   const bool ip_y = (ipmask & 1) && (s->phases & 1) && bn_takes_parts(d.B);
+  int ip_r0 = 0;
   if (ipmask) {
     p.ip_err = w.iperr;
     p.ip_zero = w.dcnt; p.ip_nzero = w.nrb * 32 + 32;                   // the first pass clears the second pass's counters
-    if (ip_y) { p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; }
+    if (ip_y) {
+      p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; p.ip_y = w.y;
+      // rows of images that end a round before the pass does get their y whole (hidden under the last round)
+      const StreamGridInfo gi = pool_stream_grid(p);
+      ip_r0 = gi.rounds > 1 && gi.helpers > 0 ? bn_parts_r0(d.B, (gi.rounds - 1) * gi.grid) : 0;
+      p.ip_yr0 = ip_r0;
+    }
   }
   // a deferred large update of the previous step (phases bit 5): v.weight / fc.* are first read behind the first token
   // pass -- unless that pass computes the projection itself
@@ -527,7 +534,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     mark_pass(1, st);
   }
   if (wait_defer && !ip_y) EP_HIP(hipStreamWaitEvent(st, (hipEvent_t)s->defer_event, 0));
-  p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_zero = nullptr; p.ip_nzero = 0;
+  p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_y = nullptr; p.ip_yr0 = 0; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
     if (pl) {
       if (split_done) EP_HIP(hipStreamWaitEvent(st, pev[1], 0));
@@ -538,7 +545,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     }
     if (ip_y)   // the K-quarter partials of the in-pass projection are summed by the BatchNorm kernel (which also writes y)
       EP_TRY(bn_forward_train(w.ypart, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
-                              s->num_batches_tracked, w.bnpart, st, IP_YPARTS, (int64_t)d.B * Dp, w.y));
+                              s->num_batches_tracked, w.bnpart, st, IP_YPARTS, (int64_t)d.B * Dp, w.y, ip_r0));
     else
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));

@@ -180,12 +180,13 @@ __device__ __attribute__((noinline)) void ip_dp_task_call(const float* dy, const
   ip_dp_task_body<KT>(dy, Wv, dP, nB, b, lds_raw);
 }
 
-// ---- first pass: one K quarter of y for (row block, query) -------------------------------------------------------
+// ---- first pass: K quarters ks0 .. ks0 + nks - 1 of y for (row block, query) -----------------------------------------
 // A = P[32 rows, q, K quarter of 64 KT] (K layout, row stride Q D), B = Wv[q-slice rows (32 KT outputs), K quarter]
-// (K layout).  Output 32 x 32 KT into the partial buffer of that quarter; wave (wm, wn) owns 16 rows x 16 KT columns.
-// All 2 KT K-tiles are fetched up front (2 KT (1 + KT) float4 per thread), then pass through a double LDS buffer.
+// (K layout).  Output 32 x 32 KT at `out` (row stride D: a K-quarter partial buffer, or y itself when all four quarters
+// are summed here); wave (wm, wn) owns 16 rows x 16 KT columns.  The 2 KT K-tiles of a quarter are fetched up front
+// (2 KT (1 + KT) float4 per thread), then pass through a double LDS buffer; quarters follow one another.
 template <int KT>
-__device__ __forceinline__ void ip_y_task(const PoolParams& p, int b, char* lds_raw) {
+__device__ __forceinline__ void ip_y_task(const PoolParams& p, int rb, int q, int ks0, int nks, float* out, char* lds_raw) {
   constexpr int DQ = 32 * KT, D = 256 * KT, Q = 8, NKT = 2 * KT;
   constexpr int LDK2 = BK + 2;
   constexpr int STAGE = (32 + DQ) * LDK2;             // floats per stage: A image then B image
@@ -193,56 +194,56 @@ __device__ __forceinline__ void ip_y_task(const PoolParams& p, int b, char* lds_
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id_uniform();
   const int wm = w >> 1, wn = w & 1, i16 = lane & 15, kk = lane >> 4;
-  const int rb = b >> 5, r = b & 31, q = r >> 2, ks = r & 3;
   const int row0 = rb * 32;
   const __amdgpu_buffer_rsrc_t rP = ip_rsrc(p.P, (size_t)p.B * Q * D * sizeof(float));   // rows handed over in this launch
-  const unsigned a_off = (unsigned)((((int64_t)row0 * Q + q) * D + ks * (64 * KT)) * sizeof(float));
-  const float* W = p.ip_WvF + (int64_t)q * DQ * D + ks * (64 * KT);
-  float* C = p.ip_ypart + ((int64_t)ks * p.B + row0) * D + q * DQ;
-
-  f4v ra[NKT], rw[NKT][KT];
+  float* C = out + (int64_t)row0 * D + q * DQ;
   const int lrow = tid >> 3, lc = 4 * (tid & 7);
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    ra[t] = ip_load16_coherent(rP, a_off + (unsigned)(((int64_t)lrow * Q * D + 32 * t + lc) * sizeof(float)));
-#pragma unroll
-    for (int i = 0; i < KT; ++i) rw[t][i] = *reinterpret_cast<const f4v*>(W + (int64_t)(lrow + 32 * i) * D + 32 * t + lc);
-  }
-  auto lstore = [&](int t) {
-    float* sa = stage + (t & 1) * STAGE;
-    float* d = sa + lrow * LDK2 + lc;
-    *reinterpret_cast<f2*>(d) = f2{ra[t].x, ra[t].y};
-    *reinterpret_cast<f2*>(d + 2) = f2{ra[t].z, ra[t].w};
-#pragma unroll
-    for (int i = 0; i < KT; ++i) {
-      float* e = sa + (32 + lrow + 32 * i) * LDK2 + lc;
-      *reinterpret_cast<f2*>(e) = f2{rw[t][i].x, rw[t][i].y};
-      *reinterpret_cast<f2*>(e + 2) = f2{rw[t][i].z, rw[t][i].w};
-    }
-  };
   f4v acc[KT];
 #pragma unroll
   for (int bi = 0; bi < KT; ++bi) acc[bi] = f4v{0.f, 0.f, 0.f, 0.f};
-  lstore(0);
-  __syncthreads();
+  for (int ks = ks0; ks < ks0 + nks; ++ks) {
+    const unsigned a_off = (unsigned)((((int64_t)row0 * Q + q) * D + ks * (64 * KT)) * sizeof(float));
+    const float* W = p.ip_WvF + (int64_t)q * DQ * D + ks * (64 * KT);
+    f4v ra[NKT], rw[NKT][KT];
 #pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    if (t + 1 < NKT) lstore(t + 1);                    // the other buffer: everyone left it before the last barrier
-    const float* sa = stage + (t & 1) * STAGE;
-    const float* sb = sa + 32 * LDK2;
-    float af[8], bf[8][KT];
+    for (int t = 0; t < NKT; ++t) {
+      ra[t] = ip_load16_coherent(rP, a_off + (unsigned)(((int64_t)lrow * Q * D + 32 * t + lc) * sizeof(float)));
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      af[s] = sa[(wm * 16 + i16) * LDK2 + 4 * s + kk];
-#pragma unroll
-      for (int bi = 0; bi < KT; ++bi) bf[s][bi] = sb[(wn * 16 * KT + bi * 16 + i16) * LDK2 + 4 * s + kk];
+      for (int i = 0; i < KT; ++i) rw[t][i] = *reinterpret_cast<const f4v*>(W + (int64_t)(lrow + 32 * i) * D + 32 * t + lc);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    auto lstore = [&](int t) {
+      float* sa = stage + (t & 1) * STAGE;
+      float* d = sa + lrow * LDK2 + lc;
+      *reinterpret_cast<f2*>(d) = f2{ra[t].x, ra[t].y};
+      *reinterpret_cast<f2*>(d + 2) = f2{ra[t].z, ra[t].w};
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int bi = 0; bi < KT; ++bi) acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s][bi], acc[bi], 0, 0, 0);
+      for (int i = 0; i < KT; ++i) {
+        float* e = sa + (32 + lrow + 32 * i) * LDK2 + lc;
+        *reinterpret_cast<f2*>(e) = f2{rw[t][i].x, rw[t][i].y};
+        *reinterpret_cast<f2*>(e + 2) = f2{rw[t][i].z, rw[t][i].w};
+      }
+    };
+    lstore(0);
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      if (t + 1 < NKT) lstore(t + 1);                    // the other buffer: everyone left it before the last barrier
+      const float* sa = stage + (t & 1) * STAGE;
+      const float* sb = sa + 32 * LDK2;
+      float af[8], bf[8][KT];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        af[s] = sa[(wm * 16 + i16) * LDK2 + 4 * s + kk];
+#pragma unroll
+        for (int bi = 0; bi < KT; ++bi) bf[s][bi] = sb[(wn * 16 * KT + bi * 16 + i16) * LDK2 + 4 * s + kk];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int bi = 0; bi < KT; ++bi) acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s][bi], acc[bi], 0, 0, 0);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int bi = 0; bi < KT; ++bi)

@@ -39,6 +39,8 @@ struct PoolParams {
   // first pass: y = P_q Wv_q^T as four K-quarter partials ip_ypart[ks][b][:] by the workgroups that have finished their
   // images (the matrix pipe is idle under the pass); BatchNorm sums the partials in fixed order
   const float* ip_WvF; float* ip_ypart; int* ip_ycnt;
+  float* ip_y; int ip_yr0;      // rows < ip_yr0 (row blocks whose images end before the last round) get their y directly, all
+                                // four K quarters summed in one task by a workgroup that is done early; rows >= ip_yr0 as partials
   int* ip_zero; int ip_nzero;   // counters this launch clears for the OTHER pass (first instructions of workgroup 0)
   // ticketed second pass (ep_pool_bwd2.hip): images are handed out by a device-wide counter (zero at launch); workgroups
   // with index < tick_base stream image `index` first, a ticket t names image tick_base + t
@@ -113,6 +115,8 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv);   // ... and comput
 // In-pass contractions (ep_inpass.h) possible for this shape on BOTH passes?  bit 0: y inside the first pass, bit 1: dP
 // inside the second (EP_INPASS=<mask> switches them, default 3).  Dv = width of the projection (must equal D).
 int pool_inpass_mask(const PoolParams& p, int Dv);
+struct StreamGridInfo { int grid, rounds, helpers; };          // pooling workgroups, ceil(B / grid), workgroups without an image of the last round
+StreamGridInfo pool_stream_grid(const PoolParams& p);
 // bit 2 of that mask: the ticketed second pass (ep_pool_bwd2.hip: dP and the weight-gradient side tasks under the stream)
 int bwd2_launch(const PoolParams& p, int grid, int first, hipStream_t st, const SideTasks* side);
 constexpr int IP_YPARTS = 4;                                   // K quarters of the in-pass value projection
@@ -131,7 +135,9 @@ size_t bn_workspace_bytes(int B, int Dp);
 // fixed order ((p0 + p1) + (p2 + p3)); the sum is also written to y_out (may be null)
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
                      float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st, int nparts = 1,
-                     int64_t pstride = 0, float* y_out = nullptr);
+                     int64_t pstride = 0, float* y_out = nullptr, int r0 = 0);   // rows < r0: already summed, in y_out
+// rows in front of which the in-pass projection may write y directly (0: none; the BatchNorm kernel has this one split)
+int bn_parts_r0(int B, int r0);
 bool bn_takes_parts(int B);
 int bn_forward_eval(const float* y, int B, int Dp, float eps, const float* rmean, const float* rvar, float* z,
                     hipStream_t st);

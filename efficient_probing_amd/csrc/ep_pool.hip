@@ -468,6 +468,16 @@ int pool_inpass_mask(const PoolParams& p, int Dv) {
   return m;
 }
 
+StreamGridInfo pool_stream_grid(const PoolParams& p) {
+  const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+  StreamGridInfo g{c.grid, 1, 0};
+  if (c.ok && c.grid > 0) {
+    g.rounds = (p.B + c.grid - 1) / c.grid;
+    g.helpers = c.grid - (p.B - (g.rounds - 1) * c.grid);
+  }
+  return g;
+}
+
 int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side,
                   DeferredReduce* defer) {
   PoolParams p = p0;

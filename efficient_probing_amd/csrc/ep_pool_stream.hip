@@ -299,20 +299,26 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       const int R = (p.B + G - 1) / G;
       const int nfull = p.B - (R - 1) * G;                   // workgroups with R images (== G when B % G == 0)
       const int nh = G - nfull;                              // helpers: done one round before the end of the pass
-      const bool owner_last = wg < nfull;
-      int ntask;
-      if (owner_last) ntask = nh == 0 ? R : 1;               // no helpers: all of its images' tasks, at the end
-      else ntask = (R - 1) + ((R - 1) * nfull - (wg - nfull) + nh - 1) / nh;
-      for (int i = 0; i < ntask; ++i) {                      // ONE copy of the task body in the kernel
-        int b;
-        if (owner_last) b = nh == 0 ? wg + i * G : wg + (R - 1) * G;
-        else if (i < R - 1) b = wg + i * G;
-        else { const int e = (wg - nfull) + (i - (R - 1)) * nh; b = (e % nfull) + (e / nfull) * G; }
+      // Tasks.  Row blocks below ip_yr0 (= (R - 1) G when the BatchNorm kernel has that split, else 0) belong to images
+      // that end a round before the pass does: their y is computed whole (all four K quarters in one task, 8 tasks per
+      // row block) by the helpers, hidden under the last round.  The row blocks of the LAST round are on the critical
+      // path: four K-quarter tasks per (row block, query), one per owner, summed by the BatchNorm kernel.
+      const int r0 = p.ip_yr0;
+      for (int b = wg; b < p.B; b += G) {                    // this workgroup's images of the last round (all of them if r0 == 0)
+        if (b < r0) continue;
         ip_wait<false>(p.ip_ycnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);   // the task reads P with sc1 loads
-        if (i == 0) stamp(2);
-        if (!(p.ablate & 1)) ip_y_task<KP>(p, b, ring);
-        if (i == 0) stamp(3);
+        stamp(2);
+        const int r = b & 31;
+        ip_y_task<KP>(p, b >> 5, r >> 2, r & 3, 1, p.ip_ypart + (int64_t)(r & 3) * p.B * D, ring);
+        stamp(3);
       }
+      if (wg >= nfull && nh > 0)
+        for (int t = wg - nfull; t < r0 / 4; t += nh) {      // whole-y task t: row block t / 8, query t % 8
+          ip_wait<false>(p.ip_ycnt + (t >> 3) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
+          stamp(2);
+          ip_y_task<KP>(p, t >> 3, t & 7, 0, 4, p.ip_y, ring);
+          stamp(3);
+        }
       stamp(4);
     }
   }

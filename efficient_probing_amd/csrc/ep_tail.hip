@@ -108,7 +108,9 @@ __device__ __forceinline__ float bnf_reduce(float v, float (*sm)[16], int tx, in
 
 // PARTS: y arrives as four partial matrices `pstride` floats apart (the K quarters of the in-pass value projection,
 // ep_inpass.h), summed here as (p0 + p1) + (p2 + p3); the sum is written to y_out for the second token pass.
-template <bool PARTS>
+// I0 (PARTS only): rows [0, 64 I0) are already summed and sit in y_out (the whole-y tasks of the in-pass projection),
+// rows behind them arrive as the four partials.
+template <bool PARTS, int I0 = 0>
 __global__ __launch_bounds__(1024) void ep_bn_fused_kernel(const float* __restrict__ y, int B, int Dp, float eps, float momentum,
                                                          float* __restrict__ z, float* __restrict__ rstd_out,
                                                          float* __restrict__ rmean, float* __restrict__ rvar,
@@ -121,19 +123,22 @@ __global__ __launch_bounds__(1024) void ep_bn_fused_kernel(const float* __restri
   float v[BNF_RPT];
   float s = 0.f;
   if constexpr (PARTS) {
-    float pq[BNF_RPT][4];
+    float pq[BNF_RPT - I0][4];
 #pragma unroll
     for (int i = 0; i < BNF_RPT; ++i) {                // branch-free loads (clamped address): all in flight together
       const int b = ty + 64 * i;
       const int64_t at = (int64_t)(b < B ? b : B - 1) * Dp + (ok ? col : 0);
+      if (i < I0) v[i] = y_out[at];
+      else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pq[i][k] = y[(int64_t)k * pstride + at];
+        for (int k = 0; k < 4; ++k) pq[i - I0][k] = y[(int64_t)k * pstride + at];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < BNF_RPT; ++i) v[i] = (pq[i][0] + pq[i][1]) + (pq[i][2] + pq[i][3]);
+    for (int i = I0; i < BNF_RPT; ++i) v[i] = (pq[i - I0][0] + pq[i - I0][1]) + (pq[i - I0][2] + pq[i - I0][3]);
     if (y_out) {
 #pragma unroll
-      for (int i = 0; i < BNF_RPT; ++i) {
+      for (int i = I0; i < BNF_RPT; ++i) {
         const int b = ty + 64 * i;
         if (ok && b < B) y_out[(int64_t)b * Dp + col] = v[i];
       }
@@ -522,13 +527,20 @@ static bool bn_fused(int B) {
 size_t bn_workspace_bytes(int B, int Dp) { (void)B; return round_up((size_t)RS_MAX * 2 * Dp * sizeof(float), 256); }
 
 bool bn_takes_parts(int B) { return bn_fused(B); }
+// the one split of "rows already summed | rows as partials" the kernel is instantiated for: 768 | rest (B = 1024 images on
+// 768 pooling workgroups)
+int bn_parts_r0(int B, int r0) { return (bn_fused(B) && r0 == 768 && B > 768) ? 768 : 0; }
 
 int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, float* z, float* rstd,
                      float* rmean, float* rvar, int64_t* nbt, float* partial, hipStream_t st, int nparts, int64_t pstride,
-                     float* y_out) {
+                     float* y_out, int r0) {
   EP_REQUIRE(nparts == 1 || (nparts == 4 && bn_fused(B)), EP_E_UNSUPPORTED, "BatchNorm over partial sums: 4 parts, B <= %d", 64 * BNF_RPT);
+  EP_REQUIRE(r0 == 0 || (nparts == 4 && r0 == 768 && y_out), EP_E_UNSUPPORTED, "BatchNorm over partial sums: row split %d not instantiated", r0);
   if (bn_fused(B)) {
-    if (nparts == 4)
+    if (nparts == 4 && r0 == 768)
+      hipLaunchKernelGGL((ep_bn_fused_kernel<true, 12>), dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean,
+                         rvar, nbt, pstride, y_out);
+    else if (nparts == 4)
       hipLaunchKernelGGL(ep_bn_fused_kernel<true>, dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean,
                          rvar, nbt, pstride, y_out);
     else

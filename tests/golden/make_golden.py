@@ -156,8 +156,20 @@ def run_case(case, optimizer_name="lars"):
                 g = p.grad.detach().numpy()
                 out[f"grad_{n}"] = g if n in ("cls_token", "fc_bias") else keep(g)
                 out[f"gradnorm_{n}"] = np.float64(p.grad.double().norm().item())
-        opt.step()
         tag = f"{optimizer_name}{step + 1}"
+        if optimizer_name == "lars":
+            # the trust ratio util/lars.py:21-29 is about to use, twice: with torch-CPU's float32 norms (what the reference
+            # computes: its naive accumulation over 1e5..1e7 elements is off by up to ~1e-3) and in float64 (the exact
+            # value of the same formula).  Tests pin the GPU's ratio on the float64 one; the float32 one explains the
+            # common factor between the GPU's momentum and the reference's.
+            for n, p in zip(names, plist):
+                if p.ndim > 1:
+                    dp = p.grad.add(p.detach(), alpha=case.weight_decay)
+                    pn32, un32 = torch.norm(p.detach()), torch.norm(dp)
+                    pn64, un64 = torch.norm(p.detach().double()), torch.norm(dp.double())
+                    out[f"{tag}_q32_{n}"] = np.float64((0.001 * pn32 / un32).item() if pn32 > 0 and un32 > 0 else 1.0)
+                    out[f"{tag}_q64_{n}"] = np.float64((0.001 * pn64 / un64).item() if pn64 > 0 and un64 > 0 else 1.0)
+        opt.step()
         out[f"{tag}_loss"] = np.float32(loss.item())
         for n, p in zip(names, plist):
             a = p.detach().numpy().copy()

@@ -19,6 +19,10 @@ DEV = "cuda:0"
 
 SHAPES = [(1024, 256, 768, 8), (1025, 256, 768, 8), (1024, 197, 768, 8), (1025, 197, 768, 8)]
 IDS = ["c2_b1024", "c2_b1025", "ns_b1024", "ns_b1025"]
+# BASELINE configs[2] / [3] at the bench batch (round 3): MAE ViT-L/16 196x1024 and SigLIP2 SO400M 256x1152 -- other kernel
+# families (the matrix-core token passes), the same B = 1024 the `configs` object of bench.py times
+WIDE = [(1024, 196, 1024, 8), (1024, 256, 1152, 8)]
+WIDE_IDS = ["c3_b1024", "c4_b1024"]
 
 
 def fp64_reference(x, cls, scale, dP, chunk=128):
@@ -40,7 +44,7 @@ def fp64_reference(x, cls, scale, dP, chunk=128):
     return P, S, dcls
 
 
-@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+@pytest.mark.parametrize("shape", SHAPES + WIDE, ids=IDS + WIDE_IDS)
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_token_passes_at_bench_batch_vs_fp64(shape, storage):
     from efficient_probing_amd import functional as F_, _native
@@ -89,14 +93,21 @@ def _heads(Nn, D, Q, Cc):
     return head.to(DEV).train(), port.train()
 
 
-@pytest.mark.parametrize("shape", SHAPES[:2] + SHAPES[3:], ids=IDS[:2] + IDS[3:])
-def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape):
+@pytest.mark.parametrize("one_call", [False, True], ids=["two_calls", "one_call"])
+@pytest.mark.parametrize("shape", SHAPES + WIDE, ids=IDS + WIDE_IDS)
+def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
     """Two full iterations at the bench configuration (lr = blr * B / 256 as main_linprobe.py:572-573) against the
     torch-CPU port of the reference step: loss, every gradient (incl. the side-task weight gradients over 1024 / 1025
-    rows), the LARS momentum, the updated parameters and the BatchNorm running statistics."""
+    rows), the LARS momentum, the updated parameters and the BatchNorm running statistics.  ``one_call``: the form the
+    bench times (engine.train_step -> ONE ep_head_train_step with phases = 3: the optimizer finishes the cls_token
+    gradient reduction, the in-pass contractions run inside the token passes) at the full 256 / 197 tokens."""
     from efficient_probing_amd.engine import ProbeHeadEngine
     from oracle import torch_port
     B, Nn, D, Q = shape
+    if one_call and (B != 1024 or D != 768):
+        pytest.skip("the one-call form is compared at the two benchmarked 768-wide shapes")
+    if not one_call and shape == SHAPES[2]:
+        pytest.skip("197x768 at B = 1024: covered by the one-call form (and B = 1025 by this one)")
     Cc = 1000
     head, port = _heads(Nn, D, Q, Cc)
     lr = 0.1 * B / 256
@@ -111,12 +122,18 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape):
         x = torch.randn(B, Nn, D, generator=g)
         t = torch.randint(0, Cc, (B,), generator=g)
         xd, td = x.to(DEV), t.to(DEV)
-        # gradients first (phase 1 alone), then the update, so both are compared
-        eng.forward_backward(xd, td)
-        torch.cuda.synchronize()
-        grads = [p.grad.detach().cpu().clone() for p in eng.params_list]
-        eng.all_reduce_grads()
-        eng.optimizer_step(lr)
+        if one_call:
+            assert eng._one_call_step()
+            eng.train_step(xd, td, lr=lr)
+            torch.cuda.synchronize()
+            grads = [p.grad.detach().cpu().clone() for p in eng.params_list]     # (the norms kernel wrote cls_token's back)
+        else:
+            # gradients first (phase 1 alone), then the update, so both are compared
+            eng.forward_backward(xd, td)
+            torch.cuda.synchronize()
+            grads = [p.grad.detach().cpu().clone() for p in eng.params_list]
+            eng.all_reduce_grads()
+            eng.optimizer_step(lr)
         loss, top1, top5, bad = eng.read_stats()
         want_loss = float(torch_port.train_step(port, mus, x, t, lr))
         assert bad == 0
