@@ -259,15 +259,19 @@ def main():
     from efficient_probing_amd import probe_heads, functional as F_
     from efficient_probing_amd.engine import make_engine
 
+    # EP_BENCH_SHARE_DEVICE=1 (tests on a one-GPU box only): every rank runs on device 0 and the collectives go over
+    # gloo (it moves device tensors through the host) -- the whole world > 1 path of this file with the real kernels
+    share = world > 1 and os.environ.get("EP_BENCH_SHARE_DEVICE") == "1"
+    backend = "gloo" if share else "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)     # "nccl" IS RCCL on ROCm
+        torch.cuda.set_device(0 if share else local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)    # "nccl" IS RCCL on ROCm
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
     rccl_ranks = dist.get_world_size() if world > 1 else 1
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
 
     Nn, D, Q, Cc, desc = WORKLOADS[args.workload]
@@ -634,7 +638,8 @@ def main():
                        "simpool": "SimPool-head train images/sec", "esimpool": "eSimPool-head train images/sec",
                        "cait": "CaiT-head train images/sec", "clip": "CLIP-head train images/sec",
                        "cbam": "CBAM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "rccl_ranks": rccl_ranks, **({"collective_backend": "gloo (EP_BENCH_SHARE_DEVICE=1: all ranks on one device, a test mode)"} if share else {}),
+            "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "step_ms_p10": pct(0.10), "step_ms_p50": pct(0.50), "step_ms_p90": pct(0.90), "step_ms_window": me,
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),

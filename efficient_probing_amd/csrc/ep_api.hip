@@ -520,7 +520,11 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       p.ip_WvF = Wv; p.ip_ypart = w.ypart; p.ip_ycnt = w.ycnt; p.ip_y = w.y;
       // rows of images that end a round before the pass does get their y whole (hidden under the last round)
       const StreamGridInfo gi = pool_stream_grid(p);
-      ip_r0 = gi.rounds > 1 && gi.helpers > 0 ? bn_parts_r0(d.B, (gi.rounds - 1) * gi.grid) : 0;
+      // EP_INPASS_YSPLIT=1 only: measured WORSE than K-quarter tasks for every row block (first pass 171 against 159 us at
+      // 256x768 -- a whole-y task takes ~28 us and the helpers only get to it ~25 us before the pass ends)
+      static int ysplit = -1;
+      if (ysplit < 0) { const char* e = getenv("EP_INPASS_YSPLIT"); ysplit = e ? atoi(e) : 0; }
+      ip_r0 = ysplit && gi.rounds > 1 && gi.helpers > 0 ? bn_parts_r0(d.B, (gi.rounds - 1) * gi.grid) : 0;
       p.ip_yr0 = ip_r0;
     }
   }

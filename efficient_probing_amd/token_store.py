@@ -176,9 +176,9 @@ class ResidentTokenStore:
             stop = self.num_batches(batch_size) * batch_size
         else:
             stop = self.num_images - (self.num_images % batch_size if drop_last else 0)
+        labels = self.labels[order.long()]          # ONE gather per epoch: a batch is then two views, no kernel of its own
         for lo in range(0, stop, batch_size):
-            idx = order[lo:lo + batch_size].contiguous()
-            yield self.tokens, idx, self.labels[idx.long()]
+            yield self.tokens, order[lo:lo + batch_size], labels[lo:lo + batch_size]
 
 
 class StoreEpoch:

@@ -80,3 +80,25 @@ def test_two_ranks_equal_simulation(tmp_path, overlap):
     assert torch.equal(got[0]["p"], reps[0].flat_p.cpu())
     assert torch.equal(got[0]["mu"], reps[0].state[0].cpu())
     assert torch.equal(got[0]["rm"], reps[0].bn.running_mean.cpu())
+
+
+def test_bench_two_ranks_end_to_end_on_one_device():
+    """``python bench.py --gpus 2`` end to end with the real kernels: the launcher spawns two fresh child ranks, they
+    rendezvous on 127.0.0.1, run the data-parallel step (flat-gradient all-reduce, 1 / world in the optimizer), barrier,
+    flush(), take the MAX of the elapsed time and rank 0 prints the contract line.  On this one-GPU box both ranks share
+    device 0 and the collectives go over gloo (EP_BENCH_SHARE_DEVICE=1); on a node the same code runs over RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, EP_BENCH_SHARE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--spinup", "4",
+           "--batch", "256", "--no-cpu-baseline", "--no-bf16-secondary", "--no-north-star", "--no-configs",
+           "--no-through-engine", "--kernel-iters", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 6
+    assert line["config"]["global_batch"] == 512 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and np.isfinite(line["check"]["mean_loss_over_timed_steps"])
+    assert line["value"] == pytest.approx(512 * 6 / (line["ms_per_step"] * 6e-3), rel=1e-3)   # whole-job images per second
