@@ -58,6 +58,7 @@ int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, in
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
   float* ypart;                                // in-pass value projection: IP_YPARTS K-quarter partials of y (ep_inpass.h)
+  float* colstat;                              // per-32-row-tile column sums of dz and dz z (folded BatchNorm backward)
   int *ycnt, *dcnt, *tick, *iperr; int nrb;    // arrival counters per 32-image row block and the image ticket counter
                                                // (each on a 128-byte line of its own, zero between steps), give-up count
   uint16_t *plWv, *plWvT, *plWc, *plWcT;       // bf16 planes of the two weight matrices, both orientations (ep_planes.hip)
@@ -103,6 +104,7 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
   w.dy = take(B * Dp);
   w.dP = take(B * d.Q * d.D);
   w.ypart = take((size_t)IP_YPARTS * B * Dp);
+  w.colstat = take(((size_t)(d.B + 31) / 32 + 1) * 2 * Dp);
   w.nrb = (d.B + 31) / 32;
   // one counter per 128-byte line (IP_CNT_STRIDE ints apart): ycnt | dcnt | ticket | give-up count
   w.ycnt = reinterpret_cast<int*>(take(2 * (size_t)w.nrb * 32 + 64));
@@ -566,13 +568,31 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
     if (ipmask) { p.ip_zero = w.ycnt; p.ip_nzero = w.nrb * 32; }            // the second pass clears the first pass's counters
     if (pool_backward_takes_side(p) && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
-      if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
-      else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
-      EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       // the softmax-correction rows dy_q . y_q: inside the second pass where its kernel can (one launch less)
       const bool in_pass = pool_backward_takes_delta(p, Dp);
-      if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
       const bool ip_dp = (ipmask & 2) != 0;
+      // BatchNorm backward FOLDED into the in-pass dP tasks (ep_inpass.h): the dz contraction leaves per-tile column
+      // statistics in its epilogue, the tasks form dy = rstd (dz - m1 - z m2) while they stage their A tile and publish
+      // dy for the delta items and the dWv side tasks -- ep_bn_bwd_fused_kernel (8 us, 48 workgroups on 256 CUs)
+      // leaves the chain between the passes.  OPT-IN (EP_BN_FOLD=1): measured slower so far -- the tasks in front of the
+      // token stream grow by ~9 us (one more operand tile, the tile-ordered column sums) for the 8 us launch they replace
+      // (second pass 201 -> 210 us, step 0.441 -> 0.444 ms at 256x768).
+      GemmParams gz{};
+      gz.A = w.dlogits; gz.lda = w.ldl; gz.B = Wc; gz.ldb = Dp; gz.extB = Dp; gz.C = w.dz; gz.ldc = Dp;
+      gz.M = d.B; gz.N = Dp; gz.K = d.C; gz.alpha = 1.f;
+      static int fold_on = -1;
+      if (fold_on < 0) { const char* e = getenv("EP_BN_FOLD"); fold_on = e ? atoi(e) : 0; }
+      const bool fold = fold_on && ip_dp && in_pass && !(ipmask & 4) && !pl && d.B % 32 == 0 && gemm_colstats_ok(true, false, gz, 1);
+      if (fold) {
+        gz.cs_z = w.z; gz.cs_out = w.colstat;
+        EP_TRY(gemm(true, false, gz, 1, st));
+        p.ip_fold_dz = w.dz; p.ip_fold_z = w.z; p.ip_fold_rstd = w.rstd; p.ip_fold_cs = w.colstat;
+      } else {
+        if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
+        else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
+        EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
+      }
+      if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
       if (ip_dp) { p.ip_dy = w.dy; p.ip_Wv = Wv; p.ip_dcnt = w.dcnt; }   // dP rows by the pooling workgroups themselves
       if ((ipmask & 4) && in_pass) p.tick = w.tick;                      // ... in the ticketed form (ep_pool_bwd2.hip)
       if (pl) {

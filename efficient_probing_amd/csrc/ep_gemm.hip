@@ -419,6 +419,45 @@ __global__ __launch_bounds__(512) void ep_gemm_kt96_kernel(GemmParams p) {
 #pragma unroll
   for (int bi = 0; bi < 3; ++bi) { rb[bi] = m0 + wm * 16; cb[bi] = n0 + wn * 48 + bi * 16; }
   store_acc_blocks<3>(p, C, z, rb, cb, acc, kk, i16);
+  if (p.cs_out) {
+    // column statistics of this 32-row tile (GemmParams.cs_out): a lane holds rows 4 kk + r of a 16-row block in one
+    // column; sum its rows, fold the four lane groups, then the two row halves (wm) through LDS -- fixed order
+    float s1[3], s2[3];
+#pragma unroll
+    for (int bi = 0; bi < 3; ++bi) {
+      const int col = n0 + wn * 48 + bi * 16 + i16;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 16 + 4 * kk + r;
+        const float zz = p.cs_z[(int64_t)(row < p.M ? row : p.M - 1) * p.ldc + col];
+        const float v = row < p.M ? p.alpha * acc[bi][r] : 0.f;
+        a += v; b = fmaf(v, zz, b);
+      }
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      s1[bi] = a; s2[bi] = b;
+    }
+    float* ex = reinterpret_cast<float*>(lds);          // [wm][stat][96]; the ring is idle (the loader waves drained it)
+    ws_barrier();
+    if (kk == 0) {
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        ex[(wm * 2 + 0) * 96 + wn * 48 + bi * 16 + i16] = s1[bi];
+        ex[(wm * 2 + 1) * 96 + wn * 48 + bi * 16 + i16] = s2[bi];
+      }
+    }
+    ws_barrier();
+    if (wm == 0 && kk == 0) {
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        const int c = wn * 48 + bi * 16 + i16;
+        float* o = p.cs_out + ((int64_t)blockIdx.y * 2) * p.N + n0 + c;
+        o[0] = ex[0 * 96 + c] + ex[2 * 96 + c];
+        o[p.N] = ex[1 * 96 + c] + ex[3 * 96 + c];
+      }
+    }
+  }
 }
 
 // K/T layout on 32 x 96 tiles: where the 64 x 64 grid is a partial round of the chip and the 32 x 96 grid a whole one
@@ -431,6 +470,15 @@ static bool gemm_kt96_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {
   const long t96 = (long)(p.N / 96) * ((p.M + 31) / 32) * batch;
   // one partial round of 64 x 64 tiles against whole rounds of the smaller ones (same matrix work per round)
   return t64 < cus && t96 % cus == 0 && (p.K + BK - 1) / BK >= 8;
+}
+
+bool gemm_colstats_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {
+  static int use_dma = -1;
+  if (use_dma < 0) { const char* e = getenv("EP_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
+  static int force_bm = -1;
+  if (force_bm < 0) { const char* e = getenv("EP_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
+  const bool vec = aligned16(p.A) && aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.K % 4 == 0 && p.extB % 4 == 0;
+  return batch == 1 && use_dma && !force_bm && vec && !p.skws && p.M % 32 == 0 && gemm_kt96_ok(a_k, b_k, p, batch);
 }
 
 static bool gemm_kk96_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {

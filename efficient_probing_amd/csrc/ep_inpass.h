@@ -74,9 +74,12 @@ __device__ __forceinline__ void ip_wait(int* cnt, int target, int* err) {
 }
 
 // LDS bytes the tasks need (the token ring of the pass is idle while they run)
-constexpr size_t ip_dp_lds_bytes(int kt) {      // A image + one B tile (>= the 32 x 68 output staging tile that reuses it)
-  return (size_t)(32 * (((32 * kt + 29) / 64) * 64 + 34) + (32 * kt * (64 + 16) > 32 * 68 ? 32 * kt * (64 + 16) : 32 * 68)) * sizeof(float);
+constexpr size_t ip_dp_lds_bytes(int kt) {      // A image + one B tile (>= the 32 x 68 output staging tile that reuses it) + 3 x 32 kt column scalars
+  return (size_t)(32 * (((32 * kt + 29) / 64) * 64 + 34) + (32 * kt * (64 + 16) > 32 * 68 ? 32 * kt * (64 + 16) : 32 * 68) + 3 * 32 * kt) * sizeof(float);
 }
+// BatchNorm backward folded into the dP tasks (PoolParams.ip_fold_*): dz, z (B x D), rstd (D), the per-32-row-tile column
+// statistics of dz (cs: [B / 32][2][D]) and where column quarter 0 writes dy
+struct IpFold { const float* dz; const float* z; const float* rstd; const float* cs; float* dy; };
 constexpr size_t ip_y_lds_bytes(int kt) { return (size_t)2 * (32 + 32 * kt) * (BK + 2) * sizeof(float); }
 
 // ---- second pass: dP rows of one (row block, query, column quarter) --------------------------------------------
@@ -85,7 +88,7 @@ constexpr size_t ip_y_lds_bytes(int kt) { return (size_t)2 * (32 + 32 * kt) * (B
 // A image stays in LDS, the KT 64-column B tiles pass through one LDS buffer.  Exact fp32 (v_mfma_f32_16x16x4_f32).
 template <int KT>
 __device__ __forceinline__ void ip_dp_task_body(const float* __restrict__ dy, const float* __restrict__ Wv, float* dP, int nB, int b,
-                                               char* lds_raw) {
+                                               char* lds_raw, const IpFold fold = IpFold{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   constexpr int DQ = 32 * KT, D = 256 * KT, Q = 8, CW = 64 * KT;
   constexpr int SA = ((DQ + 29) / 64) * 64 + 34;      // A row stride in floats, == 34 (mod 64): conflict-free fragment reads
   constexpr int SB = 64 + 16;                         // B k-row stride
@@ -103,11 +106,26 @@ __device__ __forceinline__ void ip_dp_task_body(const float* __restrict__ dy, co
   const __amdgpu_buffer_rsrc_t rC = ip_rsrc(dP, (size_t)nB * Q * D * sizeof(float));
   const unsigned c_off = (unsigned)((((int64_t)row0 * Q + q) * D + ch * CW) * sizeof(float));
 
-  f4v ra[KT], rw[KT][2 * KT];
+  f4v ra[KT], rz[KT], rw[KT][2 * KT];
+  float* cst = Bs + (DQ * SB > 32 * 68 ? DQ * SB : 32 * 68);   // [m1 | m2 | rstd][DQ] column scalars of the folded BatchNorm backward
+  if (fold.dz) {
+    // A = dy is formed HERE: dy = rstd (dz - m1 - z m2), m1 = mean_b dz, m2 = mean_b dz z (probe_heads.py:109-110
+    // BatchNorm1d(affine=False) backward); the means from the per-tile column sums the dz contraction left, summed in tile order
+    const float* Az = fold.dz + (int64_t)row0 * D + q * DQ;
+    const float* Zz = fold.z + (int64_t)row0 * D + q * DQ;
 #pragma unroll
-  for (int i = 0; i < KT; ++i) {
-    const int idx = tid + 256 * i;
-    ra[i] = *reinterpret_cast<const f4v*>(A + (int64_t)(idx / (DQ / 4)) * D + 4 * (idx % (DQ / 4)));
+    for (int i = 0; i < KT; ++i) {
+      const int idx = tid + 256 * i;
+      const int64_t at = (int64_t)(idx / (DQ / 4)) * D + 4 * (idx % (DQ / 4));
+      ra[i] = *reinterpret_cast<const f4v*>(Az + at);
+      rz[i] = *reinterpret_cast<const f4v*>(Zz + at);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      const int idx = tid + 256 * i;
+      ra[i] = *reinterpret_cast<const f4v*>(A + (int64_t)(idx / (DQ / 4)) * D + 4 * (idx % (DQ / 4)));
+    }
   }
 #pragma unroll
   for (int nt = 0; nt < KT; ++nt)
@@ -116,6 +134,39 @@ __device__ __forceinline__ void ip_dp_task_body(const float* __restrict__ dy, co
       const int idx = tid + 256 * i;
       rw[nt][i] = *reinterpret_cast<const f4v*>(W + (int64_t)(idx >> 4) * D + nt * 64 + 4 * (idx & 15));
     }
+  if (fold.dz) {
+    const int ntile = nB >> 5;
+    for (int t = tid; t < 3 * DQ; t += 256) {
+      if (t < 2 * DQ) {                                // column sums over the batch: 32-row tiles in order
+        const int which = t / DQ, col = t - which * DQ;
+        const float* c = fold.cs + (int64_t)which * D + q * DQ + col;
+        float acc_ = 0.f;
+        for (int k0 = 0; k0 < ntile; k0 += 16) {       // 16 loads in flight per trip (clamped address, masked value)
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = c[(int64_t)((k0 + u) < ntile ? (k0 + u) : ntile - 1) * 2 * D];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc_ += (k0 + u) < ntile ? v[u] : 0.f;
+        }
+        cst[t] = acc_ / (float)nB;
+      } else {
+        cst[t] = fold.rstd[q * DQ + t - 2 * DQ];
+      }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rY = ip_rsrc(fold.dy, (size_t)nB * D * sizeof(float));
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      const int idx = tid + 256 * i, row = idx / (DQ / 4), c0 = 4 * (idx % (DQ / 4));
+      f4v v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = cst[2 * DQ + c0 + j] * (ra[i][j] - cst[c0 + j] - rz[i][j] * cst[DQ + c0 + j]);
+      ra[i] = v;
+      // dy itself is read by the delta items of the pooling workgroups and by the dWv side tasks of this launch: the
+      // tasks of column quarter 0 publish it (write-through, whole 128-byte lines per instruction)
+      if (ch == 0) ip_store16_wt(rY, (unsigned)((((int64_t)(row0 + row)) * D + q * DQ + c0) * sizeof(float)), v);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < KT; ++i) {
     const int idx = tid + 256 * i;
@@ -170,7 +221,8 @@ __device__ __forceinline__ void ip_dp_task_body(const float* __restrict__ dy, co
 
 template <int KT>
 __device__ __forceinline__ void ip_dp_task(const PoolParams& p, int b, char* lds_raw) {
-  ip_dp_task_body<KT>(p.ip_dy, p.ip_Wv, const_cast<float*>(p.dP), p.B, b, lds_raw);
+  ip_dp_task_body<KT>(p.ip_dy, p.ip_Wv, const_cast<float*>(p.dP), p.B, b, lds_raw,
+                      IpFold{p.ip_fold_dz, p.ip_fold_z, p.ip_fold_rstd, p.ip_fold_cs, const_cast<float*>(p.ip_dy)});
 }
 // the same as a CALL: inside the ticketed second pass the task sits in the middle of the token loop, and inlined there its
 // ~90 staging registers pushed the loop's own values into scratch (64 spilled registers); as a function the caller only

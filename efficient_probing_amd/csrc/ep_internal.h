@@ -36,6 +36,10 @@ struct PoolParams {
   // second pass: dP[b, q, :] = dy[b, q-slice] Wv[q-slice, :] is produced by the pooling workgroups themselves before they
   // stream (no ep_gemm launch in front of the pass): ip_dy (B, D), ip_Wv (D, D), the result goes to the buffer `dP` points at
   const float* ip_dy; const float* ip_Wv; int* ip_dcnt;
+  // ... with the BatchNorm backward folded into those tasks (ip_fold_dz != null): dy = rstd (dz - m1 - z m2) is formed while a
+  // task stages its A tile, m1 / m2 from the per-tile column statistics the dz contraction left (GemmParams.cs_out); the
+  // tasks of column quarter 0 also WRITE dy (ip_dy) for the delta items and the dWv side tasks of the same launch
+  const float* ip_fold_dz; const float* ip_fold_z; const float* ip_fold_rstd; const float* ip_fold_cs;
   // first pass: y = P_q Wv_q^T as four K-quarter partials ip_ypart[ks][b][:] by the workgroups that have finished their
   // images (the matrix pipe is idle under the pass); BatchNorm sums the partials in fixed order
   const float* ip_WvF; float* ip_ypart; int* ip_ycnt;
@@ -66,6 +70,10 @@ struct GemmParams {
   float* skws; size_t skws_floats;  // optional scratch for a split of K (few output tiles, very long K): >= 2 M N floats
   int ablate;                       // diagnostic only
   int npers;                        // LDS-DMA kernel: N-tiles one workgroup walks (0 / 1: one; set by gemm())
+  // 32 x 96-tile K/T kernel only (gemm_colstats_ok): column statistics of every 32-row tile of C in its epilogue, for a
+  // BatchNorm backward folded into C's consumer (ep_inpass.h): cs_out[(tile row * 2 + 0) * N + col] = sum_rows C,
+  // [.. + 1 ..] = sum_rows C * cs_z (cs_z: M x N, leading dimension ldc)
+  const float* cs_z; float* cs_out;
   // ep_planes.hip: the B operand as pre-split bf16 planes (weights; see planes_split) -- [term][row][ldbp], K contiguous
   const uint16_t* Bpl; int64_t pl_term, ldbp, sBpz;   // plane base, term stride, row stride, batch offset (elements)
 };
@@ -129,6 +137,7 @@ int attention_from_scores(const float* S, const float* ML, int rows, int N, floa
 
 // a_k / b_k: operand contiguous along K (true) or along its free dimension (false)
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st);
+bool gemm_colstats_ok(bool a_k, bool b_k, const GemmParams& p, int batch);   // will gemm() run the kernel that honours cs_out?
 
 size_t bn_workspace_bytes(int B, int Dp);
 // nparts > 1 (one-launch kernel only, B <= 1024): y is given as nparts partial matrices `pstride` floats apart, summed in

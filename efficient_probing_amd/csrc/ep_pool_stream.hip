@@ -346,6 +346,26 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
   if constexpr (NW == 4) {
     if (wg >= side.first_block) {
       if (wg < side.first_block + side.total) {
+        // dy, an operand of the dWv side tasks, may be written inside this launch (folded BatchNorm backward of the dP
+        // tasks): wait until every row block's tasks have arrived (they run in front of the token stream, normally ~100 us
+        // before a side task gets a CU slot -- but not with a small pooling grid), then one acquire per workgroup
+        if (p.ip_fold_dz) {
+          const int nrb = p.B >> 5;
+          if (threadIdx.x < 64) {
+            int spins = 0;
+            for (;;) {
+              bool ok = true;
+              for (int r = threadIdx.x; r < nrb; r += 64)
+                ok &= __hip_atomic_load(p.ip_dcnt + r * IP_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= IP_TARGET;
+              if (__all(ok)) break;
+              if (++spins > IP_SPIN_LIMIT) { if (threadIdx.x == 0 && p.ip_err) atomicAdd(p.ip_err, 1); break; }
+              __builtin_amdgcn_s_sleep(64);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+        }
         run_side_task(side, wg - side.first_block, ring);
         return;
       }
@@ -467,7 +487,9 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
             const bool second = pc >= dv_rp;
             unsigned off = (unsigned)(second ? pc - dv_rp : pc) * 1024u + lane16;
             off = off < (unsigned)(dv_row - 16) ? off : (unsigned)(dv_row - 16);
-            __builtin_amdgcn_global_load_lds((gptr_t)((second ? pimg_y : pimg_dy) + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, 0);
+            // (dy written inside this launch by the folded BatchNorm backward of the dP tasks is read with sc1)
+            if (IPOK && p.ip_fold_dz) __builtin_amdgcn_global_load_lds((gptr_t)((second ? pimg_y : pimg_dy) + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, IP_SC1);
+            else __builtin_amdgcn_global_load_lds((gptr_t)((second ? pimg_y : pimg_dy) + off), (lds_ptr_t)(slot + pc * 1024), 16, 0, 0);
           }
           __builtin_amdgcn_global_load_lds((gptr_t)pimg_ML, (lds_ptr_t)small, 4, 0, 0);
         } else {

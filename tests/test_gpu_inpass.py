@@ -53,7 +53,7 @@ torch.save({"loss": losses, "p": eng.flat_p.cpu(), "g": eng.flat_g.cpu(), "mu": 
 def run(env_extra):
     with tempfile.NamedTemporaryFile(suffix=".pt") as f:
         env = dict(os.environ)
-        for k in ("EP_INPASS", "EP_POOL_GRID"):
+        for k in ("EP_INPASS", "EP_POOL_GRID", "EP_BN_FOLD"):
             env.pop(k, None)
         env.update(env_extra)
         subprocess.run([sys.executable, "-c", CODE, f.name], check=True, env=env, cwd=ROOT)
@@ -104,3 +104,22 @@ def test_each_half_alone_and_run_to_run_bit_equality():
         for k in ("p", "g", "mu", "rm"):
             assert torch.equal(a[k], b[k]), (mask, k)
         assert a["loss"] == b["loss"]
+
+
+@pytest.mark.parametrize("B,N,D,bf16,extra", [(1024, 50, 768, False, {}), (1024, 37, 768, True, {}), (256, 40, 768, False, {}),
+                                               # a small pooling grid: the side tasks get CU slots at once and must WAIT for dy
+                                               (1024, 20, 768, False, {"EP_POOL_GRID": "256"})])
+def test_folded_batchnorm_backward_matches_the_separate_launch(B, N, D, bf16, extra):
+    """BatchNorm1d backward folded into the in-pass dP tasks (column statistics from the epilogue of the dz contraction,
+    dy formed while a task stages its A tile and published for the delta items and the dWv side tasks of the same launch)
+    against ep_bn_bwd_fused_kernel in front of the pass (EP_BN_FOLD=0)."""
+    base = {"T_B": str(B), "T_N": str(N), "T_D": str(D), "T_BF16": "1" if bf16 else "0", "EP_INPASS": "2", **extra}
+    on = run({**base, "EP_BN_FOLD": "1"})
+    off = run({**base, "EP_BN_FOLD": "0"})
+    assert on["giveups"] == 0 and off["giveups"] == 0
+    assert np.allclose(on["loss"], off["loss"], rtol=3e-6)
+    assert torch.allclose(on["p"], off["p"], rtol=2e-4, atol=2e-6)
+    assert torch.allclose(on["mu"], off["mu"], rtol=2e-3, atol=1e-7)
+    again = run({**base, "EP_BN_FOLD": "1"})                    # fixed summation orders: the same bits every run
+    for k in ("p", "g", "mu"):
+        assert torch.equal(on[k], again[k]), k
