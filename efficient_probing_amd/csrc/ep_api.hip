@@ -638,7 +638,9 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       } else {
         EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
       }
+      mark_pass(2, st);
       EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, nullptr, (s->phases & 2) ? &red : nullptr));
+      mark_pass(3, st);
       if (side != st) {
         EP_HIP(hipEventRecord(ev[2], side));
         EP_HIP(hipStreamWaitEvent(st, ev[2], 0));           // join: grads complete on `stream`

@@ -5,7 +5,7 @@ set -uo pipefail
 tag="$1"; shift
 out="gpurun_out/profiles_$tag"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="${EP_PROF_STEPS:---steps 30 --warmup 5} --no-cpu-baseline --no-north-star --kernel-iters 10 $*"
+args="${EP_PROF_STEPS:---steps 30 --warmup 5} --no-cpu-baseline --no-north-star --no-configs --no-through-engine --no-bf16-secondary --kernel-iters 10 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py $args > "$out/bench_under_trace.json" 2> "$out/trace.log"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $args > /dev/null 2> "$out/pmc_fetch.log"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py $args > /dev/null 2> "$out/pmc_write.log"
