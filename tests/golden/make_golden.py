@@ -146,6 +146,17 @@ def run_case(case, optimizer_name="lars"):
         loss = crit(logits, t)
         loss.backward()
         if step == 0 and optimizer_name == "lars":
+            # the published runs train under --amp bfloat16 (README.md:639-645; engine_finetune.py:52-55): the same head, same
+            # inputs, train mode, under CPU bf16 autocast (Linear / matmul operands and results bf16; softmax, BatchNorm
+            # statistics and the loss fp32) -- a FIDELITY fixture: how far the fp32 head is from the published protocol's head
+            with torch.no_grad():
+                rm, rv, nb = head[1].running_mean.clone(), head[1].running_var.clone(), head[1].num_batches_tracked.clone()
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    lg16 = head[2](head[1](head[0](x)))
+                    ls16 = crit(lg16, t)
+                head[1].running_mean.copy_(rm); head[1].running_var.copy_(rv); head[1].num_batches_tracked.copy_(nb)
+            out["logits_bf16_autocast"] = lg16.float().numpy()
+            out["loss_bf16_autocast"] = np.float32(ls16.float().item())
             a1, a5 = topk_acc(logits, t)
             attn = ((head[0].cls_token * case.D ** -0.5) @ x.transpose(1, 2)).softmax(-1)
             out.update(pooled=pooled.detach().numpy(), z=z.detach().numpy(),

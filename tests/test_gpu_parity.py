@@ -14,7 +14,8 @@ import pytest
 import torch
 from argparse import Namespace
 
-from cases import CASES, CASE_BY_NAME, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol, trust_ratio_gaps
+from cases import (CASES, CASE_BY_NAME, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol,
+                   trust_ratio_gaps, assert_amp_bf16_fidelity)
 from oracle import ep_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -123,6 +124,8 @@ def test_module_forward_backward_golden(case):
     np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], **post_bn_tol(case))
     np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], **post_bn_tol(case))
     assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-5)
+    # ... and the distance of this fp32 head from the reference head under the published --amp bfloat16 protocol
+    assert_amp_bf16_fidelity(logits.detach().cpu().numpy(), float(loss), g, err_msg=case.name)
     st = stats.cpu().numpy()
     assert st[1] * 100.0 / case.B == pytest.approx(float(g["acc1"]))
     assert st[2] * 100.0 / case.B == pytest.approx(float(g["acc5"]))

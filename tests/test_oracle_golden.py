@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import CASES, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol, trust_ratio_gaps
+from cases import CASES, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol, trust_ratio_gaps, assert_amp_bf16_fidelity
 from oracle import ep_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -39,6 +39,7 @@ def test_forward_and_grads(case):
     np.testing.assert_allclose(out["z"], g["z"], **tol)
     np.testing.assert_allclose(out["logits"], g["logits"], **tol)
     np.testing.assert_allclose(out["loss"], g["loss"], rtol=1e-5)
+    assert_amp_bf16_fidelity(out["logits"], out["loss"], g, err_msg=case.name)     # distance from the published --amp bfloat16 head
     a1, a5 = O.accuracy(out["logits"], inp["targets"])
     assert a1 == pytest.approx(float(g["acc1"])) and a5 == pytest.approx(float(g["acc5"]))
     gr = O.head_backward(st, cache)
