@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       const int nh = G - nfull;                              // helpers
       int first = 1;
       auto run = [&](int b) {
-        if (!(p.ablate & 1)) ip_dp_task<KP>(p, b, ring);
+        ip_dp_task<KP>(p, b, ring);
         if (first) { stamp(1); first = 0; }
         ip_arrive(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE);
       };

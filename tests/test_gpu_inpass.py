@@ -69,6 +69,8 @@ CASES = [
     (1024, 48, 768, True, {}),                        # bf16-stored tokens
     (1024, 20, 768, False, {"EP_POOL_GRID": "256"}),  # four rounds, no helpers: every workgroup runs its tasks at its end
     (1024, 20, 768, False, {"EP_POOL_GRID": "320"}),  # four rounds, 64 busy owners, 256 helpers
+    (2048, 24, 768, False, {}),                       # three rounds on 768 workgroups: five later-round dP tasks per helper
+                                                      # (no in-pass y: the one-launch BatchNorm takes B <= 1024)
 ]
 
 

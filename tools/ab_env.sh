@@ -1,8 +1,9 @@
 #!/usr/bin/env bash
-# usage (via gpurun): bash tools/r3_ab3.sh TAG "<env sets ';' separated>" "<workloads>" ["<pytest env>" pytest targets...]
+# Same-box A/B of bench.py over environment switches (optionally a pytest run in front): one gpurun call, fresh processes.
+# usage (via gpurun): bash tools/ab_env.sh TAG "<env sets ';' separated>" "<workloads>" ["<pytest env>" pytest targets...]
 set -uo pipefail
 tag="${1:-x}"; IFS=';' read -ra runs <<< "${2:-EP_INPASS=0}"; wls="${3:-c2}"; shift 3 || true
-out="gpurun_out/r3_$tag"; mkdir -p "$out"
+out="gpurun_out/ab_$tag"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 if [ "$#" -gt 1 ]; then
   penv="$1"; shift

@@ -1,7 +1,9 @@
 #!/usr/bin/env bash
-# usage (via gpurun): bash tools/r3_stamp2.sh TAG "<env assignments per run, ';' separated>"
+# Per-workgroup timelines of the in-pass contractions (EP_IP_STAMP=1: the launches synchronise, so the step time of these
+# runs means nothing).
+# usage (via gpurun): bash tools/inpass_stamps.sh TAG "<env assignments per run, ';' separated>"
 set -uo pipefail
-tag="${1:-s}"; out="gpurun_out/r3_$tag"; mkdir -p "$out"
+tag="${1:-s}"; out="gpurun_out/ab_$tag"; mkdir -p "$out"
 cd "$GRAFT_REPO_ROOT"
 quick="--no-cpu-baseline --no-bf16-secondary --no-north-star --no-configs --no-through-engine"
 IFS=';' read -ra runs <<< "${2:-EP_INPASS=7}"

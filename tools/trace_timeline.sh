@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
-# usage (via gpurun): bash tools/r3_trace.sh TAG "<env>" [workload]
+# rocprofv3 kernel trace of bench.py under one set of environment switches -> kernel stats summary + one step's timeline.
+# usage (via gpurun): bash tools/trace_timeline.sh TAG "<env>" [workload]
 set -uo pipefail
-tag="${1:-tr}"; envs="${2:-EP_X=1}"; wl="${3:-c2}"; out="gpurun_out/r3_$tag"; mkdir -p "$out"
+tag="${1:-tr}"; envs="${2:-EP_X=1}"; wl="${3:-c2}"; out="gpurun_out/ab_$tag"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 quick="--no-cpu-baseline --no-bf16-secondary --no-north-star --no-configs --no-through-engine"
 export $envs
