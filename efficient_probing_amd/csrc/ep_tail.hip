@@ -540,7 +540,7 @@ int bn_forward_train(const float* y, int B, int Dp, float eps, float momentum, f
     if (nparts == 4 && r0 == 768)
       hipLaunchKernelGGL((ep_bn_fused_kernel<true, 12>), dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean,
                          rvar, nbt, pstride, y_out);
-    else if (nparts == 4)
+    else if (nparts == 4)   // (a 4-column-per-workgroup variant for the four-fold input measured 22 us against 14.5: 16-byte row segments)
       hipLaunchKernelGGL(ep_bn_fused_kernel<true>, dim3((Dp + 15) / 16), dim3(1024), 0, st, y, B, Dp, eps, momentum, z, rstd, rmean,
                          rvar, nbt, pstride, y_out);
     else
