@@ -13,12 +13,17 @@
 // Guideline 16): the handed-off rows are stored WRITE-THROUGH (16-byte `sc1` buffer stores, every 128-byte line written
 // whole by one instruction), every storing wave drains its stores (s_waitcnt vmcnt(0)) and adds for itself to the row
 // block's arrival counter (agent-scope atomic; zero at launch); a consumer polls the counter from one lane (sc1 load +
-// s_sleep), passes a workgroup barrier and then reads the rows with `sc1` buffer loads (first pass) or, where the
-// reader is the LDS-DMA ring, behind ONE agent-scope acquire per workgroup (second pass).  No release fences: one
-// `buffer_wbl2` per wave and image measured +220 us per pass (4096 L2 write-backs).  A consumer only ever waits for
-// workgroups that are resident (dispatch is in block order and the producers of a row block have block indices no
-// higher than 31 above the consumer's), and every wait is bounded (PoolParams.ip_err counts give-ups; tests assert it
-// stays zero).
+// s_sleep), passes a workgroup barrier and then reads the rows with `sc1` loads -- buffer loads to registers (first
+// pass) or `sc1` LDS-DMA copies (the header items of the second pass) -- so no acquire either.  No release fences: one
+// `buffer_wbl2` per wave and image measured +220 us per pass (4096 L2 write-backs).
+//
+// Progress: a producer never waits before it has arrived (tasks first, waits after).  First-round row blocks are produced
+// by the consumer's own aligned group of 32 workgroups (dispatch is in block order, so they are resident with it); the
+// row blocks of later rounds are produced by the workgroups that stream the fewest images -- higher block indices, which
+// become resident at the latest when single-image workgroups in front of them retire (those wait only on their own
+// group).  So the launch makes progress whenever more workgroups are resident than stream an image of the last round
+// (768 against 256 at B = 1024); and every wait is bounded all the same (PoolParams.ip_err counts give-ups; tests
+// assert it stays zero).
 //
 // Shapes: Q = 8, D = 256 KT (KT = 1..3), d_out = 1, B % 32 == 0, pooling grid % 32 == 0 (host-checked: ep_pool.hip).
 #pragma once
