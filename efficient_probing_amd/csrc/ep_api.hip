@@ -1,4 +1,7 @@
 // extern "C" entry points of libep_hip.so (declared in include/ep_hip.h).
+#ifndef EP_PLANES_DEFAULT
+#define EP_PLANES_DEFAULT 0
+#endif
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
@@ -68,17 +71,21 @@ struct HeadWs {
   size_t total;
 };
 
-// EXPERIMENT, off by default (EP_GEMM_PLANES=1): the four critical-path contractions of a train step against pre-split
-// weight planes (ep_planes.hip).  Needs the per-query slice width to be a multiple of the MFMA K (32) for the dP
-// contraction.  Measured on MI355X at 1024 x 256 x 768: the logits / dz kernels alone are faster than the f32 kernel
-// (17.1 / 20.3 us against 20.4 / 25.3 us), the whole step is not (0.490 against 0.467 ms: the split launch, the
-// half-empty 96-column tiles of the per-query projection and the 3-K-tile dP contraction eat the gain).
-static bool head_planes_ok(const ep_head_dims& d) {
+// The classifier contractions (logits = z Wc^T, dz = dlogits Wc) against pre-split weight planes on the bf16 matrix cores
+// (ep_planes.hip) -- EP_GEMM_PLANES: 0 off, 2 those two (the planes of Wc are split beside the first token pass),
+// 1 all four critical-path contractions (round 2's experiment: needs the per-query slice width to be a multiple of the
+// MFMA K (32) for the dP contraction, and switches the in-pass contractions off).  Measured on MI355X at 1024 x 256 x 768,
+// kernels alone: logits 14.7 against 20.4 us, dz 16.7 against 20.8 us (f32 kernel); the per-query projection (half-empty
+// 96-column tiles) and the 3-K-tile dP contraction do not gain, which is why mode 1 loses (0.490 against 0.467 ms per step).
+static int head_planes_mode(const ep_head_dims& d) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : 0; }
+  if (on < 0) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : EP_PLANES_DEFAULT; }
   const int Dp = d.D / d.d_out;
-  return on && (Dp / d.Q) % 32 == 0 && d.D % 4 == 0 && Dp % 4 == 0;
+  if (!on || d.D % 4 != 0 || Dp % 4 != 0) return 0;
+  if (on == 1) return (Dp / d.Q) % 32 == 0 ? 1 : 0;
+  return 2;
 }
+static bool head_planes_ok(const ep_head_dims& d) { return head_planes_mode(d) != 0; }
 static HeadWs carve(const ep_head_dims& d, void* base) {
   HeadWs w{};
   const int Dp = d.D / d.d_out;
@@ -128,8 +135,8 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
 
 static int head_planes_split(const ep_head_dims& d, const HeadWs& w, const float* Wv, const float* Wc, hipStream_t st) {
   const int Dp = d.D / d.d_out;
-  PlaneSpec sp[2] = {{Wv, Dp, d.D, d.D, w.plWv, w.plWvT}, {Wc, d.C, Dp, Dp, w.plWc, w.plWcT}};
-  return planes_split(sp, 2, st);
+  PlaneSpec sp[2] = {{Wc, d.C, Dp, Dp, w.plWc, w.plWcT}, {Wv, Dp, d.D, d.D, w.plWv, w.plWvT}};
+  return planes_split(sp, head_planes_mode(d) == 1 ? 2 : 1, st);
 }
 static GemmParams planes_gemm(const float* A, int64_t lda, int64_t sAz, const uint16_t* pl, int rowsW, int Kw, int64_t sBpz,
                               float* C, int64_t ldc, int64_t sCz, int M, int N, int K, const float* bias) {
@@ -494,10 +501,11 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   // the first token pass (it needs the weights only, the pass the queries only): fork before the pass is enqueued, join
   // in front of the first contraction.  Split phases (data-parallel overlap): the large update of the previous step
   // lands between phase 4 and phase 8, so the split runs in phase 8 on the main stream.
-  const bool pl = head_planes_ok(d) && (s->phases & (1 | 8));
+  const bool plc = head_planes_ok(d) && (s->phases & (1 | 8));           // classifier contractions on the planes kernel
+  const bool pl = plc && head_planes_mode(d) == 1;                        // ... and the two projections
   hipEvent_t pev[2] = {nullptr, nullptr};
   bool split_done = false;
-  if (pl && (s->phases & 1) && s->aux_stream && (hipStream_t)s->aux_stream != st) {
+  if (plc && (s->phases & 1) && s->aux_stream && (hipStream_t)s->aux_stream != st) {
     hipStream_t ax = (hipStream_t)s->aux_stream;
     hipEvent_t evs[6];
     EP_TRY(get_events(evs, 6));
@@ -542,9 +550,11 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   if (wait_defer && !ip_y) EP_HIP(hipStreamWaitEvent(st, (hipEvent_t)s->defer_event, 0));
   p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_y = nullptr; p.ip_yr0 = 0; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
-    if (pl) {
+    if (plc) {
       if (split_done) EP_HIP(hipStreamWaitEvent(st, pev[1], 0));
       else EP_TRY(head_planes_split(d, w, Wv, Wc, st));
+    }
+    if (pl) {
       EP_TRY(project_forward_pl(w, d, st));
     } else if (!ip_y) {
       EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
@@ -555,7 +565,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     else
     EP_TRY(bn_forward_train(w.y, d.B, Dp, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));
-    if (pl) EP_TRY(linear_forward_pl(w, d, bc, st));
+    if (plc) EP_TRY(linear_forward_pl(w, d, bc, st));
     else EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
     EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
     // The weight gradients dWc / dbc / dWv and the statistics feed nothing before the optimizer.
@@ -582,13 +592,13 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       gz.M = d.B; gz.N = Dp; gz.K = d.C; gz.alpha = 1.f;
       static int fold_on = -1;
       if (fold_on < 0) { const char* e = getenv("EP_BN_FOLD"); fold_on = e ? atoi(e) : 0; }
-      const bool fold = fold_on && ip_dp && in_pass && !(ipmask & 4) && !pl && d.B % 32 == 0 && gemm_colstats_ok(true, false, gz, 1);
+      const bool fold = fold_on && ip_dp && in_pass && !(ipmask & 4) && !plc && d.B % 32 == 0 && gemm_colstats_ok(true, false, gz, 1);
       if (fold) {
         gz.cs_z = w.z; gz.cs_out = w.colstat;
         EP_TRY(gemm(true, false, gz, 1, st));
         p.ip_fold_dz = w.dz; p.ip_fold_z = w.z; p.ip_fold_rstd = w.rstd; p.ip_fold_cs = w.colstat;
       } else {
-        if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
+        if (plc) EP_TRY(linear_backward_dz_pl(w, d, st));
         else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
         EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       }
@@ -623,7 +633,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
       EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
                              s->accumulate, side));
-      if (pl) EP_TRY(linear_backward_dz_pl(w, d, st));
+      if (plc) EP_TRY(linear_backward_dz_pl(w, d, st));
       else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       if (side != st) {

@@ -1,4 +1,5 @@
-// EXPERIMENT (opt-in: EP_GEMM_PLANES=1; the default train step uses the f32 contraction kernel of ep_gemm.hip).
+// EXPERIMENT (opt-in: EP_GEMM_PLANES=2 classifier contractions, =1 all four; the default train step uses the f32
+// contraction kernels of ep_gemm.hip).
 // fp32 contractions against PRE-SPLIT weights on the gfx950 BF16 matrix cores, at fp32 accuracy.
 //
 // The head's four critical-path contractions (value projection y = P Wv_q^T, logits = z Wc^T, dz = dlogits Wc,
@@ -13,28 +14,41 @@
 // replace eight f32 instructions at 96 instead of 256 matrix cycles, with fp32 accumulation
 // (tests/test_gpu_planes.py: error against float64 at or below the f32 kernel's).
 //
-// What was tried and measured on the way (MI355X, rocprofv3 device durations of the 1024 x 1000 x 768 logits contraction;
-// f32 kernel 20.4 us; operand ring alone, no arithmetic, 10.5 us):
+// Measured on MI355X (rocprofv3 device durations of the 1024 x 1000 x 768 logits / 1024 x 768 x 1000 dz contractions; f32
+// kernel 20.4 / 20.8 us):
+//   round 2
 //   1. both operands split in registers by every wave that multiplies them: 19.5 us -- bound by the split's vector
 //      instructions (132 per wave and K-tile);
 //   2. both operands split once per workgroup, the terms handed over through LDS plane images: 20.0 us (21.5 us with
 //      32-row tiles, two workgroups per CU) -- the round trip adds 6 bytes per element of LDS traffic;
-//   3. THIS file: the weights arrive split (planes in global memory, written once per step), the activations are split in
-//      registers (one 16-row block per wave, 36 vector instructions per K-tile): 21.1 us with the multiply waves also
-//      issuing the DMA, 17.1 us with four loader waves and double-buffered fragments (dz: 20.3 against 25.3 us).
-// Every variant sits near 0.5 .. 0.64 us per K-tile although none of matrix pipe (19 % busy), LDS (27 %) and vector issue
-// is saturated: with ONE workgroup per CU the K-tile step is a chain of latencies (barrier, LDS reads, split, 6-deep MFMA
-// chains) at the ~1.65 GHz the chip holds under this load.  In the whole train step the planes path is slower than the f32
-// kernels (0.490 against 0.467 ms per step at 1024 x 256 x 768): the split launch (10 us, hidden only partly beside the
-// first token pass), the half-empty 96-column tiles of the per-query projection and the 3-K-tile dP contraction (1536
-// workgroups of 100 KiB LDS, one per CU) eat what logits and dz gain.  Kept as an opt-in with its tests; what remains to
-// try is a deeper software pipeline inside the multiply waves (split of tile t+1 under the MFMAs of tile t).
+//   3. the weights arrive split (planes in global memory, written once per step), the activations are split in registers:
+//      21.1 us with the multiply waves also issuing the DMA, 17.1 / 20.3 us with four loader waves and double-buffered
+//      fragments.
+//   round 3 (in-kernel cycle stamps per K-tile, and the same kernel with one kind of work left out at a time)
+//   4. Two independent limits sat at the same ~890 cycles per K-tile, which is why no change to either alone moved the time:
+//      a. the loaders: 888 cycles with the multiply waves idle, the same when every workgroup streams the SAME operands and
+//         with an XCD-aware tile order -- not bandwidth.  The plane pieces were copied lane (i16, kk) <- row i16: a
+//         quarter-wave touched 16 cache lines, 64 tag look-ups per instruction.  With four consecutive lanes on one row's
+//         64 bytes (and the matching swizzle on the read side): 550 cycles.  Staging through registers
+//         (global_load_dwordx4 + ds_write_b128, two LDS stages) instead of LDS-DMA: 705.
+//      b. one multiply wave per SIMD: matrix instructions 370, split 124 (44 hand-placed instructions) and LDS reads 232
+//         cycles ADD UP in one wave's instruction stream whatever their order -- split pinned two instructions behind each
+//         MFMA (matrix instructions as volatile asm: 866 cycles between barriers; as builtins held by asm pins, which cost
+//         an s_nop each: 907), compiler order (884).
+//   5. THIS file: two multiply waves per SIMD on alternate K-tiles, so that one wave's matrix instructions run beside the
+//      other wave's reads and split: 16.4 / 18.8 us with the split in C (60 instructions, sunk or pinned), 14.7 / 16.7 us
+//      with the split as 44 volatile single instructions.  Per own K-tile a multiply wave now spends 640 cycles reading and
+//      splitting and 485 in its 24 matrix instructions (384 if nothing else issued): 730 cycles per K-tile.  Moving the lo
+//      term's 12 instructions into the matrix phase: 15.1 / 17.1 us (worse).
+// In the whole train step at 1024 x 256 x 768 the planes still do not pay: mode 2 (logits and dz only, the planes of Wc
+// split on the aux stream beside the first token pass) 0.442 against 0.437 ms -- the two kernels save 10 us, the split beside
+// the HBM-bound pass costs it 12-20 us; mode 1 0.460 ms.  Kept as an opt-in with its tests.
 //
 // The contraction kernel
 //   * streams the fp32 activation tile AND the weight planes into LDS by LDS-DMA (20 KiB per K-tile), issued by four
-//     loader waves (an LDS-DMA instruction costs its issuing wave ~100 cycles);
+//     loader waves;
 //   * splits only its own activation fragment in registers;
-//   * reads the weight operands ready-made (linear ds_read_b128, no vector work, no LDS write-back);
+//   * reads the weight operands ready-made (ds_read_b128, no vector work, no LDS write-back);
 //   * issues 6 v_mfma_f32_16x16x32_bf16 per 16x16x32 block pair.
 //
 // Plane format (ep_planes_split_kernel): for a row-major matrix W (R x K) the three terms hi / mid / lo of every element
@@ -164,14 +178,53 @@ int planes_split(const PlaneSpec* specs, int n, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C[z][m][n] (+)= alpha * sum_k A[z](m,k) * W[z](n,k) (+ bias[n]):  A fp32 (K contiguous), W as planes (K contiguous)
-// 64 x 64 tile per workgroup, 8 waves as 4 (rows) x 2 (columns): a wave owns ONE 16-row block of A and TWO 16-column
-// blocks of W.  K-tile 32 = one MFMA K.  LDS stage = fp32 A image (8 KiB, XOR-swizzled on the DMA source address like
-// ep_gemm_dma_kernel) + 12 plane pieces of 1 KiB in MFMA lane order ([block][term][lane], 16 bytes per lane): 20 KiB.
+// 64 x 64 tile per workgroup, K-tile 32 = one MFMA K.  12 waves: 4 loaders + 8 multiply waves, two per SIMD, as
+// 4 (16-row blocks of A) x 2 (K-tile parity): a multiply wave owns one 16-row block of A against all four 16-column blocks of
+// W on every other K-tile; the two partial sums of a block meet through LDS at the end.
+// LDS stage = fp32 A image (8 KiB, XOR-swizzled on the DMA source address like ep_gemm_dma_kernel) + 12 plane pieces of 1 KiB
+// ([block][term], 16 rows x 64 bytes each): 20 KiB; five stages.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PLG_STB = 8192 + 12 * 1024;            // bytes per ring stage
+constexpr int PLG_NST = 5;                           // ring stages (100 KiB)
 
-template <int NST>
+// The split of one 8-value fragment as 44 single instructions (11 per value pair, pair index fastest so that neighbours are
+// independent), each a volatile asm statement.  Per pair (x0, x1):
+//   0 hi = cvt_pk(x0, x1) | 1, 2 the fp32 images of hi | 3, 4 r = x - image (exact) | 5 mid = cvt_pk(r) | 6, 7 images |
+//   8, 9 s = r - image (exact, <= 8 bits left) | 10 lo = cvt_pk(s)
+// Why asm: from the C form (pl_split8) hipcc makes 60 instructions with packed subtractions (v_pk_add_f32 beside matrix
+// instructions costs ~13 cycles more than two v_sub_f32, MI355X_MICROARCH.md) and, the values being pure, sinks them across the
+// workgroup barrier to the matrix instructions that use them -- the half of the K-tile step they are meant to stay out of.
+struct PlSplit { float v[8]; float t[8]; };
+template <int U>
+__device__ __forceinline__ void pl_split_uop(PlSplit& s, const f4v (&x)[2], pl_u4 (&a)[3]) {
+  constexpr int q = U & 3, o = U >> 2, e0 = 2 * q, e1 = 2 * q + 1, g = q >> 1, j0 = e0 & 3;
+  if constexpr (o == 0 || o == 5 || o == 10) {
+    unsigned pk;
+    if constexpr (o == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x[g][j0]), "v"(x[g][j0 + 1]));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(s.v[e0]), "v"(s.v[e1]));
+    a[o / 5][q] = pk;
+  } else if constexpr (o == 1 || o == 6) {
+    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(s.t[e0]) : "v"(a[o / 5][q]));
+  } else if constexpr (o == 2 || o == 7) {
+    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(s.t[e1]) : "v"(a[o / 5][q]));
+  } else if constexpr (o == 3) {
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(s.v[e0]) : "v"(x[g][j0]), "v"(s.t[e0]));
+  } else if constexpr (o == 4) {
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(s.v[e1]) : "v"(x[g][j0 + 1]), "v"(s.t[e1]));
+  } else if constexpr (o == 8) {
+    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(s.v[e0]) : "v"(s.t[e0]));
+  } else {
+    static_assert(o == 9, "11 instructions per pair");
+    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(s.v[e1]) : "v"(s.t[e1]));
+  }
+}
+template <int U0, int U1>
+__device__ __forceinline__ void pl_split_uops(PlSplit& s, const f4v (&x)[2], pl_u4 (&a)[3]) {
+  if constexpr (U0 < U1) { pl_split_uop<U0>(s, x, a); pl_split_uops<U0 + 1, U1>(s, x, a); }
+}
+
 __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
+  constexpr int NST = PLG_NST, NB = 4;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -180,13 +233,12 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int z = blockIdx.z;
   const int nk = (p.K + BK - 1) / BK;
-  // Barrier k (k = 0 .. nk): K-tile k has landed completely AND every multiply wave holds tile k-1 in registers, so the
-  // stage of tile k-1 may be refilled.  Both roles pass the same nk + 1 barriers.
+  const bool ktail = (p.K % BK) != 0;
+  // Barrier k (k = 0 .. nk): K-tile k has landed completely AND the reads of tile k-1 are done, so its stage may be refilled.
+  // Every wave passes the same nk + 1 barriers, then F1 (the ring is quiet) and -- the multiply waves -- F2 (partial sums stored).
 
   if (w >= 8) {
-    // ---- loader waves: 20 pieces of 1 KiB per K-tile (8 of the fp32 A image, 12 of the weight planes), 5 per wave.
-    // An LDS-DMA instruction costs its issuing wave ~100 cycles: on the multiply waves that would sit in the per-tile
-    // critical path (barrier -> issue -> reads -> split -> MFMA chain), here it runs beside it.
+    // ---- loader waves: 20 pieces of 1 KiB per K-tile (8 of the fp32 A image, 12 of the weight planes), 5 LDS-DMA per wave
     const int lw = w - 8;
     const float* A = p.A + (int64_t)z * p.sAz;
     const uint16_t* Wp = p.Bpl + (int64_t)z * p.sBpz;
@@ -200,15 +252,20 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
       int row = m0 + r; row = row < p.M ? row : p.M - 1;
       srcA[jj] = (int64_t)row * p.lda + 4 * kqA[jj];
     }
-    // W: piece (blk, term) = lw + 4 jj: lane (i16, kk) copies the 16 bytes at row n0 + 16 blk + i16, position k0 + 8 kk
+    // W: piece (blk, term) = lw + 4 jj, 16 rows x 64 bytes.  Lane L fills chunk L of the piece: row L >> 2, and of that row's
+    // four 16-byte k-chunks the one a multiply lane (i16, kk) looks for in slot kk ^ 2 (i16 >> 3) (conflict-free for the lane
+    // groups of ds_read_b128).  Four CONSECUTIVE lanes read one row's 64 contiguous bytes: a quarter-wave touches 4 cache
+    // lines.  (Round 2: lane (i16, kk) copied row i16 -- 16 lines per quarter-wave, 64 tag look-ups per instruction; that, not
+    // bandwidth, made the loaders alone take 888 cycles per K-tile, the same with every workgroup streaming the SAME operands;
+    // 550 now.)
     int64_t srcW[3];
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
       const int pb = lw + 4 * jj, blk = pb / 3, term = pb - 3 * blk;
-      int row = n0 + 16 * blk + i16; row = row < p.N ? row : p.N - 1;
-      srcW[jj] = term * p.pl_term + (int64_t)row * p.ldbp + 8 * kk;
+      const int r16 = lane >> 2, kq = (lane & 3) ^ (2 * (r16 >> 3));
+      int row = n0 + 16 * blk + r16; row = row < p.N ? row : p.N - 1;
+      srcW[jj] = term * p.pl_term + (int64_t)row * p.ldbp + 8 * kq;
     }
-    const bool ktail = (p.K % BK) != 0;
     auto issue = [&](int t) {                        // K-tile t (clamped to the last one) into stage t % NST
       const int tt = t < nk ? t : nk - 1;
       char* st = lds + (t % NST) * PLG_STB;
@@ -231,80 +288,92 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
       issue(k + NST - 1);                            // into the stage of tile k-1
     }
     pl_dma_wait<0>();
+    pl_barrier();                                    // F1: the ring is quiet, its first 16 KiB serve the final reduction
     return;
   }
 
-  // ---- multiply waves: 4 (rows) x 2 (columns); rows 16 wm .. +15, columns 32 wn .. +31 ----
-  const int wm = w >> 1, wn = w & 1;
+  // ---- multiply waves: rows 16 wm .. +15, all four column blocks, K-tiles of parity `par` ----
+  const int wm = w & 3, par = w >> 2;
   float* C = p.C + (int64_t)z * p.sCz;
-  const bool ktail = (p.K % BK) != 0;
   int fragA[2];
   {
     const int r = wm * 16 + i16;
     fragA[0] = r * 128 + 16 * ((0 + kk) ^ ((r >> 1) & 7));
     fragA[1] = r * 128 + 16 * ((4 + kk) ^ ((r >> 1) & 7));
   }
-  const int fragW = 8192 + (2 * wn * 3) * 1024 + lane * 16;
-  f4v acc[2] = {f4v{0.f, 0.f, 0.f, 0.f}, f4v{0.f, 0.f, 0.f, 0.f}};
-  f4v xs[2][2];                                      // [set][g]: fp32 fragment of A block wm
-  pl_u4 bs[2][2][3];                                 // [set][block][term]: planes of W blocks 2 wn, 2 wn + 1
-  auto read_tile = [&](int t, f4v (&x)[2], pl_u4 (&b3)[2][3]) {
+  const int fragW = 8192 + (4 * i16 + (kk ^ (2 * (i16 >> 3)))) * 16;
+  f4v acc[NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) acc[bi] = f4v{0.f, 0.f, 0.f, 0.f};
+  f4v xs[2];                                         // [g]: fp32 fragment of A block wm
+  pl_u4 a3[3];                                       // [term]: its split
+  pl_u4 bs[NB][3];                                   // [block][term]: planes of the four W blocks
+  PlSplit sp;
+  // Between barriers k and k+1 the waves of tile k's parity read it and split their fragment; between k+1 and k+2 they issue
+  // its 24 matrix instructions -- while the waves of the other parity read and split tile k+1.  One wave feeds a SIMD's matrix
+  // pipe while the other wave's LDS reads and vector instructions issue beside it.  Inside ONE wave the three kinds of work
+  // add up whatever the instruction order (370 matrix + 124 split + 232 LDS-read cycles per K-tile, measured by leaving each
+  // out in turn; 866 cycles between barriers with the split hand-placed two instructions behind each MFMA).
+  auto phase_read = [&](int t) {
     const char* st = lds + (t % NST) * PLG_STB;
-    x[0] = *reinterpret_cast<const f4v*>(st + fragA[0]);
-    x[1] = *reinterpret_cast<const f4v*>(st + fragA[1]);
+    xs[0] = *reinterpret_cast<const f4v*>(st + fragA[0]);
+    xs[1] = *reinterpret_cast<const f4v*>(st + fragA[1]);
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+    for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-      for (int tm = 0; tm < 3; ++tm) b3[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
-  };
-  auto compute = [&](int t, const f4v (&x)[2], const pl_u4 (&b3)[2][3]) {
-    float v[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[1][0], x[1][1], x[1][2], x[1][3]};
-    if (ktail && t == nk - 1) {
+      for (int tm = 0; tm < 3; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
+    if (ktail && t == nk - 1) {                      // zero the positions at or past K (last tile of a ragged K only)
+      const int klim = p.K - t * BK;
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * g + j] = (t * BK + 16 * g + 4 * kk + j >= p.K) ? 0.f : v[4 * g + j];
+        for (int j = 0; j < 4; ++j) xs[g][j] = (16 * g + 4 * kk + j >= klim) ? 0.f : xs[g][j];
     }
-    pl_u4 a3[3];
-    pl_split8(v, a3);
+    pl_split_uops<0, 44>(sp, xs, a3);                // volatile: the split stays on this side of the barrier
+  };
+  auto phase_mfma = [&]() {
     // smallest terms first: lo x hi, hi x lo, mid x mid, then the 2^-8 pair, then hi x hi
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) acc[bi] = pl_mfma(a3[2], b3[bi][0], acc[bi]);
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi) acc[bi] = pl_mfma(a3[0], b3[bi][2], acc[bi]);
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi) acc[bi] = pl_mfma(a3[1], b3[bi][1], acc[bi]);
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi) acc[bi] = pl_mfma(a3[1], b3[bi][0], acc[bi]);
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi) acc[bi] = pl_mfma(a3[0], b3[bi][1], acc[bi]);
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi) acc[bi] = pl_mfma(a3[0], b3[bi][0], acc[bi]);
+    for (int i = 0; i < 6 * NB; ++i) {
+      const int pr = i / NB, bi = i % NB;
+      const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+      acc[bi] = pl_mfma(a3[ta], bs[bi][tb], acc[bi]);
+    }
   };
-  pl_barrier();                                      // barrier 0: tile 0 landed
-  read_tile(0, xs[0], bs[0]);
-  // step it: barrier it+1 (tile it+1 landed; the reads of tile it have completed: lgkmcnt(0) in front of the barrier) ->
-  // start the reads of tile it+1 into the other register set -> split + multiply tile it while they fly
-#define EP_PL_STEP(IT, F)                                    \
-  {                                                          \
-    pl_barrier();                                            \
-    read_tile((IT) + 1, xs[(F) ^ 1], bs[(F) ^ 1]);           \
-    compute((IT), xs[F], bs[F]);                             \
+  unsigned long long t_b0 = 0, t_rd = 0, t_b1 = 0, t_mm = 0;   // diagnostic only (EP_PLANES_STAMP)
+  const bool stamped = p.ablate == 77;
+  int k = 0;
+  if (par) { pl_barrier(); k = 1; }                  // barrier 0 belongs to the other parity's first tile
+  for (; k < nk; k += 2) {
+    const unsigned long long c0 = stamped ? __builtin_readcyclecounter() : 0ull;
+    pl_barrier();                                    // barrier k: tile k landed
+    const unsigned long long c1 = stamped ? __builtin_readcyclecounter() : 0ull;
+    phase_read(k);
+    const unsigned long long c2 = stamped ? __builtin_readcyclecounter() : 0ull;
+    pl_barrier();                                    // barrier k + 1: my reads are done, the stage may be refilled
+    const unsigned long long c3 = stamped ? __builtin_readcyclecounter() : 0ull;
+    phase_mfma();
+    if (stamped) { const unsigned long long c4 = __builtin_readcyclecounter(); t_b0 += c1 - c0; t_rd += c2 - c1; t_b1 += c3 - c2; t_mm += c4 - c3; }
   }
-  int it = 0;
-  for (; it + 1 < nk; it += 2) {
-    EP_PL_STEP(it, 0)
-    EP_PL_STEP(it + 1, 1)
+  if (stamped && lane == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(p.skws) + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 4;
+    d[0] = t_b0; d[1] = t_rd; d[2] = t_b1; d[3] = t_mm;
   }
-  if (it < nk) EP_PL_STEP(it, 0)
-#undef EP_PL_STEP
-
-  {
-    int rb[2], cb[2];
+  if ((nk & 1) == par) pl_barrier();                 // both parities pass barriers 0 .. nk
+  pl_barrier();                                      // F1: the loaders are done with the ring
+  float* red = reinterpret_cast<float*>(lds) + (wm * NB * 64 + lane) * 4;
+  if (par) {
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) { rb[bi] = m0 + wm * 16; cb[bi] = n0 + wn * 32 + bi * 16; }
-    store_acc_blocks<2>(p, C, z, rb, cb, acc, kk, i16);
+    for (int bi = 0; bi < NB; ++bi) *reinterpret_cast<f4v*>(red + bi * 256) = acc[bi];
   }
+  pl_barrier();                                      // F2 (the loader waves have left)
+  if (par) return;
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) acc[bi] += *reinterpret_cast<const f4v*>(red + bi * 256);
+  int rb[NB], cb[NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) { rb[bi] = m0 + wm * 16; cb[bi] = n0 + bi * 16; }
+  store_acc_blocks<NB>(p, C, z, rb, cb, acc, kk, i16);
 }
 
 bool gemm_planes_ok(const GemmParams& p) {
@@ -312,23 +381,39 @@ bool gemm_planes_ok(const GemmParams& p) {
          p.pl_term % 8 == 0 && p.sBpz % 8 == 0 && p.M > 0 && p.N > 0 && p.K > 0;
 }
 
-template <int NST>
 static void planes_launch(const GemmParams& p, int batch, hipStream_t st) {
-  constexpr int lds = NST * PLG_STB;
-  auto k = ep_gemm_planes_kernel<NST>;
+  constexpr int lds = PLG_NST * PLG_STB;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
-  hipLaunchKernelGGL(k, grid, dim3(768), lds, st, p);
+  hipLaunchKernelGGL(ep_gemm_planes_kernel, grid, dim3(768), lds, st, p);
 }
 
 int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
   EP_REQUIRE(gemm_planes_ok(p), EP_E_ALIGN, "gemm_planes: operands must be 16-byte aligned (A: lda %% 4; planes: row stride %% 32)");
-  static int nst = -1;
-  if (nst < 0) { const char* e = getenv("EP_PLANES_NST"); nst = e ? atoi(e) : 5; }
-  if (nst == 7) planes_launch<7>(p, batch, st);      // 140 KiB
-  else if (nst == 4) planes_launch<4>(p, batch, st); // 80 KiB: two workgroups per CU
-  else planes_launch<5>(p, batch, st);               // 100 KiB: one 12-wave workgroup per CU, 3 K-tiles in flight
+  static int stamp = -1;                             // diagnostic only (EP_PLANES_STAMP=1): cycles per phase of a K-tile to stderr
+  if (stamp < 0) { const char* e = getenv("EP_PLANES_STAMP"); stamp = e ? atoi(e) : 0; }
+  const int nwg = ((p.N + 63) / 64) * ((p.M + 63) / 64);
+  if (stamp && batch == 1 && nwg <= 4096) {
+    static unsigned long long* dbg = nullptr;
+    static unsigned long long host[4096 * 8 * 4];
+    if (!dbg) (void)hipMalloc(&dbg, sizeof(host));
+    GemmParams q = p;
+    q.skws = reinterpret_cast<float*>(dbg); q.ablate = 77;
+    (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * 4 * sizeof(unsigned long long), st);
+    planes_launch(q, 1, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(host, dbg, (size_t)nwg * 8 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double a[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nwg * 8; ++i) for (int j = 0; j < 4; ++j) a[j] += (double)host[4 * i + j];
+    const double n = (double)nwg * 8 * (((p.K + 31) / 32) / 2.0);
+    static int printed = 0;
+    if (printed++ % 10 == 5)
+      fprintf(stderr, "[EP_PLANES_STAMP] %d x %d x %d, per own K-tile of a multiply wave: barrier k %.0f, read+split %.0f, barrier k+1 %.0f, matrix %.0f cycles\n",
+              p.M, p.N, p.K, a[0] / n, a[1] / n, a[2] / n, a[3] / n);
+    return 0;
+  }
+  planes_launch(p, batch, st);
   EP_LAUNCH_CHECK("ep_gemm_planes_kernel");
   return 0;
 }

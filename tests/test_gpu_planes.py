@@ -68,9 +68,11 @@ def test_matmul_against_planes_matches_float64(shape):
     assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 3e-6
 
 
-def test_fused_step_with_and_without_planes_agree():
-    """The same three LARS steps with the planes path (default) and with EP_GEMM_PLANES=0 semantics are compared through
-    the engine's public results: losses to 1e-6 relative, parameters to fp32 summation-order noise."""
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["all_four", "classifier_only"])
+def test_fused_step_with_and_without_planes_agree(mode):
+    """The same three LARS steps with the planes path (EP_GEMM_PLANES=1: all four contractions; =2: logits and dz) and
+    without it are compared through the engine's public results: losses to 1e-6 relative, parameters to fp32
+    summation-order noise."""
     import os
     import subprocess
     import sys
@@ -95,7 +97,7 @@ torch.save({"loss": losses, "p": eng.flat_p.cpu()}, sys.argv[1])
 '''
     import tempfile
     outs = []
-    for flag in ("1", "0"):
+    for flag in (mode, "0"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
             env = dict(os.environ, EP_GEMM_PLANES=flag)
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env,
