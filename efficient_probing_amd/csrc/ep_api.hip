@@ -1,7 +1,4 @@
 // extern "C" entry points of libep_hip.so (declared in include/ep_hip.h).
-#ifndef EP_PLANES_DEFAULT
-#define EP_PLANES_DEFAULT 0
-#endif
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
@@ -71,18 +68,21 @@ struct HeadWs {
   size_t total;
 };
 
-// The classifier contractions (logits = z Wc^T, dz = dlogits Wc) against pre-split weight planes on the bf16 matrix cores
-// (ep_planes.hip) -- EP_GEMM_PLANES: 0 off, 2 those two (the planes of Wc are split beside the first token pass),
-// 1 all four critical-path contractions (round 2's experiment: needs the per-query slice width to be a multiple of the
-// MFMA K (32) for the dP contraction, and switches the in-pass contractions off).  Measured on MI355X at 1024 x 256 x 768,
-// kernels alone: logits 14.7 against 20.4 us, dz 16.7 against 20.8 us (f32 kernel); the per-query projection (half-empty
-// 96-column tiles) and the 3-K-tile dP contraction do not gain, which is why mode 1 loses (0.490 against 0.467 ms per step).
+// Contractions against pre-split weight planes on the bf16 matrix cores (ep_planes.hip) -- EP_GEMM_PLANES: 0 off, 1 all four
+// critical-path contractions (needs the per-query slice width to be a multiple of the MFMA K (32) for the dP contraction;
+// switches the in-pass contractions off), 2 the classifier's two (logits = z Wc^T, dz = dlogits Wc; the planes of Wc are
+// split beside the first token pass).  Unset: mode 1 for D >= 2048, off below.  Measured on MI355X, ms per step, f32 kernels
+// against mode 1 (mode 2): 196 x 4096 (DINOv3 ViT-7B) 2.67 -> 2.49; 256 x 1152 0.746 -> 0.749; 196 x 1024 0.521 -> 0.553;
+// 256 x 768 0.437 -> 0.460 (0.442).  Kernels alone at 256 x 768: logits 14.6 against 20.4 us, dz 16.4 against 20.8 us; at
+// 1024 x 4096 x 4096 (the value projection of the 7B tokens) 184 against 353 us -- the small shapes lose it again to the split
+// launch beside the HBM-bound first pass, the half-empty 96-column tiles of their per-query projection and the in-pass dP.
 static int head_planes_mode(const ep_head_dims& d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : EP_PLANES_DEFAULT; }
+  static int on = -2;
+  if (on == -2) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : -1; }
   const int Dp = d.D / d.d_out;
-  if (!on || d.D % 4 != 0 || Dp % 4 != 0) return 0;
-  if (on == 1) return (Dp / d.Q) % 32 == 0 ? 1 : 0;
+  const int mode = on >= 0 ? on : (d.D >= 2048 ? 1 : 0);
+  if (!mode || d.D % 4 != 0 || Dp % 4 != 0) return 0;
+  if (mode == 1) return (Dp / d.Q) % 32 == 0 ? 1 : 0;
   return 2;
 }
 static bool head_planes_ok(const ep_head_dims& d) { return head_planes_mode(d) != 0; }
@@ -640,6 +640,8 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
         EP_HIP(hipEventRecord(ev[1], st));
         EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
       }
+      // (The weight gradient of v started only when dP is done, so that it runs beside the HBM-bound second pass instead of
+      // beside dP: measured, the pass then takes 1070 instead of 555 us at 196 x 4096 -- the two kernels do not share CUs.)
       EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
                               s->accumulate, side));
       if (pl) {

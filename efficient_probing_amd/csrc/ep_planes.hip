@@ -184,8 +184,15 @@ int planes_split(const PlaneSpec* specs, int n, hipStream_t st) {
 // LDS stage = fp32 A image (8 KiB, XOR-swizzled on the DMA source address like ep_gemm_dma_kernel) + 12 plane pieces of 1 KiB
 // ([block][term], 16 rows x 64 bytes each): 20 KiB; five stages.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int PLG_STB = 8192 + 12 * 1024;            // bytes per ring stage
-constexpr int PLG_NST = 5;                           // ring stages (100 KiB)
+// NB = 16-column blocks of W per workgroup: 4 (64 x 64 tile, five stages of 20 KiB) or 8 (64 x 128 tile, four stages of
+// 32 KiB) -- the wide tile halves the activation bytes and the split per matrix instruction: 48 instead of 24 matrix
+// instructions stand against one fragment split and 26 instead of 14 LDS reads; for contractions with enough 64 x 128 tiles
+// to fill the chip twice (planes_wide).
+template <int NB> struct PlGeom {
+  static constexpr int stb = 8192 + 3 * NB * 1024;   // bytes per ring stage
+  static constexpr int nst = NB == 8 ? 4 : 5;        // ring stages (128 / 100 KiB)
+  static constexpr int npc = (8 + 3 * NB) / 4;       // 1-KiB pieces per loader wave and K-tile (8 / 5)
+};
 
 // The split of one 8-value fragment as 44 single instructions (11 per value pair, pair index fastest so that neighbours are
 // independent), each a volatile asm statement.  Per pair (x0, x1):
@@ -223,14 +230,15 @@ __device__ __forceinline__ void pl_split_uops(PlSplit& s, const f4v (&x)[2], pl_
   if constexpr (U0 < U1) { pl_split_uop<U0>(s, x, a); pl_split_uops<U0 + 1, U1>(s, x, a); }
 }
 
+template <int NB>
 __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
-  constexpr int NST = PLG_NST, NB = 4;
+  constexpr int NST = PlGeom<NB>::nst, PLG_STB = PlGeom<NB>::stb, NPC = PlGeom<NB>::npc;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 multiply, 8..11 only move data
   const int i16 = lane & 15, kk = lane >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * (16 * NB);
   const int z = blockIdx.z;
   const int nk = (p.K + BK - 1) / BK;
   const bool ktail = (p.K % BK) != 0;
@@ -258,9 +266,9 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
     // lines.  (Round 2: lane (i16, kk) copied row i16 -- 16 lines per quarter-wave, 64 tag look-ups per instruction; that, not
     // bandwidth, made the loaders alone take 888 cycles per K-tile, the same with every workgroup streaming the SAME operands;
     // 550 now.)
-    int64_t srcW[3];
+    int64_t srcW[NPC - 2];
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
+    for (int jj = 0; jj < NPC - 2; ++jj) {
       const int pb = lw + 4 * jj, blk = pb / 3, term = pb - 3 * blk;
       const int r16 = lane >> 2, kq = (lane & 3) ^ (2 * (r16 >> 3));
       int row = n0 + 16 * blk + r16; row = row < p.N ? row : p.N - 1;
@@ -276,19 +284,19 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
         __builtin_amdgcn_global_load_lds((pl_gptr_t)(A + oa), (pl_lds_ptr_t)(st + (lw + 4 * jj) * 1024), 16, 0, 0);
       }
 #pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
+      for (int jj = 0; jj < NPC - 2; ++jj)
         __builtin_amdgcn_global_load_lds((pl_gptr_t)(Wp + srcW[jj] + (int64_t)tt * BK),
                                          (pl_lds_ptr_t)(st + 8192 + (lw + 4 * jj) * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t);
     for (int k = 0; k <= nk; ++k) {
-      pl_dma_wait<5 * (NST - 2)>();                  // my pieces of tile k
+      pl_dma_wait<NPC * (NST - 2)>();                // my pieces of tile k
       pl_barrier();
       issue(k + NST - 1);                            // into the stage of tile k-1
     }
     pl_dma_wait<0>();
-    pl_barrier();                                    // F1: the ring is quiet, its first 16 KiB serve the final reduction
+    pl_barrier();                                    // F1: the ring is quiet, its first NB x 4 KiB serve the final reduction
     return;
   }
 
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
     xs[0] = *reinterpret_cast<const f4v*>(st + fragA[0]);
     xs[1] = *reinterpret_cast<const f4v*>(st + fragA[1]);
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi)
+    for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
       for (int tm = 0; tm < 3; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
     if (ktail && t == nk - 1) {                      // zero the positions at or past K (last tile of a ragged K only)
@@ -330,6 +338,12 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) xs[g][j] = (16 * g + 4 * kk + j >= klim) ? 0.f : xs[g][j];
     }
     pl_split_uops<0, 44>(sp, xs, a3);                // volatile: the split stays on this side of the barrier
+    if constexpr (NB == 8) {                         // the other four blocks once the split's registers are free
+#pragma unroll
+      for (int bi = 4; bi < 8; ++bi)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
+    }
   };
   auto phase_mfma = [&]() {
     // smallest terms first: lo x hi, hi x lo, mid x mid, then the 2^-8 pair, then hi x hi
@@ -381,19 +395,27 @@ bool gemm_planes_ok(const GemmParams& p) {
          p.pl_term % 8 == 0 && p.sBpz % 8 == 0 && p.M > 0 && p.N > 0 && p.K > 0;
 }
 
+template <int NB>
 static void planes_launch(const GemmParams& p, int batch, hipStream_t st) {
-  constexpr int lds = PLG_NST * PLG_STB;
+  constexpr int lds = PlGeom<NB>::nst * PlGeom<NB>::stb;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
-  dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
-  hipLaunchKernelGGL(ep_gemm_planes_kernel, grid, dim3(768), lds, st, p);
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  dim3 grid((p.N + 16 * NB - 1) / (16 * NB), (p.M + 63) / 64, batch);
+  hipLaunchKernelGGL(ep_gemm_planes_kernel<NB>, grid, dim3(768), lds, st, p);
+}
+// 64 x 128 tiles when they fill the chip at least twice (EP_PLANES_WIDE=0 / 1 forces)
+static bool planes_wide(const GemmParams& p, int batch) {
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("EP_PLANES_WIDE"); force = e ? atoi(e) : -1; }
+  if (force >= 0) return force != 0;
+  return (long)((p.N + 127) / 128) * ((p.M + 63) / 64) * batch >= 2 * 256;
 }
 
 int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
   EP_REQUIRE(gemm_planes_ok(p), EP_E_ALIGN, "gemm_planes: operands must be 16-byte aligned (A: lda %% 4; planes: row stride %% 32)");
   static int stamp = -1;                             // diagnostic only (EP_PLANES_STAMP=1): cycles per phase of a K-tile to stderr
   if (stamp < 0) { const char* e = getenv("EP_PLANES_STAMP"); stamp = e ? atoi(e) : 0; }
-  const int nwg = ((p.N + 63) / 64) * ((p.M + 63) / 64);
+  const int tw = planes_wide(p, batch) ? 128 : 64, nwg = ((p.N + tw - 1) / tw) * ((p.M + 63) / 64);
   if (stamp && batch == 1 && nwg <= 4096) {
     static unsigned long long* dbg = nullptr;
     static unsigned long long host[4096 * 8 * 4];
@@ -401,7 +423,7 @@ int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
     GemmParams q = p;
     q.skws = reinterpret_cast<float*>(dbg); q.ablate = 77;
     (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * 4 * sizeof(unsigned long long), st);
-    planes_launch(q, 1, st);
+    if (planes_wide(p, 1)) planes_launch<8>(q, 1, st); else planes_launch<4>(q, 1, st);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host, dbg, (size_t)nwg * 8 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double a[4] = {0, 0, 0, 0};
@@ -413,7 +435,7 @@ int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
               p.M, p.N, p.K, a[0] / n, a[1] / n, a[2] / n, a[3] / n);
     return 0;
   }
-  planes_launch(p, batch, st);
+  if (planes_wide(p, batch)) planes_launch<8>(p, batch, st); else planes_launch<4>(p, batch, st);
   EP_LAUNCH_CHECK("ep_gemm_planes_kernel");
   return 0;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One planes contraction launched back to back (GPU box; run under rocprofv3).  usage: planes_one.py {logits|dz|split} [iters]"""
+"""One planes contraction launched back to back (GPU box; run under rocprofv3).  usage: planes_one.py {logits|dz|split|mm} [iters] [M K N]  (mm: an M x K activation against an N x K weight, and the f32 kernel on the same)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,5 +13,14 @@ pn, pt = F_.planes_split(Wc, True, True)
 if op == "logits": fn = lambda: F_.matmul_planes(z, pn, C, bias=bc)
 elif op == "dz": fn = lambda: F_.matmul_planes(dl, pt, D)
 elif op == "split": fn = lambda: F_.planes_split(Wc, True, True)
+if op == "mm":
+    M, K, Nw = (int(v) for v in sys.argv[3:6])
+    A = torch.randn(M, K, device=dev); W = torch.randn(Nw, K, device=dev) * 0.03
+    pw, _ = F_.planes_split(W)
+    got = F_.matmul_planes(A, pw, Nw); ref = A.double() @ W.double().t()
+    f32 = F_.linear_forward(A, W, None)
+    print(f"mm {M}x{K}x{Nw}: planes err {float((got.double() - ref).abs().max() / ref.abs().max()):.2e}, f32 kernel err {float((f32.double() - ref).abs().max() / ref.abs().max()):.2e}")
+    def fn():
+        F_.matmul_planes(A, pw, Nw); F_.linear_forward(A, W, None)
 for i in range(it): fn()
 torch.cuda.synchronize()
