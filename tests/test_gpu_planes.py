@@ -43,7 +43,9 @@ def test_three_terms_are_exact_in_both_orientations(shape):
 
 
 @pytest.mark.parametrize("shape", [(1024, 768, 1000), (1024, 1000, 768), (130, 772, 1004), (37, 100, 52), (5, 36, 8),
-                                   (64, 32, 64), (200, 96, 768), (1025, 4096, 132)], ids=lambda s: "x".join(map(str, s)))
+                                   (64, 32, 64), (200, 96, 768), (1025, 4096, 132),
+                                   (1024, 520, 4000)],      # enough 64 x 128 tiles for the wide form, ragged K and N
+                         ids=lambda s: "x".join(map(str, s)))
 def test_matmul_against_planes_matches_float64(shape):
     """M x K activations times (N x K weights)^T, with a bias: error relative to the largest output entry at the level
     of the fp32 kernel (tools/gemm_fuzz.py: 1.2e-6 at K = 768), for ragged M / N / K (K tail, row and column edges)."""
