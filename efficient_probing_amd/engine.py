@@ -372,6 +372,28 @@ class ProbeHeadEngine:
             self.stats.zero_()
         return vals
 
+    def read_stats_async(self):
+        """The same four sums WITHOUT draining the queue: they are copied into pinned host memory behind the steps
+        enqueued so far (and the device counters cleared behind the copy); ``wait_stats(handle)`` returns them once the
+        copy has happened.  A training loop reads window k's handle when it enqueues window k+1's, so logging costs no
+        pipeline bubble (a blocking read every 20 iterations costs one step latency: ~5 % at 0.43 ms per step)."""
+        if not hasattr(self, "_stats_host"):
+            self._stats_host = [torch.empty_like(self.stats, device="cpu").pin_memory() for _ in range(2)]
+            self._stats_turn = 0
+        host = self._stats_host[self._stats_turn]
+        self._stats_turn ^= 1
+        host.copy_(self.stats, non_blocking=True)
+        self.stats.zero_()
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
+    @staticmethod
+    def wait_stats(handle):
+        host, ev = handle
+        ev.synchronize()
+        return host.tolist()
+
 
 class CocaHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(CrossAttention (CoCa pooler), BatchNorm1d, Linear): same flat-buffer

@@ -236,8 +236,10 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     optimizer.zero_grad()
     pending = 0                                   # fused steps whose statistics are still on the GPU
 
-    def flush_stats(n_steps):
-        loss_sum, top1, top5, bad = engine.read_stats()
+    reads = []                                    # (handle, steps) of windows whose statistics are on their way to the host
+
+    def account(vals, n_steps):
+        loss_sum, top1, top5, bad = vals
         if bad > 0 or not math.isfinite(loss_sum):
             print(f"Loss is non-finite ({loss_sum}), stopping training")
             sys.exit(1)
@@ -245,6 +247,17 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         metric_logger.meters["loss"].update(loss_sum / n_steps, n_steps)
         metric_logger.meters["acc1"].update(top1 * 100.0 / (bsz * n_steps), n_steps)
         metric_logger.meters["acc5"].update(top5 * 100.0 / (bsz * n_steps), n_steps)
+
+    def flush_stats(n_steps, last=False):
+        # a window's sums are read when the NEXT window's read-back is enqueued (the last one at the end of the epoch), so
+        # the meters -- and the non-finite check, reference engine_finetune.py:62-64 -- run one window behind the queue
+        # instead of draining it; engines without the asynchronous form read in place
+        if not hasattr(engine, "read_stats_async"):
+            return account(engine.read_stats(), n_steps)
+        reads.append((engine.read_stats_async(), n_steps))
+        while len(reads) > (0 if last else 1):
+            handle, n = reads.pop(0)
+            account(engine.wait_stats(handle), n)
 
     for step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         samples, targets = batch[0], batch[-1]
@@ -269,7 +282,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
                     engine.optimizer_step(lr=max(g["lr"] for g in optimizer.param_groups))
             pending += 1
             if pending == print_freq or step == n_iter - 1:
-                flush_stats(pending)
+                flush_stats(pending, last=step == n_iter - 1)
                 pending = 0
         else:
             if mixup_fn is not None:
@@ -294,6 +307,9 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             epoch_1000x = int((step / n_iter + epoch) * 1000)
             log_writer.add_scalar("loss", misc.all_reduce_mean(metric_logger.meters["loss"].value), epoch_1000x)
             log_writer.add_scalar("lr", metric_logger.meters["lr"].value, epoch_1000x)
+    while reads:                          # (a loader shorter than its len(): the window still on its way)
+        handle, n = reads.pop(0)
+        account(engine.wait_stats(handle), n)
     eng = getattr(model.module if hasattr(model, "module") else model, "_ep_engine", None)
     if eng is not None:
         eng.flush()                       # a pipelined / deferred step leaves its large update half a step behind
