@@ -171,7 +171,13 @@ class ResidentTokenStore:
     def batches(self, batch_size: int, epoch: int = 0, shuffle: bool = True, drop_last: bool = True):
         g = torch.Generator(device="cpu").manual_seed(self.seed * 1000003 + epoch * 101 + self.rank)
         order = torch.randperm(self.num_images, generator=g) if shuffle else torch.arange(self.num_images)
-        order = order.to(dtype=torch.int32, device=self.tokens.device)
+        order = order.to(dtype=torch.int32)
+        if self.tokens.is_cuda:
+            # through pinned memory, asynchronously: a copy from pageable memory blocks the host until the queue has drained
+            # (one step latency per epoch -- visible when a store holds only a few batches); the host copy is kept until the
+            # next epoch's replaces it
+            self._order_host = order.pin_memory()
+            order = self._order_host.to(self.tokens.device, non_blocking=True)
         if self.world > 1:                 # equal step counts on all ranks: each step all-reduces the gradients
             stop = self.num_batches(batch_size) * batch_size
         else:

@@ -277,3 +277,29 @@ def test_store_batches_through_train_one_epoch_and_evaluate():
     assert s1["loss"] == pytest.approx(s2["loss"], rel=1e-6)
     assert torch.equal(p1, p2)                    # same kernels on the same images: bit-equal parameters
     assert e1["acc1"] == e2["acc1"] and e1["loss"] == pytest.approx(e2["loss"], rel=1e-6)
+
+
+def test_epoch_meters_read_one_window_behind_account_every_step():
+    """train_one_epoch reads a window's statistics when the next window's read-back is enqueued (no queue drain): over an
+    epoch of 2 1/2 print windows the averaged loss still equals the mean of the per-step losses of a plain loop, and the
+    asynchronous read-back itself returns what the blocking one does."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd.util.lars import LARS
+    case = Case("meters", B=8, N=12, D=64, Q=4, C=10, seed=11)
+    inp = make_inputs(case)
+    x = torch.from_numpy(inp["x_buf"]).to(DEV); t = torch.from_numpy(inp["targets"]).to(DEV)
+    n_it = 50                                                     # print_freq = 20: windows of 20, 20 and 10 steps
+    per_step = []
+    model = make_model(case, inp)
+    opt = LARS(model.head.parameters(), lr=0.05, weight_decay=1e-4)
+    eng = EF.get_engine(model, opt, ARGS)
+    for _ in range(n_it):
+        eng.train_step(x, t, lr=0.05)
+        h = eng.read_stats_async()
+        per_step.append(eng.wait_stats(h)[0])
+    assert eng.read_stats()[0] == 0.0                             # the asynchronous read cleared the counters behind it
+    model = make_model(case, inp)
+    opt = LARS(model.head.parameters(), lr=0.05, weight_decay=1e-4)
+    args = Namespace(**{**vars(ARGS), "lr": 0.05, "min_lr": 0.05, "warmup_epochs": 0, "epochs": 1})
+    stats = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), [(x, t)] * n_it, opt, torch.device(DEV), 0, None, args=args)
+    assert stats["loss"] == pytest.approx(float(np.mean(per_step)), rel=1e-5)
