@@ -62,6 +62,7 @@ struct HeadWs {
   int *ycnt, *dcnt, *tick, *iperr; int nrb;    // arrival counters per 32-image row block and the image ticket counter
                                                // (each on a 128-byte line of its own, zero between steps), give-up count
   uint16_t *plWv, *plWvT, *plWc, *plWcT;       // bf16 planes of the two weight matrices, both orientations (ep_planes.hip)
+  uint16_t *ptP, *ptZ; float *dyT, *dlT;       // weight gradients on the planes kernel: planes of P^T and z^T, fp32 dy^T and dlogits^T
   void* pool_ws; size_t pool_ws_bytes;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
@@ -86,6 +87,15 @@ static int head_planes_mode(const ep_head_dims& d) {
   return 2;
 }
 static bool head_planes_ok(const ep_head_dims& d) { return head_planes_mode(d) != 0; }
+// The weight gradients dWv = dy^T P and dWc = dlogits^T z (sums over the batch index) on the planes kernel as well
+// (EP_PLANES_WGRAD, default on in mode 1): the activation that plays the weight -- P, z -- is split into planes of its
+// transpose (ep_planes_split_kernel's transposed orientation), the other one transposed in fp32.  196 x 4096 tokens: the split
+// of P (134 MB read, 201 MB written) runs on the side stream beside the contractions between the passes.
+static bool head_planes_wgrad(const ep_head_dims& d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_PLANES_WGRAD"); on = e ? atoi(e) : 1; }
+  return on && head_planes_mode(d) == 1 && d.B % 4 == 0 && d.B >= 128;
+}
 static HeadWs carve(const ep_head_dims& d, void* base) {
   HeadWs w{};
   const int Dp = d.D / d.d_out;
@@ -128,6 +138,10 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
     auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
     w.plWv = take16(planes_elems(Dp, d.D)); w.plWvT = take16(planes_elems(d.D, Dp));
     w.plWc = take16(planes_elems(d.C, Dp)); w.plWcT = take16(planes_elems(Dp, d.C));
+    if (head_planes_wgrad(d)) {
+      w.ptP = take16(planes_elems(d.Q * d.D, d.B)); w.ptZ = take16(planes_elems(Dp, d.B));
+      w.dyT = take((size_t)Dp * d.B); w.dlT = take((size_t)d.C * d.B);
+    }
   }
   w.total = off;
   return w;
@@ -163,6 +177,30 @@ static int linear_forward_pl(const HeadWs& w, const ep_head_dims& d, const float
 static int linear_backward_dz_pl(const HeadWs& w, const ep_head_dims& d, hipStream_t st) {
   const int Dp = d.D / d.d_out;
   return gemm_planes(planes_gemm(w.dlogits, w.ldl, 0, w.plWcT, Dp, d.C, 0, w.dz, Dp, 0, d.B, Dp, d.C, nullptr), 1, st);
+}
+
+// dWc[c, :] (+)= sum_b dlogits[b, c] z[b, :]  and  dWv[q Dq + m, :] (+)= sum_b dy[b, q Dq + m] P[b, q, :]  on the planes kernel
+static int wgrad_dwc_pl(const HeadWs& w, const ep_head_dims& d, float* dWc, int accumulate, hipStream_t st) {
+  const int Dp = d.D / d.d_out;
+  EP_TRY(transpose_f32(w.dlogits, d.B, d.C, w.ldl, w.dlT, d.B, st));
+  PlaneSpec sp{w.z, d.B, Dp, Dp, nullptr, w.ptZ};
+  EP_TRY(planes_split(&sp, 1, st));
+  GemmParams g = planes_gemm(w.dlT, d.B, 0, w.ptZ, Dp, d.B, 0, dWc, Dp, 0, d.C, Dp, d.B, nullptr);
+  g.accumulate = accumulate;
+  return gemm_planes(g, 1, st);
+}
+static int wgrad_split_P(const HeadWs& w, const ep_head_dims& d, hipStream_t st) {
+  PlaneSpec sp{w.P, d.B, d.Q * d.D, (int64_t)d.Q * d.D, nullptr, w.ptP};
+  return planes_split(&sp, 1, st);
+}
+static int wgrad_dwv_pl(const HeadWs& w, const ep_head_dims& d, float* dWv, int accumulate, hipStream_t st) {
+  const int Dp = d.D / d.d_out, Dq = Dp / d.Q;
+  const int64_t ldb = (int64_t)round_up((size_t)d.B, 32);
+  EP_TRY(transpose_f32(w.dy, d.B, Dp, Dp, w.dyT, d.B, st));
+  GemmParams g = planes_gemm(w.dyT, d.B, (int64_t)Dq * d.B, w.ptP, d.Q * d.D, d.B, (int64_t)d.D * ldb, dWv, d.D, (int64_t)Dq * d.D,
+                             Dq, d.D, d.B, nullptr);
+  g.accumulate = accumulate;
+  return gemm_planes(g, d.Q, st);
 }
 
 static int check_dims(const ep_head_dims& d) {
@@ -497,7 +535,8 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   }
   PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale, s->x_dtype);
   p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
-  // Weight planes of THIS step (ep_planes.hip).  With the whole step in one call and an aux stream the split runs BESIDE
+  // Weight planes of THIS step (ep_planes.hip).  (In front of the first pass on the same stream instead: 2.377 against 2.385 ms
+  // at 196 x 4096 -- the same.)  With the whole step in one call and an aux stream the split runs BESIDE
   // the first token pass (it needs the weights only, the pass the queries only): fork before the pass is enqueued, join
   // in front of the first contraction.  Split phases (data-parallel overlap): the large update of the previous step
   // lands between phase 4 and phase 8, so the split runs in phase 8 on the main stream.
@@ -548,6 +587,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     mark_pass(1, st);
   }
   if (wait_defer && !ip_y) EP_HIP(hipStreamWaitEvent(st, (hipEvent_t)s->defer_event, 0));
+  const bool plw = pl && (s->phases & 1) && head_planes_wgrad(d) && w.ptP;     // weight gradients on the planes kernel
   p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_y = nullptr; p.ip_yr0 = 0; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
     if (plc) {
@@ -556,6 +596,18 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     }
     if (pl) {
       EP_TRY(project_forward_pl(w, d, st));
+      // the planes of P^T (for dWv) are split on the side stream behind the value projection -- beside BatchNorm, logits, CE,
+      // dz: started right behind the first pass the HBM-bound split slows the projection, which reads P too, from 225 to 331 us
+      if (plw) {
+        hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
+        if (side != st) {
+          hipEvent_t ev4[4];
+          EP_TRY(get_events(ev4, 4));
+          EP_HIP(hipEventRecord(ev4[3], st));
+          EP_HIP(hipStreamWaitEvent(side, ev4[3], 0));
+        }
+        EP_TRY(wgrad_split_P(w, d, side));
+      }
     } else if (!ip_y) {
       EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
     }
@@ -631,8 +683,13 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
         EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
       }
       EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
-      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
-                             s->accumulate, side));
+      if (plw) {
+        EP_TRY(wgrad_dwc_pl(w, d, s->grads + offs[2], s->accumulate, side));
+        EP_TRY(colsum(w.dlogits, d.B, d.C, w.ldl, s->accumulate, s->grads + offs[3], side));
+      } else {
+        EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
+                               s->accumulate, side));
+      }
       if (plc) EP_TRY(linear_backward_dz_pl(w, d, st));
       else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
@@ -642,8 +699,9 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       }
       // (The weight gradient of v started only when dP is done, so that it runs beside the HBM-bound second pass instead of
       // beside dP: measured, the pass then takes 1070 instead of 555 us at 196 x 4096 -- the two kernels do not share CUs.)
-      EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
-                              s->accumulate, side));
+      if (plw) EP_TRY(wgrad_dwv_pl(w, d, s->grads + offs[1], s->accumulate, side));
+      else EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
+                                   s->accumulate, side));
       if (pl) {
         EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));

@@ -89,6 +89,8 @@ int planes_split(const PlaneSpec* specs, int n, hipStream_t st);
 bool gemm_planes_ok(const GemmParams& p);
 // C[z] (+)= alpha * A[z] W[z]^T (+ bias): A fp32 with K contiguous (lda), W given as planes (Bpl ...); fp32 accuracy
 int gemm_planes(const GemmParams& p, int batch, hipStream_t st);
+// dst (C x R, ldd) = src (R x C, lds_)^T, fp32 (ep_planes.hip)
+int transpose_f32(const float* src, int R, int C, int64_t lds_, float* dst, int64_t ldd, hipStream_t st);
 
 // Work appended to the launch of the second token pass (ep_side.h: run_side_task)
 struct SideTasks {

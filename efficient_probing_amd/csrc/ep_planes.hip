@@ -177,6 +177,33 @@ int planes_split(const PlaneSpec* specs, int n, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dst (C x R, leading dimension ldd) = src (R x C, leading dimension lds_)^T -- the fp32 operand of a weight-gradient
+// contraction (sum over the batch index) in the K-contiguous form the planes kernel reads.  64 x 64 tiles through LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ep_transpose_kernel(const float* __restrict__ src, int R, int C, int64_t lds_,
+                                                           float* __restrict__ dst, int64_t ldd) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(int64_t)(r0 + r) * lds_ + c0 + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i, c = e >> 6, r = e & 63;
+    if (c0 + c < C && r0 + r < R) dst[(int64_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
+  }
+}
+int transpose_f32(const float* src, int R, int C, int64_t lds_, float* dst, int64_t ldd, hipStream_t st) {
+  EP_REQUIRE(src && dst && R > 0 && C > 0 && lds_ >= C && ldd >= R, EP_E_ARG, "transpose_f32: bad argument");
+  hipLaunchKernelGGL(ep_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, R, C, lds_, dst, ldd);
+  EP_LAUNCH_CHECK("ep_transpose_kernel");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // C[z][m][n] (+)= alpha * sum_k A[z](m,k) * W[z](n,k) (+ bias[n]):  A fp32 (K contiguous), W as planes (K contiguous)
 // 64 x 64 tile per workgroup, K-tile 32 = one MFMA K.  12 waves: 4 loaders + 8 multiply waves, two per SIMD, as
 // 4 (16-row blocks of A) x 2 (K-tile parity): a multiply wave owns one 16-row block of A against all four 16-column blocks of

@@ -194,10 +194,11 @@ def test_fused_engine_steps_golden(case, opt):
             assert (ev16.argmax(1) != want.argmax(1)).sum() <= max(1, case.B // 32)      # near-ties at an untrained head
 
 
-ADHOC = [dict(B=16, N=50, D=256, Q=8, C=33), dict(B=6, N=37, D=2048, Q=8, C=20), dict(B=5, N=20, D=4096, Q=4, C=12)]
+ADHOC = [dict(B=16, N=50, D=256, Q=8, C=33), dict(B=6, N=37, D=2048, Q=8, C=20), dict(B=5, N=20, D=4096, Q=4, C=12),
+         dict(B=132, N=9, D=2048, Q=8, C=37)]    # D >= 2048 and B >= 128: all six contractions on the bf16-plane kernel
 
 
-@pytest.mark.parametrize("shape", ADHOC, ids=["d256", "wide2048", "wide4096"])
+@pytest.mark.parametrize("shape", ADHOC, ids=["d256", "wide2048", "wide4096", "wide2048_b132"])
 def test_engine_matches_oracle_multi_step_random(shape):
     """Oracle (not golden) parity on shapes no fixture has (incl. the wide-row kernels), 4 LARS steps with weight
     decay."""
