@@ -54,6 +54,20 @@ __device__ __forceinline__ float block_sum(float v, float* sm, int tid) {
   return r;
 }
 
+// four such sums at once (two barriers instead of eight): `sm` holds 16 floats here.  Component by component the same
+// arithmetic as block_sum -- wave sums, then (w0 + w1) + (w2 + w3).
+__device__ __forceinline__ f4 block_sum4(f4 v, float* sm, int tid) {
+  v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) *reinterpret_cast<f4*>(sm + 4 * w) = v;
+  __syncthreads();
+  const f4 a = *reinterpret_cast<const f4*>(sm), b = *reinterpret_cast<const f4*>(sm + 4), c = *reinterpret_cast<const f4*>(sm + 8),
+           d = *reinterpret_cast<const f4*>(sm + 12);
+  const f4 r = (a + b) + (c + d);
+  __syncthreads();
+  return r;
+}
+
 // norms of one chunk: the body of ep_opt_norms_kernel.  Returns the four partial sums in every thread of the group.
 __device__ __forceinline__ f4 chunk_norms(const OptParams& o, const OptSegs& segs, int chunk, int tid, float* sm) {
   const int k = seg_of_chunk(segs, chunk);
@@ -108,12 +122,11 @@ __device__ __forceinline__ f4 chunk_norms(const OptParams& o, const OptSegs& seg
       for (int64_t t = i; t < end && t < i + 4; ++t) acc1(o.p[t], o.g[t]);
     }
   }
-  pp = block_sum(pp, sm, tid); uu = block_sum(uu, sm, tid); gg = block_sum(gg, sm, tid); bad = block_sum(bad, sm, tid);
-  return f4{pp, uu, gg, bad};
+  return block_sum4(f4{pp, uu, gg, bad}, sm, tid);
 }
 
 __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs segs) {
-  __shared__ float sm[4];
+  __shared__ __attribute__((aligned(16))) float sm[16];
   const f4 r = chunk_norms(o, segs, blockIdx.x, threadIdx.x, sm);
   if (threadIdx.x == 0) *reinterpret_cast<f4*>(o.partial + (int64_t)blockIdx.x * 4) = r;
 }
@@ -145,20 +158,22 @@ __device__ __forceinline__ void chunk_update(const OptParams& o, const OptSegs& 
     avr[v] = *reinterpret_cast<const f4*>(s0p + ic);
     bvr[v] = *reinterpret_cast<const f4*>(s1p + ic);
   }
-  bad = block_sum(bad, sm, tid);
-  gg = block_sum(gg, sm, tid);
+  // the tensor's own sums (trust ratio) in the same round of loads and the same two barriers as the global ones
+  const bool ratio = o.mode == 0 && segs.trust[k];
+  float pp = 0.f, uu = 0.f;
+  if (ratio)
+    for (int c = segs.first_chunk[k] + tid; c < segs.first_chunk[k + 1]; c += 256) {
+      pp += partial[(int64_t)c * 4 + 0]; uu += partial[(int64_t)c * 4 + 1];
+    }
+  const f4 sums = block_sum4(f4{bad, gg, pp, uu}, sm, tid);
+  bad = sums.x; gg = sums.y; pp = sums.z; uu = sums.w;
   if (active && chunk == 0 && tid == 0) {
     *o.found_inf = bad > 0.f ? 1 : 0;
     if (o.grad_norm) *o.grad_norm = sqrtf(gg);
   }
   const bool skip = bad > 0.f || !active;                // GradScaler.step: skip the update (block sums stay uniform)
   float q = 1.0f;
-  if (o.mode == 0 && segs.trust[k]) {
-    float pp = 0.f, uu = 0.f;
-    for (int c = segs.first_chunk[k] + tid; c < segs.first_chunk[k + 1]; c += 256) {
-      pp += partial[(int64_t)c * 4 + 0]; uu += partial[(int64_t)c * 4 + 1];
-    }
-    pp = block_sum(pp, sm, tid); uu = block_sum(uu, sm, tid);
+  if (ratio) {
     const float pn = sqrtf(pp), un = sqrtf(uu);
     q = (pn > 0.f && un > 0.f) ? o.tc * pn / un : 1.0f;  // util/lars.py:26-29
   }
@@ -206,7 +221,7 @@ __device__ __forceinline__ void chunk_update(const OptParams& o, const OptSegs& 
 }
 
 __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs segs) {
-  __shared__ float sm[4];
+  __shared__ __attribute__((aligned(16))) float sm[16];
   chunk_update(o, segs, blockIdx.x, threadIdx.x, sm, o.partial, true);
 }
 
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256) void ep_opt_update_kernel(OptParams o, OptSegs
 // (ep_head_train_step, phases bit 4) has only this in front of the next step's first token pass.
 constexpr int OPT_SMALL_CHUNKS = 4;
 __global__ __launch_bounds__(256 * OPT_SMALL_CHUNKS) void ep_opt_small_kernel(OptParams o, OptSegs segs) {
-  __shared__ float sm[OPT_SMALL_CHUNKS][4];
+  __shared__ __attribute__((aligned(16))) float sm[OPT_SMALL_CHUNKS][16];
   __shared__ __attribute__((aligned(16))) float part[OPT_SMALL_CHUNKS * 4];
   const int g = threadIdx.x >> 8, tid = threadIdx.x & 255;
   const bool active = g < o.nchunks;
