@@ -160,8 +160,9 @@ int ep_linear_backward(const float* dlogits, int ldl, const float* z, const floa
 
 /* ------------------------------------------------------------------------------------------
  * Pre-split weights ("planes") for the bf16 matrix cores at fp32 accuracy (csrc/ep_planes.hip).
- * The fused train step splits the head's two weight matrices once per step and runs its four
- * critical-path contractions (reference poolings/ep.py:40, probe_heads.py:76 and their autograd)
+ * For heads with D >= 2048 (or as EP_GEMM_PLANES says) the fused train step splits the head's two
+ * weight matrices once per step and runs its contractions (reference poolings/ep.py:40,
+ * probe_heads.py:76 and their autograd; the two weight gradients against planes of P^T and z^T)
  * against the planes; these three entry points expose the same kernels.
  *   ep_planes_elems : 16-bit elements of the planes of a rows x K matrix (3 terms, K padded to 32)
  *   ep_planes_split : W (R x K, row-major, leading dimension ldw) -> planes of W (`planes_n`,
