@@ -187,12 +187,26 @@ __global__ __launch_bounds__(256) void ep_sum_kernel(const float* __restrict__ v
 struct AbWs {
   float *QKV, *SA, *O, *Xa, *H, *s, *a, *da, *ds, *dXa, *dS, *dQKV, *part, *stage, *skws;
   size_t skws_floats;
+  // contractions on the bf16-plane kernel (ep_planes.hip): planes of the three weight matrices (qkv natural; proj_w, w1 both
+  // orientations)
+  uint16_t *plQ, *plP, *plPT, *plW1, *plW1T;
   size_t pool_total;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
   size_t total;
 };
+
+// EP_ABMILP_PLANES=0: every contraction on the f32 matrix instruction (rounds 1 - 2).  Default: the weight contractions of
+// the forward pass (qkv, proj, the predictor's first layer) and the two activation gradients that go through a weight (dXa, dO)
+// on the bf16 pipe at fp32 accuracy -- 1.22 of the step's 2.32 TFLOP at 256 x 1152, B = 256: 22.3 -> 20.8 ms per step (the
+// kernel runs them at ~140 TFLOP/s against ~100 on the f32 instruction: on operands that stream from HBM its 64 x 128 tile is
+// bound by the CU's fill path).
+static bool ab_planes() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_ABMILP_PLANES"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
 
 static int64_t ab_offsets(const ep_abmilp_dims& d, int64_t offs[9]) {
   const int64_t D = d.D;
@@ -216,6 +230,12 @@ static AbWs ab_carve(const ep_abmilp_dims& d, void* base, bool head) {
   w.dXa = take(BN * D); w.dS = take(BN * d.N); w.dQKV = take(BN * 3 * D);
   w.part = take((size_t)WCS_RS * D); w.stage = take(16 * D);
   w.skws_floats = (size_t)16 * D * D; w.skws = take(w.skws_floats);     // split-K slices of the D x D weight gradients
+  if (ab_planes()) {
+    auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
+    w.plQ = take16(planes_elems(3 * d.D, d.D));
+    w.plP = take16(planes_elems(d.D, d.D)); w.plPT = take16(planes_elems(d.D, d.D));
+    w.plW1 = take16(planes_elems(d.D, d.D)); w.plW1T = take16(planes_elems(d.D, d.D));
+  }
   w.pool_total = off;
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
@@ -267,11 +287,27 @@ static int wcolsum(const float* src, const float* wgt, int64_t rows, int ncol, i
   return reduce_partials(w.part, WCS_RS, ncol, 1.0f, accumulate, out, w.stage, st);
 }
 
+// C (M x N, ldc) (+)= A (M x K, lda) . (the rowsW x Kw matrix whose planes are given)^T + bias
+static int ab_pl(const float* A, int64_t lda, const uint16_t* pl, int rowsW, int Kw, float* C, int64_t ldc, int M, int N, int K,
+                 const float* bias, int accumulate, hipStream_t st) {
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.bias = bias; g.accumulate = accumulate;
+  g.Bpl = pl; g.ldbp = (int64_t)round_up((size_t)Kw, 32); g.pl_term = (int64_t)rowsW * g.ldbp;
+  return gemm_planes(g, 1, st);
+}
+
 static int ab_forward_core(const ep_abmilp_dims& d, const float* x, const ep_abmilp_params& pr, const AbWs& w,
                            float* out, float* attn_map, hipStream_t st) {
   const int D = d.D, N = d.N, BN = d.B * d.N;
   const float scale = (float)pow((double)D, -0.5);                       // head_dim ** -0.5, one head (models_vit.py:59-60)
-  EP_TRY(gemm(true, true, mk(x, D, pr.qkv, D, w.QKV, 3 * D, BN, 3 * D, D), 1, st));
+  const bool pl = w.plQ != nullptr;
+  if (pl) {
+    PlaneSpec sp[3] = {{pr.qkv, 3 * D, D, D, w.plQ, nullptr}, {pr.proj_w, D, D, D, w.plP, w.plPT}, {pr.w1, D, D, D, w.plW1, w.plW1T}};
+    EP_TRY(planes_split(sp, 3, st));
+    EP_TRY(ab_pl(x, D, w.plQ, 3 * D, D, w.QKV, 3 * D, BN, 3 * D, D, nullptr, 0, st));
+  } else {
+    EP_TRY(gemm(true, true, mk(x, D, pr.qkv, D, w.QKV, 3 * D, BN, 3 * D, D), 1, st));
+  }
   {
     GemmParams g = mk(w.QKV, 3 * D, w.QKV + D, 3 * D, w.SA, N, N, N, D);   // S = (q scale) k^T per image
     g.sAz = (int64_t)N * 3 * D; g.sBz = g.sAz; g.sCz = (int64_t)N * N; g.alpha = scale;
@@ -283,13 +319,18 @@ static int ab_forward_core(const ep_abmilp_dims& d, const float* x, const ep_abm
     g.sAz = (int64_t)N * N; g.sBz = (int64_t)N * 3 * D; g.sCz = (int64_t)N * D; g.extB = D;
     EP_TRY(gemm(true, false, g, d.B, st));
   }
-  {
-    GemmParams g = mk(w.O, D, pr.proj_w, D, w.Xa, D, BN, D, D); g.bias = pr.proj_b;
-    EP_TRY(gemm(true, true, g, 1, st));
-  }
-  {
-    GemmParams g = mk(w.Xa, D, pr.w1, D, w.H, D, BN, D, D); g.bias = pr.b1;
-    EP_TRY(gemm(true, true, g, 1, st));
+  if (pl) {
+    EP_TRY(ab_pl(w.O, D, w.plP, D, D, w.Xa, D, BN, D, D, pr.proj_b, 0, st));
+    EP_TRY(ab_pl(w.Xa, D, w.plW1, D, D, w.H, D, BN, D, D, pr.b1, 0, st));
+  } else {
+    {
+      GemmParams g = mk(w.O, D, pr.proj_w, D, w.Xa, D, BN, D, D); g.bias = pr.proj_b;
+      EP_TRY(gemm(true, true, g, 1, st));
+    }
+    {
+      GemmParams g = mk(w.Xa, D, pr.w1, D, w.H, D, BN, D, D); g.bias = pr.b1;
+      EP_TRY(gemm(true, true, g, 1, st));
+    }
   }
   const int64_t n4 = (int64_t)BN * D / 4;
   hipLaunchKernelGGL(ep_tanh_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.H, n4);
@@ -323,7 +364,10 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
   }
   hipLaunchKernelGGL(ep_outer_rows_kernel, dim3(eg), dim3(256), 0, st, w.a, dout, (int64_t)BN, N, D / 4, w.dXa);
   EP_LAUNCH_CHECK("ep_outer_rows_kernel");
-  {
+  const bool pl = w.plQ != nullptr;          // (the planes are those the forward pass of this step split: same weights)
+  if (pl) {
+    EP_TRY(ab_pl(w.H, D, w.plW1T, D, D, w.dXa, D, BN, D, D, nullptr, 1, st));         // dXa += dG W1
+  } else {
     GemmParams g = mk(w.H, D, pr.w1, D, w.dXa, D, BN, D, D); g.accumulate = 1;        // dXa += dG W1
     EP_TRY(gemm(true, false, g, 1, st));
   }
@@ -335,7 +379,8 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
     EP_TRY(gemm(false, false, g, 1, st));
   }
   float* dO = w.H;                                                                   // dG is dead from here on
-  EP_TRY(gemm(true, false, mk(w.dXa, D, pr.proj_w, D, dO, D, BN, D, D), 1, st));     // dO = dXa Wp
+  if (pl) EP_TRY(ab_pl(w.dXa, D, w.plPT, D, D, dO, D, BN, D, D, nullptr, 0, st));    // dO = dXa Wp
+  else EP_TRY(gemm(true, false, mk(w.dXa, D, pr.proj_w, D, dO, D, BN, D, D), 1, st));
   // attention
   {
     GemmParams g = mk(dO, D, w.QKV + 2 * D, 3 * D, w.dS, N, N, N, D);                 // dA = dO v^T
@@ -360,6 +405,9 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
     EP_TRY(gemm(false, false, g, d.B, st));
   }
   {
+    // (On the planes kernel -- dQKV transposed in fp32, the tokens split into planes of their transpose -- this contraction
+    // over the B N = 65536 token rows takes 4.75 ms + 0.48 ms of transpose and split against 5.1 ms here: both stream 40 GB
+    // of operand panels; not kept.)
     GemmParams g = mk(w.dQKV, 3 * D, x, D, gr.qkv, D, 3 * D, D, BN); g.accumulate = acc;   // dWqkv = dQKV^T x
     g.skws = w.skws; g.skws_floats = w.skws_floats;
     EP_TRY(gemm(false, false, g, 1, st));
