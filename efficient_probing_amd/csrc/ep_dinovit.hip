@@ -128,11 +128,30 @@ struct DvWs {
   float *stat1, *h, *QKV, *S, *ctx, *x1, *stat2, *h2, *pre, *h1, *x2, *h1sum;
   float *g0, *g1, *dx1, *dh2, *dctx, *dS, *dQKV, *scr, *skws;
   size_t skws_floats;
+  // contractions through a weight matrix on the bf16-plane kernel (ep_planes.hip): planes of qkv / proj / fc1 (both
+  // orientations) and fc2
+  uint16_t *plQ, *plQT, *plP, *plPT, *plF1, *plF1T, *plF2;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
   size_t total;
 };
+
+// EP_DINOVIT_PLANES=0: every contraction on the f32 matrix instruction (rounds 1 - 2).  Default: the four forward projections
+// and the three activation gradients that go through a weight on the bf16 pipe at fp32 accuracy (as in ep_abmilp.hip).
+static bool dv_planes() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_DINOVIT_PLANES"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+// C (M x N, ldc) (+)= A (M x K, lda) . (the rowsW x Kw matrix whose planes are given)^T + bias
+static int dv_pl(const float* A, int64_t lda, const uint16_t* pl, int rowsW, int Kw, float* C, int64_t ldc, int M, int N, int K,
+                 const float* bias, int accumulate, hipStream_t st) {
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.bias = bias; g.accumulate = accumulate;
+  g.Bpl = pl; g.ldbp = (int64_t)round_up((size_t)Kw, 32); g.pl_term = (int64_t)rowsW * g.ldbp;
+  return gemm_planes(g, 1, st);
+}
 
 static void dv_sizes(const ep_dinovit_dims& d, int64_t sizes[DV_NT]) {
   const int64_t D = d.D, Hd = d.hidden;
@@ -164,6 +183,13 @@ static DvWs dv_carve(const ep_dinovit_dims& d, void* base, bool head) {
   const size_t wmax = 3 * D > Hd ? 3 * D : Hd;
   w.scr = take((size_t)(DV_RS + 16 + 2) * 2 * wmax);
   w.skws_floats = (size_t)16 * D * D; w.skws = take(w.skws_floats);      // split-K slices of the weight gradients
+  if (dv_planes()) {
+    auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
+    w.plQ = take16(planes_elems(3 * d.D, d.D)); w.plQT = take16(planes_elems(d.D, 3 * d.D));
+    w.plP = take16(planes_elems(d.D, d.D)); w.plPT = take16(planes_elems(d.D, d.D));
+    w.plF1 = take16(planes_elems(d.hidden, d.D)); w.plF1T = take16(planes_elems(d.D, d.hidden));
+    w.plF2 = take16(planes_elems(d.D, d.hidden));
+  }
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
     w.y = take(B * D); w.z = take(B * D); w.rstd = take(D);
@@ -211,7 +237,15 @@ static int dv_forward_core(const ep_dinovit_dims& d, const float* x, const ep_di
   EP_TRY(token_stats(x, 0, (int64_t)N * D, B, N, D, d.ln_eps, w.stat1, st));
   hipLaunchKernelGGL(ep_rowln_apply_kernel, dim3(eg), dim3(256), 0, st, x, w.stat1, pr.n1_w, pr.n1_b, nd, D, w.h);
   EP_LAUNCH_CHECK("ep_rowln_apply_kernel");
-  EP_TRY(gemm(true, true, vg(w.h, D, pr.qkv_w, D, w.QKV, 3 * D, R, 3 * D, D), 1, st));                 // QKV = h Wqkv^T
+  const bool pl = w.plQ != nullptr;
+  if (pl) {
+    PlaneSpec sp[4] = {{pr.qkv_w, 3 * D, D, D, w.plQ, w.plQT}, {pr.proj_w, D, D, D, w.plP, w.plPT},
+                       {pr.fc1_w, Hd, D, D, w.plF1, w.plF1T}, {pr.fc2_w, D, Hd, Hd, w.plF2, nullptr}};
+    EP_TRY(planes_split(sp, 4, st));
+    EP_TRY(dv_pl(w.h, D, w.plQ, 3 * D, D, w.QKV, 3 * D, R, 3 * D, D, nullptr, 0, st));                 // QKV = h Wqkv^T
+  } else {
+    EP_TRY(gemm(true, true, vg(w.h, D, pr.qkv_w, D, w.QKV, 3 * D, R, 3 * D, D), 1, st));
+  }
   const int64_t s3 = (int64_t)N * 3 * D, sS = (int64_t)H * N * N;
   for (int hh = 0; hh < H; ++hh) {                                                                      // S_h = scale q_h k_h^T
     GemmParams g = vg(w.QKV + hh * dh, 3 * D, w.QKV + D + hh * dh, 3 * D, w.S + (int64_t)hh * N * N, N, N, N, dh);
@@ -226,15 +260,18 @@ static int dv_forward_core(const ep_dinovit_dims& d, const float* x, const ep_di
     EP_TRY(gemm(true, false, g, B, st));
   }
   EP_HIP(hipMemcpyAsync(w.x1, x, (size_t)nd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  { GemmParams g = vg(w.ctx, D, pr.proj_w, D, w.x1, D, R, D, D); g.bias = pr.proj_b; g.accumulate = 1; EP_TRY(gemm(true, true, g, 1, st)); }
+  if (pl) EP_TRY(dv_pl(w.ctx, D, w.plP, D, D, w.x1, D, R, D, D, pr.proj_b, 1, st));
+  else { GemmParams g = vg(w.ctx, D, pr.proj_w, D, w.x1, D, R, D, D); g.bias = pr.proj_b; g.accumulate = 1; EP_TRY(gemm(true, true, g, 1, st)); }
   EP_TRY(token_stats(w.x1, 0, (int64_t)N * D, B, N, D, d.ln_eps, w.stat2, st));
   hipLaunchKernelGGL(ep_rowln_apply_kernel, dim3(eg), dim3(256), 0, st, w.x1, w.stat2, pr.n2_w, pr.n2_b, nd, D, w.h2);
-  { GemmParams g = vg(w.h2, D, pr.fc1_w, D, w.pre, Hd, R, Hd, D); g.bias = pr.fc1_b; EP_TRY(gemm(true, true, g, 1, st)); }
+  if (pl) EP_TRY(dv_pl(w.h2, D, w.plF1, Hd, D, w.pre, Hd, R, Hd, D, pr.fc1_b, 0, st));
+  else { GemmParams g = vg(w.h2, D, pr.fc1_w, D, w.pre, Hd, R, Hd, D); g.bias = pr.fc1_b; EP_TRY(gemm(true, true, g, 1, st)); }
   const int64_t n4 = (int64_t)R * Hd / 4;
   hipLaunchKernelGGL(ep_gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.h1);
   EP_LAUNCH_CHECK("ep_dinovit MLP kernels");
   EP_HIP(hipMemcpyAsync(w.x2, w.x1, (size_t)nd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  { GemmParams g = vg(w.h1, Hd, pr.fc2_w, Hd, w.x2, D, R, D, Hd); g.bias = pr.fc2_b; g.accumulate = 1; EP_TRY(gemm(true, true, g, 1, st)); }
+  if (pl) EP_TRY(dv_pl(w.h1, Hd, w.plF2, D, Hd, w.x2, D, R, D, Hd, pr.fc2_b, 1, st));
+  else { GemmParams g = vg(w.h1, Hd, pr.fc2_w, Hd, w.x2, D, R, D, Hd); g.bias = pr.fc2_b; g.accumulate = 1; EP_TRY(gemm(true, true, g, 1, st)); }
   hipLaunchKernelGGL(ep_dv_imgsum_kernel, dim3(B, (D / 4 + 255) / 256), dim3(256), 0, st, w.x2, N, D, 1.0f / (float)N, out);
   hipLaunchKernelGGL(ep_dv_imgsum_kernel, dim3(B, (Hd / 4 + 255) / 256), dim3(256), 0, st, w.h1, N, Hd, 1.0f, w.h1sum);
   EP_LAUNCH_CHECK("ep_dv_imgsum_kernel");
@@ -261,7 +298,9 @@ static int dv_backward_core(const ep_dinovit_dims& d, const float* x, const ep_d
   float* dpre = w.h1;
   EP_TRY(dv_colsum(dpre, nullptr, nullptr, R, Hd, acc, gr.fc1_b, nullptr, w.scr, st));
   { GemmParams g = vg(dpre, Hd, w.h2, D, gr.fc1_w, D, Hd, D, R); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }       // d W1
-  EP_TRY(gemm(true, false, vg(dpre, Hd, pr.fc1_w, D, w.dh2, D, R, D, Hd), 1, st));                        // dh2 = dpre W1
+  const bool pl = w.plQ != nullptr;            // (the planes are those the forward pass of this step split: same weights)
+  if (pl) EP_TRY(dv_pl(dpre, Hd, w.plF1T, D, Hd, w.dh2, D, R, D, Hd, nullptr, 0, st));                    // dh2 = dpre W1
+  else EP_TRY(gemm(true, false, vg(dpre, Hd, pr.fc1_w, D, w.dh2, D, R, D, Hd), 1, st));
   EP_TRY(dv_colsum(w.dh2, w.x1, w.stat2, R, D, acc, gr.n2_w, gr.n2_b, w.scr, st));
   // d x1 = g0 (broadcast) + LayerNorm backward of dh2
   hipLaunchKernelGGL(ep_dv_bcast_kernel, dim3((unsigned)((nd / 4 + 255) / 256)), dim3(256), 0, st, w.g0, nd / 4, N, D / 4, 1.0f, w.dx1);
@@ -271,7 +310,8 @@ static int dv_backward_core(const ep_dinovit_dims& d, const float* x, const ep_d
   EP_TRY(dv_colsum(w.dx1, nullptr, nullptr, R, D, acc, gr.proj_b, nullptr, w.scr, st));
   { GemmParams g = vg(w.dx1, D, w.ctx, D, gr.proj_w, D, D, D, R); g.accumulate = acc; g.skws = w.skws; g.skws_floats = w.skws_floats;
     EP_TRY(gemm(false, false, g, 1, st)); }                                                               // d Wp
-  EP_TRY(gemm(true, false, vg(w.dx1, D, pr.proj_w, D, w.dctx, D, R, D, D), 1, st));                       // dctx = dx1 Wp
+  if (pl) EP_TRY(dv_pl(w.dx1, D, w.plPT, D, D, w.dctx, D, R, D, D, nullptr, 0, st));                      // dctx = dx1 Wp
+  else EP_TRY(gemm(true, false, vg(w.dx1, D, pr.proj_w, D, w.dctx, D, R, D, D), 1, st));
   const int64_t s3 = (int64_t)N * 3 * D, sS = (int64_t)H * N * N, sD = (int64_t)N * D;
   for (int hh = 0; hh < H; ++hh) {
     { GemmParams g = vg(w.dctx + hh * dh, D, w.QKV + 2 * D + hh * dh, 3 * D, w.dS + (int64_t)hh * N * N, N, N, N, dh);           // dA_h = dctx_h v_h^T
@@ -290,7 +330,8 @@ static int dv_backward_core(const ep_dinovit_dims& d, const float* x, const ep_d
   // QKV = h Wqkv^T ; h = LayerNorm1(x): the tokens are frozen, only the affine parameters take a gradient
   { GemmParams g = vg(w.dQKV, 3 * D, w.h, D, gr.qkv_w, D, 3 * D, D, R); g.accumulate = acc; g.skws = w.skws; g.skws_floats = w.skws_floats;
     EP_TRY(gemm(false, false, g, 1, st)); }
-  EP_TRY(gemm(true, false, vg(w.dQKV, 3 * D, pr.qkv_w, D, w.dh2, D, R, D, 3 * D), 1, st));               // dh (reusing dh2)
+  if (pl) EP_TRY(dv_pl(w.dQKV, 3 * D, w.plQT, D, 3 * D, w.dh2, D, R, D, 3 * D, nullptr, 0, st));          // dh (reusing dh2)
+  else EP_TRY(gemm(true, false, vg(w.dQKV, 3 * D, pr.qkv_w, D, w.dh2, D, R, D, 3 * D), 1, st));
   EP_TRY(dv_colsum(w.dh2, x, w.stat1, R, D, acc, gr.n1_w, gr.n1_b, w.scr, st));
   return 0;
 }

@@ -193,6 +193,7 @@ constexpr int DOLG_NT = 8;    // conv1.weight conv1.bias | bn.weight bn.bias | c
 constexpr int DOLG_KSPLIT = 8;
 struct DolgWs {
   float *Z, *G, *rstd, *tok, *part, *dssum, *wpart, *bnpart;
+  uint16_t* plC1;                  // planes of conv1.weight: the 1x1 convolution on the bf16-plane kernel (ep_planes.hip)
   float *y, *z, *hrstd, *logits, *dlogits, *rowstat, *hbnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
@@ -225,6 +226,11 @@ static DolgWs dolg_carve(const ep_dolg_dims& d, void* base, bool head) {
   w.part = take((B + 16) * 3 * D + 16 * 3 * D); w.dssum = take(B);
   w.wpart = take((size_t)(DOLG_KSPLIT + 16) * D * D);
   w.bnpart = take(bn_workspace_bytes((int)R, d.D) / sizeof(float));
+  {
+    static int on = -1;            // EP_DOLG_PLANES=0: the convolution on the f32 matrix instruction (rounds 1 - 2)
+    if (on < 0) { const char* e = getenv("EP_DOLG_PLANES"); on = e ? atoi(e) : 1; }
+    if (on) w.plC1 = reinterpret_cast<uint16_t*>(take((planes_elems(d.D, d.D) + 1) / 2));
+  }
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
     w.y = take(B * D); w.z = take(B * D); w.hrstd = take(D);
@@ -269,7 +275,16 @@ struct DolgBn { int training; float eps, momentum; float *running_mean, *running
 static int dolg_forward_core(const ep_dolg_dims& d, const float* x, const DolgBn& bn, const ep_dolg_params& pr, const DolgWs& w,
                              float* y, hipStream_t st) {
   const int D = d.D, R = d.B * d.N;
-  { GemmParams g = dg(x, D, pr.conv1_w, D, w.Z, D, R, D, D); g.bias = pr.conv1_b; EP_TRY(gemm(true, true, g, 1, st)); }   // Y = x W1^T + c1
+  if (w.plC1) {                                                                                                          // Y = x W1^T + c1
+    PlaneSpec sp{pr.conv1_w, D, D, D, w.plC1, nullptr};
+    EP_TRY(planes_split(&sp, 1, st));
+    GemmParams g{};
+    g.A = x; g.lda = D; g.C = w.Z; g.ldc = D; g.M = R; g.N = D; g.K = D; g.alpha = 1.f; g.bias = pr.conv1_b;
+    g.Bpl = w.plC1; g.ldbp = (int64_t)round_up((size_t)D, 32); g.pl_term = (int64_t)D * g.ldbp;
+    EP_TRY(gemm_planes(g, 1, st));
+  } else {
+    GemmParams g = dg(x, D, pr.conv1_w, D, w.Z, D, R, D, D); g.bias = pr.conv1_b; EP_TRY(gemm(true, true, g, 1, st));
+  }
   if (bn.training) {
     EP_TRY(bn_forward_train(w.Z, R, D, bn.eps, bn.momentum, w.Z, w.rstd, bn.running_mean, bn.running_var, bn.nbt, w.bnpart, st));
   } else {
