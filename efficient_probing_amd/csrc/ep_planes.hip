@@ -349,12 +349,15 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   // pipe while the other wave's LDS reads and vector instructions issue beside it.  Inside ONE wave the three kinds of work
   // add up whatever the instruction order (370 matrix + 124 split + 232 LDS-read cycles per K-tile, measured by leaving each
   // out in turn; 866 cycles between barriers with the split hand-placed two instructions behind each MFMA).
+  // (Measured and dropped on the 64 x 128 tile: the second half of the plane reads behind the split (as first written: 894
+  // cycles of read + split per own K-tile) or all reads in front of it (912) make no difference, and odd row blocks splitting
+  // first while the even ones read first -- two waves contending for the LDS at a time -- is slower: 975.)
   auto phase_read = [&](int t) {
     const char* st = lds + (t % NST) * PLG_STB;
     xs[0] = *reinterpret_cast<const f4v*>(st + fragA[0]);
     xs[1] = *reinterpret_cast<const f4v*>(st + fragA[1]);
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi)
+    for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
       for (int tm = 0; tm < 3; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
     if (ktail && t == nk - 1) {                      // zero the positions at or past K (last tile of a ragged K only)
@@ -365,12 +368,6 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) xs[g][j] = (16 * g + 4 * kk + j >= klim) ? 0.f : xs[g][j];
     }
     pl_split_uops<0, 44>(sp, xs, a3);                // volatile: the split stays on this side of the barrier
-    if constexpr (NB == 8) {                         // the other four blocks once the split's registers are free
-#pragma unroll
-      for (int bi = 4; bi < 8; ++bi)
-#pragma unroll
-        for (int tm = 0; tm < 3; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
-    }
   };
   auto phase_mfma = [&]() {
     // smallest terms first: lo x hi, hi x lo, mid x mid, then the 2^-8 pair, then hi x hi
