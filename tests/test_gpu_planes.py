@@ -109,3 +109,19 @@ torch.save({"loss": losses, "p": eng.flat_p.cpu()}, sys.argv[1])
     assert np.allclose(a["loss"], b["loss"], rtol=2e-6)
     assert not torch.equal(a["p"], b["p"])                       # two different kernels really ran
     assert torch.allclose(a["p"], b["p"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("head", ["abmilp", "dinovit", "dolg"])
+def test_matrix_core_heads_keep_their_f32_contractions(head):
+    """The AbMILP / DINOv2-block / DOLG heads run their contractions through a weight matrix on the planes kernel by default
+    (that is what their own test files exercise); EP_ABMILP_PLANES=0 / EP_DINOVIT_PLANES=0 / EP_DOLG_PLANES=0 puts them back
+    on the f32 kernel, and the same golden comparisons must hold there."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{f"EP_{head.upper()}_PLANES": "0"})
+    r = subprocess.run([sys.executable, "-m", "pytest", f"tests/test_gpu_{head}.py", "-x", "-q", "-m", "gpu",
+                        "-k", "module_forward_backward or engine_lars_steps"], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
