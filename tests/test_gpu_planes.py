@@ -70,9 +70,10 @@ def test_matmul_against_planes_matches_float64(shape):
     assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 3e-6
 
 
-@pytest.mark.parametrize("mode", ["1", "2"], ids=["all_four", "classifier_only"])
+@pytest.mark.parametrize("mode", ["1", "2", "auto4096"], ids=["all_four", "classifier_only", "default_at_d4096"])
 def test_fused_step_with_and_without_planes_agree(mode):
-    """The same three LARS steps with the planes path (EP_GEMM_PLANES=1: all four contractions; =2: logits and dz) and
+    """The same three LARS steps with the planes path (EP_GEMM_PLANES=1: all four contractions; =2: logits and dz; the
+    default at D = 4096 with B >= 128: all six, weight gradients included, on 64 x 128 tiles where they fill the chip) and
     without it are compared through the engine's public results: losses to 1e-6 relative, parameters to fp32
     summation-order noise."""
     import os
@@ -84,16 +85,17 @@ sys.path.insert(0, os.getcwd())
 from argparse import Namespace
 from efficient_probing_amd import probe_heads
 from efficient_probing_amd.engine import ProbeHeadEngine
+D, B, N = (4096, 256, 24) if os.environ.get("EP_TEST_BIG") else (768, 96, 50)
 class Enc(torch.nn.Module):
     def __init__(self):
-        super().__init__(); self.head = torch.nn.Linear(768, 1000)
+        super().__init__(); self.head = torch.nn.Linear(D, 1000)
 torch.manual_seed(0); enc = Enc()
 probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=8, d_out=1, nb_classes=1000))
 eng = ProbeHeadEngine(enc.head.to("cuda:0").train(), optimizer="lars", lr=0.4, weight_decay=1e-4)
 g = torch.Generator().manual_seed(5)
 losses = []
 for s in range(3):
-    x = torch.randn(96, 50, 768, generator=g).to("cuda:0"); t = torch.randint(0, 1000, (96,), generator=g).to("cuda:0")
+    x = torch.randn(B, N, D, generator=g).to("cuda:0"); t = torch.randint(0, 1000, (B,), generator=g).to("cuda:0")
     eng.train_step(x, t); losses.append(eng.read_stats()[0])
 torch.save({"loss": losses, "p": eng.flat_p.cpu()}, sys.argv[1])
 '''
@@ -102,6 +104,10 @@ torch.save({"loss": losses, "p": eng.flat_p.cpu()}, sys.argv[1])
     for flag in (mode, "0"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
             env = dict(os.environ, EP_GEMM_PLANES=flag)
+            if mode == "auto4096":
+                env["EP_TEST_BIG"] = "1"
+                if flag != "0":
+                    del env["EP_GEMM_PLANES"]                     # the library's own choice at D >= 2048
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             outs.append(torch.load(f.name))
