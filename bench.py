@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-secondary", action="store_true", help="skip the bf16-token-storage line of the default EP run")
     ap.add_argument("--no-north-star", action="store_true", help="skip the north-star-shape (197x768) object of the default EP run")
-    ap.add_argument("--no-configs", action="store_true", help="skip the 20-step secondaries of the other BASELINE configurations (c1, c3, c4, c5)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 20-step secondaries of the other BASELINE configurations (c1, c3, c4, c5; CoCa and AbMILP at c4)")
     ap.add_argument("--no-through-engine", action="store_true",
                     help="skip the train_one_epoch() secondary (the same workload through the reference's loop surface)")
     ap.add_argument("--engine-steps", type=int, default=200, help="iterations of the train_one_epoch() secondary")
@@ -582,6 +582,25 @@ def main():
             line["workload"] = cdesc
             line["classes"] = cC
             configs[name] = line
+        # BASELINE configs[3] compares three heads on the SO400M tokens: the other two (CoCa pooler: HBM-bound like EP; AbMILP:
+        # matrix-core-bound) as short child runs of this file, rank 0 at N = 1 only (their own engines and workspaces)
+        if world == 1:
+            import subprocess
+            torch.cuda.empty_cache()
+            for hname in ("coca", "abmilp"):
+                cmd = [sys.executable, os.path.abspath(__file__), "--head", hname, "--workload", "c4", "--steps", "10", "--warmup", "3",
+                       "--spinup", "5", "--no-cpu-baseline", "--no-configs", "--no-north-star", "--no-bf16-secondary",
+                       "--no-through-engine", "--kernel-iters", "3"]
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                    d = json.loads(r.stdout.strip().splitlines()[-1])
+                    configs["c4_" + hname] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "n_gpus": 1, "steps": d["steps"],
+                                              "ms_per_step": d["ms_per_step"], "batch_per_gpu": d["config"]["batch_per_gpu"],
+                                              "workload": d["config"]["workload"], "bound": d["roofline"]["bound"],
+                                              "step_frac": d["roofline"].get("step_frac"),
+                                              "mean_loss_over_timed_steps": d["check"]["mean_loss_over_timed_steps"]}
+                except Exception as e:                          # a secondary never takes the headline line down with it
+                    configs["c4_" + hname] = {"error": f"{type(e).__name__}: {e}"[:200]}
         torch.cuda.empty_cache()
     # the same workload through the reference's loop surface (engine_finetune.train_one_epoch, reference
     # engine_finetune.py:22-103): a resident token store, adjust_learning_rate every iteration, meters every 20
