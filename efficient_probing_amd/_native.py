@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
-EP_ABI_VERSION = 21        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
+EP_ABI_VERSION = 22        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
 
@@ -314,6 +314,8 @@ SIGNATURES = {
                                 c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),
     "ep_pool_backward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p,
                                  c_f32p, c_f32p, c_int, c_void, c_size, c_void]),
+    "ep_pool_backward_per_image": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p,
+                                           c_f32p, c_f32p, c_void]),
     "ep_attention_from_scores": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_project_forward": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void]),
     "ep_project_backward": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p,
@@ -340,6 +342,7 @@ SIGNATURES = {
     "ep_head_param_offsets": (c_i64, [C.POINTER(EPHeadDims), C.POINTER(c_i64)]),
     "ep_head_workspace_bytes": (c_size, [C.POINTER(EPHeadDims)]),
     "ep_head_workspace_flag_offset": (C.c_int64, [C.POINTER(EPHeadDims)]),
+    "ep_head_workspace_init": (c_int, [C.POINTER(EPHeadDims), c_void, c_size, c_void]),
     "ep_debug_set_pass_events": (c_int, [c_void, c_void, c_void, c_void]),
     "ep_head_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),
     "ep_head_eval_forward": (c_int, [C.POINTER(EPHeadDims), c_void, c_int, c_i64, c_void, c_f32p, c_f32p, c_f32p,

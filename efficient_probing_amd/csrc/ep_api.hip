@@ -355,6 +355,19 @@ int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_
   return pool_backward(p, dcls, accumulate, (hipStream_t)stream);
 }
 
+int ep_pool_backward_per_image(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N,
+                               int D, int Q, float scale, const float* S, const float* ML, const float* dP, float* dq,
+                               ep_stream_t stream) {
+  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  EP_REQUIRE(S && ML && dP && dq, EP_E_ARG, "ep_pool_backward_per_image: null pointer");
+  EP_REQUIRE(aligned16(dP) && aligned16(dq) && aligned16(ML), EP_E_ALIGN,
+             "ep_pool_backward_per_image: dP / dq / ML must be 16-byte aligned");
+  PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale, x_dtype);
+  p.S = const_cast<float*>(S); p.ML = const_cast<float*>(ML); p.dP = dP; p.index = image_index;
+  p.cls_bstride = (int64_t)Q * D;                     // per-image query rows (selects the per-image kernels)
+  return pool_backward_per_image(p, dq, (hipStream_t)stream);
+}
+
 int ep_token_stats(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, float eps, float* stats,
                    ep_stream_t stream) {
   EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, 1));
@@ -512,6 +525,16 @@ int64_t ep_head_workspace_flag_offset(const ep_head_dims* dims) {
   char* base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // carve() only does address arithmetic on a non-null base
   const HeadWs w = carve(*dims, base);
   return reinterpret_cast<char*>(w.iperr) - base;
+}
+
+int ep_head_workspace_init(const ep_head_dims* dims, void* ws, size_t ws_bytes, ep_stream_t stream) {
+  EP_REQUIRE(dims && ws, EP_E_ARG, "ep_head_workspace_init: null pointer");
+  EP_TRY(check_dims(*dims));
+  const HeadWs w = carve(*dims, ws);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_workspace_init: workspace %zu < %zu", ws_bytes, w.total);
+  // ycnt | dcnt | ticket | give-up count are one contiguous block (carve)
+  EP_HIP(hipMemsetAsync(w.ycnt, 0, (2 * (size_t)w.nrb * 32 + 64) * sizeof(int), (hipStream_t)stream));
+  return 0;
 }
 
 int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream_t stream) {
@@ -728,25 +751,28 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     const ep_segment* use = (s->optimizer == 0 || sub) ? segs + (sub ? s->opt_first_segment : 0) : nullptr;
     const int nuse = (s->optimizer == 0 || sub) ? (sub ? s->opt_num_segments : 4) : 0;
     hipStream_t ax = (hipStream_t)s->aux_stream;
+    // a give-up of an in-pass hand-off wait (w.iperr != 0: ep_inpass.h) must be loud: the optimizer then skips the update,
+    // sets found_inf and bumps the non-finite row count of the step statistics, which stops train_one_epoch
+    float* abort_stat = s->stats ? s->stats + 3 : nullptr;
     if ((s->phases & 16) && s->defer_event && ax && ax != st && !sub) {
       // deferred large update: cls_token here (one launch; it also finishes the cls_token gradient reduction), the three
       // large tensors on the aux stream beside whatever the caller enqueues next on `stream`
       EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total, segs, 1, s->lr,
                         s->weight_decay, s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps,
-                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red));
+                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat));
       hipEvent_t evs[6];
       EP_TRY(get_events(evs, 6));
       EP_HIP(hipEventRecord(evs[3], st));                      // the gradients are complete on `stream` here
       EP_HIP(hipStreamWaitEvent(ax, evs[3], 0));
       EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total, segs + 1, 3, s->lr,
                         s->weight_decay, s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps,
-                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, ax, nullptr));
+                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, ax, nullptr, w.iperr, abort_stat));
       EP_HIP(hipEventRecord((hipEvent_t)s->defer_event, ax));
     } else
     EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
                       use, nuse, s->lr, s->weight_decay,
                       s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,
-                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red));
+                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat));
   }
   return 0;
 }

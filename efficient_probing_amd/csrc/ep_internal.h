@@ -181,6 +181,7 @@ size_t optim_workspace_bytes(int64_t total, int nseg);
 int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,
                int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
-               hipStream_t st, const DeferredReduce* red = nullptr);   // red: finish that reduction into g first (g is written)
+               hipStream_t st, const DeferredReduce* red = nullptr,    // red: finish that reduction into g first (g is written)
+               const int* abort_flag = nullptr, float* abort_stat = nullptr);   // nonzero *abort_flag: skip the update, set found_inf, bump *abort_stat
 
 }  // namespace ep

@@ -34,6 +34,10 @@ struct OptParams {
   // deferred last stage of a partial reduction (DeferredReduce): g[red_off .. red_off + red_n) is produced HERE, by the
   // norms kernel, from 16 stage rows -- and written back to g for the update kernel and for readers of the gradients
   const float* red_stage; float* gw; int64_t red_off; int red_n; float red_scale; int red_accumulate;
+  // a nonzero *abort_flag (the give-up count of the in-pass hand-off waits, ep_inpass.h) makes this step count as
+  // non-finite: the update is skipped, found_inf is set and *abort_stat (the step statistics' non-finite row count, which
+  // stops the training loop) is bumped -- a pass that read unfinished rows must never reach the parameters silently
+  const int* abort_flag; float* abort_stat;
 };
 
 __device__ __forceinline__ int seg_of_chunk(const OptSegs& s, int chunk) {
@@ -167,9 +171,12 @@ __device__ __forceinline__ void chunk_update(const OptParams& o, const OptSegs& 
     }
   const f4 sums = block_sum4(f4{bad, gg, pp, uu}, sm, tid);
   bad = sums.x; gg = sums.y; pp = sums.z; uu = sums.w;
+  const bool aborted = o.abort_flag && *o.abort_flag != 0;       // uniform: every thread reads the same word
+  if (aborted) bad += 1.f;
   if (active && chunk == 0 && tid == 0) {
     *o.found_inf = bad > 0.f ? 1 : 0;
     if (o.grad_norm) *o.grad_norm = sqrtf(gg);
+    if (aborted && o.abort_stat) *o.abort_stat += 1.f;
   }
   const bool skip = bad > 0.f || !active;                // GradScaler.step: skip the update (block sums stay uniform)
   float q = 1.0f;
@@ -269,7 +276,7 @@ size_t optim_workspace_bytes(int64_t total, int nseg) {
 int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t total, const ep_segment* segs,
                int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
-               hipStream_t st, const DeferredReduce* red) {
+               hipStream_t st, const DeferredReduce* red, const int* abort_flag, float* abort_stat) {
   EP_REQUIRE(p && g && found_inf && ws, EP_E_ARG, "optimizer: null pointer");
   EP_REQUIRE(mode != 0 || s0, EP_E_ARG, "LARS needs the momentum buffer");
   EP_REQUIRE(mode != 2 || (s0 && s1), EP_E_ARG, "AdamW needs exp_avg and exp_avg_sq");
@@ -287,6 +294,7 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
     o.bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   }
   o.partial = (float*)ws; o.nchunks = nchunks; o.found_inf = found_inf; o.grad_norm = grad_norm;
+  o.abort_flag = abort_flag; o.abort_stat = abort_stat;
   if (red && red->stage) {
     // the range must be one whole segment of whole float4s (the norms kernel decides per chunk)
     const int64_t off = red->out - g;

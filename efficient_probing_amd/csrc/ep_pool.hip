@@ -460,6 +460,28 @@ int pool_inpass_mask(const PoolParams& p, int Dv) {
   static int bwd_grid = -1;           // (diagnostic grid override of the second pass, see pool_backward)
   if (bwd_grid < 0) { const char* e = getenv("EP_POOL_BWD_GRID"); bwd_grid = e ? atoi(e) : 0; }
   if (bwd_grid > 0 && bwd_grid % 32 != 0) return 0;
+  // Progress of the hand-off needs every pooling workgroup of the grid resident at once (a workgroup waits on row blocks
+  // that later-indexed workgroups of the same launch produce): ask the runtime how many workgroups of each pass -- with
+  // the tasks' LDS -- a CU holds, and keep the contractions as launches of their own when the grid is larger than that.
+  // (A chip shared with another process or a CU mask can still starve a launch: the waits are bounded and a give-up stops
+  // the training loop through the optimizer's abort flag, ep_api.hip.)
+  {
+    static int res[2][4][2] = {};      // [pass][kp][bf16]: 0 unknown, else blocks per CU + 1 (0 -> "cannot tell" is stored as INT_MAX)
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      if (!((want >> bwd) & 1)) continue;
+      int& r = res[bwd][c.kp][p.x_bf16 ? 1 : 0];
+      if (r == 0) {
+        PoolParams q = p;
+        int dummy = 0;
+        if (bwd) { q.ip_dy = reinterpret_cast<const float*>(&dummy); } else { q.ip_ycnt = &dummy; }
+        SideTasks sd{};
+        sd.total = 1;
+        const int nb = stream_resident_blocks_per_cu(bwd != 0, c, q, bwd ? &sd : nullptr);
+        r = nb < 0 ? 0x7fffffff : nb + 1;
+      }
+      if (r != 0x7fffffff && (int64_t)(r - 1) * cu_count() < c.grid) return 0;
+    }
+  }
   int m = want & 3;
   // ticketed second pass: at least 20 token tiles per image (its task point and the row-block check sit inside an image)
   // and at least 64 pooling workgroups (a row block's 32 tickets are then drawn by workgroups that never wait on it)

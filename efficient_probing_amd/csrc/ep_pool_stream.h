@@ -81,5 +81,6 @@ int wide_grid(int D, int B, int x_bf16 = 0);
 bool stream_ln_supported(int D, int Q);
 bool stream_ln_bf16_supported(int D, int Q);
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side = nullptr);
+int stream_resident_blocks_per_cu(bool bwd, const StreamPlan& c, const PoolParams& p, const SideTasks* side = nullptr);
 
 }  // namespace ep

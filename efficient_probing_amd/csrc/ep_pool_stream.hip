@@ -637,6 +637,9 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
 // ---------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------
+// stream_resident_blocks_per_cu(): launch_one answers with the occupancy of the kernel it WOULD launch instead of launching
+static thread_local int* t_occ_query = nullptr;
+
 template <int QW, int KP, int NW, int DFIX, bool BF16, bool LN>
 static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   using Cfg = StreamCfgT<QW, KP, NW>;
@@ -697,6 +700,12 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+  if (t_occ_query) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NW * 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = -1; }
+    *t_occ_query = nb;
+    return 0;
+  }
   if (bwd) hipLaunchKernelGGL(kb, dim3(grid + sd.total), dim3(NW * 64), lds, st, p, sd);
   else hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, st, p);
   EP_LAUNCH_CHECK(bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel");
@@ -748,6 +757,17 @@ bool stream_ln_bf16_supported(int D, int Q) {
   if (!c.ok) return false;
   const int tt = 2 * stream_tt(c.qw, c.kp, c.nw);
   return c.qw * tt + 2 * tt <= 64;
+}
+
+// Workgroups of the pass (with its in-pass tasks and side tasks, as `p` / `side` ask for them) that one CU holds at a time
+// by registers and LDS; -1 when the runtime cannot tell.  The in-pass hand-off (ep_inpass.h) needs the whole pooling
+// grid resident, so ep_pool.hip: pool_inpass_mask asks before it lets a workgroup wait on another one.
+int stream_resident_blocks_per_cu(bool bwd, const StreamPlan& c, const PoolParams& p, const SideTasks* side) {
+  int nb = -1;
+  t_occ_query = &nb;
+  const int rc = stream_launch(bwd, c, p, nullptr, side);
+  t_occ_query = nullptr;
+  return rc == 0 ? nb : -1;
 }
 
 int stream_launch(bool bwd, const StreamPlan& c, const PoolParams& p, hipStream_t st, const SideTasks* side) {

@@ -990,35 +990,9 @@ class _LPView:
 
 
 def make_engine(head: nn.Sequential, **kw) -> ProbeHeadEngine:
-    """The fused engine matching a native head (EP, CoCa, AbMILP or plain linear probing)."""
-    from .probe_heads import (is_native_abmilp_head, is_native_aim_head, is_native_cae_head, is_native_coca_head,
-                              is_native_jepa_head, is_native_lp_head, is_native_siglip_head, is_native_simpool_head)
-    if is_native_lp_head(head):
-        return LinearProbeEngine(head, **kw)
-    if is_native_simpool_head(head):
-        return SimpoolHeadEngine(head, **kw)
-    from .probe_heads import is_native_cait_head, is_native_clip_head, is_native_dolg_head
-    if is_native_dolg_head(head):
-        return DolgHeadEngine(head, **kw)
-    from .probe_heads import is_native_cbam_head, is_native_dinovit_head
-    if is_native_cbam_head(head):
-        return CbamHeadEngine(head, **kw)
-    if is_native_dinovit_head(head):
-        return DinovitHeadEngine(head, **kw)
-    if is_native_cait_head(head):
-        return CaitHeadEngine(head, **kw)
-    if is_native_clip_head(head):
-        return ClipHeadEngine(head, **kw)
-    if is_native_aim_head(head):
-        return AimHeadEngine(head, **kw)
-    if is_native_jepa_head(head):
-        return JepaHeadEngine(head, **kw)
-    if is_native_cae_head(head):
-        return CaeHeadEngine(head, **kw)
-    if is_native_siglip_head(head):
-        return SiglipHeadEngine(head, **kw)
-    if is_native_coca_head(head):
-        return CocaHeadEngine(head, **kw)
-    if is_native_abmilp_head(head):
-        return AbmilpHeadEngine(head, **kw)
-    return ProbeHeadEngine(head, **kw)
+    """The fused engine matching a native head: looked up in ``probe_heads.NATIVE_HEADS`` (pooling class -> engine)."""
+    from .probe_heads import native_engine_name
+    name = native_engine_name(head)
+    if name is None:
+        return ProbeHeadEngine(head, **kw)           # its constructor says what a native EP head looks like
+    return globals()[name](head, **kw)

@@ -29,6 +29,7 @@ import torch
 from .util import lr_sched
 from .util import misc
 from .util.misc import AMP_PRECISIONS
+from .token_store import StoreBatch
 
 
 class SmoothedValue:
@@ -215,8 +216,9 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
                     token_fn: Optional[Callable] = None):
     """``token_fn(samples) -> (B, N, D) tokens`` (the frozen encoder) enables the fused path for image
     loaders; loaders that already yield 3-D token tensors take it directly.  A loader may also yield
-    ``(store_tensor, image_index, targets)`` (``token_store.ResidentTokenStore.loader``): the batch is then read in
-    place from the HBM-resident store through ``image_index`` -- no gather copy."""
+    ``token_store.StoreBatch(store_tensor, image_index, targets)`` (``token_store.ResidentTokenStore.loader``): the batch
+    is then read in place from the HBM-resident store through ``image_index`` -- no gather copy.  Any other batch is read
+    as the reference reads it: ``batch[0]`` the samples, ``batch[-1]`` the targets (engine_finetune.py:40-41 there)."""
     model.train(True)
     metric_logger = MetricLogger()
     metric_logger.add_meter("lr", SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -234,34 +236,34 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         # beside the next step's first token pass (flushed below, before anything can read them)
         engine.defer_update = True
     optimizer.zero_grad()
-    pending = 0                                   # fused steps whose statistics are still on the GPU
+    pending = pending_images = 0                  # fused steps (and their images) whose statistics are still on the GPU
 
     reads = []                                    # (handle, steps) of windows whose statistics are on their way to the host
 
-    def account(vals, n_steps):
+    def account(vals, n_steps, n_images):
         loss_sum, top1, top5, bad = vals
         if bad > 0 or not math.isfinite(loss_sum):
             print(f"Loss is non-finite ({loss_sum}), stopping training")
             sys.exit(1)
-        bsz = engine.dims.B
         metric_logger.meters["loss"].update(loss_sum / n_steps, n_steps)
-        metric_logger.meters["acc1"].update(top1 * 100.0 / (bsz * n_steps), n_steps)
-        metric_logger.meters["acc5"].update(top5 * 100.0 / (bsz * n_steps), n_steps)
+        metric_logger.meters["acc1"].update(top1 * 100.0 / n_images, n_steps)
+        metric_logger.meters["acc5"].update(top5 * 100.0 / n_images, n_steps)
 
-    def flush_stats(n_steps, last=False):
+    def flush_stats(n_steps, n_images, last=False):
         # a window's sums are read when the NEXT window's read-back is enqueued (the last one at the end of the epoch), so
         # the meters -- and the non-finite check, reference engine_finetune.py:62-64 -- run one window behind the queue
         # instead of draining it; engines without the asynchronous form read in place
+        # (the image count of a window is recorded WITH it: a last partial batch must not change an earlier window's mean)
         if not hasattr(engine, "read_stats_async"):
-            return account(engine.read_stats(), n_steps)
-        reads.append((engine.read_stats_async(), n_steps))
+            return account(engine.read_stats(), n_steps, n_images)
+        reads.append((engine.read_stats_async(), n_steps, n_images))
         while len(reads) > (0 if last else 1):
-            handle, n = reads.pop(0)
-            account(engine.wait_stats(handle), n)
+            handle, n, ni = reads.pop(0)
+            account(engine.wait_stats(handle), n, ni)
 
     for step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         samples, targets = batch[0], batch[-1]
-        image_index = batch[1] if len(batch) == 3 else None          # (store, index, targets): resident token store
+        image_index = batch[1] if isinstance(batch, StoreBatch) else None      # resident token store, read in place
         if step % accum_iter == 0:
             lr = lr_sched.adjust_learning_rate(optimizer, step / n_iter + epoch, args)
         samples = samples.to(device, non_blocking=True)
@@ -281,9 +283,10 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
                     engine.all_reduce_grads()
                     engine.optimizer_step(lr=max(g["lr"] for g in optimizer.param_groups))
             pending += 1
+            pending_images += int(targets.shape[0])
             if pending == print_freq or step == n_iter - 1:
-                flush_stats(pending, last=step == n_iter - 1)
-                pending = 0
+                flush_stats(pending, pending_images, last=step == n_iter - 1)
+                pending = pending_images = 0
         else:
             if mixup_fn is not None:
                 samples, targets = mixup_fn(samples, targets)
@@ -307,9 +310,11 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             epoch_1000x = int((step / n_iter + epoch) * 1000)
             log_writer.add_scalar("loss", misc.all_reduce_mean(metric_logger.meters["loss"].value), epoch_1000x)
             log_writer.add_scalar("lr", metric_logger.meters["lr"].value, epoch_1000x)
-    while reads:                          # (a loader shorter than its len(): the window still on its way)
-        handle, n = reads.pop(0)
-        account(engine.wait_stats(handle), n)
+    if pending:                           # (a loader shorter than its len(): steps not yet enqueued for read-back)
+        flush_stats(pending, pending_images, last=True)
+    while reads:                          # ... and the window still on its way
+        handle, n, ni = reads.pop(0)
+        account(engine.wait_stats(handle), n, ni)
     eng = getattr(model.module if hasattr(model, "module") else model, "_ep_engine", None)
     if eng is not None:
         eng.flush()                       # a pipelined / deferred step leaves its large update half a step behind
@@ -336,7 +341,7 @@ def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = Fal
     all_t, all_p = [], []
     for batch in metric_logger.log_every(data_loader, 10, "Test:"):
         images, target = batch[0].to(device, non_blocking=True), batch[-1].to(device, non_blocking=True)
-        index = batch[1] if len(batch) == 3 else None                # (store, image_index, targets): resident token store
+        index = batch[1] if isinstance(batch, StoreBatch) else None  # resident token store, read in place
         if index is not None and engine is None:
             raise RuntimeError("(store, image_index, targets) batches need a native head (the fused engine path)")
         if engine is not None and (images.dim() == 3 or token_fn is not None):

@@ -105,6 +105,23 @@ def pool_backward(x: torch.Tensor, S: torch.Tensor, ML: torch.Tensor, dP: torch.
     return dcls
 
 
+def pool_backward_per_image(x: torch.Tensor, S: torch.Tensor, ML: torch.Tensor, dP: torch.Tensor, scale: float,
+                            image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient of PER-IMAGE query rows (the ``cls=`` override of reference poolings/ep.py:32-33): (B, Q, D), one
+    gradient per image -- the second token pass without the sum over the batch."""
+    lib = N.load()
+    x, bstride = as_token_view(x)
+    _, Nn, D = x.shape
+    iptr, B = _index_arg(image_index, x)
+    Q = S.shape[1]
+    dP = _f32c(dP, "dP")
+    dq = torch.empty((B, Q, D), device=x.device, dtype=torch.float32)
+    N.check(lib.ep_pool_backward_per_image(x.data_ptr(), token_dtype_code(x), bstride, iptr, B, Nn, D, Q, float(scale),
+                                           S.data_ptr(), ML.data_ptr(), dP.data_ptr(), dq.data_ptr(),
+                                           N.current_stream_ptr(x.device)), "ep_pool_backward_per_image")
+    return dq
+
+
 def attention_from_scores(S: torch.Tensor, ML: torch.Tensor) -> torch.Tensor:
     lib = N.load()
     B, Q, Nn = S.shape
@@ -348,15 +365,15 @@ class _EPPoolProject(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise RuntimeError("EfficientProbing (native): gradient w.r.t. the tokens is not implemented -- "
                                "the probe trains on a frozen encoder (detach the tokens)")
-        need_cls = ctx.needs_input_grad[1] and not ctx.per_image
+        need_cls = ctx.needs_input_grad[1]
         dy = dy.contiguous()
         dP, dWv = project_backward(dy, y, P, v_weight, ML, need_dP=need_cls,
                                    need_dWv=ctx.needs_input_grad[2])
         dcls = None
-        if need_cls:
+        if need_cls and ctx.per_image:        # cls=... (reference poolings/ep.py:32-33): one gradient per image
+            dcls = pool_backward_per_image(x, S, ML, dP, ctx.scale).reshape(ctx.cls_shape)
+        elif need_cls:
             dcls = pool_backward(x, S, ML, dP, ctx.scale).reshape(ctx.cls_shape)
-        elif ctx.needs_input_grad[1]:
-            raise RuntimeError("gradient w.r.t. per-image queries (cls=...) is not implemented")
         return None, dcls, dWv, None, None
 
 

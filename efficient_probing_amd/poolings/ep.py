@@ -45,6 +45,10 @@ class EfficientProbing(nn.Module):
             raise ValueError(f"expected tokens (B, N, {self.v.in_features}), got {tuple(x.shape)}")
         out_dtype = x.dtype
         if cls is not None:
+            # per-image queries override the learned ones (reference ep.py:32-33); their gradient is one (Q, D) row block
+            # per image (csrc: ep_pool_backward_per_image), cls_token takes none
+            if tuple(cls.shape) != (x.shape[0], self.num_queries, x.shape[-1]):
+                raise ValueError(f"cls must be (B, {self.num_queries}, {x.shape[-1]}) = one query set per image, got {tuple(cls.shape)}")
             y = F_.ep_pool_project(x, cls, self.v.weight, self.scale, per_image=True)
         else:
             y = F_.ep_pool_project(x, self.cls_token, self.v.weight, self.scale, per_image=False)

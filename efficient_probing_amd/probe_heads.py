@@ -135,98 +135,61 @@ def build_probe_head(model: nn.Module, args) -> None:
     model.head = nn.Sequential(pooling, _batchnorm(classifier.in_features), classifier)
 
 
-def is_native_ep_head(head: nn.Module) -> bool:
-    """True for Sequential(EfficientProbing, BatchNorm1d, Linear) built by this registry -- the
-    shape the fused train step (engine.ProbeHeadEngine) accelerates."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], EfficientProbing)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+# pooling class -> (name of its fused engine class in engine.py, short kind).  ONE table instead of a predicate per head:
+# ``native_head_kind`` names the kind of a Sequential(pooling, BatchNorm1d, Linear) built by this registry (or "lp" for
+# plain linear probing), ``engine.make_engine`` looks the engine class up here.
+NATIVE_HEADS = {
+    EfficientProbing: ("ProbeHeadEngine", "ep"),
+    CocaPooling: ("CocaHeadEngine", "coca"),
+    ABMILPHead: ("AbmilpHeadEngine", "abmilp"),
+    AttentionPoolLatent: ("SiglipHeadEngine", "siglip"),
+    CAEAttentiveBlock: ("CaeHeadEngine", "cae"),
+    AttentivePooler: ("JepaHeadEngine", "jepa"),
+    AttentionPoolingClassifier: ("AimHeadEngine", "aim"),
+    SimPool: ("SimpoolHeadEngine", "simpool"),
+    SimPool_nolinears: ("SimpoolHeadEngine", "simpool"),
+    CAPooling: ("CaitHeadEngine", "cait"),
+    AttentionPool2d: ("ClipHeadEngine", "clip"),
+    SpatialAttention2d: ("DolgHeadEngine", "dolg"),
+    CbamPooling: ("CbamHeadEngine", "cbam"),
+    DinoViTBlockPooling: ("DinovitHeadEngine", "dinovit"),
+}
 
 
-def is_native_coca_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.coca.CrossAttention, BatchNorm1d, Linear) -- engine.CocaHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], CocaPooling)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
+def native_head_kind(head: nn.Module):
+    """"ep", "coca", ... for Sequential(<native pooling>, BatchNorm1d, Linear); "lp" for Sequential(BatchNorm1d(affine=False),
+    Linear) (plain linear probing, reference probe_heads.py:96-99); None for anything else."""
+    if not isinstance(head, nn.Sequential):
+        return None
+    if len(head) == 2 and isinstance(head[0], nn.BatchNorm1d) and not head[0].affine and isinstance(head[1], nn.Linear):
+        return "lp"
+    if len(head) == 3 and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear):
+        entry = NATIVE_HEADS.get(type(head[0]))
+        return entry[1] if entry else None
+    return None
 
 
-def is_native_abmilp_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.abmilp.ABMILPHead, BatchNorm1d, Linear) -- engine.AbmilpHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], ABMILPHead)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_siglip_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.siglip.AttentionPoolLatent, BatchNorm1d, Linear) -- engine.SiglipHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], AttentionPoolLatent)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_cae_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.cae.CAEAttentiveBlock, BatchNorm1d, Linear) -- engine.CaeHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], CAEAttentiveBlock)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_jepa_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.jepa.AttentivePooler, BatchNorm1d, Linear) -- engine.JepaHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], AttentivePooler)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_aim_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.aim.AttentionPoolingClassifier, BatchNorm1d, Linear) -- engine.AimHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], AttentionPoolingClassifier)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_simpool_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.simpool.SimPool | SimPool_nolinears, BatchNorm1d, Linear) -- engine.SimpoolHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], (SimPool, SimPool_nolinears))
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_cait_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.cait.CAPooling, BatchNorm1d, Linear) -- engine.CaitHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], CAPooling)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_clip_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.clip.AttentionPool2d, BatchNorm1d, Linear) -- engine.ClipHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], AttentionPool2d)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_dolg_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.dolg.SpatialAttention2d, BatchNorm1d, Linear) -- engine.DolgHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], SpatialAttention2d)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_cbam_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.cbam.CbamPooling, BatchNorm1d, Linear) -- engine.CbamHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], CbamPooling)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_dinovit_head(head: nn.Module) -> bool:
-    """True for Sequential(poolings.dinovit.DinoViTBlockPooling, BatchNorm1d, Linear) -- engine.DinovitHeadEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], DinoViTBlockPooling)
-            and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear))
-
-
-def is_native_lp_head(head: nn.Module) -> bool:
-    """True for Sequential(BatchNorm1d(affine=False), Linear): plain linear probing (build_probe_head for names
-    without a pooling entry, reference probe_heads.py:96-99) -- engine.LinearProbeEngine."""
-    return (isinstance(head, nn.Sequential) and len(head) == 2 and isinstance(head[0], nn.BatchNorm1d)
-            and not head[0].affine and isinstance(head[1], nn.Linear))
+def native_engine_name(head: nn.Module):
+    """Name of the engine.py class that runs this head's fused step (None: not a native head)."""
+    kind = native_head_kind(head)
+    if kind == "lp":
+        return "LinearProbeEngine"
+    return NATIVE_HEADS[type(head[0])][0] if kind else None
 
 
 def is_native_head(head: nn.Module) -> bool:
-    return (is_native_ep_head(head) or is_native_coca_head(head) or is_native_abmilp_head(head)
-            or is_native_siglip_head(head) or is_native_cae_head(head) or is_native_jepa_head(head)
-            or is_native_aim_head(head) or is_native_simpool_head(head) or is_native_cait_head(head)
-            or is_native_clip_head(head) or is_native_dolg_head(head) or is_native_cbam_head(head)
-            or is_native_dinovit_head(head) or is_native_lp_head(head))
+    return native_head_kind(head) is not None
+
+
+def __getattr__(name: str):
+    """``is_native_<kind>_head(head)`` for every kind of the table (kept as the per-head spelling the engines' constructor
+    checks and the tests use)."""
+    m = __import__("re").fullmatch(r"is_native_([a-z0-9]+)_head", name)
+    kinds = {k for _, k in NATIVE_HEADS.values()} | {"lp"}
+    if m and m.group(1) in kinds:
+        kind = m.group(1)
+        return lambda head: native_head_kind(head) == kind
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 assert sorted(POOLINGS) == sorted(ATTENTIVE_POOLINGS), sorted(set(POOLINGS) ^ set(ATTENTIVE_POOLINGS))

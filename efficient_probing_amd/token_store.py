@@ -158,7 +158,7 @@ class ResidentTokenStore:
         return self
 
     def loader(self, batch_size: int, epoch: int = 0, shuffle: bool = True, drop_last: bool = True) -> "StoreEpoch":
-        """One epoch as a sized iterable of ``(store_tensor, image_index, targets)`` -- what
+        """One epoch as a sized iterable of ``StoreBatch(store_tensor, image_index, targets)`` -- what
         ``engine_finetune.train_one_epoch`` / ``evaluate`` take in place of a DataLoader (they need ``len()``)."""
         return StoreEpoch(self, batch_size, epoch, shuffle, drop_last)
 
@@ -184,7 +184,18 @@ class ResidentTokenStore:
             stop = self.num_images - (self.num_images % batch_size if drop_last else 0)
         labels = self.labels[order.long()]          # ONE gather per epoch: a batch is then two views, no kernel of its own
         for lo in range(0, stop, batch_size):
-            yield self.tokens, order[lo:lo + batch_size], labels[lo:lo + batch_size]
+            yield StoreBatch(self.tokens, order[lo:lo + batch_size], labels[lo:lo + batch_size])
+
+
+class StoreBatch(tuple):
+    """``(store_tensor, image_index, targets)``: a batch of a resident token store, read in place through the int32
+    ``image_index``.  A type of its own so that ``engine_finetune.train_one_epoch`` / ``evaluate`` can tell it from a loader
+    that yields ``(images, extra, target)`` -- for any other 3-tuple they keep the reference's ``batch[0]`` / ``batch[-1]``
+    reading (reference engine_finetune.py:125-126,185-186)."""
+    __slots__ = ()
+
+    def __new__(cls, store, image_index, targets):
+        return super().__new__(cls, (store, image_index, targets))
 
 
 class StoreEpoch:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 21
+#define EP_ABI_VERSION 22
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -115,6 +115,12 @@ int ep_pool_backward(const void* x, int x_dtype, int64_t x_bstride, const int32_
                      int Q, float scale, const float* S, const float* ML, const float* dP,
                      float* dcls, int accumulate,
                      void* workspace, size_t workspace_bytes, ep_stream_t stream);
+/* The same second pass for PER-IMAGE query rows (ep_pool_forward with cls_bstride = Q*D; reference poolings/ep.py:32-33,
+ * the `cls=` override of EfficientProbing.forward): dq[b,q,:] = scale * sum_n dS[b,q,n] x[b,n,:], one (Q, D) gradient per
+ * image, not summed over the batch.  ML[...,2] must hold delta (ep_project_backward writes it).  No workspace. */
+int ep_pool_backward_per_image(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N,
+                               int D, int Q, float scale, const float* S, const float* ML, const float* dP, float* dq,
+                               ep_stream_t stream);
 
 /* Attention maps A = softmax(S) from the saved scores (reference tools/ep_attention_maps.py:52-58). */
 int ep_attention_from_scores(const float* S, const float* ML, int B, int Q, int N, float* A,
@@ -234,10 +240,14 @@ int ep_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
  * phases: 1 = forward+loss+backward into `grads` (accumulating if accumulate != 0);
  *         2 = optimizer only; 3 = both.  Between 1 and 2 the caller may all-reduce `grads`
  *         (the single RCCL all-reduce per step that replaces DDP, main_linprobe.py:581-583).
- * Workspace contract (ABI v21): `ws` must be ZERO-FILLED by the caller before its first use (hipMemset once after the
- * allocation) and must not be written by the caller between steps.  It holds the arrival counters of the in-pass
- * contractions (csrc/ep_inpass.h: the value projection and its dP gradient computed inside the two token passes), which
- * every step leaves at zero again.  A workspace may serve another (B, N) of the same byte size after being zero-filled. */
+ * Workspace contract (ABI v21): `ws` holds the arrival counters of the in-pass contractions (csrc/ep_inpass.h: the value
+ * projection and its dP gradient computed inside the two token passes), which every step leaves at zero again, and the
+ * give-up count of their bounded waits.  Before its first use -- and before it serves another (B, N) -- the caller either
+ * zero-fills the whole workspace (hipMemset) or calls ep_head_workspace_init (ABI v22: clears exactly those words, on
+ * `stream`); it must not write the workspace between steps.  A give-up (nonzero count: a wait on another workgroup of the
+ * same launch ran into its bound, e.g. on a partitioned or shared GPU) is LOUD: from then on every optimizer phase run
+ * through ep_head_train_step skips its update, sets *found_inf and adds 1 to stats[3] (the non-finite row count that
+ * stops the training loop), until the workspace is initialised again. */
 typedef struct ep_head_dims {
   int32_t B, N, D, Q, d_out, C;
 } ep_head_dims;
@@ -286,6 +296,8 @@ size_t ep_head_workspace_bytes(const ep_head_dims* dims);
 /* byte offset inside `ws` of an int32 that counts bounded flag waits of the in-pass contractions that gave up (always 0
  * in a correct run; a diagnostic for tests).  -1: bad dims. */
 int64_t ep_head_workspace_flag_offset(const ep_head_dims* dims);
+/* clear the counters the step keeps in `ws` (see "Workspace contract" above); asynchronous on `stream` */
+int ep_head_workspace_init(const ep_head_dims* dims, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_head_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 /* eval forward: logits (B, ldl) from tokens using running statistics
  * (reference engine_finetune.py:106-166 inner forward).                                    */

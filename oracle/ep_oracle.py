@@ -76,7 +76,7 @@ def ep_forward(x: np.ndarray, cls_token: np.ndarray, v_weight: np.ndarray,
     attn = _softmax_lastdim(attn)                                  # ep.py:43
     x_cls = np.matmul(attn[:, :, None, :], v).astype(F32)          # ep.py:44   (B,Q,1,Dq)
     out = x_cls.reshape(B, c_prime)                                # ep.py:45
-    cache = dict(x=x, attn=attn, v=v, scale=scale, Q=Q, dq=dq)
+    cache = dict(x=x, attn=attn, v=v, scale=scale, Q=Q, dq=dq, per_image=cls is not None)
     return out, cache
 
 
@@ -94,7 +94,8 @@ def ep_attention(x: np.ndarray, cls_token: np.ndarray, num_heads: int = 1,
 
 def ep_backward(dout: np.ndarray, cache: dict, v_weight: np.ndarray):
     """Autograd of ep_forward w.r.t. ``v.weight`` and ``cls_token`` (x is frozen:
-    main_linprobe.py:393-400, so no dx).  Returns (dcls_token (1,Q,C), dv_weight)."""
+    main_linprobe.py:393-400, so no dx).  Returns (dcls_token (1,Q,C), dv_weight); after a forward with per-image
+    queries (``cls=``, ep.py:32-33) the first result is the gradient of those queries, (B,Q,C)."""
     x, attn, v, scale, Q, dq = (cache[k] for k in ("x", "attn", "v", "scale", "Q", "dq"))
     B, N, C = x.shape
     d = np.asarray(dout, dtype=F32).reshape(B, Q, 1, dq)
@@ -109,6 +110,8 @@ def ep_backward(dout: np.ndarray, cache: dict, v_weight: np.ndarray):
     ds = (attn * (dattn - inner)).astype(F32)                                 # (B,Q,N)
     # attn_logits = (cls_token * scale) @ x^T ; cls_token expanded over the batch
     dq_tok = np.matmul(ds, x).astype(F32)                                     # (B,Q,C)
+    if cache.get("per_image"):                                                # cls= given: no expand, so no batch sum
+        return (dq_tok * scale).astype(F32), dv_weight
     dcls = (dq_tok.sum(axis=0, dtype=F32) * scale).astype(F32)[None]          # (1,Q,C)
     return dcls, dv_weight
 

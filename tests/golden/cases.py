@@ -48,6 +48,22 @@ CASES = [
 ]
 CASE_BY_NAME = {c.name: c for c in CASES}
 
+# EfficientProbing.forward(x, cls=...) (reference poolings/ep.py:32-33: per-image queries override the learned ones):
+# the EP cases whose shapes it is recorded for, fixtures ``epcls_<name>.npz``
+EPCLS_CASE_NAMES = ("tiny_q4", "tiny_q8", "tiny_q4_dout2", "tiny_strided", "vitb16_q8")
+EPCLS_CASES = [c for c in CASES if c.name in EPCLS_CASE_NAMES]
+
+
+def make_epcls_inputs(case: Case) -> Dict[str, np.ndarray]:
+    """The case's tokens and value projection + per-image queries ``cls`` (B, Q, D) and an upstream gradient ``dy``
+    (B, D // d_out) for the pooled vector."""
+    inp = make_inputs(case)
+    rng = np.random.default_rng(7000 + case.seed)
+    cls_scale = 2.0 if case.big_scores else 0.3
+    cls = (cls_scale * rng.standard_normal((case.B, case.Q, case.D), dtype=np.float32)).astype(np.float32)
+    dy = rng.standard_normal((case.B, case.D // case.d_out), dtype=np.float32)
+    return dict(x_buf=inp["x_buf"], v_weight=inp["v_weight"], cls_token=inp["cls_token"], cls=cls, dy=dy)
+
 # subsampling strides for the large gradient tensors of ``full=False`` cases
 SUB_ROWS = 16
 

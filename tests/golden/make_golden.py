@@ -27,7 +27,7 @@ sys.path.insert(0, HERE)
 REF = os.environ.get("EP_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 
-from cases import (CASES, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper,   # noqa: E402
+from cases import (CASES, EPCLS_CASES, make_epcls_inputs, INIT_DIMS, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper,   # noqa: E402
                    COCA_CASES, COCA_INIT_DIMS, COCA_PARAM_NAMES, make_coca_inputs,
                    ABMILP_CASES, ABMILP_INIT_DIMS, ABMILP_PARAM_NAMES, ABMILP_SMALL, make_abmilp_inputs,
                    KNN_CASES, KNN_GRID, make_knn_inputs,
@@ -202,6 +202,22 @@ def run_case(case, optimizer_name="lars"):
             with torch.autocast("cpu", dtype=torch.float16):
                 out["eval_logits_fp16_autocast"] = head(x).float().numpy()
     return out
+
+
+def run_epcls_case(case):
+    """EfficientProbing.forward(x, cls=...) of the real reference (poolings/ep.py:32-33): pooled vector, and the gradients
+    of the per-image queries and of v.weight under the upstream gradient ``dy`` (the learned cls_token takes none)."""
+    inp = make_epcls_inputs(case)
+    pool = EfficientProbing(case.D, num_queries=case.Q, d_out=case.d_out)
+    with torch.no_grad():
+        pool.cls_token.copy_(torch.from_numpy(inp["cls_token"]))
+        pool.v.weight.copy_(torch.from_numpy(inp["v_weight"]))
+    x = torch.from_numpy(view_tokens(case, inp["x_buf"]))
+    cls = torch.from_numpy(inp["cls"]).requires_grad_(True)
+    pooled = pool(x, cls=cls)
+    pooled.backward(torch.from_numpy(inp["dy"]))
+    assert pool.cls_token.grad is None
+    return dict(pooled=pooled.detach().numpy(), grad_cls=cls.grad.numpy(), grad_v_weight=keeper(case)(pool.v.weight.grad.numpy()))
 
 
 def coca_ref_params(head):
@@ -1272,7 +1288,7 @@ def main():
                 sgd = run_case(case, "sgd")
                 out.update({k: v for k, v in sgd.items() if k.startswith("sgd")})
             dump("ep", case, out)
-    for fam, cases, run in (("coca", COCA_CASES, run_coca_case), ("aim", AIM_CASES, run_aim_case),
+    for fam, cases, run in (("epcls", EPCLS_CASES, run_epcls_case), ("coca", COCA_CASES, run_coca_case), ("aim", AIM_CASES, run_aim_case),
                             ("jepa", JEPA_CASES, run_jepa_case), ("cae", CAE_CASES, run_cae_case),
                             ("siglip", SIGLIP_CASES, run_siglip_case), ("abmilp", ABMILP_CASES, run_abmilp_case),
                             ("simpool", SIMPOOL_CASES, run_simpool_case), ("esimpool", ESIMPOOL_CASES, run_simpool_case),

@@ -279,6 +279,41 @@ def test_store_batches_through_train_one_epoch_and_evaluate():
     assert e1["acc1"] == e2["acc1"] and e1["loss"] == pytest.approx(e2["loss"], rel=1e-6)
 
 
+def test_three_element_batches_are_read_like_the_reference_and_partial_last_batch():
+    """A loader that yields ``(tokens, extra, target)`` is read as the reference reads it -- ``batch[0]`` and ``batch[-1]``
+    (reference engine_finetune.py:40-41,125-126) -- even when ``extra`` looks like an index vector; only a
+    ``token_store.StoreBatch`` is dereferenced in place.  The epoch ends on a PARTIAL batch: the accuracy meters divide every
+    window by the images it really held."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd.token_store import StoreBatch
+    from efficient_probing_amd.util.lars import LARS
+    case = Case("three", B=16, N=24, D=128, Q=4, C=12, seed=5)
+    inp = make_inputs(case)
+    x = torch.from_numpy(inp["x_buf"]).to(DEV); t = torch.from_numpy(inp["targets"]).to(DEV)
+    extra = torch.arange(case.B, device=DEV, dtype=torch.int32).flip(0)        # would permute the batch if it were used as an index
+    part = 5                                                                    # last batch: 5 of 16 images
+    two = [(x, t)] * 22 + [(x[:part].contiguous(), t[:part])]
+    three = [(x, extra, t)] * 22 + [(x[:part].contiguous(), extra[:part].contiguous(), t[:part])]
+    outs = []
+    for loader in (two, three):
+        model = make_model(case, inp)
+        opt = LARS(model.head.parameters(), lr=0.0)
+        st = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), loader, opt, torch.device(DEV), 1, None, args=ARGS)
+        ev = EF.evaluate(loader, model, torch.device(DEV))
+        outs.append((st, ev, torch.cat([p.detach().flatten() for p in model.head.parameters()]).cpu()))
+    (s2, e2, p2), (s3, e3, p3) = outs
+    assert torch.equal(p2, p3) and s2["loss"] == s3["loss"] and e2["acc1"] == e3["acc1"]
+    assert 0.0 <= s2["acc1"] <= 100.0 and 0.0 <= s2["acc5"] <= 100.0
+    # the same images as a store batch ARE dereferenced: flipped order, flipped targets -> the same loss as the dense flipped batch
+    model = make_model(case, inp)
+    opt = LARS(model.head.parameters(), lr=0.0)
+    sa = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), [StoreBatch(x, extra, t.flip(0))], opt, torch.device(DEV), 1, None, args=ARGS)
+    model = make_model(case, inp)
+    opt = LARS(model.head.parameters(), lr=0.0)
+    sb = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), [(x.flip(0).contiguous(), t.flip(0))], opt, torch.device(DEV), 1, None, args=ARGS)
+    assert sa["loss"] == pytest.approx(sb["loss"], rel=1e-6)
+
+
 def test_epoch_meters_read_one_window_behind_account_every_step():
     """train_one_epoch reads a window's statistics when the next window's read-back is enqueued (no queue drain): over an
     epoch of 2 1/2 print windows the averaged loss still equals the mean of the per-step losses of a plain loop, and the

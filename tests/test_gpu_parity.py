@@ -14,7 +14,7 @@ import pytest
 import torch
 from argparse import Namespace
 
-from cases import (CASES, CASE_BY_NAME, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol,
+from cases import (EPCLS_CASES, make_epcls_inputs, CASES, CASE_BY_NAME, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol,
                    trust_ratio_gaps, assert_amp_bf16_fidelity)
 from oracle import ep_oracle as O
 
@@ -77,6 +77,43 @@ def test_pool_forward_matches_reference_attention(case):
     Pref = np.matmul(g["attn"].astype(np.float64), xn.astype(np.float64))
     np.testing.assert_allclose(P.cpu().numpy(), Pref, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(A.sum(-1), 1.0, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tok", ["f32", "bf16"])
+@pytest.mark.parametrize("case", EPCLS_CASES, ids=lambda c: c.name)
+def test_per_image_queries_module_matches_reference(case, tok):
+    """EfficientProbing.forward(x, cls=...) -- per-image queries override the learned ones (reference poolings/ep.py:32-33) --
+    through the module: pooled vector, gradient of ``cls`` (one (Q, D) gradient per image) and of v.weight against the
+    real reference's (tests/golden/epcls_*.npz); the learned cls_token takes no gradient.  bf16-stored tokens: the same
+    checks against the oracle fed the rounded tokens."""
+    from efficient_probing_amd.poolings.ep import EfficientProbing
+    g = np.load(os.path.join(GOLD, f"epcls_{case.name}.npz"))
+    inp = make_epcls_inputs(case)
+    pool = EfficientProbing(case.D, num_queries=case.Q, d_out=case.d_out).to(DEV)
+    with torch.no_grad():
+        pool.cls_token.copy_(torch.from_numpy(inp["cls_token"]))
+        pool.v.weight.copy_(torch.from_numpy(inp["v_weight"]))
+    x = tokens(case, inp["x_buf"])
+    want = dict(pooled=g["pooled"], cls=g["grad_cls"], v=g["grad_v_weight"])
+    if tok == "bf16":
+        if case.strided:
+            pytest.skip("bf16 token views need 16-byte aligned rows: covered by the dense cases")
+        x = x.to(torch.bfloat16)
+        xr = x.float().cpu().numpy()
+        out, cache = O.ep_forward(xr, inp["cls_token"], inp["v_weight"], case.Q, d_out=case.d_out, cls=inp["cls"])
+        dc, dw = O.ep_backward(inp["dy"], cache, inp["v_weight"])
+        want = dict(pooled=out, cls=dc, v=keeper(case)(dw))
+    cls = torch.from_numpy(inp["cls"]).to(DEV).requires_grad_(True)
+    pooled = pool(x, cls=cls)
+    assert pooled.dtype == x.dtype
+    pooled.float().backward(torch.from_numpy(inp["dy"]).to(DEV)) if tok == "f32" else pooled.backward(torch.from_numpy(inp["dy"]).to(DEV).to(pooled.dtype))
+    assert pool.cls_token.grad is None
+    ftol = dict(rtol=1e-5, atol=2e-6) if tok == "f32" else dict(rtol=1e-2, atol=1e-2)      # bf16 OUTPUT rounding (module returns x.dtype)
+    np.testing.assert_allclose(pooled.detach().float().cpu().numpy(), want["pooled"], **ftol)
+    np.testing.assert_allclose(cls.grad.cpu().numpy(), want["cls"], **gtol(want["cls"]))
+    np.testing.assert_allclose(keeper(case)(pool.v.weight.grad.cpu().numpy()), want["v"], **gtol(want["v"]))
+    with pytest.raises(ValueError):
+        pool(x, cls=cls[:, :-1])
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)

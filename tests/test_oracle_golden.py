@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import CASES, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol, trust_ratio_gaps, assert_amp_bf16_fidelity
+from cases import EPCLS_CASES, make_epcls_inputs, CASES, LR_POINTS, STEP_LRS, make_inputs, view_tokens, sub, keeper, assert_mu_close, post_bn_tol, trust_ratio_gaps, assert_amp_bf16_fidelity
 from oracle import ep_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -50,6 +50,21 @@ def test_forward_and_grads(case):
         scale = np.abs(want).max()
         np.testing.assert_allclose(got, want, rtol=GRAD["rtol"], atol=max(GRAD["atol"], 2e-5 * scale), err_msg=n)
         assert np.linalg.norm(gr[n].astype(np.float64)) == pytest.approx(float(g[f"gradnorm_{n}"]), rel=1e-4)
+
+
+@pytest.mark.parametrize("case", EPCLS_CASES, ids=lambda c: c.name)
+def test_per_image_queries_forward_and_grads(case):
+    """EfficientProbing.forward(x, cls=...) (reference poolings/ep.py:32-33) against the real reference: the pooled vector
+    and the gradients of the per-image queries and of v.weight."""
+    g = np.load(os.path.join(GOLD, f"epcls_{case.name}.npz"))
+    inp = make_epcls_inputs(case)
+    x = view_tokens(case, inp["x_buf"])
+    out, cache = O.ep_forward(x, inp["cls_token"], inp["v_weight"], case.Q, d_out=case.d_out, cls=inp["cls"])
+    np.testing.assert_allclose(out, g["pooled"], **FWD)
+    dcls, dWv = O.ep_backward(inp["dy"], cache, inp["v_weight"])
+    assert dcls.shape == (case.B, case.Q, case.D)
+    for got, want, n in ((dcls, g["grad_cls"], "cls"), (keeper(case)(dWv), g["grad_v_weight"], "v_weight")):
+        np.testing.assert_allclose(got, want, rtol=GRAD["rtol"], atol=max(GRAD["atol"], 2e-5 * np.abs(want).max()), err_msg=n)
 
 
 @pytest.mark.parametrize("opt", ["lars", "sgd"])
