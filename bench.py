@@ -51,6 +51,10 @@ def parse():
                          "the same token passes, or the matrix-core-bound AbMILP head")
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU per step (weak scaling); default 1024 (256 for --head abmilp / dolg / dinovit)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling at the published protocol's batch (reference README.md:119-120: effective batch 4096): the "
+                         "per-GPU batch is G / --gpus and lr = 0.1 * G / 256 (main_linprobe.py:572-573) whatever N is; the line then "
+                         "says \"scaling\": \"strong\"")
     ap.add_argument("--spinup", type=int, default=40,
                     help="untimed steps run during setup, before the W warm-up steps, so that the chip's clock has settled under load")
     ap.add_argument("--mark-every", type=int, default=10, help="steps between the device events the step-time spread is read from")
@@ -131,9 +135,14 @@ def rendezvous_only(args, world, rank):
     else:
         ranks = 1
     ok = bool((flat == world * (world + 1) / 2).all())
+    if args.global_batch and args.global_batch % world != 0:
+        raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of --gpus {world}")
+    bpg = args.global_batch // world if args.global_batch else (args.batch or 1024)
     if rank == 0:
         print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo",
-                          "allreduce_elements": flat.numel(), "allreduce_ok": ok}), flush=True)
+                          "allreduce_elements": flat.numel(), "allreduce_ok": ok, "batch_per_gpu": bpg,
+                          "global_batch": bpg * world, "lr": 0.1 * bpg * world / 256,
+                          "scaling": "strong" if args.global_batch else "weak"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok and ranks == args.gpus else 3
@@ -212,7 +221,7 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
         out = {
             "metric": label + "-head train images/sec", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": getattr(args, "_scaling", "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc.split(",")[0] + (f", DOLG spatial attention (1x1 conv, BatchNorm2d, softplus), {Cc} classes" if dolg
                                                           else f", DINOv2 block (8-head self-attention + GELU MLP) and token mean, {Cc} classes" if dino
                                                           else f", AbMILP head (self-attention + tanh predictor), {Cc} classes"),
@@ -282,6 +291,15 @@ def main():
 
     Nn, D, Q, Cc, desc = WORKLOADS[args.workload]
     B = args.batch or (256 if args.head in ("abmilp", "dolg", "dinovit") else 1024)
+    scaling = "weak"
+    if args.global_batch:
+        if args.batch:
+            raise SystemExit("--global-batch and --batch are exclusive")
+        if args.global_batch % world != 0:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of --gpus {world}")
+        B = args.global_batch // world                     # total work fixed as N grows
+        scaling = "strong"
+    args._scaling = scaling
     if args.head in ("abmilp", "dolg", "dinovit"):
         return bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B)
     if args.head == "coca":
@@ -385,6 +403,54 @@ def main():
         elapsed = float(t.item())
     loss_sum, top1, _, bad = eng.read_stats()
 
+    # ---- data parallel (N > 1): the one exchange step of the path alone, and the two schedules side by side ----
+    dp_obj = None
+    if world > 1 and args.head == "ep":
+        # (a) the flat-gradient all-reduce of a step, event-bracketed in untimed steps (forward/backward, all-reduce, update
+        # as three calls -- what train_step does for N > 1)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ar = []
+        for i in range(12):
+            eng.forward_backward(xs[i % args.buffers], ts[i % args.buffers])
+            ea.record(); eng.all_reduce_grads(); eb.record()
+            eng.optimizer_step()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ar.append(ea.elapsed_time(eb) * 1e3)
+        eng.read_stats()
+        ar.sort()
+        ar_us = ar[len(ar) // 2]
+        nbytes = int(eng.flat_g.numel()) * 4
+        # (b) the overlapped schedule (engine.py: cls_token's bucket first, the large bucket beside the next first token pass;
+        # opt-in) on a second engine, same protocol, same K -- `value` above stays the default schedule
+        torch.manual_seed(0)
+        enc_o = Enc()
+        probe_heads.build_probe_head(enc_o, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
+                                                      model="vit_base_patch16"))
+        eng_o = make_engine(enc_o.head.to(dev).train(), optimizer="lars", lr=lr, weight_decay=0.0, overlap_comm=True)
+        for i in range(args.spinup + args.warmup):
+            eng_o.train_step(xs[i % args.buffers], ts[i % args.buffers])
+        eng_o.flush(); eng_o.read_stats()
+        barrier()
+        to0 = time.perf_counter()
+        for i in range(args.steps):
+            eng_o.train_step(xs[i % args.buffers], ts[i % args.buffers])
+        eng_o.flush()
+        barrier()
+        el_o = time.perf_counter() - to0
+        t = torch.tensor([el_o], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_o = float(t.item())
+        lo = eng_o.read_stats()[0]
+        dp_obj = {"allreduce_us": round(ar_us, 2), "allreduce_bytes": nbytes,
+                  "allreduce_busbw_GBs": round(2.0 * (world - 1) / world * nbytes / (ar_us * 1e-6) / 1e9, 2),
+                  "allreduce_method": "torch.cuda events around the ONE sum all-reduce of the flat fp32 gradient buffer in 10 untimed steps (median)",
+                  "overlap_comm": {"off": {"ms_per_step": round(elapsed / args.steps * 1e3, 4), "value": round(B * world * args.steps / elapsed, 1),
+                                           "note": "the default schedule = the headline `value`"},
+                                   "on": {"ms_per_step": round(el_o / args.steps * 1e3, 4), "value": round(B * world * args.steps / el_o, 1),
+                                          "pipelined": bool(eng_o._pipelined), "mean_loss_over_timed_steps": round(lo / max(1, args.steps), 5)}}}
+        del eng_o
+
     # ---- eval forward (reference engine_finetune.py:106-166 inner forward), outside the timed training region ----
     n_eval = max(10, args.steps // 2)
     eng.eval_logits(xs[0]); torch.cuda.synchronize()
@@ -467,27 +533,28 @@ def main():
 
     # ---- the two token-pass launches INSIDE the step (they carry the in-pass contractions and the weight-gradient side
     # work): event-bracketed by the library in a few untimed, instrumented steps (ep_debug_set_pass_events)
-    in_step = None
-    if args.head == "ep":
+    def pass_events(e_, toks_, ts_):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         for e in evs:
             e.record()                                       # (creates the underlying hipEvent_t)
         torch.cuda.synchronize()
         fw, bw = [], []
         try:
-            eng.lib.ep_debug_set_pass_events(*[e.cuda_event for e in evs])
+            e_.lib.ep_debug_set_pass_events(*[e.cuda_event for e in evs])
             for i in range(12):
-                eng.train_step(xs[i % args.buffers], ts[i % args.buffers])
+                e_.train_step(toks_[i % len(toks_)], ts_[i % len(ts_)])
                 torch.cuda.synchronize()
                 if i >= 2:
                     fw.append(evs[0].elapsed_time(evs[1]) * 1e3); bw.append(evs[2].elapsed_time(evs[3]) * 1e3)
         finally:
-            eng.lib.ep_debug_set_pass_events(None, None, None, None)
-        eng.flush(); eng.read_stats()
+            e_.lib.ep_debug_set_pass_events(None, None, None, None)
+        e_.flush(); e_.read_stats()
         fw.sort(); bw.sort()
-        in_step = {"fwd_us": round(fw[len(fw) // 2], 2), "bwd_us": round(bw[len(bw) // 2], 2), "samples": len(fw),
-                   "method": "hipEvents recorded by the library around the two pass launches of 10 untimed steps (median); "
-                             "an event drains the queue, so each figure includes the ~2 us fill of an empty chip"}
+        return {"fwd_us": round(fw[len(fw) // 2], 2), "bwd_us": round(bw[len(bw) // 2], 2), "samples": len(fw),
+                "method": "hipEvents recorded by the library around the two pass launches of 10 untimed steps (median); "
+                          "an event drains the queue, so each figure includes the ~2 us fill of an empty chip"}
+
+    in_step = pass_events(eng, xs, ts) if args.head == "ep" else None
 
     algo_bytes = B * Nn * D * esize                           # one streaming read of the stored tokens
     dt = 1 if args.tokens == "bf16" else 0
@@ -496,12 +563,13 @@ def main():
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic, traffic_source = None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"{args.workload}_hbm_traffic_pmc.json")
         if traffic is None and os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
             try:
                 pk = json.load(open(tpath))["per_kernel"]
-                traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pk.items() if k.startswith(kname_f)), None)
+                # (of the dominant kernel: the second pass; the counters average its in-step and stand-alone launches)
+                traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pk.items() if k.startswith(kname_b)), None)
                 if traffic is not None:
                     traffic_source = f"profiles/{rnd}/{args.workload}_hbm_traffic_pmc.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
             except Exception:
@@ -510,8 +578,9 @@ def main():
     bwd_gbs = algo_bytes / t_bwd / 1e9
 
     # ---- secondary runs of the SAME step (never `value`): a fresh head + engine per run, the same timing protocol
-    def secondary(sN, sD, sQ, storage, steps, toks=None, sC=None):
+    def secondary(sN, sD, sQ, storage, steps, toks=None, sC=None, sB=None, passes=False):
         sC = sC or Cc
+        sB = sB or B
         torch.manual_seed(0)
 
         class Enc2(torch.nn.Module):
@@ -521,14 +590,16 @@ def main():
         enc2 = Enc2()
         probe_heads.build_probe_head(enc2, Namespace(cls_features="ep", ep_queries=sQ, d_out=1, nb_classes=sC, num_heads=16,
                                                      model="vit_base_patch16"))
-        ts = [t % sC for t in ts_all]
+        ts = [(t % sC)[:sB].contiguous() for t in ts_all]
         h2 = enc2.head.to(dev).train()
-        eng2 = make_engine(h2, optimizer="lars", lr=lr, weight_decay=0.0)
+        eng2 = make_engine(h2, optimizer="lars", lr=0.1 * (sB * world) / 256, weight_decay=0.0)
         if hasattr(eng2, "defer_update"):
             eng2.defer_update = True
         if toks is None:
             g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
-            toks = [torch.randn(B, sN, sD, device=dev, generator=g2) for _ in range(args.buffers)]
+            toks = [torch.randn(sB, sN, sD, device=dev, generator=g2) for _ in range(args.buffers)]
+        elif sB != B:
+            toks = [x[:sB] for x in toks]                     # (a batch-strided view of the first sB images)
         if storage == "bf16":
             toks = [x.to(torch.bfloat16) for x in toks]
         es = 2 if storage == "bf16" else 4
@@ -549,21 +620,29 @@ def main():
         l2 = eng2.read_stats()[0]
         c2_, sc2 = h2[0].cls_token.detach(), h2[0].scale
         tf2 = time_kernel(lambda i: F_.pool_forward(toks[i % args.buffers], c2_, sc2), args.kernel_iters)
-        v2 = B * world * steps / el2
-        return {"value": round(v2, 1), "unit": "images/s", "n_gpus": world, "steps": steps, "ms_per_step": round(el2 / steps * 1e3, 4),
-                "tokens": sN, "dim": sD, "queries": sQ, "batch_per_gpu": B, "token_storage": storage, "arithmetic": "f32",
-                "kernel": eng.lib.ep_pool_kernel_name_ex(B, sN, sD, sQ, 0, 1 if storage == "bf16" else 0).decode(),
-                "us_per_launch": round(tf2 * 1e6, 2), "algorithmic_bytes": B * sN * sD * es,
-                "frac": round(B * sN * sD * es / tf2 / 1e9 / HBM_PEAK_GBS, 4),
+        v2 = sB * world * steps / el2
+        line = {"value": round(v2, 1), "unit": "images/s", "n_gpus": world, "steps": steps, "ms_per_step": round(el2 / steps * 1e3, 4),
+                "tokens": sN, "dim": sD, "queries": sQ, "batch_per_gpu": sB, "token_storage": storage, "arithmetic": "f32",
+                "kernel": eng.lib.ep_pool_kernel_name_ex(sB, sN, sD, sQ, 0, 1 if storage == "bf16" else 0).decode(),
+                "us_per_launch": round(tf2 * 1e6, 2), "algorithmic_bytes": sB * sN * sD * es,
+                "frac": round(sB * sN * sD * es / tf2 / 1e9 / HBM_PEAK_GBS, 4),
                 "step_frac": round(v2 / world * 2 * sN * sD * es / 1e9 / HBM_PEAK_GBS, 4),
                 "mean_loss_over_timed_steps": round(l2 / steps, 5)}
+        if passes:                                            # the two pass launches INSIDE this engine's step
+            ins = pass_events(eng2, toks, ts)
+            ab = sB * sN * sD * es
+            line["in_step"] = {"fwd_us": ins["fwd_us"], "bwd_us": ins["bwd_us"],
+                               "fwd_frac": round(ab / (ins["fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                               "bwd_frac": round(ab / (ins["bwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                               "bwd_kernel": eng.lib.ep_pool_kernel_name_ex(sB, sN, sD, sQ, 1, 1 if storage == "bf16" else 0).decode()}
+        return line
 
     default_ep = args.head == "ep" and args.tokens == "f32" and args.workload == "c2"
     # (N = 1 only) the same tokens STORED as bf16 (fp32 arithmetic and results; the token passes run on the bf16
     # matrix cores, csrc/ep_pool_mb.hip)
     bf16_line = None
     if world == 1 and args.head == "ep" and args.tokens == "f32" and not args.no_bf16_secondary:
-        bf16_line = secondary(Nn, D, Q, "bf16", max(10, min(args.steps, 50)), toks=xs)
+        bf16_line = secondary(Nn, D, Q, "bf16", max(10, min(args.steps, 50)), toks=xs, passes=True)
     # the north-star shape (ViT-B/16 tokens 197x768, BASELINE.json north_star) beside the configs[1] headline
     ns_line = None
     if default_ep and not args.no_north_star:
@@ -582,6 +661,20 @@ def main():
             line["workload"] = cdesc
             line["classes"] = cC
             configs[name] = line
+        # the headline shape at the per-GPU batches a fixed global batch gives on more GPUs (the published protocol's effective
+        # batch is 4096 -- reference README.md:119-120 -- i.e. 512 per GPU on 8): what a --global-batch point is read against
+        for nb in (512, 256):
+            if nb < B:
+                line = secondary(Nn, D, Q, "f32", 20, toks=xs, sB=nb)
+                line["workload"] = desc + f", batch {nb} per GPU"
+                configs[f"{args.workload}_b{nb}"] = line
+        # configs[4] as it fits 8 x 288 GB: the pre-dumped ViT-7B tokens stored as bf16, both passes in the step
+        torch.cuda.empty_cache()
+        cN, cD, cQ, cC, cdesc = WORKLOADS["c5"]
+        line = secondary(cN, cD, cQ, "bf16", 20, sC=cC, passes=True)
+        line["workload"] = cdesc + " [tokens stored as bf16, fp32 arithmetic]"
+        line["classes"] = cC
+        configs["c5_bf16"] = line
         # BASELINE configs[3] compares three heads on the SO400M tokens: the other two (CoCa pooler: HBM-bound like EP; AbMILP:
         # matrix-core-bound) as short child runs of this file, rank 0 at N = 1 only (their own engines and workspaces)
         if world == 1:
@@ -656,6 +749,30 @@ def main():
         value = B * world * args.steps / elapsed
         if through is not None:
             through["vs_train_step"] = round(through["value"] / value, 4)
+        # The roofline object prices the DOMINANT kernel of the step as it runs IN the step: the second token pass
+        # (it carries the in-pass dP tasks in front of its stream and the weight-gradient side workgroups behind it), measured
+        # by the library's own HIP events around that launch.  The first pass and both passes launched alone are sub-objects.
+        alone = {"fwd": {"kernel": kname_f, "us_per_launch": round(t_fwd * 1e6, 2), "achieved": round(fwd_gbs, 1),
+                         "frac": round(fwd_gbs / HBM_PEAK_GBS, 4)},
+                 "bwd": {"kernel": kname_b, "us_per_launch": round(t_bwd * 1e6, 2), "achieved": round(bwd_gbs, 1),
+                         "frac": round(bwd_gbs / HBM_PEAK_GBS, 4)},
+                 "note": "the same kernels launched alone (no in-pass tasks, no side workgroups), HIP events over --kernel-iters launches"}
+        step_frac = round(value / world * 2 * Nn * D * esize / 1e9 / HBM_PEAK_GBS, 4)
+        if in_step is not None:
+            dom_us, dom_name, dom_how = in_step["bwd_us"], kname_b, "in the step: " + in_step["method"]
+            fwd_us = in_step["fwd_us"]
+        else:                                                  # heads without the pass events: the slower pass, launched alone
+            dom_us, dom_name = (t_bwd * 1e6, kname_b) if t_bwd >= t_fwd else (t_fwd * 1e6, kname_f)
+            dom_how, fwd_us = alone["note"], None
+        dom_gbs = algo_bytes / (dom_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "us_per_launch": round(dom_us, 2), "algorithmic_bytes": algo_bytes, "measured": dom_how,
+                    "step_frac": step_frac, "alone": alone}
+        if fwd_us is not None:
+            roofline["fwd_kernel"] = {"kernel": kname_f, "us_per_launch": fwd_us,
+                                      "achieved": round(algo_bytes / (fwd_us * 1e-6) / 1e9, 1),
+                                      "frac": round(algo_bytes / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         out = {
             "metric": {"ep": "EP-head train images/sec", "coca": "CoCa-head train images/sec",
                        "siglip": "SigLIP-head train images/sec", "cae": "CAE-head train images/sec",
@@ -665,30 +782,25 @@ def main():
                        "cbam": "CBAM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, **({"collective_backend": "gloo (EP_BENCH_SHARE_DEVICE=1: all ranks on one device, a test mode)"} if share else {}),
             "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "step_ms_p10": pct(0.10), "step_ms_p50": pct(0.50), "step_ms_p90": pct(0.90), "step_ms_window": me,
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
                        "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B, "token_storage": args.tokens,
                        "global_batch": B * world, "optimizer": "lars", "token_buffers": args.buffers,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": kname_f, "achieved": round(fwd_gbs, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fwd_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes": algo_bytes,
-                         "bwd_kernel": {"kernel": kname_b, "achieved": round(bwd_gbs, 1),
-                                        "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
-                                        "us_per_launch": round(t_bwd * 1e6, 2)},
-                         "step_frac": round(value / world * 2 * Nn * D * esize / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roofline,
             "check": {"mean_loss_over_timed_steps": round(loss_sum / max(1, args.steps), 5),
                       "nonfinite_rows": bad,
                       "step_ms_device": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}},
             "eval_forward": {"value": round(B / eval_s, 1), "unit": "images/s per GPU", "ms_per_batch": round(eval_s * 1e3, 4)},
         }
         if in_step is not None:
-            # the stand-alone figures above price the pass kernels alone; these are the same launches inside the step
             in_step["fwd_frac"] = round(algo_bytes / (in_step["fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             in_step["bwd_frac"] = round(algo_bytes / (in_step["bwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             in_step["between_and_after_us"] = round(ms_per_step * 1e3 - in_step["fwd_us"] - in_step["bwd_us"], 2)
             out["roofline"]["in_step"] = in_step
+        if dp_obj is not None:
+            out["data_parallel"] = dp_obj
         if configs is not None:
             out["configs"] = configs
         if through is not None:

@@ -55,6 +55,7 @@ class EPHeadStep(C.Structure):
         ("aux_stream", C.c_void_p),
         ("opt_first_segment", C.c_int32), ("opt_num_segments", C.c_int32),
         ("defer_event", C.c_void_p),
+        ("planes_valid", C.c_int32),
     ]
 
 

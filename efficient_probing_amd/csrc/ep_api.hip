@@ -81,7 +81,10 @@ static int head_planes_mode(const ep_head_dims& d) {
   static int on = -2;
   if (on == -2) { const char* e = getenv("EP_GEMM_PLANES"); on = e ? atoi(e) : -1; }
   const int Dp = d.D / d.d_out;
-  const int mode = on >= 0 ? on : (d.D >= 2048 ? 1 : 0);
+  // unset: all four contractions for wide rows; below, the classifier's two -- their planes come for free since round 4 (the
+  // optimizer's update kernel writes them, ep_optim.hip: tile_update_emit; ep_head_step.planes_valid): 256 x 768, same box,
+  // mode 0 against mode 2: 0.4343 -> 0.4285 ms (f32 tokens), 0.3141 -> 0.3060 ms (bf16-stored tokens)
+  const int mode = on >= 0 ? on : (d.D >= 2048 ? 1 : 2);
   if (!mode || d.D % 4 != 0 || Dp % 4 != 0) return 0;
   if (mode == 1) return (Dp / d.Q) % 32 == 0 ? 1 : 0;
   return 2;
@@ -567,7 +570,9 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   const bool pl = plc && head_planes_mode(d) == 1;                        // ... and the two projections
   hipEvent_t pev[2] = {nullptr, nullptr};
   bool split_done = false;
-  if (plc && (s->phases & 1) && s->aux_stream && (hipStream_t)s->aux_stream != st) {
+  if (plc && s->planes_valid) {
+    split_done = true;                                 // written by the previous optimizer phase (ep_optim.hip: tile_update_emit)
+  } else if (plc && (s->phases & 1) && s->aux_stream && (hipStream_t)s->aux_stream != st) {
     hipStream_t ax = (hipStream_t)s->aux_stream;
     hipEvent_t evs[6];
     EP_TRY(get_events(evs, 6));
@@ -614,7 +619,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   p.ip_WvF = nullptr; p.ip_ypart = nullptr; p.ip_ycnt = nullptr; p.ip_y = nullptr; p.ip_yr0 = 0; p.ip_zero = nullptr; p.ip_nzero = 0;
   if (s->phases & (1 | 8)) {
     if (plc) {
-      if (split_done) EP_HIP(hipStreamWaitEvent(st, pev[1], 0));
+      if (split_done) { if (pev[1]) EP_HIP(hipStreamWaitEvent(st, pev[1], 0)); }
       else EP_TRY(head_planes_split(d, w, Wv, Wc, st));
     }
     if (pl) {
@@ -667,7 +672,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       gz.M = d.B; gz.N = Dp; gz.K = d.C; gz.alpha = 1.f;
       static int fold_on = -1;
       if (fold_on < 0) { const char* e = getenv("EP_BN_FOLD"); fold_on = e ? atoi(e) : 0; }
-      const bool fold = fold_on && ip_dp && in_pass && !(ipmask & 4) && !plc && d.B % 32 == 0 && gemm_colstats_ok(true, false, gz, 1);
+      const bool fold = fold_on && ip_dp && in_pass && !(ipmask & 4) && !plc && d.B % 32 == 0 && s->x_dtype == EP_DTYPE_F32 && gemm_colstats_ok(true, false, gz, 1);
       if (fold) {
         gz.cs_z = w.z; gz.cs_out = w.colstat;
         EP_TRY(gemm(true, false, gz, 1, st));
@@ -748,31 +753,40 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     const bool sub = s->opt_num_segments > 0;
     EP_REQUIRE(!sub || (s->opt_first_segment >= 0 && s->opt_first_segment + s->opt_num_segments <= 4), EP_E_ARG,
                "optimizer segment range [%d, +%d) outside the four tensors", s->opt_first_segment, s->opt_num_segments);
-    const ep_segment* use = (s->optimizer == 0 || sub) ? segs + (sub ? s->opt_first_segment : 0) : nullptr;
-    const int nuse = (s->optimizer == 0 || sub) ? (sub ? s->opt_num_segments : 4) : 0;
+    // always per tensor (SGD / AdamW do not need the segments for their arithmetic -- no trust ratio -- but the update
+    // kernel finds the weight matrices whose planes it writes among them)
+    const ep_segment* use = segs + (sub ? s->opt_first_segment : 0);
+    const int nuse = sub ? s->opt_num_segments : 4;
     hipStream_t ax = (hipStream_t)s->aux_stream;
     // a give-up of an in-pass hand-off wait (w.iperr != 0: ep_inpass.h) must be loud: the optimizer then skips the update,
     // sets found_inf and bumps the non-finite row count of the step statistics, which stops train_one_epoch
     float* abort_stat = s->stats ? s->stats + 3 : nullptr;
+    // the planes of the matrices this phase updates are written by the update itself (no split launch in the next step)
+    PlaneSpec emit[2];
+    int n_emit = 0;
+    if (head_planes_ok(d)) {
+      emit[n_emit++] = PlaneSpec{Wc, d.C, Dp, Dp, w.plWc, w.plWcT};
+      if (head_planes_mode(d) == 1) emit[n_emit++] = PlaneSpec{Wv, Dp, d.D, d.D, w.plWv, w.plWvT};
+    }
     if ((s->phases & 16) && s->defer_event && ax && ax != st && !sub) {
       // deferred large update: cls_token here (one launch; it also finishes the cls_token gradient reduction), the three
       // large tensors on the aux stream beside whatever the caller enqueues next on `stream`
       EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total, segs, 1, s->lr,
                         s->weight_decay, s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps,
-                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat));
+                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat, emit, n_emit));
       hipEvent_t evs[6];
       EP_TRY(get_events(evs, 6));
       EP_HIP(hipEventRecord(evs[3], st));                      // the gradients are complete on `stream` here
       EP_HIP(hipStreamWaitEvent(ax, evs[3], 0));
       EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total, segs + 1, 3, s->lr,
                         s->weight_decay, s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps,
-                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, ax, nullptr, w.iperr, abort_stat));
+                        s->opt_step, s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, ax, nullptr, w.iperr, abort_stat, emit, n_emit));
       EP_HIP(hipEventRecord((hipEvent_t)s->defer_event, ax));
     } else
     EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
                       use, nuse, s->lr, s->weight_decay,
                       s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,
-                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat));
+                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat, emit, n_emit));
   }
   return 0;
 }

@@ -182,6 +182,9 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
                int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
                hipStream_t st, const DeferredReduce* red = nullptr,    // red: finish that reduction into g first (g is written)
-               const int* abort_flag = nullptr, float* abort_stat = nullptr);   // nonzero *abort_flag: skip the update, set found_inf, bump *abort_stat
+               const int* abort_flag = nullptr, float* abort_stat = nullptr,   // nonzero *abort_flag: skip the update, set found_inf, bump *abort_stat
+               const PlaneSpec* emit = nullptr, int n_emit = 0);   // weight matrices (whole segments) whose planes the update writes (<= 2)
+// how many of `emit` optim_step will really serve for this segment list (the others need planes_split)
+int optim_emits(const float* p, const ep_segment* segs, int nseg, const PlaneSpec* emit, int n_emit);
 
 }  // namespace ep

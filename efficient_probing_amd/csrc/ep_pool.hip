@@ -424,7 +424,9 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
 bool pool_backward_takes_side(const PoolParams& p) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
-  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || force_generic()) return false;
+  if (use_mb(p)) return mb_takes_side(p.D);          // bf16 tokens: the two-workgroup matrix-core pass carries them too
+  if (use_mm(p, true) || use_mf(p, true)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   return c.ok && c.nw == 4;
 }
@@ -434,7 +436,9 @@ bool pool_backward_takes_side(const PoolParams& p) {
 bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_DELTA"); allow = e ? atoi(e) : 1; }
-  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) || force_generic()) return false;
+  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || force_generic()) return false;
+  if (use_mb(p)) return mb_takes_delta(p.D, p.Q, Dv);
+  if (use_mm(p, true) || use_mf(p, true)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (!c.ok || !stream_takes(p) || Dv <= 0 || Dv % (4 * p.Q) != 0) return false;
   // ring slot of the kernel that will run = (tokens per tile) * D * (bytes per stored element).  A bf16 tile holds TWICE
@@ -451,8 +455,17 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
 int pool_inpass_mask(const PoolParams& p, int Dv) {
   static int want = -1;
   if (want < 0) { const char* e = getenv("EP_INPASS"); want = e ? atoi(e) : 2; }   // default: dP inside the second pass
-  if (!want || needs_generic(p) || p.tokstat || use_wide(p) || use_mb(p) || use_mm(p, true) || use_mf(p, true) ||
-      use_mm(p, false) || use_mf(p, false) || force_generic() || !stream_takes(p)) return 0;
+  if (!want || needs_generic(p) || p.tokstat || use_wide(p) || force_generic()) return 0;
+  if (use_mb(p)) {
+    // bf16-stored tokens: dP inside the second matrix-core pass (ep_pool_mb.hip); same shape rules as below
+    static int mb_ip = -1;
+    if (mb_ip < 0) { const char* e = getenv("EP_INPASS_MB"); mb_ip = e ? atoi(e) : 1; }
+    if (!(want & 2) || !mb_ip || Dv != p.D || p.B % 32 != 0 || mb_grid(p.D, p.B) % 32 != 0 || p.cls_bstride != 0 ||
+        (int64_t)p.B * p.Q * p.D * 4 >= (int64_t)0x7fffffff || !pool_backward_takes_side(p) || !mb_takes_inpass_dp(p))
+      return 0;
+    return 2;
+  }
+  if (use_mm(p, true) || use_mf(p, true) || use_mm(p, false) || use_mf(p, false) || !stream_takes(p)) return 0;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (!c.ok || c.nw != 4 || c.qw != 2 || c.kp > 3 || p.Q != 8 || p.D != 256 * c.kp || Dv != p.D || p.B % 32 != 0 ||
       c.grid % 32 != 0 || p.cls_bstride != 0 || (int64_t)p.B * p.Q * p.D * 4 >= (int64_t)0x7fffffff)   // (32-bit buffer offsets)
@@ -506,13 +519,13 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   int nparts;
   EP_REQUIRE(!side || side->total == 0 || pool_backward_takes_side(p), EP_E_UNSUPPORTED,
-             "pool_backward: side tasks need the 4-wave streaming kernel");
+             "pool_backward: side tasks need the 4-wave streaming kernel or the two-workgroup bf16 matrix-core pass");
   if (use_wide(p)) {
     nparts = wide_grid(p.D, p.B, p.x_bf16);
     EP_TRY(wide_launch(true, p, nparts, st));
   } else if (use_mb(p)) {
     nparts = mb_grid(p.D, p.B);
-    EP_TRY(mb_launch(true, p, nparts, st));
+    EP_TRY(mb_launch(true, p, nparts, st, side));
   } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);
     EP_TRY(mm_launch(true, p, nparts, st));

@@ -32,6 +32,8 @@
 #include "ep_common.h"
 #include "ep_internal.h"
 #include "ep_pool_stream.h"
+#include "ep_sidetask.h"
+#include "ep_inpass.h"
 
 namespace ep {
 
@@ -39,6 +41,24 @@ typedef __attribute__((address_space(3))) void* mb_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* mb_gptr_t;
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// EP_MB_ABLATE=1 (diagnostic BUILDS only: tools/build_variant.sh -DEP_MB_ABLATE=1) compiles the stage-ablation switches
+// of PoolParams.ablate into the forward kernels.  As run-time branches in the shipped kernels they cost 27 - 70 registers
+// (D = 768: 256 + 2 spilled against 188; D = 1024: 51 spilled registers, the pass 184 instead of 81 us; D = 384: 142
+// against 115, one workgroup per CU fewer) -- measured in round 4, which is why they are compiled out by default.
+#ifndef EP_MB_ABLATE
+#define EP_MB_ABLATE 0
+#endif
+constexpr bool MB_ABLATE = EP_MB_ABLATE != 0;
+// EP_MB2_PIPE=1 (A/B builds): the software-pipelined tile loop of the two-workgroup form -- the pooling MFMAs of tile it-1
+// issued behind the score MFMAs of tile it, between the two barriers of an iteration.  Measured in round 4 (same box,
+// alternating runs, 256 x 768 / 197 x 768 / 196 x 384): the step is SLOWER with it, 0.318 - 0.322 against 0.311 - 0.314 ms,
+// 0.2985 against 0.289, 0.163 against 0.159 -- the second pass 131 - 135 against 125 - 128 us in the step.  The ring slot of
+// tile it-1 is then free only behind the second barrier, so the refill runs one iteration ahead of its use instead of
+// almost two, and the two workgroups of a CU already cover each other's chains.  Kept as the measured alternative; off.
+#ifndef EP_MB2_PIPE
+#define EP_MB2_PIPE 0
+#endif
 
 constexpr int MB_TT = 32;             // tokens per tile (two 16-token MFMA blocks)
 constexpr float MB_LOG2E = 1.4426950408889634f;
@@ -311,10 +331,10 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
 #pragma unroll
       for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
     }
-    if (p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
+    if (MB_ABLATE && p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
     mb_scores<NK, NW, PK>(tile, aoff, bq, spart, w, lane, produce);
     float sc[8], ue[8];
-    if (p.ablate == 2) {                            // diagnostic: no exchange
+    if (MB_ABLATE && p.ablate == 2) {               // diagnostic: no exchange
 #pragma unroll
       for (int e = 0; e < 8; ++e) sc[e] = 0.f;
     } else {
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
         if (t0 + 3 < nvalid) Srow[3] = s3;
       }
     }
-    if (p.ablate != 3) mb_pool<NK, NW>(tile, poff, pseg, wgt, accE, accO);
+    if (!MB_ABLATE || p.ablate != 3) mb_pool<NK, NW>(tile, poff, pseg, wgt, accE, accO);
     if (ctile == tiles_per_img - 1) {
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
@@ -619,6 +639,8 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
   const int G = gridDim.x, wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * tiles_per_img;
+  if (wg == 0 && p.ip_zero)                         // the second pass's in-pass counters (ep_inpass.h): zero before it starts
+    for (int t = threadIdx.x; t < p.ip_nzero; t += MB2_NW * 64) p.ip_zero[t] = 0;
   if (n_items <= 0) return;
   const int j = lane & 15, g = lane >> 4;
   const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
@@ -666,6 +688,91 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
   f4 accE[NK], accO[NK];
   float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;
   int cimg = 0, ctile = 0, cslot = 0;
+  if constexpr (NS >= 3 && EP_MB2_PIPE) {
+    // SOFTWARE-PIPELINED tile loop (round 4): the pooling MFMAs of tile it-1 are issued between the two barriers of
+    // iteration `it`, right behind the score MFMAs of tile it -- two independent chains, so one's LDS-read and
+    // matrix-pipe latencies are covered by the other instead of adding up (no unit of the CU is more than ~40 % busy
+    // in this pass: it is bound by the serial chain of a tile).  The slot of tile it-1 is therefore free only after the
+    // SECOND barrier of iteration it, where the ring is refilled (tile it+2: three slots hold it-1 | it | it+1).
+    // The raw scores of tile it-1 are stored in iteration `it` as well, IN FRONT of the ring refill: vmcnt retires in
+    // order, so a store issued behind the newest tile's copies would make the counted wait at the top of the next
+    // iteration wait for the first of those copies too.
+    float pwgt[4] = {0.f, 0.f, 0.f, 0.f}, psc[4] = {0.f, 0.f, 0.f, 0.f};
+    const char* ptile_ = ring;
+    bool plast = false; int pb = 0, pn0 = 0, pnvalid = 0;
+    for (int it = 0; it <= n_items; ++it) {
+      const bool live = it < n_items;
+      if (live) mb_wait_vmcnt((pi - 1 - it) * KDMA);
+      mb_barrier();                                 // tile `it` landed everywhere; everyone is past gather(it-1)
+      const int b = wg + cimg * G;
+      const int n0 = ctile * MB2_TT;
+      const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+      const char* tile = ring + cslot * SLOT;
+      if (live) mb2_scores<NK>(tile, aoff, bq, spart, w, lane, [] {});
+      if (it > 0) {
+        mb2_pool<NK>(ptile_, poff, pseg, pwgt, accE, accO);
+        if (w == ((it - 1) & 3) && j < Q) {         // every wave holds the same scores: one writes the tile
+          float* Srow = p.S + ((int64_t)pb * Q + j) * N + pn0 + 4 * g;
+          if (n4) {
+            if (4 * g < pnvalid) *reinterpret_cast<f4*>(Srow) = f4{psc[0], psc[1], psc[2], psc[3]};
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (4 * g + r < pnvalid) Srow[r] = psc[r];
+          }
+        }
+        if (plast) {                                // tile it-1 closed its image: normalise and store
+          const float l = mb_q4_sum(lsum);
+          const float inv = 1.0f / l;
+          if (j < Q) {
+            float* Pq = p.P + ((int64_t)pb * Q + j) * D + 32 * NK * w + 8 * g;
+#pragma unroll
+            for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
+            if (w == 0 && g == 0) {
+              const f4 rec = {m_j, l, 0.f, 0.f};
+              *reinterpret_cast<f4*>(p.ML + ((int64_t)pb * Q + j) * 4) = rec;
+            }
+          }
+        }
+      }
+      if (!live) break;
+      mb_barrier();                                 // all partial score blocks are in the scratch; slot of tile it-1 is free
+      produce();
+      if (ctile == 0) {
+        m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
+#pragma unroll
+        for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      float sc[4], ue[4];
+      mb2_gather(spart, lane, sc);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ue[e] = (4 * g + e) < nvalid ? sc[e] : -INFINITY;
+        mx = fmaxf(mx, ue[e]);
+      }
+      if (__builtin_amdgcn_ballot_w64(mx > m_j + MB_LAZY_MAX_THR) != 0ull) {
+        const float mn = fmaxf(m_j, mb_q4_max(mx));
+        const float f = __builtin_amdgcn_exp2f((m_j - mn) * MB_LOG2E);
+        m_j = mn; mL_j = mn * MB_LOG2E;
+        lsum *= f;
+#pragma unroll
+        for (int dg = 0; dg < NK; ++dg) { accE[dg] *= f; accO[dg] *= f; }      // holds the tiles up to it-1 of this image
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pwgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));
+        lsum += pwgt[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) psc[e] = sc[e];
+      ptile_ = tile; pb = b; pn0 = n0; pnvalid = nvalid;
+      plast = ctile == tiles_per_img - 1;
+      cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+      if (plast) { ctile = 0; ++cimg; } else { ++ctile; }
+    }
+    return;
+  }
   for (int it = 0; it < n_items; ++it) {
     mb_wait_vmcnt((pi - 1 - it) * KDMA);
     mb_barrier();
@@ -679,10 +786,10 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
 #pragma unroll
       for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
     }
-    if (p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
+    if (MB_ABLATE && p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
     mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
     float sc[4], ue[4];
-    if (p.ablate == 2) {                            // diagnostic: no exchange
+    if (MB_ABLATE && p.ablate == 2) {               // diagnostic: no exchange
 #pragma unroll
       for (int e = 0; e < 4; ++e) sc[e] = 0.f;
     } else {
@@ -709,7 +816,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));
       lsum += wgt[e];
     }
-    if (w == (it & 3) && j < Q && p.ablate != 4) {  // every wave holds the same scores: one writes the tile
+    if (w == (it & 3) && j < Q && (!MB_ABLATE || p.ablate != 4)) {  // every wave holds the same scores: one writes the tile
       float* Srow = p.S + ((int64_t)b * Q + j) * N + n0 + 4 * g;
       if (n4) {
         if (4 * g < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[0], sc[1], sc[2], sc[3]};
@@ -719,7 +826,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
           if (4 * g + r < nvalid) Srow[r] = sc[r];
       }
     }
-    if (p.ablate != 3) mb2_pool<NK>(tile, poff, pseg, wgt, accE, accO);
+    if (!MB_ABLATE || p.ablate != 3) mb2_pool<NK>(tile, poff, pseg, wgt, accE, accO);
     if (ctile == tiles_per_img - 1) {
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
@@ -739,11 +846,20 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
   }
 }
 
-template <int NK, int NS>
-__global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolParams p) {
+// SIDE: the launch carries the step's weight-gradient contractions, the bias column sum and the statistics fold as extra
+// workgroups behind the pooling grid (ep_sidetask.h: the dispatcher places them as pooling workgroups retire, i.e. into
+// the tail of the pass -- no second stream, no cross-queue events).  A template flag because the contraction tile's
+// registers must not push the D <= 384 pooling kernels below four workgroups per CU when nothing rides along.
+template <int NK, int NS, bool SIDE>
+__global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolParams p, SideTasks side) {
   using C = Mb2Cfg<NK, NS>;
   constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int G = SIDE ? (int)gridDim.x - side.total : (int)gridDim.x;      // pooling workgroups
+  const int wg = blockIdx.x;
+  if constexpr (SIDE) {
+    if (wg >= G) { run_side_task(side, wg - G, lds); return; }
+  }
   char* ring = lds;
   char* spart = lds + NSLOT * SLOT;
   const int lane = lane_id();
@@ -751,12 +867,34 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
   const int N = p.N, Q = p.Q;
   const bool n4 = (N & 3) == 0;
   const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
-  const int G = gridDim.x, wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * tiles_per_img;
   const int j = lane & 15, g = lane >> 4;
   const int jq = j < Q ? j : Q - 1;
   const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+  // ---- in-pass dP (ep_inpass.h; Q = 8, D = 256 KT, whole row blocks of 32 images, the whole pooling grid resident --
+  // host-checked, ep_pool.hip: pool_inpass_mask): this workgroup's tasks first, then the wait for the row blocks of its own
+  // images, then the stream.  The dP rows are read with sc1 loads below (written by other workgroups of this launch).
+  constexpr bool IPOK = SIDE && (NK == 2 || NK == 4 || NK == 6);
+  if constexpr (IPOK) {
+    if (wg == 0 && p.ip_zero)
+      for (int t = threadIdx.x; t < p.ip_nzero; t += MB2_NW * 64) p.ip_zero[t] = 0;
+    if (p.ip_dy) {
+      const int R = (p.B + G - 1) / G;
+      const int nfull = p.B - (R - 1) * G;                   // workgroups with R images
+      const int nh = G - nfull;                              // helpers
+      auto run = [&](int b) {
+        // (a CALL: inlined, the task's ~90 staging registers pushed this kernel's token loop into scratch)
+        ip_dp_task_call<NK / 2>(p.ip_dy, p.ip_Wv, const_cast<float*>(p.dP), p.B, b, lds);
+        ip_arrive(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE);
+      };
+      run(wg);
+      if (nh == 0) { for (int b = wg + G; b < p.B; b += G) run(b); }
+      else if (wg >= nfull)                                  // later-round image G + e goes to helper G - 1 - (e % nh)
+        for (int e = G - 1 - wg; e < p.B - G; e += nh) run(G + e);
+      for (int b = wg; b < p.B; b += G) ip_wait<false>(p.ip_dcnt + (b >> 5) * IP_CNT_STRIDE, IP_TARGET, p.ip_err);
+    }
+  }
 
   f4 gE[NK], gO[NK];
 #pragma unroll
@@ -809,6 +947,80 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
     u4 bq[NK][3];
     float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
     int cimg = 0, ctile = 0, cslot = 0;
+    // a dP row chunk: plain load, or -- rows produced inside this launch by the in-pass tasks -- an sc1 buffer load
+    const __amdgpu_buffer_rsrc_t rP = ip_rsrc(p.dP, (size_t)p.B * Q * D * sizeof(float));
+    auto ld_dp = [&](const float* src, int off) -> f4 {
+      if constexpr (IPOK) {
+        if (p.ip_dy) return ip_load16_coherent(rP, (unsigned)((src - p.dP + off) * (int64_t)sizeof(float)));
+      }
+      return *reinterpret_cast<const f4*>(src + off);
+    };
+    if constexpr (NS >= 3 && EP_MB2_PIPE) {
+      // software-pipelined like the forward (see there): dA MFMAs of tile it, then the pooling MFMAs of tile it-1 between
+      // the two barriers; saved scores of tile it+1 and the ring refill (tile it+2) behind the second one, in that order
+      // (the plain loads first: the counted wait at the top then covers them)
+      float pwgt[4] = {0.f, 0.f, 0.f, 0.f};
+      const char* ptile_ = ring;
+      for (int it = 0; it <= n_items; ++it) {
+        const bool live = it < n_items;
+        if (live) mb_wait_vmcnt((pi - 1 - it) * KDMA);
+        mb_barrier();
+        const int n0 = ctile * MB2_TT;
+        const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+        const char* tile = ring + cslot * SLOT;
+        if (live && ctile == 0) {
+          const int b = wg + cimg * G;                 // new image: its dP rows (this wave's slice) and ML row; the other
+          const float* src = p.dP + ((int64_t)b * Q + jq) * D + 32 * NK * w + 8 * g;      // workgroup of the CU covers the wait
+          const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const f4 a = ld_dp(src, 32 * ks), c = ld_dp(src, 32 * ks + 4);
+            float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            if (j >= Q) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            mb_split8(v, bq[ks]);
+          }
+          mL_j = hml.x * MB_LOG2E; il_j = 1.0f / hml.y; dl_j = hml.z;
+          if (p.dyv) {
+            const int Dq = p.Dv / Q;
+            const float* dyr = p.dyv + (int64_t)b * p.Dv + jq * Dq;
+            const float* yr = p.yv + (int64_t)b * p.Dv + jq * Dq;
+            float acc = 0.f;
+            for (int c = 4 * g; c < Dq; c += 16) {
+              const f4 a = *reinterpret_cast<const f4*>(dyr + c), y4 = *reinterpret_cast<const f4*>(yr + c);
+              acc = fmaf(a.x, y4.x, acc); acc = fmaf(a.y, y4.y, acc); acc = fmaf(a.z, y4.z, acc); acc = fmaf(a.w, y4.w, acc);
+            }
+            dl_j = mb_q4_sum(acc);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // keeps the counted waits below exact
+        }
+        if (live) mb2_scores<NK>(tile, aoff, bq, spart, w, lane, [] {});      // dA partial blocks
+        if (it > 0) mb2_pool<NK>(ptile_, poff, pseg, pwgt, gE, gO);
+        if (!live) break;
+        mb_barrier();                                  // partial blocks complete; the slot of tile it-1 is free
+        float cur[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur[e] = sv[e];
+        {
+          int nimg = cimg, ntile = ctile + 1;
+          if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
+          if (nimg < n_img) load_scores(nimg, ntile);
+        }
+        produce();
+        float u[4];
+        mb2_gather(spart, lane, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
+          pwgt[e] = ((4 * g + e) < nvalid && j < Q) ? a * (u[e] - dl_j) : 0.f;
+        }
+        ptile_ = tile;
+        cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+        if (++ctile == tiles_per_img) { ctile = 0; ++cimg; }
+      }
+    } else
     for (int it = 0; it < n_items; ++it) {
       mb_wait_vmcnt((pi - 1 - it) * KDMA);
       mb_barrier();
@@ -822,7 +1034,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
         const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-          const f4 a = *reinterpret_cast<const f4*>(src + 32 * ks), c = *reinterpret_cast<const f4*>(src + 32 * ks + 4);
+          const f4 a = ld_dp(src, 32 * ks), c = ld_dp(src, 32 * ks + 4);
           float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
           if (j >= Q) {
 #pragma unroll
@@ -831,6 +1043,20 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
           mb_split8(v, bq[ks]);
         }
         mL_j = hml.x * MB_LOG2E; il_j = 1.0f / hml.y; dl_j = hml.z;
+        if (p.dyv) {
+          // the softmax-correction term delta[b, j] = dy[b, j-slice] . y[b, j-slice] (= dP[b,j] . P[b,j]) computed here instead
+          // of being read from ML[b,j,2] (no ep_delta_kernel launch in front of the pass): lane (j, g) sums quarter g of the
+          // slice in float4 steps, the four lanes of a query combine in fixed order -- every wave gets the same bits
+          const int Dq = p.Dv / Q;
+          const float* dyr = p.dyv + (int64_t)b * p.Dv + jq * Dq;
+          const float* yr = p.yv + (int64_t)b * p.Dv + jq * Dq;
+          float acc = 0.f;
+          for (int c = 4 * g; c < Dq; c += 16) {
+            const f4 a = *reinterpret_cast<const f4*>(dyr + c), y4 = *reinterpret_cast<const f4*>(yr + c);
+            acc = fmaf(a.x, y4.x, acc); acc = fmaf(a.y, y4.y, acc); acc = fmaf(a.z, y4.z, acc); acc = fmaf(a.w, y4.w, acc);
+          }
+          dl_j = mb_q4_sum(acc);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // keeps the counted waits below exact
       }
       float cur[4];
@@ -861,16 +1087,39 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
   }
 }
 
+static thread_local int* g_mb_occ_query = nullptr;
+
 template <int NK, int NS = 3>
-static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   using C = Mb2Cfg<NK, NS>;
-  const size_t lds = C::LDS;
+  size_t lds = C::LDS;
+  const bool with_side = bwd && side && side->total > 0;
+  SideTasks sd{};
+  if (with_side) {
+    sd = *side;
+    sd.first_block = grid;
+    if (lds < SIDE_LDS_BYTES) lds = SIDE_LDS_BYTES;
+  }
+  if (bwd && p.ip_dy) {
+    if (!with_side || (NK != 2 && NK != 4 && NK != 6)) { set_error("in-pass dP needs the side-carrying pass at D = 256 / 512 / 768"); return EP_E_UNSUPPORTED; }
+    if (lds < ip_dp_lds_bytes(NK / 2)) lds = ip_dp_lds_bytes(NK / 2);
+  }
+  if (g_mb_occ_query) {                              // mb_resident_blocks_per_cu(): answer instead of launching
+    auto kq = ep_pool_mb2_bwd_kernel<NK, NS, true>;
+    int nb = 0;
+    (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kq, MB2_NW * 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = -1; }
+    *g_mb_occ_query = nb;
+    return 0;
+  }
   auto kf = ep_pool_mb2_fwd_kernel<NK, NS>;
-  auto kb = ep_pool_mb2_bwd_kernel<NK, NS>;
-  const void* fn = bwd ? (const void*)kb : (const void*)kf;
+  auto kb = ep_pool_mb2_bwd_kernel<NK, NS, false>;
+  auto ks = ep_pool_mb2_bwd_kernel<NK, NS, true>;
+  const void* fn = bwd ? (with_side ? (const void*)ks : (const void*)kb) : (const void*)kf;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
-  if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
+  if (with_side) hipLaunchKernelGGL(ks, dim3(grid + sd.total), dim3(MB2_NW * 64), lds, st, p, sd);
+  else if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(MB2_NW * 64), lds, st, p, sd);
   else hipLaunchKernelGGL(kf, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
   EP_LAUNCH_CHECK(bwd ? "ep_pool_mb2_bwd_kernel" : "ep_pool_mb2_fwd_kernel");
   return 0;
@@ -933,17 +1182,42 @@ static int mb_variant() {             // diagnostic: EP_POOL_MB_WAVES=12 runs D 
   return v;
 }
 
-int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+// the two-workgroup form carries the step's side work (SideTasks) and computes the softmax-correction rows itself (dyv / yv)
+bool mb_takes_side(int D) { return mb2_use(D); }
+// In-pass dP (ep_inpass.h) inside the second pass of this shape: Q = 8, D = 256 KT <= 768, and the WHOLE pooling grid
+// resident at once (workgroups wait on row blocks that other workgroups of the launch produce) -- asked of the runtime for
+// the side-carrying kernel with the tasks' LDS.  Cached per D.
+bool mb_takes_inpass_dp(const PoolParams& p) {
+  if (!mb2_use(p.D) || p.Q != 8 || (p.D != 256 && p.D != 512 && p.D != 768)) return false;
+  static int res[4] = {0, 0, 0, 0};                  // per D / 256: 0 unknown, else blocks per CU + 1 (INT_MAX: cannot tell)
+  int& r = res[p.D / 256];
+  if (r == 0) {
+    PoolParams q = p;
+    int dummy = 0, nb = -1;
+    q.ip_dy = reinterpret_cast<const float*>(&dummy);
+    SideTasks sd{};
+    sd.total = 1;
+    g_mb_occ_query = &nb;
+    const int rc = mb_launch(true, q, 1, nullptr, &sd);
+    g_mb_occ_query = nullptr;
+    r = (rc != 0 || nb < 0) ? 0x7fffffff : nb + 1;
+  }
+  return r == 0x7fffffff || (int64_t)(r - 1) * cu_count() >= mb_grid(p.D, p.B);
+}
+bool mb_takes_delta(int D, int Q, int Dv) { return mb2_use(D) && Dv > 0 && Dv % (4 * Q) == 0; }
+
+int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side) {
   const bool pk = p.Q <= 8;
   if (mb2_use(p.D)) {
     switch (p.D) {
-      case 256: return mb2_launch_one<2>(bwd, p, grid, st);
-      case 384: return mb2_launch_one<3>(bwd, p, grid, st);
-      case 512: return mb2_launch_one<4>(bwd, p, grid, st);
-      case 768: return mb2_launch_one<6>(bwd, p, grid, st);
-      case 1024: return mb2_launch_one<8, 2>(bwd, p, grid, st);
+      case 256: return mb2_launch_one<2>(bwd, p, grid, st, side);
+      case 384: return mb2_launch_one<3>(bwd, p, grid, st, side);
+      case 512: return mb2_launch_one<4>(bwd, p, grid, st, side);
+      case 768: return mb2_launch_one<6>(bwd, p, grid, st, side);
+      case 1024: return mb2_launch_one<8, 2>(bwd, p, grid, st, side);
     }
   }
+  if (bwd && side && side->total > 0) { set_error("side tasks need the two-workgroup bf16 matrix-core pass"); return EP_E_UNSUPPORTED; }
   switch (p.D) {
     case 256: return pk ? mb_launch_one<1, 8, true>(bwd, p, grid, st) : mb_launch_one<1, 8, false>(bwd, p, grid, st);
     case 384: if (pk) return mb_launch_one<1, 12, true>(bwd, p, grid, st); break;

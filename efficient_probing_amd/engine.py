@@ -152,6 +152,7 @@ class ProbeHeadEngine:
             # zero-filled: the step keeps arrival counters in it that it leaves at zero (include/ep_hip.h, ABI v21)
             self._ws = torch.zeros(nbytes, device=self.device, dtype=torch.uint8)
             self._ws_key = key
+            self._planes_token = None
         return self._ws
 
     def _step_struct(self, x, bstride, targets, phases, accumulate, lr):
@@ -180,7 +181,28 @@ class ProbeHeadEngine:
         s.opt_step = self.opt_step
         s.phases = phases
         s.aux_stream = self.aux_stream.cuda_stream if self.aux_stream is not None else 0
+        if hasattr(s, "planes_valid"):
+            s.planes_valid = int(self._planes_current())
         return s
+
+    # ---- bf16 weight planes kept in the workspace (csrc/ep_planes.hip; include/ep_hip.h: ep_head_step.planes_valid) ----
+    # A forward phase establishes them for the parameters it sees (it splits them itself when told they are not valid); an
+    # optimizer phase over the weight matrices rewrites them as it updates.  They stay valid as long as nobody else writes
+    # the parameters: every torch-side write (load_state_dict, broadcast into .data, an optimizer of torch's own ...) bumps
+    # the flat buffer's version counter, the library's kernels do not.
+    def _planes_current(self) -> bool:
+        tok = getattr(self, "_planes_token", None)
+        return (tok is not None and self._ws is not None and tok == (self._ws.data_ptr(), self.flat_p._version)
+                and type(self) is ProbeHeadEngine)
+
+    def _planes_after_call(self, phases: int, first_seg: int = 0, num_segs: int = 0) -> None:
+        if type(self) is not ProbeHeadEngine or self._ws is None:
+            return
+        established = self._planes_current()
+        if phases & (1 | 8):
+            established = True                               # the step made them valid for the parameters it ran on
+        # (an optimizer phase never invalidates them: whichever matrices it updates, it rewrites their planes)
+        self._planes_token = (self._ws.data_ptr(), self.flat_p._version) if established else None
 
     # ------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor,
@@ -197,6 +219,7 @@ class ProbeHeadEngine:
         s = self._step_struct(xv, bstride, targets, 1, self._micro > 0, None)
         s.image_index = iptr
         N.check(self._call_train(s, ws), "head train step (fwd+bwd)")
+        self._planes_after_call(1)
         self._micro += 1
 
     def all_reduce_grads(self) -> None:
@@ -216,6 +239,7 @@ class ProbeHeadEngine:
         if num_segs:
             s.opt_first_segment, s.opt_num_segments = first_seg, num_segs
         N.check(self._call_train(s, ws), "head train step (optimizer)")
+        self._planes_after_call(2, first_seg, num_segs)
 
     def optimizer_step(self, lr: Optional[float] = None) -> None:
         self.flush()
@@ -249,6 +273,7 @@ class ProbeHeadEngine:
         s = self._step_struct(xv, bstride, targets, 8, False, None)
         s.image_index = iptr
         N.check(self._call_train(s, ws), "head train step (rest of fwd+bwd)")
+        self._planes_after_call(8)
         cut = self.offsets[1]
         w1 = w2 = None
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
@@ -285,6 +310,7 @@ class ProbeHeadEngine:
         s = self._step_struct(xv, bstride, targets, 3, False, lr)
         s.image_index = iptr
         N.check(self._call_train(s, ws), "head train step")
+        self._planes_after_call(3)
         self._micro = 0
 
     def _train_step_deferred(self, x, targets, lr, image_index) -> None:
@@ -307,6 +333,7 @@ class ProbeHeadEngine:
         s.image_index = iptr
         s.defer_event = self._defer_event.cuda_event
         N.check(self._call_train(s, ws), "head train step (deferred update)")
+        self._planes_after_call(3)
         self._deferred = True
         self._micro = 0
 
@@ -333,7 +360,7 @@ class ProbeHeadEngine:
         before they project: the reference rounds the (B, Q, N) scores and the per-token values V to fp16; both are
         below the fp16 resolution of the result (tests/test_gpu_parity.py::test_fused_engine_steps_golden pins the distance on the fp16-autocast goldens)."""
         if type(self) is not ProbeHeadEngine:
-            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
+            return self._eval_logits_fp16_operands(x, image_index)
         self.flush()
         r16 = lambda t: t.to(torch.float16).to(torch.float32)
         xv, _ = F_.as_token_view(x)
@@ -345,6 +372,42 @@ class ProbeHeadEngine:
         y16 = r16(F_.project_forward(P, r16(self.pool.v.weight.detach())))   # self.v under autocast, attn @ v
         z16 = r16(F_.bn_forward_eval(y16, self.bn.running_mean, self.bn.running_var, self.bn.eps))
         return r16(F_.linear_forward(z16, r16(self.fc.weight.detach()), r16(self.fc.bias.detach())))
+
+    def _norm_parameter_ids(self):
+        """ids of the parameters autocast leaves in fp32: those of normalisation layers (layer_norm / batch_norm run in
+        fp32 under autocast and take their weights as they are; CoCa's own LayerNorm class, coca_pytorch.py:70-77, too)."""
+        ids = set()
+        for m in self.head.modules():
+            if isinstance(m, (nn.LayerNorm, nn.BatchNorm1d, nn.BatchNorm2d, nn.GroupNorm)) or type(m).__name__ == "LayerNorm":
+                ids.update(id(p) for p in m.parameters(recurse=False))
+        return ids
+
+    @torch.no_grad()
+    def _eval_logits_fp16_operands(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The reference's evaluation mode (fp16 autocast, engine_finetune.py:131) for the heads whose forward is ONE fused
+        library call: the roundings autocast applies to the OPERANDS -- the tokens and every weight a Linear / matmul
+        consumes are rounded to fp16 (normalisation weights stay fp32), the fused fp32 forward runs on them and the logits
+        are rounded to fp16 on the way out.  The intermediate fp16 roundings inside the pooling (per-token keys / values,
+        attention products) are not placed: each is one fp16 ulp of a value that is then averaged over the tokens, below
+        the fp16 resolution of the logits.  Pinned on the reference's own fp16-autocast logits (``eval_logits_fp16_autocast``
+        of the CoCa and AbMILP fixtures, tests/test_gpu_coca.py / test_gpu_abmilp.py) to a few fp16 ulps of their scale."""
+        self.flush()
+        r16 = lambda t: t.to(torch.float16).to(torch.float32)
+        xv, _ = F_.as_token_view(x)
+        if image_index is not None:
+            xv = xv[image_index.long()]
+        x16 = r16(xv).contiguous()
+        keep = self.flat_p.clone()
+        skip = self._norm_parameter_ids()
+        try:
+            for p, o in zip(self.params_list, self.offsets):
+                if id(p) not in skip:
+                    seg = self.flat_p[o:o + p.numel()]
+                    seg.copy_(r16(seg))
+            out = self.eval_logits(x16, None, precision="fp32")
+        finally:
+            self.flat_p.copy_(keep)
+        return r16(out)
 
     @torch.no_grad()
     def eval_logits(self, x: torch.Tensor, image_index: Optional[torch.Tensor] = None,
@@ -469,9 +532,9 @@ class AbmilpHeadEngine(ProbeHeadEngine):
         super().forward_backward(self._tokens(x, image_index), targets, None)
 
     def eval_logits(self, x, image_index=None, precision="fp32"):
-        if precision != "fp32":
-            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
-        return super().eval_logits(self._tokens(x, image_index), None)
+        if precision == "fp16_autocast":
+            return self._eval_logits_fp16_operands(self._tokens(x, image_index), None)
+        return super().eval_logits(self._tokens(x, image_index), None, precision)
 
     def _call_train(self, s, ws) -> int:
         return self.lib.ep_abmilp_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(),
@@ -796,9 +859,9 @@ class DolgHeadEngine(ProbeHeadEngine):
         super().forward_backward(self._tokens(x, image_index), targets, None)
 
     def eval_logits(self, x, image_index=None, precision="fp32"):
-        if precision != "fp32":
-            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
-        return super().eval_logits(self._tokens(x, image_index), None)
+        if precision == "fp16_autocast":
+            return self._eval_logits_fp16_operands(self._tokens(x, image_index), None)
+        return super().eval_logits(self._tokens(x, image_index), None, precision)
 
     def sync_buffers(self):
         super().sync_buffers()
@@ -964,9 +1027,16 @@ class LinearProbeEngine(ProbeHeadEngine):
         super().forward_backward(f.view(f.shape[0], 1, f.shape[1]), targets, None)
 
     def eval_logits(self, x, image_index=None, precision="fp32"):
-        if precision != "fp32":
-            raise NotImplementedError(f"{type(self).__name__}: precision='fp16_autocast' is implemented for the EP head")
         f = self._features(x, image_index)
+        if precision == "fp16_autocast":
+            # reference engine_finetune.py:131 on Sequential(BatchNorm1d, Linear): batch_norm keeps the fp32 features, the
+            # Linear takes its input, weight and bias rounded to fp16 and returns fp16
+            self.flush()
+            r16 = lambda t: t.to(torch.float16).to(torch.float32)
+            z = F_.bn_forward_eval(f, self.bn.running_mean, self.bn.running_var, self.bn.eps)
+            return r16(F_.linear_forward(r16(z), r16(self.fc.weight.detach()), r16(self.fc.bias.detach())))
+        if precision != "fp32":
+            raise ValueError("precision must be 'fp32' or 'fp16_autocast'")
         return super().eval_logits(f.view(f.shape[0], 1, f.shape[1]), None)
 
     def _call_train(self, s, ws) -> int:

@@ -327,10 +327,17 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
 
 @torch.no_grad()
 def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = False, cls_features: str = "cls",
-             return_block: Optional[int] = None, token_fn: Optional[Callable] = None, precision: str = "fp32"):
-    """``precision``: "fp32" (default: the kernels' own arithmetic) or "fp16_autocast" -- the reference's evaluation
-    mode (it always evaluates under ``torch.cuda.amp.autocast()``, engine_finetune.py:131), reproduced on the fused
-    path by ``ProbeHeadEngine.eval_logits_fp16_autocast`` and on the module path by torch's autocast itself."""
+             return_block: Optional[int] = None, token_fn: Optional[Callable] = None, precision: Optional[str] = None):
+    """``precision``: "fp16_autocast" -- the DEFAULT, because it is what the reference does: it always evaluates under
+    ``torch.cuda.amp.autocast()`` (engine_finetune.py:131), so a drop-in must not change the numbers silently -- or "fp32"
+    (the kernels' own arithmetic, on request).  The environment variable EP_EVAL_PRECISION overrides the default for callers
+    that cannot pass the argument (the reference's main_linprobe.py call sites).  The fp16 mode is reproduced on the fused
+    path by ``engine.eval_logits(..., precision="fp16_autocast")`` (EP and plain linear probing: every autocast rounding
+    placed; the other heads: operands and logits rounded, see ``ProbeHeadEngine._eval_logits_fp16_operands``) and on the
+    module path by torch's autocast itself."""
+    if precision is None:
+        import os
+        precision = os.environ.get("EP_EVAL_PRECISION", "fp16_autocast")
     if precision not in ("fp32", "fp16_autocast"):
         raise ValueError("precision must be 'fp32' or 'fp16_autocast'")
     model.eval()
@@ -364,4 +371,55 @@ def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = Fal
     print("* Acc@1 {:.3f} Acc@5 {:.3f} loss {:.3f}".format(stats.get("acc1", 0), stats.get("acc5", 0), stats.get("loss", 0)))
     if return_targets_and_preds:
         stats["targets"], stats["preds"] = torch.cat(all_t), torch.cat(all_p)
+    return stats
+
+
+@torch.no_grad()
+def extract_features(data_loader, model, device, *, return_targets_and_preds: bool = False, cls_features: str = "cls",
+                     return_block: Optional[int] = None, token_fn: Optional[Callable] = None):
+    """One feature vector per image for the k-NN evaluation -- signature and result of the reference's
+    ``extract_features`` (engine_finetune.py:168-222 there): ``stats`` (the meters: none are updated, as there) plus
+    ``stats["targets"]`` / ``stats["features"]`` (CPU tensors) when ``return_targets_and_preds``.
+
+    Where the features come from, in this order:
+      * a ``token_store.StoreBatch`` -- the batch's tokens are read in place from the resident store and averaged over the
+        token axis by the streaming token pass (``knn.mean_tokens``; the reference takes ``output_feat.mean(dim=1)`` of 3-D
+        wrapper outputs, :205-206);
+      * ``token_fn(images)`` (the frozen encoder) when given;
+      * otherwise the model itself, called the way the reference calls its ViT wrappers:
+        ``model.forward(images, return_features=cls_features, return_block=return_block, return_backbone_features=True)``
+        -> ``(_, features)`` (:197).
+    3-D outputs are mean-pooled (on the GPU by the token pass), higher ranks flattened (:207-208)."""
+    from .knn import mean_tokens
+    metric_logger = MetricLogger()
+    if model is not None:
+        model.eval()
+    targets, features = [], []
+    for batch in metric_logger.log_every(data_loader, 10, "Test:"):
+        images, target = batch[0], batch[-1]
+        target = target.to(device, non_blocking=True)
+        if isinstance(batch, StoreBatch):
+            feat = mean_tokens(images, image_index=batch[1])
+        else:
+            images = images.to(device, non_blocking=True)
+            if token_fn is not None:
+                feat = token_fn(images)
+            elif images.dim() == 3:                       # a loader of pre-extracted token tensors
+                feat = images
+            else:
+                m = model.module if hasattr(model, "module") else model
+                with torch.autocast("cuda", enabled=images.is_cuda, dtype=torch.float16):   # reference :189
+                    _, feat = m.forward(images, return_features=cls_features, return_block=return_block,
+                                        return_backbone_features=True)
+            if feat.dim() == 3:
+                feat = mean_tokens(feat if feat.dtype in (torch.float32, torch.bfloat16) else feat.float())
+            elif feat.dim() > 3:
+                feat = feat.flatten(1)
+        targets.append(target.cpu())
+        features.append(feat.float().cpu())
+    metric_logger.synchronize_between_processes()
+    stats = {k: m.global_avg for k, m in metric_logger.meters.items()}
+    if return_targets_and_preds:
+        stats["targets"] = torch.cat(targets)
+        stats["features"] = torch.cat(features)
     return stats

@@ -33,11 +33,12 @@ def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     return out
 
 
-def mean_tokens(x: torch.Tensor) -> torch.Tensor:
+def mean_tokens(x: torch.Tensor, image_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(B, N, D) tokens -> (B, D) mean over tokens (reference extract_features, engine_finetune.py:205-206), computed
-    by the streaming token pass: a zero query gives uniform attention, i.e. the mean."""
+    by the streaming token pass: a zero query gives uniform attention, i.e. the mean.  With ``image_index`` (int32 (B,)),
+    ``x`` is a resident token store and the batch is read from it in place."""
     zero = torch.zeros((1, x.shape[-1]), device=x.device, dtype=torch.float32)
-    P, _, _ = F_.pool_forward(x, zero, 1.0)
+    P, _, _ = F_.pool_forward(x, zero, 1.0, image_index=image_index)
     return P[:, 0, :]
 
 

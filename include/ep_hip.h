@@ -289,6 +289,14 @@ typedef struct ep_head_step {
    * Same arithmetic and order per tensor as the undeferred step; found_inf / grad_norm then cover the tensors of the call
    * that wrote them last (use it without loss scaling only). */
   void* defer_event;
+  /* bf16 planes of the weight matrices (csrc/ep_planes.hip: the operands of the bf16 x3 contractions, used for D >= 2048 and
+   * by EP_GEMM_PLANES) live in `ws`.  Every optimizer phase run through this call WRITES the planes of the tensors it updates
+   * (ABI v22: the update kernel emits them tile by tile, no split launch).  planes_valid != 0 tells a forward/backward phase
+   * that the planes in `ws` are those of the current parameters -- i.e. the last writer of v.weight / fc.weight was an
+   * optimizer phase of this call on this workspace (or the parameters are unchanged since a forward phase established
+   * them); 0 (the safe default) makes the step split them itself, as before.  engine.ProbeHeadEngine tracks it through the
+   * parameters' torch version counter. */
+  int32_t planes_valid;
 } ep_head_step;
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);

@@ -58,3 +58,23 @@ def test_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+
+
+def test_global_batch_is_strong_scaling():
+    """``--global-batch G``: the protocol's fixed effective batch (reference README.md:119-120: 4096) split over the ranks --
+    per-GPU batch G / N, lr = 0.1 * G / 256 whatever N is (main_linprobe.py:572-573), and the line says "strong"."""
+    for n, per_gpu in ((1, 4096), (2, 2048)):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--global-batch", "4096", "--rendezvous-only"], env=_env(),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = _last_json(r.stdout)
+        assert line["scaling"] == "strong" and line["batch_per_gpu"] == per_gpu and line["global_batch"] == 4096
+        assert abs(line["lr"] - 1.6) < 1e-12
+    # the default stays weak scaling at 1024 per GPU
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], env=_env(), capture_output=True, text=True, timeout=300)
+    line = _last_json(r.stdout)
+    assert line["scaling"] == "weak" and line["batch_per_gpu"] == 1024 and line["global_batch"] == 2048
+    # a global batch the ranks cannot split evenly is refused
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--global-batch", "4097", "--rendezvous-only"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -159,3 +159,69 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
         want = port(x)
     got = eng.eval_logits(xd).cpu()
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+# what else bench.py times (round 4): BASELINE configs[4] on its default path -- D >= 2048 and B >= 128 puts all six
+# contractions on the bf16-plane kernel (csrc/ep_planes.hip) and the token passes on the wide-row kernels -- at the B = 256
+# row of DESIGN section 4, and the bf16-STORED tokens of the `bf16_token_storage` / `c5_bf16` objects (matrix-core token
+# passes that carry the weight-gradient side tasks, csrc/ep_pool_mb.hip) at the bench batch.  Against the torch-CPU port of
+# the reference step -- fed the ROUNDED tokens for bf16 storage (the contract of that mode: fp32 arithmetic on the stored
+# values) -- not against other kernels of this library.
+PATHS = [((256, 196, 4096, 8), "f32"), ((256, 196, 4096, 8), "bf16"), ((1024, 256, 768, 8), "bf16"), ((1024, 197, 768, 8), "bf16"),
+         ((1024, 196, 1024, 8), "bf16"), ((512, 196, 384, 1), "bf16")]
+PATH_IDS = ["c5_b256_f32_planes", "c5_b256_bf16", "c2_b1024_bf16", "ns_b1024_bf16", "c3_b1024_bf16", "c1_b512_bf16"]
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_IDS)
+def test_fused_lars_steps_on_the_benchmarked_paths_vs_torch_port(path):
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    from efficient_probing_amd import _native
+    from oracle import torch_port
+    from cases import assert_mu_close
+    (B, Nn, D, Q), storage = path
+    Cc = 100 if D == 384 else 1000
+    head, port = _heads(Nn, D, Q, Cc)
+    lr = 0.1 * B / 256
+    eng = ProbeHeadEngine(head, optimizer="lars", lr=lr, weight_decay=0.0)
+    lib = _native.load()
+    kname = lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1 if storage == "bf16" else 0).decode()
+    assert "generic" not in kname, kname
+    if storage == "bf16" and D <= 1024:
+        assert "mb2" in kname, kname                                   # the matrix-core pass that carries the side tasks
+    byname = dict(port.named_parameters())
+    pparams = [byname["0.cls_token"], byname["0.v.weight"], byname["2.weight"], byname["2.bias"]]
+    mus = [torch.zeros_like(p) for p in pparams]
+    g = torch.Generator().manual_seed(91)
+    names = ["cls_token", "v.weight", "fc.weight", "fc.bias"]
+    for step in range(2):
+        x = torch.randn(B, Nn, D, generator=g)
+        t = torch.randint(0, Cc, (B,), generator=g)
+        if storage == "bf16":
+            xd = x.to(torch.bfloat16).to(DEV)
+            x = xd.float().cpu()                                       # the port sees the stored (rounded) values
+        else:
+            xd = x.to(DEV)
+        td = t.to(DEV)
+        assert eng._one_call_step()
+        eng.train_step(xd, td, lr=lr)
+        torch.cuda.synchronize()
+        grads = [p.grad.detach().cpu().clone() for p in eng.params_list]
+        loss, _, _, bad = eng.read_stats()
+        want_loss = float(torch_port.train_step(port, mus, x, t, lr))
+        assert bad == 0
+        assert loss == pytest.approx(want_loss, rel=2e-5), step
+        for i, n in enumerate(names):
+            wp = pparams[i]
+            wg = wp.grad.reshape(grads[i].shape)
+            np.testing.assert_allclose(grads[i].numpy(), wg.numpy(), rtol=1e-4, atol=2e-5 * float(wg.abs().max()),
+                                       err_msg=f"step {step} grad {n}")
+            got = eng.params_list[i].detach().cpu().numpy()
+            np.testing.assert_allclose(got, wp.detach().reshape(got.shape).numpy(), rtol=1e-4, atol=3e-6, err_msg=f"step {step} param {n}")
+            mu = eng.mu_views()[i].cpu().numpy()
+            assert_mu_close(mu, mus[i].reshape(mu.shape).numpy(), err_msg=f"step {step} mu {n}")
+        np.testing.assert_allclose(head[1].running_mean.cpu().numpy(), port[1].running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(head[1].running_var.cpu().numpy(), port[1].running_var.numpy(), rtol=1e-5, atol=1e-6)
+    port.eval()
+    with torch.no_grad():
+        want = port(x)
+    np.testing.assert_allclose(eng.eval_logits(xd).cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)

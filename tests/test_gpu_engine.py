@@ -125,7 +125,7 @@ def test_evaluate_matches_oracle():
                      fc_bias=inp["fc_bias"], running_mean=model.head[1].running_mean.cpu().numpy(),
                      running_var=model.head[1].running_var.cpu().numpy(), num_queries=case.Q, d_out=1)
     loader = loader_of(case, inp, 2)
-    stats = EF.evaluate(loader, model, torch.device(DEV), return_targets_and_preds=True)
+    stats = EF.evaluate(loader, model, torch.device(DEV), return_targets_and_preds=True, precision="fp32")
     accs, losses = [], []
     for xb, tg in ((inp["x_buf"], inp["targets"]), (inp["x_buf2"], inp["targets2"])):
         logits = O.head_forward_eval(st, xb)
@@ -139,6 +139,8 @@ def test_evaluate_matches_oracle():
     # (engine emulation) and the module path (torch autocast around the native modules) agree to fp16 resolution, and
     # sit within fp16 resolution of the fp32 evaluation
     s16 = EF.evaluate(loader, model, torch.device(DEV), precision="fp16_autocast")
+    sdef = EF.evaluate(loader, model, torch.device(DEV))              # the default IS the reference's mode (fp16 autocast)
+    assert sdef["loss"] == s16["loss"] and sdef["acc1"] == s16["acc1"]
     assert s16["loss"] == pytest.approx(stats["loss"], rel=2e-3)
     assert abs(s16["acc1"] - stats["acc1"]) <= 100.0 / case.B + 1e-9
     with pytest.raises(ValueError):

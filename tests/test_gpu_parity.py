@@ -101,7 +101,8 @@ def test_per_image_queries_module_matches_reference(case, tok):
         x = x.to(torch.bfloat16)
         xr = x.float().cpu().numpy()
         out, cache = O.ep_forward(xr, inp["cls_token"], inp["v_weight"], case.Q, d_out=case.d_out, cls=inp["cls"])
-        dc, dw = O.ep_backward(inp["dy"], cache, inp["v_weight"])
+        dy = torch.from_numpy(inp["dy"]).to(torch.bfloat16).float().numpy()     # the module returns x.dtype: the upstream gradient arrives as bf16
+        dc, dw = O.ep_backward(dy, cache, inp["v_weight"])
         want = dict(pooled=out, cls=dc, v=keeper(case)(dw))
     cls = torch.from_numpy(inp["cls"]).to(DEV).requires_grad_(True)
     pooled = pool(x, cls=cls)

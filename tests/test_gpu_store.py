@@ -92,3 +92,32 @@ def test_streaming_loader_delivers_the_store(tmp_path):
     want = np.concatenate([tok[0:24], tok[25:49], tok[50:66]])
     assert np.array_equal(np.concatenate(seen_t), want)
     assert np.array_equal(np.concatenate(seen_l), np.concatenate([lab[0:24], lab[25:49], lab[50:66]]))
+
+
+def test_extract_features_from_a_dumped_store_feeds_knn(tmp_path):
+    """dump (stub encoder) -> resident store -> extract_features (reference engine_finetune.py:168-222 signature): the
+    features are the token means, equal to knn.mean_tokens of the stored tokens and to what the same encoder gives through
+    ``token_fn`` on the images; knn_classifier runs on them."""
+    from efficient_probing_amd import dump, engine_finetune as EF, knn, token_store as TS
+    torch.manual_seed(0)
+    proj = torch.nn.Conv2d(3, 64, kernel_size=4, stride=4).to(DEV).eval()
+    token_fn = lambda x: proj(x).flatten(2).transpose(1, 2)                       # (B, 16, 64)
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.randn(50, 3, 16, 16, generator=g)
+    labs = torch.randint(0, 5, (50,), generator=g)
+    loader = [(imgs[i:i + 16], labs[i:i + 16]) for i in range(0, 50, 16)]
+    meta = dump.dump_tokens(loader, token_fn, str(tmp_path), dtype="float32", shard_images=32, device=torch.device(DEV))
+    assert meta["total_images"] == 50
+    store = TS.ResidentTokenStore(str(tmp_path), device=torch.device(DEV))
+    st = EF.extract_features(store.loader(16, shuffle=False, drop_last=False), None, torch.device(DEV), return_targets_and_preds=True)
+    assert st["features"].shape == (50, 64) and torch.equal(st["targets"], labs)
+    want = knn.mean_tokens(store.tokens).cpu()
+    assert torch.equal(st["features"], want)
+    np.testing.assert_allclose(want.numpy(), store.tokens.float().mean(1).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the same features straight from the images through token_fn (3-tuple batches: batch[0] / batch[-1])
+    st2 = EF.extract_features([(a, torch.zeros(len(a)), b) for a, b in loader], None, torch.device(DEV), return_targets_and_preds=True,
+                              token_fn=token_fn)
+    np.testing.assert_allclose(st2["features"].numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    top1, top5 = knn.knn_classifier(st["features"].to(DEV), st["targets"].to(DEV), st2["features"].to(DEV), st2["targets"].to(DEV),
+                                    k=5, T=0.07, num_classes=5)
+    assert top1 == 100.0                                                          # every image finds itself
