@@ -97,6 +97,10 @@ static bool head_planes_ok(const ep_head_dims& d) { return head_planes_mode(d) !
 static bool head_planes_wgrad(const ep_head_dims& d) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_PLANES_WGRAD"); on = e ? atoi(e) : 1; }
+  // round 4: with the bf16 x3 weight-gradient tile (ep_wgrad3.h, EP_GEMM_B3) both operands are split on the fly in their
+  // natural T / T layout -- no transposes, no planes of P^T -- so this path is only taken when that tile is switched off
+  // or asked for explicitly (EP_PLANES_WGRAD=2)
+  if (on != 2 && gemm_b3_on()) return false;
   return on && head_planes_mode(d) == 1 && d.B % 4 == 0 && d.B >= 128;
 }
 static HeadWs carve(const ep_head_dims& d, void* base) {
@@ -298,6 +302,7 @@ void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch) {
   static int xcd = -1;
   if (xcd < 0) { const char* e = getenv("EP_SIDE_XCD"); xcd = e ? atoi(e) : 1; }
   sd.xcd_order = xcd;
+  sd.b3 = gemm_b3_on() && g.K >= 64 ? (i == 0 ? 1 : sd.b3) : 0;      // (one switch per launch: all of its contractions or none)
   sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
 }
 

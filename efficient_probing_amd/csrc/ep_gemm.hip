@@ -16,6 +16,8 @@
 #include "ep_side.h"
 #include "ep_gemm_dma.h"
 
+#include "ep_wgrad3.h"
+
 namespace ep {
 
 // tile body: ep_side.h (gemm_tile)
@@ -575,6 +577,23 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
   return 0;
 }
 
+// ---- weight-gradient contractions (both operands summed over their SLOW index: T / T layout) on the bf16 matrix cores at
+// fp32 accuracy (ep_wgrad3.h): the stand-alone launch of the tile the second token pass runs as side work ----
+template <int BMT>
+__global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
+  gemm_tile_b3<BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+}
+// EP_GEMM_B3=0: T / T contractions back on the exact-f32 kernels
+bool gemm_b3_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_B3"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k) {
+  return gemm_b3_on() && !a_k && !b_k && !p.bias && p.K >= 64 && vec_ok(p.A, p.lda, p.sAz, p.extA) && vec_ok(p.B, p.ldb, p.sBz, p.extB);
+}
+
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
   if (batch == 1 && p.skws) {
@@ -584,6 +603,20 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   }
   const bool vec = vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
   const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;
+  if (gemm_b3_ok(p, a_k, b_k)) {
+    // 32-row tiles where 64-row ones would leave tiles half empty or the chip under-filled (as side_add_gemm)
+    const bool m32 = !(p.M % 64 == 0 || p.M >= 256) || tiles64 < 2L * cu_count();
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
+      attr_set = true;
+    }
+    if (m32) hipLaunchKernelGGL(ep_gemm_b3_kernel<32>, dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), W3_LDS_BYTES, st, p);
+    else hipLaunchKernelGGL(ep_gemm_b3_kernel<64>, dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), W3_LDS_BYTES, st, p);
+    EP_LAUNCH_CHECK("ep_gemm_b3_kernel");
+    return 0;
+  }
   static int force_bm = -1;
   if (force_bm < 0) { const char* e = getenv("EP_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
   static int use_ws = -1;

@@ -102,6 +102,7 @@ struct SideTasks {
   int total;                        // number of extra workgroups
   int first_block;                  // set by the launcher: side workgroups occupy blocks [first_block, first_block + total)
   int xcd_order;                    // 1: tiles of a contraction are handed out XCD by XCD (run_side_task)
+  int b3;                           // 1: the contractions run on the bf16 x3 tile (ep_wgrad3.h) instead of the exact-f32 one
 };
 
 // element offset of image b of the batch inside the token buffer
@@ -133,6 +134,7 @@ constexpr int IP_YPARTS = 4;                                   // K quarters of 
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
 int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
+bool gemm_b3_on();                                             // EP_GEMM_B3 (default 1): T / T contractions on the bf16 x3 tile
 int debug_force_generic(int on);
 int token_stats(const void* x, int x_bf16, int64_t bstride, int B, int N, int D, float eps, float* stats, hipStream_t st);
 int attention_from_scores(const float* S, const float* ML, int rows, int N, float* A, hipStream_t st);

@@ -654,6 +654,15 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
   if (bwd && side && side->total > 0) {
     if (NW != 4) { set_error("side tasks need 4-wave workgroups"); return EP_E_UNSUPPORTED; }
     sd = *side;
+    // The bf16 x3 tile (ep_wgrad3.h) halves the matrix time of a side contraction but adds ~110 vector instructions per
+    // K-tile (the split) -- and these passes are vector-issue co-limited.  Measured at 256 x 768 (544 tiles, ~30 us of side
+    // work overlapping the drain of the pooling workgroups): second pass 195 against 191 us with it, the step 0.424 against
+    // 0.422 ms; with the ~1600 tiles of the SigLIP head (most of them run after the stream has ended) 0.832 against 0.858 ms.
+    // So: only when the side work is long against the drain.  EP_SIDE_B3=0 / 1 forces.
+    static int b3_env = -2;
+    if (b3_env == -2) { const char* e = getenv("EP_SIDE_B3"); b3_env = e ? atoi(e) : -1; }
+    if (b3_env >= 0) sd.b3 = sd.b3 && b3_env;
+    else if (sd.total <= 1024) sd.b3 = 0;
     if (lds < SIDE_LDS_BYTES) lds = SIDE_LDS_BYTES;
     static int early = -1;
     if (early < 0) { const char* e = getenv("EP_SIDE_EARLY"); early = e ? atoi(e) : 0; }

@@ -2,6 +2,7 @@
 // as extra workgroups of its launch): the dispatcher over the task list.  Included by the token-pass kernels only.
 #pragma once
 #include "ep_side.h"
+#include "ep_wgrad3.h"
 
 namespace ep {
 
@@ -9,7 +10,7 @@ namespace ep {
 // Workgroups with blockIdx.x >= (pooling workgroups) run these instead of streaming tokens.  They are
 // dispatched as pooling workgroups retire, i.e. into the tail of the pass where the chip would
 // otherwise drain; none of them feeds anything before the optimizer.  All T/T-layout vector GEMMs.
-constexpr size_t SIDE_LDS_BYTES = sizeof(float) * 2 * 2 * LDS_OPERAND;
+constexpr size_t SIDE_LDS_BYTES = sizeof(float) * 2 * 2 * LDS_OPERAND > W3_LDS_BYTES ? sizeof(float) * 2 * 2 * LDS_OPERAND : W3_LDS_BYTES;
 
 __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* lds_raw) {
   auto lds = reinterpret_cast<float (*)[2][LDS_OPERAND]>(lds_raw);
@@ -27,6 +28,11 @@ __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* l
       const int by = r % s.gy[i], bz = r / s.gy[i];
       // (round 3: the LDS-DMA tile body of ep_gemm_dma.h as the side body -- 3 stages, 4 symmetric waves, 64-row tiles --
       // measured SLOWER inside the pass: second pass 181 -> 192 us at 256x768, 155 -> 166 us at 197x768; removed again)
+      if (s.b3) {                                      // bf16 x3 at fp32 accuracy: 96 instead of 256 matrix cycles per block
+        if (s.bm[i] == 64) gemm_tile_b3<64>(s.g[i], bx, by, bz, lds_raw);
+        else gemm_tile_b3<32>(s.g[i], bx, by, bz, lds_raw);
+        return;
+      }
       if (s.bm[i] == 64) gemm_tile<false, false, true, 64>(s.g[i], bx, by, bz, lds);
       else gemm_tile<false, false, true, 32>(s.g[i], bx, by, bz, lds);
       return;

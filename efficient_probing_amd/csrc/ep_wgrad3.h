@@ -1,0 +1,132 @@
+// Weight-gradient contraction tile on the bf16 matrix cores at fp32 accuracy (gfx950):
+//
+//     C[m][n] (+)= alpha * sum_k A[k][m] * B[k][n]          (both operands "T layout": k = the batch index is the slow one)
+//
+// -- dWc = dlogits^T z, dWv_q = dy_q^T P_q and every other sum-over-the-batch gradient of a Linear (reference
+// probe_heads.py:76, poolings/ep.py:40 under autograd).  BOTH operands are fp32 activations, so unlike ep_planes.hip (weights
+// pre-split once per step) both are split HERE, once per workgroup and K-tile, on their way from registers into LDS:
+//
+//   x = h + m + l exactly (three bf16 terms, round-to-nearest: ep_planes_dev.h pl_split2), and
+//   a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + [<= 2^-24 |a*b|, dropped]
+//
+// i.e. six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block at 16 matrix cycles each instead of eight
+// v_mfma_f32_16x16x4_f32 at 32: 96 against 256 matrix cycles.  The f32 tile (ep_side.h: gemm_tile) spends 1024 matrix cycles
+// per wave and K-tile and is bound by them -- 544 side tiles of the EP step at 256 x 768 are 27 us of matrix time on the
+// whole chip and ~45 us in the tail of the bf16-token second pass.
+//
+// A K-tile is 32 batch rows.  A thread fetches a k-PAIR x 4 consecutive m (two float4, coalesced along m), splits the four
+// (x[2kp][m], x[2kp+1][m]) pairs into packed bf16 terms -- one b32 holds the two k of a pair, which is how the matrix
+// instruction wants them: 8 consecutive k per lane -- and writes them TRANSPOSED into plane images [term][m][k]:
+//   row stride 80 bytes (64 of data), 16-byte k-chunk c of row r stored at chunk c ^ ((r >> 4) & 3):
+//   writes (16 lanes on rows 4 mq + j) and fragment reads (ds_read_b128 of 16 consecutive rows) are both conflict-free.
+// One LDS stage (two operands x three terms x 5 KiB = 30 KiB), the next K-tile's global loads in flight in registers
+// while this one is multiplied; two barriers per K-tile (the 2 - 3 resident workgroups of a CU cover them).
+// Wave (wm, wn) of the 2 x 2 owns BMT/2 x 32 of the BMT x 64 output tile.
+#pragma once
+#include "ep_side.h"
+#include "ep_planes_dev.h"
+
+namespace ep {
+
+constexpr int W3_ROWB = 80;                       // bytes per plane-image row (32 k x 2 B + 16 B pad)
+constexpr int W3_IMG = 64 * W3_ROWB;              // one term of one operand (64 rows)
+constexpr size_t W3_LDS_BYTES = 6 * (size_t)W3_IMG;      // A: h m l | B: h m l  = 30720
+
+__device__ __forceinline__ int w3_off(int row, int kchunk) { return row * W3_ROWB + ((kchunk ^ ((row >> 4) & 3)) << 4); }
+
+// fp32 T-layout tile rows k0 + 2 kp, + 1, columns c0 + 4 mq .. + 3 -> registers (branch-free; masked in w3_stage)
+__device__ __forceinline__ void w3_load(const float* __restrict__ base, int64_t ld, int ext, int K, int c0, int k0, int kp, int mq,
+                                        f4v (&x)[2]) {
+  const int c = c0 + 4 * mq;
+  const int cc = c < ext ? c : 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = k0 + 2 * kp + h;
+    x[h] = *reinterpret_cast<const f4v*>(base + (int64_t)(k < K ? k : K - 1) * ld + cc);
+  }
+}
+// split and store this thread's 2 x 4 values into the three plane images of one operand
+__device__ __forceinline__ void w3_stage(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq) {
+  const bool cok = c0 + 4 * mq < ext;
+  const bool k0ok = cok && k0 + 2 * kp < K, k1ok = cok && k0 + 2 * kp + 1 < K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, m, l;
+    pl_split2(k0ok ? x[0][j] : 0.f, k1ok ? x[1][j] : 0.f, h, m, l);
+    const int o = w3_off(4 * mq + j, kp >> 2) + 4 * (kp & 3);
+    *reinterpret_cast<unsigned*>(img + o) = h;
+    *reinterpret_cast<unsigned*>(img + W3_IMG + o) = m;
+    *reinterpret_cast<unsigned*>(img + 2 * W3_IMG + o) = l;
+  }
+}
+
+// BMT = 64: 2 x 2 blocks per wave; BMT = 32: 1 x 2.  VEC operands (16-byte aligned, lda / ldb multiples of 4) only.
+template <int BMT>
+__device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  constexpr int MI = BMT / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * BMT, n0 = bx * 64;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  char* imgA = lds;
+  char* imgB = lds + 3 * W3_IMG;
+  // staging role: k-pair kp (0..15) x m-quad mq (0..15); lanes run over mq first (coalesced rows)
+  const int mq = tid & 15, kp = tid >> 4;
+  const bool stA = 4 * mq < BMT;                    // (32-row tiles: half of the threads have no A work)
+
+  f4v acc[MI][2];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + 31) / 32;
+  f4v xa[2], xb[2];
+  w3_load(A, p.lda, p.extA < p.M ? p.extA : p.M, p.K, m0, 0, kp, stA ? mq : 0, xa);
+  w3_load(B, p.ldb, p.extB < p.N ? p.extB : p.N, p.K, n0, 0, kp, mq, xb);
+  for (int it = 0; it < nk; ++it) {
+    if (it > 0) __syncthreads();                     // every wave has read tile it-1's fragments
+    if (stA) w3_stage(imgA, xa, p.extA < p.M ? p.extA : p.M, p.K, m0, it * 32, kp, mq);
+    w3_stage(imgB, xb, p.extB < p.N ? p.extB : p.N, p.K, n0, it * 32, kp, mq);
+    if (it + 1 < nk) {                               // next tile's rows: in flight while this one is multiplied
+      w3_load(A, p.lda, p.extA < p.M ? p.extA : p.M, p.K, m0, (it + 1) * 32, kp, stA ? mq : 0, xa);
+      w3_load(B, p.ldb, p.extB < p.N ? p.extB : p.N, p.K, n0, (it + 1) * 32, kp, mq, xb);
+    }
+    __syncthreads();                                 // the plane images are complete
+    pl_u4 fa[MI][3], fb[2][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fa[mi][t] = *reinterpret_cast<const pl_u4*>(imgA + t * W3_IMG + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3_IMG + w3_off(wn * 32 + ni * 16 + i16, kk));
+    // smallest terms first: lo x hi, hi x lo, mid x mid, then the 2^-8 pair, then hi x hi (as ep_planes.hip)
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+    }
+  }
+  f4v blk[MI * 2]; int rb[MI * 2], cb[MI * 2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
+    }
+  store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
+  __syncthreads();                                   // LDS free for the caller's next tile
+}
+
+}  // namespace ep
