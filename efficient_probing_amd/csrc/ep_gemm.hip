@@ -579,10 +579,21 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
 
 // ---- weight-gradient contractions (both operands summed over their SLOW index: T / T layout) on the bf16 matrix cores at
 // fp32 accuracy (ep_wgrad3.h): the stand-alone launch of the tile the second token pass runs as side work ----
-template <int BMT>
+template <bool A_K, bool B_K, int BMT>
 __global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
-  gemm_tile_b3<BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+  gemm_tile_b3g<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+}
+template <bool A_K, bool B_K>
+static void b3_launch(const GemmParams& p, int batch, bool m32, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
+    attr_set = true;
+  }
+  if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), W3_LDS_BYTES, st, p);
+  else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), W3_LDS_BYTES, st, p);
 }
 // EP_GEMM_B3=0: T / T contractions back on the exact-f32 kernels
 bool gemm_b3_on() {
@@ -590,8 +601,18 @@ bool gemm_b3_on() {
   if (on < 0) { const char* e = getenv("EP_GEMM_B3"); on = e ? atoi(e) : 1; }
   return on != 0;
 }
-bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k) {
-  return gemm_b3_on() && !a_k && !b_k && !p.bias && p.K >= 64 && vec_ok(p.A, p.lda, p.sAz, p.extA) && vec_ok(p.B, p.ldb, p.sBz, p.extB);
+// T / T (weight gradients): always.  The other layouts (activation x weight): LARGE contractions only -- the 1024-row
+// critical-path ones of the EP step are one tile per CU and latency-bound, where the LDS-DMA ring kernels stay ahead
+// (EP_GEMM_B3_MIN_TILES: 64 x 64 tiles from which the bf16 x3 tile takes a K / K or K / T contraction; 0 = never).
+bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
+  if (!gemm_b3_on() || p.K < 64 || p.cs_out) return false;
+  if (!vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) || !vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB)) return false;
+  if (!a_k && !b_k) return !p.bias;
+  if (!a_k) return false;                                      // (T / K does not occur)
+  static long min_tiles = -1;
+  if (min_tiles < 0) { const char* e = getenv("EP_GEMM_B3_MIN_TILES"); min_tiles = e ? atol(e) : 512; }
+  const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;
+  return min_tiles > 0 && tiles64 >= min_tiles && p.K >= 256;
 }
 
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
@@ -603,17 +624,12 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   }
   const bool vec = vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
   const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;
-  if (gemm_b3_ok(p, a_k, b_k)) {
+  if (gemm_b3_ok(p, a_k, b_k, batch)) {
     // 32-row tiles where 64-row ones would leave tiles half empty or the chip under-filled (as side_add_gemm)
     const bool m32 = !(p.M % 64 == 0 || p.M >= 256) || tiles64 < 2L * cu_count();
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
-      (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
-      attr_set = true;
-    }
-    if (m32) hipLaunchKernelGGL(ep_gemm_b3_kernel<32>, dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), W3_LDS_BYTES, st, p);
-    else hipLaunchKernelGGL(ep_gemm_b3_kernel<64>, dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), W3_LDS_BYTES, st, p);
+    if (!a_k) b3_launch<false, false>(p, batch, m32, st);
+    else if (b_k) b3_launch<true, true>(p, batch, m32, st);
+    else b3_launch<true, false>(p, batch, m32, st);
     EP_LAUNCH_CHECK("ep_gemm_b3_kernel");
     return 0;
   }

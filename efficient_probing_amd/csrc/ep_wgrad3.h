@@ -1,6 +1,10 @@
-// Weight-gradient contraction tile on the bf16 matrix cores at fp32 accuracy (gfx950):
+// Contraction tile on the bf16 matrix cores at fp32 accuracy with BOTH operands split on the fly (gfx950).  Built for the
+// weight gradients:
 //
 //     C[m][n] (+)= alpha * sum_k A[k][m] * B[k][n]          (both operands "T layout": k = the batch index is the slow one)
+//
+// (gemm_tile_b3g takes K-contiguous operands as well -- gemm() hands it the K / K and K / T contractions of 512 output tiles
+// and more, where it measured 1 - 1.5 % on the steps of the attention-pool and matrix-core-bound heads.)
 //
 // -- dWc = dlogits^T z, dWv_q = dy_q^T P_q and every other sum-over-the-batch gradient of a Linear (reference
 // probe_heads.py:76, poolings/ep.py:40 under autograd).  BOTH operands are fp32 activations, so unlike ep_planes.hip (weights
@@ -34,9 +38,10 @@ constexpr size_t W3_LDS_BYTES = 6 * (size_t)W3_IMG;      // A: h m l | B: h m l 
 
 __device__ __forceinline__ int w3_off(int row, int kchunk) { return row * W3_ROWB + ((kchunk ^ ((row >> 4) & 3)) << 4); }
 
-// fp32 T-layout tile rows k0 + 2 kp, + 1, columns c0 + 4 mq .. + 3 -> registers (branch-free; masked in w3_stage)
-__device__ __forceinline__ void w3_load(const float* __restrict__ base, int64_t ld, int ext, int K, int c0, int k0, int kp, int mq,
-                                        f4v (&x)[2]) {
+// ---- T layout (k is the slow index): a thread takes a k-PAIR x 4 consecutive columns ------------------------------------
+// fp32 tile rows k0 + 2 kp, + 1, columns c0 + 4 mq .. + 3 -> registers (branch-free; masked in w3_stage_T)
+__device__ __forceinline__ void w3_load_T(const float* __restrict__ base, int64_t ld, int ext, int K, int c0, int k0, int kp, int mq,
+                                          f4v (&x)[2]) {
   const int c = c0 + 4 * mq;
   const int cc = c < ext ? c : 0;
 #pragma unroll
@@ -45,8 +50,8 @@ __device__ __forceinline__ void w3_load(const float* __restrict__ base, int64_t 
     x[h] = *reinterpret_cast<const f4v*>(base + (int64_t)(k < K ? k : K - 1) * ld + cc);
   }
 }
-// split and store this thread's 2 x 4 values into the three plane images of one operand
-__device__ __forceinline__ void w3_stage(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq) {
+// split and store this thread's 2 x 4 values into the three plane images of one operand (transposed: image rows = columns)
+__device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq) {
   const bool cok = c0 + 4 * mq < ext;
   const bool k0ok = cok && k0 + 2 * kp < K, k1ok = cok && k0 + 2 * kp + 1 < K;
 #pragma unroll
@@ -59,10 +64,39 @@ __device__ __forceinline__ void w3_stage(char* img, const f4v (&x)[2], int ext, 
     *reinterpret_cast<unsigned*>(img + 2 * W3_IMG + o) = l;
   }
 }
+// ---- K layout (k contiguous): a thread takes 4 consecutive k of one row (two rows for 64-row tiles) ----------------------
+template <int RT>
+__device__ __forceinline__ void w3_load_K(const float* __restrict__ base, int64_t ld, int rows, int K, int r0, int k0, int tid,
+                                          f4v (&x)[2]) {
+#pragma unroll
+  for (int r = 0; r < RT / 32; ++r) {
+    const int idx = tid + 256 * r;
+    const int row = r0 + (idx >> 3), k = k0 + 4 * (idx & 7);
+    x[r] = *reinterpret_cast<const f4v*>(base + (int64_t)(row < rows ? row : rows - 1) * ld + (k < K ? k : 0));
+  }
+}
+template <int RT>
+__device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int rows, int K, int r0, int k0, int tid) {
+#pragma unroll
+  for (int r = 0; r < RT / 32; ++r) {
+    const int idx = tid + 256 * r, lrow = idx >> 3, kq = idx & 7;
+    const bool ok = r0 + lrow < rows && k0 + 4 * kq < K;
+    unsigned h0, m0, l0, h1, m1, l1;
+    pl_split2(ok ? x[r][0] : 0.f, ok ? x[r][1] : 0.f, h0, m0, l0);
+    pl_split2(ok ? x[r][2] : 0.f, ok ? x[r][3] : 0.f, h1, m1, l1);
+    typedef unsigned w3_u2 __attribute__((ext_vector_type(2)));
+    const int o = w3_off(lrow, kq >> 1) + 8 * (kq & 1);
+    *reinterpret_cast<w3_u2*>(img + o) = w3_u2{h0, h1};
+    *reinterpret_cast<w3_u2*>(img + W3_IMG + o) = w3_u2{m0, m1};
+    *reinterpret_cast<w3_u2*>(img + 2 * W3_IMG + o) = w3_u2{l0, l1};
+  }
+}
 
-// BMT = 64: 2 x 2 blocks per wave; BMT = 32: 1 x 2.  VEC operands (16-byte aligned, lda / ldb multiples of 4) only.
-template <int BMT>
-__device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by, int bz, char* lds) {
+// C (+)= alpha * op(A) op(B)^T (+ bias) on one BMT x 64 tile.  A_K / B_K: the operand is contiguous along K (true) or along
+// its free dimension (false), as in ep_side.h: gemm_tile.  BMT = 64: 2 x 2 blocks per wave; 32: 1 x 2.  16-byte aligned
+// operands with leading dimensions (and K, for K-layout operands) multiples of 4 only.
+template <bool A_K, bool B_K, int BMT>
+__device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int by, int bz, char* lds) {
   constexpr int MI = BMT / 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,9 +108,10 @@ __device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by
   const int i16 = lane & 15, kk = lane >> 4;
   char* imgA = lds;
   char* imgB = lds + 3 * W3_IMG;
-  // staging role: k-pair kp (0..15) x m-quad mq (0..15); lanes run over mq first (coalesced rows)
+  // T-layout staging role: k-pair kp (0..15) x column quad mq (0..15); lanes run over mq first (coalesced rows)
   const int mq = tid & 15, kp = tid >> 4;
-  const bool stA = 4 * mq < BMT;                    // (32-row tiles: half of the threads have no A work)
+  const bool stA = A_K || 4 * mq < BMT;             // (T layout, 32-row tiles: half of the threads have no A work)
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
 
   f4v acc[MI][2];
 #pragma unroll
@@ -86,16 +121,22 @@ __device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by
 
   const int nk = (p.K + 31) / 32;
   f4v xa[2], xb[2];
-  w3_load(A, p.lda, p.extA < p.M ? p.extA : p.M, p.K, m0, 0, kp, stA ? mq : 0, xa);
-  w3_load(B, p.ldb, p.extB < p.N ? p.extB : p.N, p.K, n0, 0, kp, mq, xb);
+  auto loadA = [&](int k0) {
+    if constexpr (A_K) w3_load_K<BMT>(A, p.lda, p.M, p.K, m0, k0, tid, xa);
+    else w3_load_T(A, p.lda, extA, p.K, m0, k0, kp, stA ? mq : 0, xa);
+  };
+  auto loadB = [&](int k0) {
+    if constexpr (B_K) w3_load_K<64>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
+    else w3_load_T(B, p.ldb, extB, p.K, n0, k0, kp, mq, xb);
+  };
+  loadA(0); loadB(0);
   for (int it = 0; it < nk; ++it) {
     if (it > 0) __syncthreads();                     // every wave has read tile it-1's fragments
-    if (stA) w3_stage(imgA, xa, p.extA < p.M ? p.extA : p.M, p.K, m0, it * 32, kp, mq);
-    w3_stage(imgB, xb, p.extB < p.N ? p.extB : p.N, p.K, n0, it * 32, kp, mq);
-    if (it + 1 < nk) {                               // next tile's rows: in flight while this one is multiplied
-      w3_load(A, p.lda, p.extA < p.M ? p.extA : p.M, p.K, m0, (it + 1) * 32, kp, stA ? mq : 0, xa);
-      w3_load(B, p.ldb, p.extB < p.N ? p.extB : p.N, p.K, n0, (it + 1) * 32, kp, mq, xb);
-    }
+    if constexpr (A_K) w3_stage_K<BMT>(imgA, xa, p.M, p.K, m0, it * 32, tid);
+    else { if (stA) w3_stage_T(imgA, xa, extA, p.K, m0, it * 32, kp, mq); }
+    if constexpr (B_K) w3_stage_K<64>(imgB, xb, p.N, p.K, n0, it * 32, tid);
+    else w3_stage_T(imgB, xb, extB, p.K, n0, it * 32, kp, mq);
+    if (it + 1 < nk) { loadA((it + 1) * 32); loadB((it + 1) * 32); }     // in flight while this tile is multiplied
     __syncthreads();                                 // the plane images are complete
     pl_u4 fa[MI][3], fb[2][3];
 #pragma unroll
@@ -127,6 +168,12 @@ __device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by
     }
   store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
   __syncthreads();                                   // LDS free for the caller's next tile
+}
+
+// the weight-gradient form (both operands T layout): what the token passes run as side work
+template <int BMT>
+__device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  gemm_tile_b3g<false, false, BMT>(p, bx, by, bz, lds);
 }
 
 }  // namespace ep

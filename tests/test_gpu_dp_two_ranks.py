@@ -102,3 +102,16 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert line["config"]["global_batch"] == 512 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and np.isfinite(line["check"]["mean_loss_over_timed_steps"])
     assert line["value"] == pytest.approx(512 * 6 / (line["ms_per_step"] * 6e-3), rel=1e-3)   # whole-job images per second
+    # round 4: the data-parallel object -- the ONE exchange step of the path timed alone, and both schedules in one invocation
+    dp = line["data_parallel"]
+    assert dp["allreduce_us"] > 0 and dp["allreduce_bytes"] == 4 * (8 * 768 + 768 * 768 + 1000 * 768 + 1000)
+    assert dp["overlap_comm"]["on"]["pipelined"] is True and dp["overlap_comm"]["on"]["value"] > 0
+    assert dp["overlap_comm"]["off"]["value"] == pytest.approx(line["value"], rel=1e-6)
+    assert np.isfinite(dp["overlap_comm"]["on"]["mean_loss_over_timed_steps"])
+    assert line["scaling"] == "weak"
+    # the protocol's fixed global batch split over the ranks: strong scaling, lr from the GLOBAL batch
+    cmd2 = [c for c in cmd if c not in ("--batch", "256")] + ["--global-batch", "512"]
+    r = subprocess.run(cmd2, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line2 = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line2["scaling"] == "strong" and line2["config"]["batch_per_gpu"] == 256 and line2["config"]["global_batch"] == 512

@@ -74,3 +74,28 @@ def test_switch_puts_the_exact_f32_kernel_back():
         assert r.returncode == 0, r.stderr[-1500:]
         errs[v] = float(r.stdout.strip().splitlines()[-1])
     assert errs["0"] < 4e-6 and errs["1"] < 4e-6, errs
+
+
+@pytest.mark.parametrize("shape", [(16384, 768, 3072), (16385, 1152, 1000), (8192, 3072, 768), (4096, 260, 772)],
+                         ids=["fc1_rows16k", "ragged_so400m", "fc2", "ragged_k260_n772"])
+def test_large_activation_times_weight_contractions_vs_fp64(shape):
+    """The same tile takes the LARGE K / K (y = x W^T + b) and K / T (dx = dy W) contractions -- 512 output tiles and more:
+    the dense layers of the matrix-core-bound heads over all B N token rows and the MLPs of the attention-pool heads --
+    with both operands split on the fly; the 1024-row contractions of the EP step stay on the LDS-DMA ring kernels."""
+    from efficient_probing_amd import functional as F_
+    M, K, N_ = shape
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N_, K, device=DEV, generator=g) * K ** -0.5
+    b = torch.randn(N_, device=DEV, generator=g)
+    y = F_.linear_forward(x, W, b)
+    want = x.double() @ W.double().t() + b.double()
+    assert rel_err(y, want) < 4e-6
+    dy = torch.randn(M, N_, device=DEV, generator=g)
+    dx, dW, db = F_.linear_backward(dy, x, W)
+    assert rel_err(dx, dy.double() @ W.double()) < 4e-6
+    # (the weight gradient sums over M = 4096 ... 16385 rows in fp32: rounding of the running sum grows like sqrt(K),
+    # for the exact-f32 instruction as well)
+    assert rel_err(dW, dy.double().t() @ x.double()) < 4e-6 * max(1.0, (M / 1024) ** 0.5)
+    y2 = F_.linear_forward(x, W, b)
+    assert torch.equal(y, y2)
