@@ -306,9 +306,19 @@ void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch) {
   sd.total += sd.gx[i] * sd.gy[i] * sd.gz[i];
 }
 
+bool side_add_colsum(SideTasks& sd, const float* src, int B, int ncol, int ld, int accumulate, float* out) {
+  if (sd.n_xcs >= 4) return false;
+  const int i = sd.n_xcs++;
+  sd.xcs_src[i] = src; sd.xcs_out[i] = out; sd.xcs_B[i] = B; sd.xcs_ncol[i] = ncol; sd.xcs_ld[i] = ld; sd.xcs_acc[i] = accumulate;
+  sd.xcs_blocks[i] = (ncol + 15) / 16;
+  sd.total += sd.xcs_blocks[i];
+  return true;
+}
+
 int side_run_standalone(const SideTasks& sd, hipStream_t st) {
   for (int i = 0; i < sd.n_gemm; ++i) EP_TRY(gemm(false, false, sd.g[i], sd.gz[i], st));
   if (sd.n_colsum) EP_TRY(colsum(sd.cs_src, sd.cs_B, sd.cs_ncol, sd.cs_ld, sd.cs_accumulate, sd.cs_out, st));
+  for (int i = 0; i < sd.n_xcs; ++i) EP_TRY(colsum(sd.xcs_src[i], sd.xcs_B[i], sd.xcs_ncol[i], sd.xcs_ld[i], sd.xcs_acc[i], sd.xcs_out[i], st));
   if (sd.n_stats) EP_TRY(ce_stats(sd.rowstat, sd.rs_B, sd.stats, st));
   return 0;
 }

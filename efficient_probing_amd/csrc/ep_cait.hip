@@ -406,11 +406,11 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   hipLaunchKernelGGL(ep_cait_scale_bwd_kernel, dim3(cgrid), dim3(256), 0, st, w.dc2, w.m2, pr.gamma_2, B, D, acc, w.dm2, gr.gamma_2,
                      (float*)nullptr);
   EP_LAUNCH_CHECK("ep_cait final-norm backward kernels");
-  EP_TRY(colsum(w.dm2, B, D, D, acc, gr.fc2_b, st));
+  if (!side_add_colsum(sd, w.dm2, B, D, D, acc, gr.fc2_b)) EP_TRY(colsum(w.dm2, B, D, D, acc, gr.fc2_b, st));
   EP_TRY(gemm(true, false, cgm(w.dm2, D, pr.fc2_w, Hd, w.dh1, Hd, B, Hd, D), 1, st));              // dh1 = dm2 W2
   hipLaunchKernelGGL(ep_gelu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.dh1);   // -> dpre
   EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
-  EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
+  if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
   EP_TRY(gemm(true, false, cgm(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.c1, w.stat2, pr.n2_w, w.dc2, B, D, w.dc1);
   EP_TRY(lnaffine_grad(w.dh2, w.c1, w.stat2, B, D, acc, gr.n2_w,
@@ -419,7 +419,7 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   hipLaunchKernelGGL(ep_cait_scale_bwd_kernel, dim3(cgrid), dim3(256), 0, st, w.dc1, w.z1, pr.gamma_1, B, D, acc, w.dz1, gr.gamma_1,
                      w.dcsum);
   EP_LAUNCH_CHECK("ep_cait block backward kernels");
-  EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
+  if (!side_add_colsum(sd, w.dz1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
   EP_TRY(gemm(true, false, cgm(w.dz1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                // dya = dz1 Wp
   EP_TRY(colsum(w.dya, B, D, D, 0, w.dbo, st));                                                    // d(Wv b1 + bv)
   EP_TRY(delta_rows(w.dya, w.ya, B * H, dh, w.ML2, st, w.bo, H));                                  // delta' = dO . (o - bias)

@@ -607,7 +607,16 @@ bool gemm_b3_on() {
 bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
   if (!gemm_b3_on() || p.K < 64 || p.cs_out) return false;
   if (!vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) || !vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB)) return false;
-  if (!a_k && !b_k) return !p.bias;
+  if (!a_k && !b_k) {
+    if (p.bias) return false;
+    // `side`: the contraction runs on a second queue BESIDE a token pass (shapes whose pass cannot carry it as side
+    // workgroups).  The tile's split instructions then compete with a vector-issue-bound stream, where the exact-f32
+    // kernel only uses the otherwise idle matrix pipe: 196 x 1024 0.536 against 0.522 ms, 256 x 1152 0.733 against 0.726 ms
+    // with it -- but 196 x 4096 (34 GFLOP of dWv beside the dP contraction, not beside a pass) 2.284 against 2.335 ms.
+    // So: side contractions only from 8 GFLOP.
+    if (p.side && 2.0 * p.M * p.N * (double)p.K * batch < 8e9) return false;
+    return true;
+  }
   if (!a_k) return false;                                      // (T / K does not occur)
   static long min_tiles = -1;
   if (min_tiles < 0) { const char* e = getenv("EP_GEMM_B3_MIN_TILES"); min_tiles = e ? atol(e) : 512; }

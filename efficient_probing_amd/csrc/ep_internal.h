@@ -99,6 +99,8 @@ struct SideTasks {
   int n_gemm;
   const float* cs_src; float* cs_out; int cs_B, cs_ncol, cs_ld, cs_accumulate, n_colsum;
   const float* rowstat; float* stats; int rs_B, n_stats;
+  // further column sums (bias gradients of the heads' dense layers: out[c] (+)= sum_b src[b][c]) -- side_add_colsum
+  const float* xcs_src[4]; float* xcs_out[4]; int xcs_B[4], xcs_ncol[4], xcs_ld[4], xcs_acc[4], xcs_blocks[4]; int n_xcs;
   int total;                        // number of extra workgroups
   int first_block;                  // set by the launcher: side workgroups occupy blocks [first_block, first_block + total)
   int xcd_order;                    // 1: tiles of a contraction are handed out XCD by XCD (run_side_task)
@@ -174,6 +176,8 @@ int linear_backward(const float* dl, int ldl, const float* z, const float* Wc, i
                     float* dWc, float* dbc, int accumulate, hipStream_t st);
 GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int C, float* dWc, int accumulate);
 void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch);
+// a bias gradient nothing consumes before the optimizer: as side workgroups too (false: the list is full -- launch it)
+bool side_add_colsum(SideTasks& sd, const float* src, int B, int ncol, int ld, int accumulate, float* out);
 // run the side tasks as stand-alone launches on `st` (kernel families that cannot carry them)
 int side_run_standalone(const SideTasks& sd, hipStream_t st);
 int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,

@@ -45,7 +45,19 @@ __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* l
     return;
   }
   t -= s.n_colsum;
-  if (t < s.n_stats) ce_stats_block(s.rowstat, s.rs_B, s.stats, reinterpret_cast<f4*>(lds_raw));
+  if (t < s.n_stats) { ce_stats_block(s.rowstat, s.rs_B, s.stats, reinterpret_cast<f4*>(lds_raw)); return; }
+  t -= s.n_stats;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < s.n_xcs) {
+      if (t < s.xcs_blocks[i]) {
+        colsum_block(s.xcs_src[i], s.xcs_B[i], s.xcs_ncol[i], s.xcs_ld[i], s.xcs_acc[i], s.xcs_out[i], t,
+                     reinterpret_cast<float (*)[CG]>(lds_raw));
+        return;
+      }
+      t -= s.xcs_blocks[i];
+    }
+  }
 }
 
 }  // namespace ep

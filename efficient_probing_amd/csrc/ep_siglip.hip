@@ -145,10 +145,11 @@ static int sig_backward_core(const ep_siglip_dims& d, const void* x, int x_dtype
     EP_TRY(gemm(true, false, g, d.H, st));
   }
   // bias gradients (column sums over the batch)
-  EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
-  EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
-  EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
-  EP_TRY(colsum(w.dya, B, D, D, acc, gr.kv_b + D, st));
+  // (nothing consumes them before the optimizer: side workgroups of the second pass, like the weight gradients)
+  if (!side_add_colsum(sd, dout, B, D, D, acc, gr.fc2_b)) EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
+  if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
+  if (!side_add_colsum(sd, w.dz1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
+  if (!side_add_colsum(sd, w.dya, B, D, D, acc, gr.kv_b + D)) EP_TRY(colsum(w.dya, B, D, D, acc, gr.kv_b + D, st));
   // weight gradients: nothing consumes them before the optimizer -> side tasks of the second token pass
   GemmParams gW2 = mkg(dout, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;       // dW2 = dout^T h1
   GemmParams gW1 = mkg(w.dh1, Hd, w.z1, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;       // dW1 = dpre^T z1
@@ -330,9 +331,9 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   EP_TRY(lnaffine_grad(w.dh2, w.q1, w.qstat, B, D, acc, gr.n2_w,
                      gr.n2_b, st));
   EP_LAUNCH_CHECK("ep_jepa LN2 backward kernels");
-  EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
-  EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
-  EP_TRY(colsum(w.dq1, B, D, D, acc, gr.proj_b, st));                                               // q1 = q0 + o Wp^T + bp
+  if (!side_add_colsum(sd, dout, B, D, D, acc, gr.fc2_b)) EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
+  if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
+  if (!side_add_colsum(sd, w.dq1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dq1, B, D, D, acc, gr.proj_b, st));   // q1 = q0 + o Wp^T + bp
   EP_TRY(gemm(true, false, mkg(w.dq1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                 // dya = dq1 Wp
   EP_TRY(colsum(w.dya, B, D, D, 0, w.dbo, st));                                                     // d(Wv b1 + bv)
   EP_TRY(delta_rows(w.dya, w.ya, B * d.H, dh, w.ML, st, w.bo, d.H));
