@@ -10,8 +10,9 @@ update.  Default workload: BASELINE.json configs[1] (DINOv2 ViT-B/14 tokens 256x
 1000 classes); ``--workload ns`` is the north-star shape (ViT-B/16, 197x768).
 
 One JSON line is printed by rank 0 (see the driver contract in the task statement) with two extra
-objects: ``roofline`` for the dominant kernel (the EP pooling forward pass, HBM-bound) measured
-live with HIP events, and ``cpu_baseline`` = the op-for-op torch-CPU port of the reference step
+objects: ``roofline`` for the dominant kernel of the step AS IT RUNS IN THE STEP (the second token pass, HBM-bound: it
+carries the in-pass dP tasks and the weight-gradient side workgroups; bracketed by the library's own HIP events; the first
+pass and both passes launched alone are sub-objects), and ``cpu_baseline`` = the op-for-op torch-CPU port of the reference step
 (oracle/torch_port.py) timed on this box's host cores for a bounded ~15 s sample.  The default EP run at N = 1 adds
 ``bf16_token_storage``: the same step on the same tokens stored as bf16 (fp32 arithmetic and results) -- a secondary
 figure, never ``value``.
@@ -149,6 +150,7 @@ def rendezvous_only(args, world, rank):
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 256 FLOP/cycle/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
+BF16X3_PEAK_TFLOPS = 2500.0 / 6  # fp32-accurate products on the bf16 pipe: six of the 2.5 PFLOP/s dense bf16 products each
 
 
 def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
@@ -210,6 +212,11 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
     torch.cuda.synchronize()
     t_k = e0.elapsed_time(e1) * 1e-3 / args.kernel_iters
     k_flop = 2.0 * B * Nn * D * (D if dolg else 3 * D)
+    # which kernel that was, and the peak it is priced against: the exact-f32 instruction (157 TFLOP/s) or -- large
+    # contractions since round 4 -- the bf16 x3 tile (csrc/ep_wgrad3.h): six bf16 MFMAs per 16 x 16 x 32 block, i.e. a sixth of
+    # the 2.5 PFLOP/s dense bf16 peak in fp32-equivalent FLOP
+    kname = eng.lib.ep_linear_kernel_name(B * Nn, D if dolg else 3 * D, D).decode()
+    k_peak = BF16X3_PEAK_TFLOPS if "b3" in kname else F32_MFMA_PEAK_TFLOPS
     # fwd + bwd, no token gradient (DOLG: the 1x1 convolution and its weight gradient)
     # DINOv2 block: 24 D^2 FLOP per token forward in the four projections; backward 32 D^2 (weight and input gradients of
     # qkv, proj and fc1 -- the fc2 ones collapse to per-image rows under the token mean, ep_dinovit.hip); attention 4 N^2 D
@@ -227,9 +234,11 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
                                                           else f", AbMILP head (self-attention + tanh predictor), {Cc} classes"),
                        "tokens": Nn, "dim": D, "classes": Cc, "batch_per_gpu": B, "global_batch": B * world,
                        "optimizer": "lars", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "ep_gemm_dma_kernel (" + ("1x1 convolution" if dolg else "qkv projection") + ")",
-                         "achieved": round(k_flop / t_k / 1e12, 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(k_flop / t_k / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": kname + " (" + ("1x1 convolution" if dolg else "qkv projection") + ")",
+                         "achieved": round(k_flop / t_k / 1e12, 1), "peak": k_peak, "unit": "TFLOP/s",
+                         "peak_note": ("bf16 x3 at fp32 accuracy: 2.5 PFLOP/s dense bf16 / 6 products per fp32 product" if "b3" in kname
+                                       else "v_mfma_f32_16x16x4_f32"),
+                         "frac": round(k_flop / t_k / 1e12 / k_peak, 4), "traffic": None,
                          "us_per_launch": round(t_k * 1e6, 1), "algorithmic_flop": k_flop,
                          "step_flop_per_image": step_flop_img,
                          "step_frac": round(value / world * step_flop_img / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},

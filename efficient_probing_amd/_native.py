@@ -311,6 +311,7 @@ SIGNATURES = {
     "ep_pool_backward_ln": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p,
                                     c_f32p, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_pool_kernel_name_ex": (C.c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ep_linear_kernel_name": (C.c_char_p, [c_int, c_int, c_int]),
     "ep_pool_forward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_f32p, c_i64, c_int, c_float,
                                 c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),
     "ep_pool_backward": (c_int, [c_void, c_int, c_i64, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p, c_f32p,

@@ -341,6 +341,12 @@ int ep_debug_set_pass_events(void* fwd_begin, void* fwd_end, void* bwd_begin, vo
 
 size_t ep_pool_workspace_bytes(int B, int N, int D, int Q) { return pool_workspace_bytes(B, N, D, Q); }
 const char* ep_pool_kernel_name(int B, int N, int D, int Q, int backward) { return pool_kernel_family(B, N, D, Q, backward); }
+const char* ep_linear_kernel_name(int M, int N, int K) {
+  GemmParams g{};
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+  g.A = reinterpret_cast<const float*>(uintptr_t(1) << 20); g.B = g.A;          // (only alignment is looked at)
+  return gemm_kernel_name(true, true, g, 1);
+}
 const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype) {
   return pool_kernel_family(B, N, D, Q, backward, x_dtype == EP_DTYPE_BF16);
 }

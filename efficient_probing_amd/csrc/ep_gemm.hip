@@ -624,6 +624,13 @@ bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
   return min_tiles > 0 && tiles64 >= min_tiles && p.K >= 256;
 }
 
+const char* gemm_kernel_name(bool a_k, bool b_k, const GemmParams& p, int batch) {
+  if (gemm_b3_ok(p, a_k, b_k, batch)) return "ep_gemm_b3_kernel";
+  if (gemm_kk96_ok(a_k, b_k, p, batch)) return "ep_gemm_kk96_kernel";
+  if (gemm_kt96_ok(a_k, b_k, p, batch)) return "ep_gemm_kt96_kernel";
+  return "ep_gemm_dma_kernel";
+}
+
 int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
   if (batch == 1 && p.skws) {

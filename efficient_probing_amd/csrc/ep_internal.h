@@ -136,6 +136,7 @@ constexpr int IP_YPARTS = 4;                                   // K quarters of 
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
 int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
+const char* gemm_kernel_name(bool a_k, bool b_k, const GemmParams& p, int batch);   // what gemm() would launch (family name)
 bool gemm_b3_on();                                             // EP_GEMM_B3 (default 1): T / T contractions on the bf16 x3 tile
 int debug_force_generic(int on);
 int token_stats(const void* x, int x_bf16, int64_t bstride, int B, int N, int D, float eps, float* stats, hipStream_t st);

@@ -99,6 +99,10 @@ int ep_pool_backward_ln(const void* x, int x_dtype, int64_t x_bstride, const int
                         ep_stream_t stream);
 /* same, for a given token storage type (EP_DTYPE_F32 / EP_DTYPE_BF16) */
 const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype);
+/* name of the device kernel a dense layer y = x W^T (x: M x K, W: N x K, both K-contiguous and 16-byte aligned) launches for
+ * this shape: "ep_gemm_b3_kernel" (bf16 x3 at fp32 accuracy, csrc/ep_wgrad3.h: large contractions) or one of the exact-f32
+ * kernels (for profiling / the bench's roofline object). */
+const char* ep_linear_kernel_name(int M, int N, int K);
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index,
                     int B, int N, int D,
                     const float* cls_token, int64_t cls_bstride, int Q, float scale,
