@@ -579,21 +579,30 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
 
 // ---- weight-gradient contractions (both operands summed over their SLOW index: T / T layout) on the bf16 matrix cores at
 // fp32 accuracy (ep_wgrad3.h): the stand-alone launch of the tile the second token pass runs as side work ----
+// EP_B3_STAGES=2 (A/B builds): the two-stage form of the tile (ep_wgrad3.h: gemm_tile_b3g2 -- 60 KiB of LDS, one barrier per
+// K-tile, rows fetched two tiles ahead).  Measured SLOWER in round 4 (same box, alternating): AbMILP 9.35 - 9.40 against
+// 8.86 - 8.93 ms per step, DINOv2 block 21.7 against 20.3 ms, 196 x 4096 2.38 - 2.41 against 2.365 - 2.374 ms -- two workgroups
+// per CU instead of four to five cover less of each other's barriers and LDS latency than the second barrier costs.
+#ifndef EP_B3_STAGES
+#define EP_B3_STAGES 1
+#endif
 template <bool A_K, bool B_K, int BMT>
 __global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
-  gemm_tile_b3g<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+  if constexpr (EP_B3_STAGES == 2) gemm_tile_b3g2<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+  else gemm_tile_b3g<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
 }
+constexpr size_t B3_KERNEL_LDS = EP_B3_STAGES * W3_LDS_BYTES;
 template <bool A_K, bool B_K>
 static void b3_launch(const GemmParams& p, int batch, bool m32, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_KERNEL_LDS);
+    (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_KERNEL_LDS);
     attr_set = true;
   }
-  if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), W3_LDS_BYTES, st, p);
-  else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), W3_LDS_BYTES, st, p);
+  if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), B3_KERNEL_LDS, st, p);
+  else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), B3_KERNEL_LDS, st, p);
 }
 // EP_GEMM_B3=0: T / T contractions back on the exact-f32 kernels
 bool gemm_b3_on() {

@@ -170,6 +170,93 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
   __syncthreads();                                   // LDS free for the caller's next tile
 }
 
+// The stand-alone form: TWO LDS stages (60 KiB) and two register sets.  Per K-tile ONE barrier; between it and the next a wave
+// reads tile it's fragments, then splits and stages tile it+1 (whose rows were fetched two tiles ahead) into the other
+// stage -- its ~110 vector instructions cover the fragment reads' latency -- and then issues tile it's matrix instructions
+// while the other resident wave of the SIMD is in its staging phase.  (The side-task form above keeps one stage: it has to
+// fit the LDS of the token pass it rides in.)
+template <bool A_K, bool B_K, int BMT>
+__device__ __forceinline__ void gemm_tile_b3g2(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  constexpr int MI = BMT / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * BMT, n0 = bx * 64;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int mq = tid & 15, kp = tid >> 4;
+  const bool stA = A_K || 4 * mq < BMT;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  f4v acc[MI][2];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  const int nk = (p.K + 31) / 32;
+  f4v xa[2][2], xb[2][2];                            // [register set][...]
+  auto load = [&](int t, f4v (&ra)[2], f4v (&rb)[2]) {
+    const int k0 = (t < nk ? t : nk - 1) * 32;       // (clamped: redundant, never out of range)
+    if constexpr (A_K) w3_load_K<BMT>(A, p.lda, p.M, p.K, m0, k0, tid, ra);
+    else w3_load_T(A, p.lda, extA, p.K, m0, k0, kp, stA ? mq : 0, ra);
+    if constexpr (B_K) w3_load_K<64>(B, p.ldb, p.N, p.K, n0, k0, tid, rb);
+    else w3_load_T(B, p.ldb, extB, p.K, n0, k0, kp, mq, rb);
+  };
+  auto stage = [&](int t, const f4v (&ra)[2], const f4v (&rb)[2]) {
+    char* imgA = lds + (t & 1) * (int)W3_LDS_BYTES;
+    char* imgB = imgA + 3 * W3_IMG;
+    if constexpr (A_K) w3_stage_K<BMT>(imgA, ra, p.M, p.K, m0, t * 32, tid);
+    else { if (stA) w3_stage_T(imgA, ra, extA, p.K, m0, t * 32, kp, mq); }
+    if constexpr (B_K) w3_stage_K<64>(imgB, rb, p.N, p.K, n0, t * 32, tid);
+    else w3_stage_T(imgB, rb, extB, p.K, n0, t * 32, kp, mq);
+  };
+  auto step = [&](int it, f4v (&ra_cur)[2], f4v (&rb_cur)[2], f4v (&ra_nxt)[2], f4v (&rb_nxt)[2]) {
+    // entering: tile `it` is staged (by every wave, before the barrier below), tile it+1's rows are in flight in *_nxt
+    __syncthreads();
+    const char* imgA = lds + (it & 1) * (int)W3_LDS_BYTES;
+    const char* imgB = imgA + 3 * W3_IMG;
+    pl_u4 fa[MI][3], fb[2][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fa[mi][t] = *reinterpret_cast<const pl_u4*>(imgA + t * W3_IMG + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3_IMG + w3_off(wn * 32 + ni * 16 + i16, kk));
+    if (it + 1 < nk) stage(it + 1, ra_nxt, rb_nxt);   // into the other stage: everyone left it before the barrier above
+    if (it + 2 < nk) load(it + 2, ra_cur, rb_cur);     // the set tile `it` came from is free
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+    }
+  };
+  load(0, xa[0], xb[0]);
+  load(1, xa[1], xb[1]);
+  stage(0, xa[0], xb[0]);
+  int it = 0;
+  for (; it + 1 < nk; it += 2) {
+    step(it, xa[0], xb[0], xa[1], xb[1]);
+    step(it + 1, xa[1], xb[1], xa[0], xb[0]);
+  }
+  if (it < nk) step(it, xa[0], xb[0], xa[1], xb[1]);
+  f4v blk[MI * 2]; int rb[MI * 2], cb[MI * 2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
+    }
+  store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
+}
+
 // the weight-gradient form (both operands T layout): what the token passes run as side work
 template <int BMT>
 __device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by, int bz, char* lds) {
