@@ -357,7 +357,8 @@ def main():
     lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
     eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0)
     if hasattr(eng, "defer_update"):
-        eng.defer_update = True          # (the loop below calls flush() before it stops the clock, as train_one_epoch does)
+        eng.defer_update = True          # (takes effect only with EP_DEFER_OPT=1 -- measured slower, engine._can_defer; the loop
+                                         # below calls flush() before it stops the clock, as train_one_epoch does)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     xs = [torch.randn(B, Nn, D, device=dev, generator=gen) for _ in range(args.buffers)]

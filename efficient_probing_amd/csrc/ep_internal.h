@@ -126,7 +126,7 @@ int pool_backward(const PoolParams& p, float* dcls, int accumulate, hipStream_t 
 bool pool_backward_takes_side(const PoolParams& p);
 bool pool_backward_takes_delta(const PoolParams& p, int Dv);   // ... and compute the delta rows itself (dyv / yv / Dv)
 // In-pass contractions (ep_inpass.h) possible for this shape on BOTH passes?  bit 0: y inside the first pass, bit 1: dP
-// inside the second (EP_INPASS=<mask> switches them, default 3).  Dv = width of the projection (must equal D).
+// inside the second (EP_INPASS=<mask> switches them; default 2: dP inside the second pass only).  Dv = width of the projection (must equal D).
 int pool_inpass_mask(const PoolParams& p, int Dv);
 struct StreamGridInfo { int grid, rounds, helpers; };          // pooling workgroups, ceil(B / grid), workgroups without an image of the last round
 StreamGridInfo pool_stream_grid(const PoolParams& p);

@@ -1,5 +1,6 @@
-// EXPERIMENT (opt-in: EP_GEMM_PLANES=2 classifier contractions, =1 all four; the default train step uses the f32
-// contraction kernels of ep_gemm.hip).
+// DEFAULT since round 4 for the classifier's two contractions at every D (EP_GEMM_PLANES unset = mode 2; mode 1 -- all four
+// critical-path contractions -- for D >= 2048; 0 = the exact-f32 kernels of ep_gemm.hip): the planes are written by the
+// optimizer's update kernel (ep_optim.hip: tile_update_emit, ep_planes_dev.h), so a step needs no split launch.
 // fp32 contractions against PRE-SPLIT weights on the gfx950 BF16 matrix cores, at fp32 accuracy.
 //
 // The head's four critical-path contractions (value projection y = P Wv_q^T, logits = z Wc^T, dz = dlogits Wc,

@@ -125,3 +125,39 @@ def test_folded_batchnorm_backward_matches_the_separate_launch(B, N, D, bf16, ex
     again = run({**base, "EP_BN_FOLD": "1"})                    # fixed summation orders: the same bits every run
     for k in ("p", "g", "mu"):
         assert torch.equal(on[k], again[k]), k
+
+
+def test_a_give_up_of_a_hand_off_wait_is_loud():
+    """a bounded wait that gives up used to leave the pass reading unfinished rows and the optimizer applying the
+    result silently.  Now the give-up count in the workspace makes every optimizer phase skip its update, set found_inf and
+    bump the non-finite row count of the step statistics (which stops engine_finetune.train_one_epoch) -- until the
+    workspace is initialised again (ep_head_workspace_init).  Simulated by poking the count."""
+    import ctypes
+    from argparse import Namespace
+    from efficient_probing_amd import probe_heads, _native as N
+    from efficient_probing_amd.engine import ProbeHeadEngine
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(256, 50)
+    torch.manual_seed(0)
+    enc = Enc()
+    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=8, d_out=1, nb_classes=50))
+    eng = ProbeHeadEngine(enc.head.to("cuda:0").train(), optimizer="lars", lr=0.4)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 20, 256, generator=g).to("cuda:0"); t = torch.randint(0, 50, (64,), generator=g).to("cuda:0")
+    eng.train_step(x, t)
+    assert eng.read_stats()[3] == 0 and int(eng.found_inf.item()) == 0
+    lib = N.load()
+    off = lib.ep_head_workspace_flag_offset(ctypes.byref(eng.dims))
+    before = eng.flat_p.clone()
+    eng._ws[off:off + 4].view(torch.int32).fill_(3)                # "three waits gave up"
+    eng.train_step(x, t)
+    torch.cuda.synchronize()
+    assert int(eng.found_inf.item()) == 1 and torch.equal(eng.flat_p, before)      # update skipped
+    assert eng.read_stats()[3] >= 1                                                  # ... and the training loop would stop
+    N.check(lib.ep_head_workspace_init(ctypes.byref(eng.dims), eng._ws.data_ptr(), eng._ws.numel(), N.current_stream_ptr(eng.device)), "init")
+    eng.train_step(x, t)
+    torch.cuda.synchronize()
+    assert int(eng.found_inf.item()) == 0 and not torch.equal(eng.flat_p, before) and eng.read_stats()[3] == 0
