@@ -56,6 +56,9 @@ def parse():
                     help="STRONG scaling at the published protocol's batch (reference README.md:119-120: effective batch 4096): the "
                          "per-GPU batch is G / --gpus and lr = 0.1 * G / 256 (main_linprobe.py:572-573) whatever N is; the line then "
                          "says \"scaling\": \"strong\"")
+    ap.add_argument("--queries", type=int, default=None,
+                    help="EP head: number of learned queries (default: the workload's, 8 for the BASELINE configurations; the "
+                         "published accuracy rows of the reference use --ep_queries 32, README.md:133-134)")
     ap.add_argument("--spinup", type=int, default=40,
                     help="untimed steps run during setup, before the W warm-up steps, so that the chip's clock has settled under load")
     ap.add_argument("--mark-every", type=int, default=10, help="steps between the device events the step-time spread is read from")
@@ -311,6 +314,9 @@ def main():
     args._scaling = scaling
     if args.head in ("abmilp", "dolg", "dinovit"):
         return bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B)
+    if args.queries and args.head == "ep":
+        Q = args.queries
+        desc = desc.replace("EP q=8", f"EP q={Q}").replace("EP q=1", f"EP q={Q}")
     if args.head == "coca":
         Q = 8                                              # 8 query heads of image query 0 (coca_pytorch.py:259)
         desc = desc.split(",")[0] + f", CoCa pooler (8 heads x 64, 196 image queries), {Cc} classes"
@@ -415,7 +421,7 @@ def main():
 
     # ---- data parallel (N > 1): the one exchange step of the path alone, and the two schedules side by side ----
     dp_obj = None
-    if world > 1 and args.head == "ep":
+    if world > 1 and args.head == "ep" and os.environ.get("EP_BENCH_DP_OBJECT", "1") != "0":
         # (a) the flat-gradient all-reduce of a step, event-bracketed in untimed steps (forward/backward, all-reduce, update
         # as three calls -- what train_step does for N > 1)
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -378,9 +378,38 @@ static bool use_wide(const PoolParams& p) {
   return !needs_generic(p) && !p.tokstat && pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
 }
 
+// More queries than the fast kernel families take at this row width -- Q > 16 beyond D = 768, Q > 8 for the wide-row kernels:
+// the reference's PUBLISHED rows all train with --ep_queries 32 (README.md:133-134), on 1024-, 1152- and 4096-wide tokens among
+// others, and those shapes used to fall to the generic kernel (196 x 1024, Q = 32: 8.7 ms per pass, 18.6 ms per step).  The pass
+// then runs in CHUNKS of queries on the fast family (PoolParams.Qs keeps the memory stride): the tokens are read once per
+// chunk -- two reads at Q = 32 on the all-matrix-core kernel, four on the wide-row kernel -- instead of once at L2 speed.
+// Returns the chunk size, 0 = no chunking.
+static int query_chunk(const PoolParams& p, bool bwd) {
+  if (needs_generic(p) || p.tokstat || force_generic() || pool_mode() != 0 || p.Q <= 8) return 0;
+  if (use_wide(p) || use_mb(p) || use_mm(p, bwd) || use_mf(p, bwd)) return 0;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_POOL_QCHUNK"); on = e ? atoi(e) : 1; }
+  if (!on) return 0;
+  if (p.x_bf16 && p.Q > 16) {            // bf16 tokens: two reads on the matrix-core pass beat one on the widening vector-ALU kernel
+    PoolParams q = p;                    // (256 x 768, Q = 32: 500 / 454 us per pass on the vector-ALU kernel)
+    q.Q = 16;
+    if (use_mb(q)) return 16;
+  }
+  const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+  if (c.ok && stream_takes(p)) return 0;
+  for (int qc = 16; qc >= 8; qc -= 8) {
+    if (p.Q <= qc) continue;
+    PoolParams q = p;
+    q.Q = qc;
+    if (use_wide(q) || use_mb(q) || use_mm(q, bwd) || use_mf(q, bwd)) return qc;
+  }
+  return 0;
+}
+
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) {
   PoolParams p{};
   p.B = B; p.N = N; p.D = D; p.Q = Q; p.x_bf16 = x_bf16;
+  if (const int qc = query_chunk(p, bwd != 0)) p.Q = qc;          // (the family the chunks run on)
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
   if (use_mb(p)) return mb_kernel_name(D, bwd != 0);
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
@@ -398,6 +427,16 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
+  if (const int qc = query_chunk(p, false)) {
+    const int qs = p.Qs ? p.Qs : p.Q;
+    for (int q0 = 0; q0 < p.Q; q0 += qc) {
+      PoolParams q = p;
+      q.Q = (p.Q - q0) < qc ? (p.Q - q0) : qc; q.Qs = qs;
+      q.cls = p.cls + (int64_t)q0 * p.D; q.P = p.P + (int64_t)q0 * p.D; q.S = p.S + (int64_t)q0 * p.N; q.ML = p.ML + (int64_t)q0 * 4;
+      EP_TRY(pool_forward(q, st));
+    }
+    return 0;
+  }
   // per-image query rows with score extras (CLIP): every token read once for all heads instead of once per head
   if (needs_generic(p) && !force_generic() && imgqf_supported(p)) return imgqf_forward(p, st);
   if (use_wide(p)) return wide_launch(false, p, wide_grid(p.D, p.B, p.x_bf16), st);
@@ -516,6 +555,18 @@ StreamGridInfo pool_stream_grid(const PoolParams& p) {
 int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side,
                   DeferredReduce* defer) {
   PoolParams p = p0;
+  if (const int qc = query_chunk(p, true)) {
+    EP_REQUIRE(!side || side->total == 0, EP_E_UNSUPPORTED, "pool_backward: side tasks with a chunked pass");
+    const int qs = p.Qs ? p.Qs : p.Q;
+    for (int q0 = 0; q0 < p.Q; q0 += qc) {
+      PoolParams q = p;
+      q.Q = (p.Q - q0) < qc ? (p.Q - q0) : qc; q.Qs = qs;
+      q.dP = p.dP + (int64_t)q0 * p.D; q.S = p.S + (int64_t)q0 * p.N; q.ML = p.ML + (int64_t)q0 * 4;
+      EP_TRY(pool_backward(q, dcls + (int64_t)q0 * p.D, accumulate, st, nullptr, nullptr));
+    }
+    if (defer) defer->stage = nullptr;
+    return 0;
+  }
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   int nparts;
   EP_REQUIRE(!side || side->total == 0 || pool_backward_takes_side(p), EP_E_UNSUPPORTED,

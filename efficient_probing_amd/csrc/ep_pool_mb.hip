@@ -265,6 +265,7 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const bool n4 = (N & 3) == 0;
   const int tiles_per_img = (N + MB_TT - 1) / MB_TT;
   const int G = gridDim.x, wg = blockIdx.x;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
     if (w < 8 && g == (w >> 1) && j < Q) {
       const int blk = w & 1;
       const int t0 = 16 * blk + 4 * g;
-      float* Srow = p.S + ((int64_t)b * Q + j) * N + n0 + t0;
+      float* Srow = p.S + ((int64_t)b * QS + j) * N + n0 + t0;
       const float s0 = blk ? sc[4] : sc[0], s1 = blk ? sc[5] : sc[1], s2 = blk ? sc[6] : sc[2], s3 = blk ? sc[7] : sc[3];
       if (n4) {
         if (t0 < nvalid) *reinterpret_cast<f4*>(Srow) = f4{s0, s1, s2, s3};
@@ -381,12 +382,12 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_fwd_kernel(PoolParams p) {
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
       if (j < Q) {
-        float* Pq = p.P + ((int64_t)b * Q + j) * D + 32 * NK * w + 8 * g;
+        float* Pq = p.P + ((int64_t)b * QS + j) * D + 32 * NK * w + 8 * g;
 #pragma unroll
         for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
         if (w == 0 && g == 0) {
           const f4 rec = {m_j, l, 0.f, 0.f};
-          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + j) * 4) = rec;
+          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * QS + j) * 4) = rec;
         }
       }
       ctile = 0; ++cimg;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p) {
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const bool n4 = (N & 3) == 0;
   const int tiles_per_img = (N + MB_TT - 1) / MB_TT;
   const int G = gridDim.x, wg = blockIdx.x;
@@ -438,19 +440,19 @@ __global__ __launch_bounds__(NW * 64) void ep_pool_mb_bwd_kernel(PoolParams p) {
     f4 hq[NK][2], hml;
     auto load_header = [&](int img) {
       const int b = wg + img * G;
-      const float* src = p.dP + ((int64_t)b * Q + jq) * D + 32 * NK * w + 8 * g;
+      const float* src = p.dP + ((int64_t)b * QS + jq) * D + 32 * NK * w + 8 * g;
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
         hq[ks][0] = *reinterpret_cast<const f4*>(src + 32 * ks);
         hq[ks][1] = *reinterpret_cast<const f4*>(src + 32 * ks + 4);
       }
-      hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
+      hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * QS + jq) * 4);
     };
     // saved scores of tile (img, tile): S[b, j, n0 + 16 blk + 4 g + r]
     float sv[8];
     auto load_scores = [&](int img, int tl) {
       const int b = wg + img * G;
-      const float* Srow = p.S + ((int64_t)b * Q + jq) * N;
+      const float* Srow = p.S + ((int64_t)b * QS + jq) * N;
       const int n0 = tl * MB_TT;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const bool n4 = (N & 3) == 0;
   const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
   const int G = gridDim.x, wg = blockIdx.x;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       if (it > 0) {
         mb2_pool<NK>(ptile_, poff, pseg, pwgt, accE, accO);
         if (w == ((it - 1) & 3) && j < Q) {         // every wave holds the same scores: one writes the tile
-          float* Srow = p.S + ((int64_t)pb * Q + j) * N + pn0 + 4 * g;
+          float* Srow = p.S + ((int64_t)pb * QS + j) * N + pn0 + 4 * g;
           if (n4) {
             if (4 * g < pnvalid) *reinterpret_cast<f4*>(Srow) = f4{psc[0], psc[1], psc[2], psc[3]};
           } else {
@@ -725,12 +728,12 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
           const float l = mb_q4_sum(lsum);
           const float inv = 1.0f / l;
           if (j < Q) {
-            float* Pq = p.P + ((int64_t)pb * Q + j) * D + 32 * NK * w + 8 * g;
+            float* Pq = p.P + ((int64_t)pb * QS + j) * D + 32 * NK * w + 8 * g;
 #pragma unroll
             for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
             if (w == 0 && g == 0) {
               const f4 rec = {m_j, l, 0.f, 0.f};
-              *reinterpret_cast<f4*>(p.ML + ((int64_t)pb * Q + j) * 4) = rec;
+              *reinterpret_cast<f4*>(p.ML + ((int64_t)pb * QS + j) * 4) = rec;
             }
           }
         }
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       lsum += wgt[e];
     }
     if (w == (it & 3) && j < Q && (!MB_ABLATE || p.ablate != 4)) {  // every wave holds the same scores: one writes the tile
-      float* Srow = p.S + ((int64_t)b * Q + j) * N + n0 + 4 * g;
+      float* Srow = p.S + ((int64_t)b * QS + j) * N + n0 + 4 * g;
       if (n4) {
         if (4 * g < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[0], sc[1], sc[2], sc[3]};
       } else {
@@ -831,12 +834,12 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
       if (j < Q) {
-        float* Pq = p.P + ((int64_t)b * Q + j) * D + 32 * NK * w + 8 * g;
+        float* Pq = p.P + ((int64_t)b * QS + j) * D + 32 * NK * w + 8 * g;
 #pragma unroll
         for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
         if (w == 0 && g == 0) {
           const f4 rec = {m_j, l, 0.f, 0.f};
-          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + j) * 4) = rec;
+          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * QS + j) * 4) = rec;
         }
       }
       ctile = 0; ++cimg;
@@ -865,6 +868,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const bool n4 = (N & 3) == 0;
   const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
   const int n_img = (p.B - wg + G - 1) / G;
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
     float sv[4];
     auto load_scores = [&](int img, int tl) {
       const int b = wg + img * G;
-      const float* Srow = p.S + ((int64_t)b * Q + jq) * N;
+      const float* Srow = p.S + ((int64_t)b * QS + jq) * N;
       int t0 = tl * MB2_TT + 4 * g;
       if (n4) {
         t0 = t0 < N ? t0 : N - 4;
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
     float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
     int cimg = 0, ctile = 0, cslot = 0;
     // a dP row chunk: plain load, or -- rows produced inside this launch by the in-pass tasks -- an sc1 buffer load
-    const __amdgpu_buffer_rsrc_t rP = ip_rsrc(p.dP, (size_t)p.B * Q * D * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = ip_rsrc(p.dP, (size_t)p.B * QS * D * sizeof(float));
     auto ld_dp = [&](const float* src, int off) -> f4 {
       if constexpr (IPOK) {
         if (p.ip_dy) return ip_load16_coherent(rP, (unsigned)((src - p.dP + off) * (int64_t)sizeof(float)));
@@ -970,8 +974,8 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
         const char* tile = ring + cslot * SLOT;
         if (live && ctile == 0) {
           const int b = wg + cimg * G;                 // new image: its dP rows (this wave's slice) and ML row; the other
-          const float* src = p.dP + ((int64_t)b * Q + jq) * D + 32 * NK * w + 8 * g;      // workgroup of the CU covers the wait
-          const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
+          const float* src = p.dP + ((int64_t)b * QS + jq) * D + 32 * NK * w + 8 * g;      // workgroup of the CU covers the wait
+          const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * QS + jq) * 4);
 #pragma unroll
           for (int ks = 0; ks < NK; ++ks) {
             const f4 a = ld_dp(src, 32 * ks), c = ld_dp(src, 32 * ks + 4);
@@ -1030,8 +1034,8 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
       cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
       if (ctile == 0) {                              // new image: its dP rows (this wave's slice) and ML row; the other
         const int b = wg + cimg * G;                 // workgroup of the CU covers the wait
-        const float* src = p.dP + ((int64_t)b * Q + jq) * D + 32 * NK * w + 8 * g;
-        const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + jq) * 4);
+        const float* src = p.dP + ((int64_t)b * QS + jq) * D + 32 * NK * w + 8 * g;
+        const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * QS + jq) * 4);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
           const f4 a = ld_dp(src, 32 * ks), c = ld_dp(src, 32 * ks + 4);

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_fwd_kernel(PoolParam
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const int tiles_per_img = (N + MF_TT - 1) / MF_TT;
   const int G = gridDim.x, wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_fwd_kernel(PoolParam
       const float pr = __builtin_amdgcn_exp2f(fmaf(ue, MF_LOG2E, -mL_l));
       lsum_l += pr;
       if (lane < 8 * QP && valid && (qbase + qi_l) < Q)
-        p.S[((int64_t)b * Q + q_l) * N + (unsigned)(n0 + t_l)] = s;
+        p.S[((int64_t)b * QS + q_l) * N + (unsigned)(n0 + t_l)] = s;
       MF_STAMP(6)
       mf_pool<NG, QP>(tile, MF_HT * h, rows, pr, lane16, acc);
       MF_STAMP(7)
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_fwd_kernel(PoolParam
             const float f2 = __builtin_amdgcn_exp2f((m2 - mn) * MF_LOG2E);
             const float l = l1 * f1 + l2 * f2;
             const float i1 = f1 / l, i2 = f2 / l;
-            float* Pq = p.P + ((int64_t)b * Q + q) * D;
+            float* Pq = p.P + ((int64_t)b * QS + q) * D;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
               const f4 other = *reinterpret_cast<const f4*>(scratch + ((r * QP + qi) * KP + k) * 1024 + lane16);
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_fwd_kernel(PoolParam
             }
             if (lane == 0) {
               const f4 rec = {mn, l, 0.f, 0.f};
-              *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + q) * 4) = rec;
+              *reinterpret_cast<f4*>(p.ML + ((int64_t)b * QS + q) * 4) = rec;
             }
           }
         }
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_bwd_kernel(PoolParam
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const int tiles_per_img = (N + MF_TT - 1) / MF_TT;
   const int items_per_img = 1 + tiles_per_img;
   const int G = gridDim.x, wg = blockIdx.x;
@@ -429,10 +431,10 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_bwd_kernel(PoolParam
         char* slot = ring + pslot * SLOT;
         char* small = small_base + (pslot * MF_NW + w) * 256;
         if (pidx == 0) {
-          const char* src = reinterpret_cast<const char*>(p.dP + (int64_t)b * Q * D);
+          const char* src = reinterpret_cast<const char*>(p.dP + (int64_t)b * QS * D);
           const int rows = Q < MF_TT ? Q : MF_TT;
           mf_dma_tile<NG>(src, (unsigned)(rows * ROWB - 16), slot, w, soff);
-          const float* ms = p.ML + ((int64_t)b * Q + hq) * 4 + (lane & 3);      // lane = 4*qi + field
+          const float* ms = p.ML + ((int64_t)b * QS + hq) * 4 + (lane & 3);      // lane = 4*qi + field
           __builtin_amdgcn_global_load_lds((gptr_t)ms, (lds_ptr_t)small, 4, 0, 0);
         } else {
           const int n0 = (pidx - 1) * MF_TT;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(MF_NW * 64, 2) void ep_pool_mf_bwd_kernel(PoolParam
           const char* src = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, b) + (int64_t)n0 * D);
           mf_dma_tile<NG>(src, (unsigned)(rows * ROWB - 16), slot, w, soff);
           int nn = n0 + t_l; nn = nn < N ? nn : N - 1;
-          const float* ss = p.S + ((int64_t)b * Q + q_l) * N + nn;              // lane = 8*qi + tt
+          const float* ss = p.S + ((int64_t)b * QS + q_l) * N + nn;              // lane = 8*qi + tt
           __builtin_amdgcn_global_load_lds((gptr_t)ss, (lds_ptr_t)small, 4, 0, 0);
         }
         ++pi;

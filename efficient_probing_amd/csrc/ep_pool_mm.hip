@@ -174,6 +174,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const int tiles_per_img = (N + MM_TT - 1) / MM_TT;
   const int G = gridDim.x, wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
     if (w == 0 && j < Q) {                          // every wave holds the same scores: one writes them
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        if ((4 * s + kk) < nvalid) p.S[((int64_t)b * Q + j) * N + (unsigned)(n0 + 4 * s + kk)] = sc[s];
+        if ((4 * s + kk) < nvalid) p.S[((int64_t)b * QS + j) * N + (unsigned)(n0 + 4 * s + kk)] = sc[s];
     }
     mm_pool<NG>(tile, plane, w, wgt, acc);
     if (ctile == tiles_per_img - 1) {
@@ -298,12 +299,12 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
       const float inv = 1.0f / l;
       const float shift = LN ? q4_sum(c2) * inv : 0.f;                        // sum_n A rstd_n mean_n
       if (j < Q) {
-        float* Pq = p.P + ((int64_t)b * Q + j) * D + 16 * NG * w + 4 * kk;      // rows i = 4*kk + r of each block
+        float* Pq = p.P + ((int64_t)b * QS + j) * D + 16 * NG * w + 4 * kk;      // rows i = 4*kk + r of each block
 #pragma unroll
         for (int blk = 0; blk < NG; ++blk) *reinterpret_cast<f4*>(Pq + 16 * blk) = acc[blk] * inv - shift;
         if (w == 0 && kk == 0) {
           const f4 rec = {m_j, l, 0.f, 0.f};
-          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + j) * 4) = rec;
+          *reinterpret_cast<f4*>(p.ML + ((int64_t)b * QS + j) * 4) = rec;
         }
       }
       ctile = 0; ++cimg;
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const int tiles_per_img = (N + MM_TT - 1) / MM_TT;
   const int items_per_img = 1 + tiles_per_img;
   const int G = gridDim.x, wg = blockIdx.x;
@@ -362,11 +364,11 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
         char* slot = ring + pslot * SLOT;
         char* small = small_base + pslot * SMALLB;
         if (pidx == 0) {
-          const char* src = reinterpret_cast<const char*>(p.dP + (int64_t)b * Q * D);
+          const char* src = reinterpret_cast<const char*>(p.dP + (int64_t)b * QS * D);
           const int rows = Q < MM_TT ? Q : MM_TT;
           mm_dma_tile<NG>(src, (unsigned)(rows * ROWB - 16), slot, w, soff);
           int hq = lane < Q ? lane : Q - 1;                                       // ML[b, lane, 0:4]
-          const float* ms = p.ML + ((int64_t)b * Q + hq) * 4;
+          const float* ms = p.ML + ((int64_t)b * QS + hq) * 4;
           __builtin_amdgcn_global_load_lds((gptr_t)ms, (lds_ptr_t)(small + 1024), 16, 0, 0);   // lanes 0-15 matter
         } else {
           const int n0 = (pidx - 1) * MM_TT;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_bwd_kernel(PoolParam
           const char* src = reinterpret_cast<const char*>(p.x + EP_IMG_OFF(p, b) + (int64_t)n0 * D);
           mm_dma_tile<NG>(src, (unsigned)(rows * ROWB - 16), slot, w, soff);
           int nn = n0 + (se & 15); nn = nn < N ? nn : N - 1;
-          const float* ss = p.S + ((int64_t)b * Q + sq) * N + nn;
+          const float* ss = p.S + ((int64_t)b * QS + sq) * N + nn;
           char* sdst = small + 256 * (w & 3);
           if (LN && w >= 4) {                         // waves 4-7 (duplicates of 0-3 otherwise) fetch the tile's {mean, rstd}
             int e = n0 * 2 + (lane & 31); e = e < 2 * N ? e : 2 * N - 1;

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const int Ds = KPW * 256;
   const int sbase = w * Ds;                                   // first element of this wave's slice inside a row
   char* ring = lds + (size_t)w * NITEM * Cfg::ITEM_BYTES;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
     }
     const float pr = __builtin_amdgcn_exp2f(fmaf(ue, W_LOG2E, -mL));
     lsum += pr;
-    if (w == 0 && lane < 16 && valid && myq < Q) p.S[((int64_t)b * Q + myq) * N + n0 + myt] = u;
+    if (w == 0 && lane < 16 && valid && myq < Q) p.S[((int64_t)b * QS + myq) * N + n0 + myt] = u;
 #pragma unroll
     for (int q = 0; q < WQ; ++q)
 #pragma unroll
@@ -236,13 +237,13 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_fwd_kernel(PoolParam
       for (int q = 0; q < WQ; ++q)
         if (q < Q) {
           const float iq = readlane_f(inv, 2 * q);
-          float* Pq = p.P + ((int64_t)b * Q + q) * D + sbase;
+          float* Pq = p.P + ((int64_t)b * QS + q) * D + sbase;
 #pragma unroll
           for (int k = 0; k < KPW; ++k) *reinterpret_cast<f4*>(Pq + Cfg::eoff(k, lane)) = acc[q][k] * iq;
         }
       if (w == 0 && lane < 16 && myt == 0 && myq < Q) {
         const f4 rec = {m, l, 0.f, 0.f};
-        *reinterpret_cast<f4*>(p.ML + ((int64_t)b * Q + myq) * 4) = rec;
+        *reinterpret_cast<f4*>(p.ML + ((int64_t)b * QS + myq) * 4) = rec;
       }
       cit = 0; ++cimg;
     } else {
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;          // queries per image in memory (a launch may cover a chunk of them)
   const int Ds = KPW * 256;
   const int sbase = w * Ds;
   char* ring = lds + (size_t)w * NITEM * Cfg::ITEM_BYTES;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
           Cfg::dma_tok(src + (int64_t)n * D * ES, slot, t, lane);
         }
         int nn = pit * WTB + myt; nn = nn < N ? nn : N - 1;   // raw score of my (query, token) pair
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.S + ((int64_t)b * Q + sq) * N + nn),
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.S + ((int64_t)b * QS + sq) * N + nn),
                                          (lds_ptr_t)(slot + Cfg::ITEM_TOK_BYTES), 4, 0, 0);
         ++pi;
         pslot = (pslot + 1 == NITEM) ? 0 : pslot + 1;
@@ -314,10 +316,10 @@ __global__ __launch_bounds__(WNW * 64, 2) void ep_pool_wide_bwd_kernel(PoolParam
 #pragma unroll
           for (int k = 0; k < KPW; ++k) {
             f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < Q) v = *reinterpret_cast<const f4*>(p.dP + ((int64_t)b * Q + q) * D + sbase + Cfg::eoff(k, lane));
+            if (q < Q) v = *reinterpret_cast<const f4*>(p.dP + ((int64_t)b * QS + q) * D + sbase + Cfg::eoff(k, lane));
             gq[q][k] = v;
           }
-        const f4 ml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * Q + sq) * 4);
+        const f4 ml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * QS + sq) * 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mLq = ml.x * W_LOG2E; il = 1.0f / ml.y; dl = ml.z;
       } else {

@@ -225,3 +225,47 @@ def test_fused_lars_steps_on_the_benchmarked_paths_vs_torch_port(path):
     with torch.no_grad():
         want = port(x)
     np.testing.assert_allclose(eng.eval_logits(xd).cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+# The reference's PUBLISHED rows train with --ep_queries 32 (README.md:133-134).  Beyond D = 768 (and for bf16-stored tokens) that
+# is more queries than one launch of the fast kernel families takes: the passes then run in chunks of 16 (8 for the wide-row
+# kernels) with the memory stride of all 32 (csrc/ep_pool.hip: query_chunk) -- not on the generic kernel.
+Q32 = [((64, 196, 1024, 32), "f32"), ((64, 196, 1024, 32), "bf16"), ((48, 256, 1152, 32), "f32"), ((24, 50, 4096, 32), "f32"),
+       ((24, 50, 4096, 32), "bf16"), ((48, 100, 768, 32), "bf16"), ((40, 64, 1152, 24), "f32"), ((16, 40, 2048, 20), "f32")]
+
+
+@pytest.mark.parametrize("case", Q32, ids=[f"{s[0]}x{s[1]}x{s[2]}_q{s[3]}_{t}" for s, t in Q32])
+def test_protocol_query_counts_run_chunked_on_the_fast_kernels_vs_fp64(case):
+    from efficient_probing_amd import functional as F_, _native
+    (B, Nn, D, Q), storage = case
+    lib = _native.load()
+    gen = torch.Generator(device=DEV).manual_seed(3 + D + Q)
+    x = torch.randn(B, Nn, D, device=DEV, generator=gen)
+    if storage == "bf16":
+        x = x.to(torch.bfloat16)
+    cls = torch.randn(Q, D, device=DEV, generator=gen) * 0.7
+    dP = torch.randn(B, Q, D, device=DEV, generator=gen)
+    scale = D ** -0.5
+    for bwd in (0, 1):
+        name = lib.ep_pool_kernel_name_ex(B, Nn, D, Q, bwd, 1 if storage == "bf16" else 0).decode()
+        assert "generic" not in name, name
+    P, S, ML = F_.pool_forward(x, cls, scale)
+    Pref, Sref, dref = fp64_reference(x.float(), cls, scale, dP, chunk=16)
+    assert torch.allclose(S.double(), Sref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(P.double(), Pref, rtol=1e-5, atol=2e-6)
+    ML2 = ML.clone()
+    ML2[:, :, 2] = (dP.double() * Pref).sum(-1).float()
+    dcls = F_.pool_backward(x, S, ML2, dP, scale)
+    assert torch.allclose(dcls.double(), dref, rtol=1e-4, atol=2e-5 * float(dref.abs().max()))
+    # accumulate into an existing gradient, and the generic kernel as the independent implementation
+    base = torch.randn_like(dcls)
+    acc = F_.pool_backward(x, S, ML2, dP, scale, dcls=base.clone(), accumulate=True)
+    assert torch.allclose(acc, base + dcls, rtol=1e-5, atol=1e-5 * float(dcls.abs().max()))
+    lib.ep_debug_force_generic_pool(1)
+    try:
+        Pg, Sg, MLg = F_.pool_forward(x, cls, scale)
+    finally:
+        lib.ep_debug_force_generic_pool(0)
+    # (the row "max" of ML is the kernels' lazily updated running maximum: only the attention it defines is comparable)
+    assert torch.allclose(P, Pg, rtol=2e-5, atol=2e-5)
+    assert torch.allclose(F_.attention_from_scores(S, ML), F_.attention_from_scores(Sg, MLg), rtol=2e-5, atol=1e-6)
