@@ -168,8 +168,11 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
 # the reference step -- fed the ROUNDED tokens for bf16 storage (the contract of that mode: fp32 arithmetic on the stored
 # values) -- not against other kernels of this library.
 PATHS = [((256, 196, 4096, 8), "f32"), ((256, 196, 4096, 8), "bf16"), ((1024, 256, 768, 8), "bf16"), ((1024, 197, 768, 8), "bf16"),
-         ((1024, 196, 1024, 8), "bf16"), ((512, 196, 384, 1), "bf16")]
-PATH_IDS = ["c5_b256_f32_planes", "c5_b256_bf16", "c2_b1024_bf16", "ns_b1024_bf16", "c3_b1024_bf16", "c1_b512_bf16"]
+         ((1024, 196, 1024, 8), "bf16"), ((512, 196, 384, 1), "bf16"),
+         # the published protocol's 32 queries (README.md:133-134) on the chunked passes (csrc/ep_pool.hip: query_chunk)
+         ((256, 196, 1024, 32), "f32"), ((256, 256, 768, 32), "bf16")]
+PATH_IDS = ["c5_b256_f32_planes", "c5_b256_bf16", "c2_b1024_bf16", "ns_b1024_bf16", "c3_b1024_bf16", "c1_b512_bf16",
+            "c3_b256_q32_f32_chunked", "c2_b256_q32_bf16_chunked"]
 
 
 @pytest.mark.parametrize("path", PATHS, ids=PATH_IDS)
@@ -187,7 +190,7 @@ def test_fused_lars_steps_on_the_benchmarked_paths_vs_torch_port(path):
     kname = lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1 if storage == "bf16" else 0).decode()
     assert "generic" not in kname, kname
     if storage == "bf16" and D <= 1024:
-        assert "mb2" in kname, kname                                   # the matrix-core pass that carries the side tasks
+        assert "mb2" in kname, kname                                   # the matrix-core pass (Q = 8: it carries the side tasks)
     byname = dict(port.named_parameters())
     pparams = [byname["0.cls_token"], byname["0.v.weight"], byname["2.weight"], byname["2.bias"]]
     mus = [torch.zeros_like(p) for p in pparams]
