@@ -190,10 +190,20 @@ class ProbeHeadEngine:
     # optimizer phase over the weight matrices rewrites them as it updates.  They stay valid as long as nobody else writes
     # the parameters: every torch-side write (load_state_dict, broadcast into .data, an optimizer of torch's own ...) bumps
     # the flat buffer's version counter, the library's kernels do not.
+    def _param_versions(self):
+        """What changes when anybody writes the parameters through torch: the version counters of the Parameters (their
+        ``.data`` are views of the flat buffer but each keeps its OWN counter -- ``load_state_dict``, an optimizer of
+        torch's own, ``p.copy_`` / ``p.add_`` under no_grad all bump it) and of the flat buffer itself.  Writes through
+        ``p.data`` (``p.data.copy_(...)``) are invisible to every version counter: after one, call ``invalidate_planes()``."""
+        return (self._ws.data_ptr(), self.flat_p._version) + tuple(p._version for p in self.params_list)
+
+    def invalidate_planes(self) -> None:
+        """Make the next step split the weight planes itself (after parameter writes that bypass torch's version counters)."""
+        self._planes_token = None
+
     def _planes_current(self) -> bool:
         tok = getattr(self, "_planes_token", None)
-        return (tok is not None and self._ws is not None and tok == (self._ws.data_ptr(), self.flat_p._version)
-                and type(self) is ProbeHeadEngine)
+        return (tok is not None and self._ws is not None and type(self) is ProbeHeadEngine and tok == self._param_versions())
 
     def _planes_after_call(self, phases: int, first_seg: int = 0, num_segs: int = 0) -> None:
         if type(self) is not ProbeHeadEngine or self._ws is None:
@@ -202,7 +212,7 @@ class ProbeHeadEngine:
         if phases & (1 | 8):
             established = True                               # the step made them valid for the parameters it ran on
         # (an optimizer phase never invalidates them: whichever matrices it updates, it rewrites their planes)
-        self._planes_token = (self._ws.data_ptr(), self.flat_p._version) if established else None
+        self._planes_token = self._param_versions() if established else None
 
     # ------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor,

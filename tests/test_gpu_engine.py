@@ -340,3 +340,43 @@ def test_epoch_meters_read_one_window_behind_account_every_step():
     args = Namespace(**{**vars(ARGS), "lr": 0.05, "min_lr": 0.05, "warmup_epochs": 0, "epochs": 1})
     stats = EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), [(x, t)] * n_it, opt, torch.device(DEV), 0, None, args=args)
     assert stats["loss"] == pytest.approx(float(np.mean(per_step)), rel=1e-5)
+
+
+def test_weight_planes_follow_torch_side_parameter_writes():
+    """The bf16 planes of fc.weight (and v.weight at D >= 2048) live in the engine's workspace and are rewritten by the
+    optimizer's update kernel; ``planes_valid`` tells a step to trust them.  A parameter write from the torch side --
+    load_state_dict, an in-place op on the Parameter -- bumps the Parameter's version counter: the engine sees it and the
+    next step splits the planes again.  Checked against a FRESH engine on the same weights (bit-equal parameters after the
+    step); a write through ``p.data`` is invisible to torch's counters and needs ``invalidate_planes()``."""
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    for D in (256, 2048):
+        case = Case("planes", B=128, N=12, D=D, Q=8, C=40, seed=3)
+        inp = make_inputs(case)
+        x = torch.from_numpy(inp["x_buf"]).to(DEV); t = torch.from_numpy(inp["targets"]).to(DEV)
+        model = make_model(case, inp)
+        eng = ProbeHeadEngine(model.head, optimizer="lars", lr=0.3)
+        eng.train_step(x, t); eng.train_step(x, t)
+        assert eng._planes_current()                                   # written by the update kernel, nobody touched the weights
+        sd = {k: v.clone() for k, v in model.head.state_dict().items()}
+        sd["2.weight"] = sd["2.weight"] * 1.5 + 0.01
+        sd["0.v.weight"] = sd["0.v.weight"] * 0.5
+        for how in ("load_state_dict", "inplace", "data"):
+            if how == "load_state_dict":
+                model.head.load_state_dict(sd)
+            elif how == "inplace":
+                with torch.no_grad():
+                    model.head[2].weight.mul_(0.9)
+            else:
+                model.head[2].weight.data.mul_(1.1)                      # invisible to version counters ...
+                assert eng._planes_current()
+                eng.invalidate_planes()                                  # ... so the caller says so
+            assert not eng._planes_current(), how
+            # a fresh engine on a copy of the same head state
+            ref_model = make_model(case, inp)
+            ref_model.head.load_state_dict(model.head.state_dict())
+            ref = ProbeHeadEngine(ref_model.head, optimizer="lars", lr=0.3)
+            ref.state[0].copy_(eng.state[0])
+            eng.train_step(x, t); ref.train_step(x, t)
+            torch.cuda.synchronize()
+            assert torch.equal(eng.flat_p, ref.flat_p), (D, how)
+            assert eng._planes_current()
