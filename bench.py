@@ -684,6 +684,13 @@ def main():
                 line = secondary(Nn, D, Q, "f32", 20, toks=xs, sB=nb)
                 line["workload"] = desc + f", batch {nb} per GPU"
                 configs[f"{args.workload}_b{nb}"] = line
+        # the published protocol's query count (--ep_queries 32, reference README.md:133-134: every published accuracy row) at
+        # the headline shape, f32 and bf16-stored tokens -- BASELINE.json's configurations say q = 8, these say what the README's
+        # own commands would run at (beyond D = 768 and for bf16 tokens the passes run in chunks of 16 queries)
+        for stor in ("f32", "bf16"):
+            line = secondary(Nn, D, 32, stor, 20, toks=xs)
+            line["workload"] = desc.replace("EP q=8", "EP q=32") + (" [tokens stored as bf16]" if stor == "bf16" else "")
+            configs[f"{args.workload}_q32" + ("_bf16" if stor == "bf16" else "")] = line
         # configs[4] as it fits 8 x 288 GB: the pre-dumped ViT-7B tokens stored as bf16, both passes in the step
         torch.cuda.empty_cache()
         cN, cD, cQ, cC, cdesc = WORKLOADS["c5"]
