@@ -721,15 +721,16 @@ def main():
     # the same workload through the reference's loop surface (engine_finetune.train_one_epoch, reference
     # engine_finetune.py:22-103): a resident token store, adjust_learning_rate every iteration, meters every 20
     through = None
-    if default_ep and world == 1 and not args.no_through_engine:
+    stream_head = args.head != "ep" and args.workload == "c2" and args.tokens == "f32"     # (the matrix heads return above)
+    if (default_ep or stream_head) and world == 1 and not args.no_through_engine:
         import contextlib
         from efficient_probing_amd import engine_finetune as EF
         from efficient_probing_amd.token_store import ResidentTokenStore
         from efficient_probing_amd.util.lars import LARS
         torch.manual_seed(0)
         enc3 = Enc()
-        probe_heads.build_probe_head(enc3, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
-                                                     model="vit_base_patch16"))
+        probe_heads.build_probe_head(enc3, Namespace(cls_features=args.head, ep_queries=Q, d_out=1, nb_classes=Cc, num_heads=16,
+                                                     model="capi_vitl14_in1k" if Nn == 256 else "vit_base_patch16"))
         enc3.to(dev)
         store = ResidentTokenStore.from_tensors(torch.cat(xs, 0), torch.cat(ts, 0))
         n_it = args.engine_steps
@@ -764,6 +765,9 @@ def main():
                               "(image_index into HBM-resident tokens), LARS, lr_sched.adjust_learning_rate per iteration, "
                               "meters read back every 20 iterations",
                    "mean_loss": round(float(st3.get("loss", float("nan"))), 5)}
+        tabs = sorted(k for k, _ in store.__dict__.get("_tables", {}))
+        if tabs:                                             # functions of the frozen tokens, computed once per store
+            through["store_tables"] = tabs
         del store
         torch.cuda.empty_cache()
 

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   unsigned long long t_b0 = 0, t_rd = 0, t_b1 = 0, t_mm = 0;   // diagnostic only (EP_PLANES_STAMP)
   const bool stamped = p.ablate == 77;
   int k = 0;
+  const unsigned long long t_c0 = stamped ? __builtin_readcyclecounter() : 0ull, t_r0 = stamped ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (par) { pl_barrier(); k = 1; }                  // barrier 0 belongs to the other parity's first tile
   for (; k < nk; k += 2) {
     const unsigned long long c0 = stamped ? __builtin_readcyclecounter() : 0ull;
@@ -326,8 +327,9 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
     if (stamped) { const unsigned long long c4 = __builtin_readcyclecounter(); t_b0 += c1 - c0; t_rd += c2 - c1; t_b1 += c3 - c2; t_mm += c4 - c3; }
   }
   if (stamped && lane == 0) {
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(p.skws) + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 4;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(p.skws) + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 6;
     d[0] = t_b0; d[1] = t_rd; d[2] = t_b1; d[3] = t_mm;
+    d[4] = __builtin_readcyclecounter() - t_c0; d[5] = __builtin_amdgcn_s_memrealtime() - t_r0;   // whole K loop: cycles, 100 MHz ticks
   }
   if ((nk & 1) == par) pl_barrier();                 // both parities pass barriers 0 .. nk
   pl_barrier();                                      // F1: the loaders are done with the ring
@@ -374,21 +376,21 @@ int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
   const int tw = planes_wide(p, batch) ? 128 : 64, nwg = ((p.N + tw - 1) / tw) * ((p.M + 63) / 64);
   if (stamp && batch == 1 && nwg <= 4096) {
     static unsigned long long* dbg = nullptr;
-    static unsigned long long host[4096 * 8 * 4];
+    static unsigned long long host[4096 * 8 * 6];
     if (!dbg) (void)hipMalloc(&dbg, sizeof(host));
     GemmParams q = p;
     q.skws = reinterpret_cast<float*>(dbg); q.ablate = 77;
-    (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * 4 * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * 6 * sizeof(unsigned long long), st);
     if (planes_wide(p, 1)) planes_launch<8>(q, 1, st); else planes_launch<4>(q, 1, st);
     (void)hipStreamSynchronize(st);
-    (void)hipMemcpy(host, dbg, (size_t)nwg * 8 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double a[4] = {0, 0, 0, 0};
-    for (int i = 0; i < nwg * 8; ++i) for (int j = 0; j < 4; ++j) a[j] += (double)host[4 * i + j];
+    (void)hipMemcpy(host, dbg, (size_t)nwg * 8 * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nwg * 8; ++i) for (int j = 0; j < 6; ++j) a[j] += (double)host[6 * i + j];
     const double n = (double)nwg * 8 * (((p.K + 31) / 32) / 2.0);
     static int printed = 0;
     if (printed++ % 10 == 5)
-      fprintf(stderr, "[EP_PLANES_STAMP] %d x %d x %d, per own K-tile of a multiply wave: barrier k %.0f, read+split %.0f, barrier k+1 %.0f, matrix %.0f cycles\n",
-              p.M, p.N, p.K, a[0] / n, a[1] / n, a[2] / n, a[3] / n);
+      fprintf(stderr, "[EP_PLANES_STAMP] %d x %d x %d, per own K-tile of a multiply wave: barrier k %.0f, read+split %.0f, barrier k+1 %.0f, matrix %.0f cycles; K loop of a workgroup %.0f cycles = %.1f us (%.2f GHz), %d workgroups\n",
+              p.M, p.N, p.K, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / (nwg * 8.0), a[5] / (nwg * 8.0) / 100.0, a[4] / a[5] / 10.0, nwg);
     return 0;
   }
   if (planes_wide(p, batch)) planes_launch<8>(p, batch, st); else planes_launch<4>(p, batch, st);

@@ -49,6 +49,38 @@ class ProbeHeadEngine:
     def _new_step(self):
         return N.EPHeadStep()
 
+
+    # ---- tables of a resident token store -------------------------------------------------------------------------------
+    # Some heads' token passes take per-token LayerNorm statistics / per-image channel statistics.  They are functions of
+    # the FROZEN tokens alone, so a resident store computes them once (token_store.ResidentTokenStore.table) and a batch read
+    # in place through ``image_index`` looks its rows up instead of re-reading the tokens every step -- which the indexed
+    # kernels cannot do at all: without the tables an indexed batch is an argument error.
+    _store_kinds = {}          # subclass: struct field -> (store table kind, eps)
+
+    def attach_store(self, store) -> None:
+        """Use ``store``'s cached tables whenever a batch is read from it in place (``engine_finetune`` calls this when it
+        sees a ``token_store.StoreBatch``).  ``None`` detaches."""
+        self._store = store
+
+    def _bind_store_tables(self, xv, image_index) -> None:
+        self._bound_tables = {}
+        st = getattr(self, "_store", None)
+        if st is None or image_index is None or not self._store_kinds:
+            return
+        if xv.data_ptr() != st.tokens.data_ptr() or xv.shape[0] != st.tokens.shape[0]:
+            return
+        for field, (kind, eps) in self._store_kinds.items():
+            self._bound_tables[field] = st.table(kind, eps)
+
+    def _table_ptr(self, field: str) -> int:
+        """Pointer for a step / eval struct: the caller's explicit per-call table, else the attached store's, else 0 (the
+        library computes the statistics of the batch itself)."""
+        explicit = getattr(self, "_tokstat" if field == "token_stats" else "_imgstat", None)
+        if explicit is not None:
+            return explicit.data_ptr()
+        t = getattr(self, "_bound_tables", {}).get(field)
+        return t.data_ptr() if t is not None else 0
+
     def _ws_bytes(self) -> int:
         return self.lib.ep_head_workspace_bytes(C.byref(self.dims))
 
@@ -224,6 +256,7 @@ class ProbeHeadEngine:
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
+        self._bind_store_tables(xv, image_index)
         ws = self._workspace(B, Nn)
         targets = targets.to(device=self.device, dtype=torch.int64)
         s = self._step_struct(xv, bstride, targets, 1, self._micro > 0, None)
@@ -274,6 +307,7 @@ class ProbeHeadEngine:
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
+        self._bind_store_tables(xv, image_index)
         ws = self._workspace(B, Nn)
         targets = targets.to(device=self.device, dtype=torch.int64)
         s = self._step_struct(xv, bstride, targets, 4, False, None)          # first token pass (needs cls_token only)
@@ -314,6 +348,7 @@ class ProbeHeadEngine:
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
+        self._bind_store_tables(xv, image_index)
         ws = self._workspace(B, Nn)
         targets = targets.to(device=self.device, dtype=torch.int64)
         self.opt_step += 1
@@ -334,6 +369,7 @@ class ProbeHeadEngine:
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
+        self._bind_store_tables(xv, image_index)
         if self._deferred and self._ws_key != (B, Nn):
             self.flush()                                      # the update in flight still uses the old workspace
         ws = self._workspace(B, Nn)
@@ -430,6 +466,7 @@ class ProbeHeadEngine:
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
+        self._bind_store_tables(xv, image_index)
         ws = self._workspace(B, Nn)
         Cc = self.dims.C
         ldl = F_.padded_ld(Cc)
@@ -533,7 +570,9 @@ class AbmilpHeadEngine(ProbeHeadEngine):
 
     def _tokens(self, x, image_index):
         if image_index is not None:
-            raise NotImplementedError("AbMILP: in-place indexed batches are not supported (gather the batch first)")
+            # a batch of a resident store: this head's step is a chain of contractions over the token matrix (matrix-core
+            # bound, 10 ... 40 x a token read), so the batch is gathered into a contiguous tensor first -- one copy of B x N x D
+            x = x.index_select(0, image_index.long())
         if self.pool.content == "patch":
             x = x[:, 1:]
         return F_._contiguous_tokens(x)
@@ -583,7 +622,9 @@ class DinovitHeadEngine(AbmilpHeadEngine):
 
     def _tokens(self, x, image_index):
         if image_index is not None:
-            raise NotImplementedError("dinovit: in-place indexed batches are not supported (gather the batch first)")
+            # a batch of a resident store: this head's step is a chain of contractions over the token matrix (matrix-core
+            # bound, 10 ... 40 x a token read), so the batch is gathered into a contiguous tensor first -- one copy of B x N x D
+            x = x.index_select(0, image_index.long())
         return F_._contiguous_tokens(x)
 
     def _call_train(self, s, ws) -> int:
@@ -634,6 +675,8 @@ class CaeHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(CAEAttentiveBlock, BatchNorm1d, Linear) through ``ep_cae_head_train_step``
     (LayerNorm-of-tokens mode of the token passes).  ``token_stats`` of a resident store can be passed per call."""
 
+    _store_kinds = {"token_stats": ("token_stats", F_.CAE_LN_EPS)}
+
     def _check_head(self, head):
         from .probe_heads import is_native_cae_head
         if not is_native_cae_head(head):
@@ -648,7 +691,7 @@ class CaeHeadEngine(ProbeHeadEngine):
 
     def _new_step(self):
         s = N.EPCaeStep()
-        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.token_stats = self._table_ptr("token_stats")
         s.ln_eps = F_.CAE_LN_EPS
         return s
 
@@ -667,7 +710,8 @@ class CaeHeadEngine(ProbeHeadEngine):
         return self.lib.ep_cae_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
-        return self.lib.ep_cae_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+        return self.lib.ep_cae_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                 self._table_ptr("token_stats"),
                                                  F_.CAE_LN_EPS, self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                                  self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
                                                  ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
@@ -676,6 +720,8 @@ class CaeHeadEngine(ProbeHeadEngine):
 class JepaHeadEngine(CaeHeadEngine):
     """Fused train / eval step of Sequential(AttentivePooler (V-JEPA), BatchNorm1d, Linear) through
     ``ep_jepa_head_train_step`` (LayerNorm-of-tokens mode of the token passes)."""
+
+    _store_kinds = {"token_stats": ("token_stats", F_.JEPA_LN_EPS)}
 
     def _check_head(self, head):
         from .probe_heads import is_native_jepa_head
@@ -692,7 +738,7 @@ class JepaHeadEngine(CaeHeadEngine):
 
     def _new_step(self):
         s = N.EPJepaStep()
-        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.token_stats = self._table_ptr("token_stats")
         s.ln_eps = F_.JEPA_LN_EPS
         return s
 
@@ -703,7 +749,8 @@ class JepaHeadEngine(CaeHeadEngine):
         return self.lib.ep_jepa_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
-        return self.lib.ep_jepa_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+        return self.lib.ep_jepa_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                 self._table_ptr("token_stats"),
                                                   F_.JEPA_LN_EPS, self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                                   self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
                                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
@@ -713,6 +760,8 @@ class AimHeadEngine(ProbeHeadEngine):
     """Fused train / eval step of Sequential(AttentionPoolingClassifier (AIM), BatchNorm1d, Linear) through
     ``ep_aim_head_train_step``.  ``image_stats`` (functional.channel_stats of a resident store, (M, 2, D)) can be passed per
     call: the token BatchNorm's batch statistics are then combined from the cached rows instead of re-reading the tokens."""
+
+    _store_kinds = {"image_stats": ("channel_stats", None)}
 
     def _check_head(self, head):
         from .probe_heads import is_native_aim_head
@@ -729,7 +778,7 @@ class AimHeadEngine(ProbeHeadEngine):
     def _new_step(self):
         s = N.EPAimStep()
         tb = self.pool.bn
-        s.image_stats = self._imgstat.data_ptr() if getattr(self, "_imgstat", None) is not None else 0
+        s.image_stats = self._table_ptr("image_stats")
         s.tok_running_mean = tb.running_mean.data_ptr(); s.tok_running_var = tb.running_var.data_ptr()
         s.tok_num_batches_tracked = tb.num_batches_tracked.data_ptr()
         s.tok_bn_eps = tb.eps; s.tok_bn_momentum = tb.momentum
@@ -768,6 +817,8 @@ class CaitHeadEngine(CaeHeadEngine):
     """Fused train / eval step of Sequential(CAPooling (CaiT class attention), BatchNorm1d, Linear) through
     ``ep_cait_head_train_step`` (LayerNorm-of-tokens mode of the token passes + the class row as an extra softmax entry)."""
 
+    _store_kinds = {"token_stats": ("token_stats", F_.CAIT_LN_EPS)}
+
     def _check_head(self, head):
         from .probe_heads import is_native_cait_head
         if not is_native_cait_head(head):
@@ -782,7 +833,7 @@ class CaitHeadEngine(CaeHeadEngine):
 
     def _new_step(self):
         s = N.EPCaitStep()
-        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.token_stats = self._table_ptr("token_stats")
         s.ln_eps = F_.CAIT_LN_EPS
         return s
 
@@ -793,7 +844,8 @@ class CaitHeadEngine(CaeHeadEngine):
         return self.lib.ep_cait_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
-        return self.lib.ep_cait_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+        return self.lib.ep_cait_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                 self._table_ptr("token_stats"),
                                                   self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                                   self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
                                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
@@ -801,6 +853,8 @@ class CaitHeadEngine(CaeHeadEngine):
 
 class ClipHeadEngine(CaeHeadEngine):
     """Fused train / eval step of Sequential(AttentionPool2d (CLIP), BatchNorm1d, Linear) through ``ep_clip_head_train_step``."""
+
+    _store_kinds = {"token_stats": ("token_stats", F_.CLIP_LN_EPS)}
 
     def _check_head(self, head):
         from .probe_heads import is_native_clip_head
@@ -816,7 +870,7 @@ class ClipHeadEngine(CaeHeadEngine):
 
     def _new_step(self):
         s = N.EPClipStep()
-        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
+        s.token_stats = self._table_ptr("token_stats")
         s.ln_eps = F_.CLIP_LN_EPS
         return s
 
@@ -827,7 +881,8 @@ class ClipHeadEngine(CaeHeadEngine):
         return self.lib.ep_clip_head_train_step(C.byref(s), ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
-        return self.lib.ep_clip_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+        return self.lib.ep_clip_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                 self._table_ptr("token_stats"),
                                                   self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                                   self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl,
                                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device))
@@ -862,7 +917,9 @@ class DolgHeadEngine(ProbeHeadEngine):
 
     def _tokens(self, x, image_index):
         if image_index is not None:
-            raise NotImplementedError("DOLG: in-place indexed batches are not supported (gather the batch first)")
+            # a batch of a resident store: this head's step is a chain of contractions over the token matrix (matrix-core
+            # bound, 10 ... 40 x a token read), so the batch is gathered into a contiguous tensor first -- one copy of B x N x D
+            x = x.index_select(0, image_index.long())
         return F_._contiguous_tokens(x)
 
     def forward_backward(self, x, targets, image_index=None):
@@ -897,6 +954,8 @@ class CbamHeadEngine(ProbeHeadEngine):
     passes over the tokens).  ``image_stats`` (functional.cbam_channel_table of a resident store, (M, 3, D)) can be passed per
     call: one streaming read per step less."""
 
+    _store_kinds = {"image_stats": ("cbam_channel_table", None)}
+
     def _check_head(self, head):
         from .probe_heads import is_native_cbam_head
         if not is_native_cbam_head(head):
@@ -912,7 +971,7 @@ class CbamHeadEngine(ProbeHeadEngine):
     def _new_step(self):
         s = N.EPCbamStep()
         tb = self.pool.spatial.conv.bn
-        s.image_stats = self._imgstat.data_ptr() if getattr(self, "_imgstat", None) is not None else 0
+        s.image_stats = self._table_ptr("image_stats")
         s.tok_running_mean = tb.running_mean.data_ptr(); s.tok_running_var = tb.running_var.data_ptr()
         s.tok_num_batches_tracked = tb.num_batches_tracked.data_ptr()
         s.tok_bn_eps = tb.eps; s.tok_bn_momentum = tb.momentum
@@ -940,7 +999,8 @@ class CbamHeadEngine(ProbeHeadEngine):
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
         tb = self.pool.spatial.conv.bn
-        return self.lib.ep_cbam_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr, 0,
+        return self.lib.ep_cbam_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
+                                                  self._table_ptr("image_stats"),
                                                   tb.eps, tb.running_mean.data_ptr(), tb.running_var.data_ptr(),
                                                   self.flat_p.data_ptr(), self.bn.running_mean.data_ptr(),
                                                   self.bn.running_var.data_ptr(), self.bn.eps, out.data_ptr(), ldl, ws.data_ptr(),
@@ -952,6 +1012,8 @@ class SimpoolHeadEngine(ProbeHeadEngine):
     ``ep_simpool_head_train_step`` (per-image-query token passes).  ``token_stats`` (functional.token_stats(store, 1e-6)) and
     ``image_stats`` (functional.channel_stats(store)) of a resident store can be passed per call; ``token_stats`` is required
     with ``image_index``."""
+
+    _store_kinds = {"token_stats": ("token_stats", F_.SIMPOOL_LN_EPS), "image_stats": ("channel_stats", None)}
 
     def _check_head(self, head):
         from .probe_heads import is_native_simpool_head
@@ -971,8 +1033,8 @@ class SimpoolHeadEngine(ProbeHeadEngine):
 
     def _new_step(self):
         s = N.EPSimpoolStep()
-        s.token_stats = self._tokstat.data_ptr() if getattr(self, "_tokstat", None) is not None else 0
-        s.image_stats = self._imgstat.data_ptr() if getattr(self, "_imgstat", None) is not None else 0
+        s.token_stats = self._table_ptr("token_stats")
+        s.image_stats = self._table_ptr("image_stats")
         s.ln_eps = F_.SIMPOOL_LN_EPS
         return s
 
@@ -991,7 +1053,7 @@ class SimpoolHeadEngine(ProbeHeadEngine):
 
     def _call_eval(self, xv, bstride, iptr, out, ldl, ws) -> int:
         return self.lib.ep_simpool_head_eval_forward(C.byref(self.dims), xv.data_ptr(), F_.token_dtype_code(xv), bstride, iptr,
-                                                     0, 0, F_.SIMPOOL_LN_EPS, self.flat_p.data_ptr(),
+                                                     self._table_ptr("token_stats"), self._table_ptr("image_stats"), F_.SIMPOOL_LN_EPS, self.flat_p.data_ptr(),
                                                      self.bn.running_mean.data_ptr(), self.bn.running_var.data_ptr(),
                                                      self.bn.eps, out.data_ptr(), ldl, ws.data_ptr(), ws.numel(),
                                                      N.current_stream_ptr(self.device))

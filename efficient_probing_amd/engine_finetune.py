@@ -210,6 +210,15 @@ def _plain_cross_entropy(criterion) -> bool:
                                  and criterion.ignore_index == -100)
 
 
+def _attach_store(engine, batch) -> None:
+    """A batch of a resident token store: let the engine look up the store's cached per-token / per-image tables (LayerNorm
+    statistics of the tokens, channel statistics -- ``ResidentTokenStore.table``) through the batch's ``image_index``.  The
+    heads whose token passes take such tables cannot read an indexed batch without them."""
+    owner = getattr(batch, "owner", None) if isinstance(batch, StoreBatch) else None
+    if engine is not None and owner is not None and getattr(engine, "_store", None) is not owner and hasattr(engine, "attach_store"):
+        engine.attach_store(owner)
+
+
 def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
                     optimizer: torch.optim.Optimizer, device: torch.device, epoch: int, loss_scaler,
                     max_norm: float = 0, mixup_fn=None, log_writer=None, args=None,
@@ -265,6 +274,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     for step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         samples, targets = batch[0], batch[-1]
         image_index = batch[1] if isinstance(batch, StoreBatch) else None      # resident token store, read in place
+        _attach_store(engine, batch)
         if step % accum_iter == 0:
             lr = lr_sched.adjust_learning_rate(optimizer, step / n_iter + epoch, args)
         samples = samples.to(device, non_blocking=True)
@@ -350,6 +360,7 @@ def evaluate(data_loader, model, device, *, return_targets_and_preds: bool = Fal
     for batch in metric_logger.log_every(data_loader, 10, "Test:"):
         images, target = batch[0].to(device, non_blocking=True), batch[-1].to(device, non_blocking=True)
         index = batch[1] if isinstance(batch, StoreBatch) else None  # resident token store, read in place
+        _attach_store(engine, batch)
         if index is not None and engine is None:
             raise RuntimeError("(store, image_index, targets) batches need a native head (the fused engine path)")
         if engine is not None and (images.dim() == 3 or token_fn is not None):

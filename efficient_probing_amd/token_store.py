@@ -157,6 +157,28 @@ class ResidentTokenStore:
         self.labels = labels.to(device=tokens.device, dtype=torch.int64)
         return self
 
+    def table(self, kind: str, eps: Optional[float] = None) -> torch.Tensor:
+        """A per-token / per-image table over the WHOLE store, computed once and kept (indexed like ``tokens``, so a batch
+        read in place through ``image_index`` finds its rows): functions of the frozen tokens alone, which the token passes
+        of some heads would otherwise recompute from a third read of the batch in every step --
+        ``"token_stats"``: (n, N, 2) {mean, rstd} of a LayerNorm over D with ``eps`` (CAE / JEPA / CaiT / CLIP / SimPool heads;
+        the reference applies that LayerNorm to the tokens in every forward, e.g. poolings/cae/cae_att.py:104,
+        poolings/simpool.py:52), ``"channel_stats"``: (n, 2, D) per-image column mean and sum of squared deviations (AIM's token
+        BatchNorm, SimPool's mean-token query), ``"cbam_channel_table"``: (n, 3, D).  ``engine.attach_store(store)`` makes an
+        engine look them up (``engine_finetune.train_one_epoch`` / ``evaluate`` do that for a ``StoreBatch``)."""
+        from . import functional as F_
+        key = (kind, None if eps is None else float(eps))
+        cache = self.__dict__.setdefault("_tables", {})
+        if key not in cache:
+            fn = {"token_stats": lambda t: F_.token_stats(t, eps), "channel_stats": F_.channel_stats,
+                  "cbam_channel_table": F_.cbam_channel_table}.get(kind)
+            if fn is None:
+                raise ValueError(f"unknown store table {kind!r}")
+            n = self.tokens.shape[0]
+            parts = [fn(self.tokens[lo:lo + 32768]) for lo in range(0, n, 32768)]      # bounded launch grids
+            cache[key] = parts[0] if len(parts) == 1 else torch.cat(parts)
+        return cache[key]
+
     def loader(self, batch_size: int, epoch: int = 0, shuffle: bool = True, drop_last: bool = True) -> "StoreEpoch":
         """One epoch as a sized iterable of ``StoreBatch(store_tensor, image_index, targets)`` -- what
         ``engine_finetune.train_one_epoch`` / ``evaluate`` take in place of a DataLoader (they need ``len()``)."""
@@ -184,7 +206,7 @@ class ResidentTokenStore:
             stop = self.num_images - (self.num_images % batch_size if drop_last else 0)
         labels = self.labels[order.long()]          # ONE gather per epoch: a batch is then two views, no kernel of its own
         for lo in range(0, stop, batch_size):
-            yield StoreBatch(self.tokens, order[lo:lo + batch_size], labels[lo:lo + batch_size])
+            yield StoreBatch(self.tokens, order[lo:lo + batch_size], labels[lo:lo + batch_size], owner=self)
 
 
 class StoreBatch(tuple):
@@ -192,10 +214,10 @@ class StoreBatch(tuple):
     ``image_index``.  A type of its own so that ``engine_finetune.train_one_epoch`` / ``evaluate`` can tell it from a loader
     that yields ``(images, extra, target)`` -- for any other 3-tuple they keep the reference's ``batch[0]`` / ``batch[-1]``
     reading (reference engine_finetune.py:125-126,185-186)."""
-    __slots__ = ()
-
-    def __new__(cls, store, image_index, targets):
-        return super().__new__(cls, (store, image_index, targets))
+    def __new__(cls, store, image_index, targets, owner=None):
+        self = super().__new__(cls, (store, image_index, targets))
+        self.owner = owner          # the ResidentTokenStore (its cached per-token / per-image tables: ``table()``), or None
+        return self
 
 
 class StoreEpoch:

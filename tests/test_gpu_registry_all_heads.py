@@ -86,3 +86,40 @@ def test_train_evaluate_checkpoint_round_trip(name, tmp_path):
         assert torch.equal(a, b), f"{name}: {k}"
     ev2 = EF.evaluate(loader(2, seed=9), other, torch.device(DEV))
     assert ev2["loss"] == ev["loss"] and ev2["acc1"] == ev["acc1"]
+
+
+@pytest.mark.parametrize("name", sorted(ATTENTIVE_POOLINGS))
+def test_resident_store_epoch_equals_gathered_batches(name):
+    """The protocol's real input for every head: batches read IN PLACE from a resident token store
+    (``ResidentTokenStore.loader`` -> ``StoreBatch``), through ``train_one_epoch`` and ``evaluate``.  The heads whose token passes
+    take per-token LayerNorm statistics / per-image channel statistics look them up in the store's cached tables
+    (``ResidentTokenStore.table``, attached by ``engine_finetune``) -- an indexed batch cannot be read without them.  Same
+    numbers as the same batches gathered into contiguous tensors (whose statistics the step computes itself)."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd import token_store as TS
+    from efficient_probing_amd.util.lars import LARS
+    from efficient_probing_amd.util.misc import NativeScalerWithGradNormCount
+    g = torch.Generator().manual_seed(11)
+    n_img = 3 * B + 3
+    tokens = torch.randn(n_img, N_TOK, D, generator=g).to(DEV)
+    labels = torch.randint(0, C, (n_img,), generator=g).to(DEV)
+    store = TS.ResidentTokenStore.from_tensors(tokens, labels, seed=2)
+    gathered = [(t[i.long()].contiguous(), y) for t, i, y in store.batches(B, epoch=0)]
+    assert len(gathered) == 3
+    args = Namespace(accum_iter=1, amp="none", lr=0.2, min_lr=0.0, warmup_epochs=0, epochs=2, output_dir="", suffix="t", resume="")
+    models = []
+    for feed in ("store", "gathered"):
+        model = fix_grid(make_model(name))
+        opt = LARS(model.head.parameters(), lr=0.0, weight_decay=0.0)
+        data = store.loader(B, epoch=0) if feed == "store" else gathered
+        EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), data, opt, torch.device(DEV), 0, NativeScalerWithGradNormCount(), args=args)
+        models.append(model)
+    eng = EF.get_engine(models[0])
+    if getattr(eng, "_store_kinds", None):
+        assert eng._store is store and store.__dict__.get("_tables"), f"{name}: the store's tables were not used"
+    for (k, a), (_, b) in zip(models[0].head.state_dict().items(), models[1].head.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=2e-5, atol=2e-6), f"{name}: {k} differs by {float((a.float() - b.float()).abs().max()):.3e}"
+    ev_store = EF.evaluate(store.loader(B, epoch=1, shuffle=False, drop_last=False), models[0], torch.device(DEV))
+    ev_gath = EF.evaluate([(t[i.long()].contiguous(), y) for t, i, y in store.batches(B, epoch=1, shuffle=False, drop_last=False)],
+                          models[0], torch.device(DEV))
+    assert abs(ev_store["loss"] - ev_gath["loss"]) <= 1e-5 * max(1.0, abs(ev_gath["loss"])) and ev_store["acc1"] == ev_gath["acc1"]
