@@ -323,6 +323,56 @@ int side_run_standalone(const SideTasks& sd, hipStream_t st) {
   return 0;
 }
 
+int aux_side_begin(AuxSide& a, hipStream_t st, hipStream_t aux) {
+  static int early_env = -1;
+  if (early_env < 0) { const char* e = getenv("EP_WGRAD_EARLY"); early_env = e ? atoi(e) : 1; }
+  a = AuxSide{};
+  a.st = st; a.side = aux ? aux : st;
+  a.early = early_env && a.side != st;
+  if (a.side != st) EP_TRY(get_events(a.ev, 6));
+  return 0;
+}
+static int aux_side_sync(AuxSide& a) {                // aux waits for everything enqueued on `st` so far
+  hipEvent_t e = a.ev[a.nev % 5];                     // (ev[5] is the join's; re-recording an event whose earlier wait is already
+  ++a.nev;                                            // enqueued is legal: a wait refers to the record in front of it)
+  EP_HIP(hipEventRecord(e, a.st));
+  EP_HIP(hipStreamWaitEvent(a.side, e, 0));
+  return 0;
+}
+int aux_side_fork(AuxSide& a, const SideTasks& sd) {
+  if (!a.early || a.launched >= sd.n_gemm) return 0;
+  EP_TRY(aux_side_sync(a));
+  for (; a.launched < sd.n_gemm; ++a.launched) EP_TRY(gemm(false, false, sd.g[a.launched], sd.gz[a.launched], a.side));
+  return 0;
+}
+int aux_side_rest(AuxSide& a, const SideTasks& sd) {
+  if (!a.early || a.rest_done) return 0;
+  EP_TRY(aux_side_sync(a));
+  SideTasks rest = sd;
+  rest.n_gemm = 0;
+  EP_TRY(side_run_standalone(rest, a.side));
+  a.rest_done = true;
+  return 0;
+}
+int aux_side_before_pass(AuxSide& a, const SideTasks& sd) {
+  if (a.rest_done && a.launched >= sd.n_gemm) return 0;
+  if (a.side != a.st) EP_TRY(aux_side_sync(a));
+  for (; a.launched < sd.n_gemm; ++a.launched) EP_TRY(gemm(false, false, sd.g[a.launched], sd.gz[a.launched], a.side));
+  if (!a.rest_done) {
+    SideTasks rest = sd;
+    rest.n_gemm = 0;
+    EP_TRY(side_run_standalone(rest, a.side));
+    a.rest_done = true;
+  }
+  return 0;
+}
+int aux_side_join(AuxSide& a) {
+  if (a.side == a.st) return 0;
+  EP_HIP(hipEventRecord(a.ev[5], a.side));
+  EP_HIP(hipStreamWaitEvent(a.st, a.ev[5], 0));
+  return 0;
+}
+
 }  // namespace ep
 
 using namespace ep;

@@ -397,6 +397,17 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   const int64_t n4 = (int64_t)B * Hd / 4;
   const unsigned cgrid = (D + CG - 1) / CG;
   if (!tokstat) tokstat = w.tstat;
+  // the weight-gradient contractions: on the aux stream, each as early as its operands exist (AuxSide, ep_internal.h)
+  AuxSide ax;
+  EP_TRY(aux_side_begin(ax, st, aux));
+  EP_TRY(aux_side_fork(ax, sd));                     // the caller's (the classifier's weight gradient)
+  GemmParams gW2 = cgm(w.dm2, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;
+  GemmParams gW1 = cgm(w.dh1, Hd, w.h2, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;
+  GemmParams gWp = cgm(w.dz1, D, w.ya, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;
+  GemmParams gWv = cgm(w.dya0, D, w.P, (int64_t)H * D, w.dWvs, D, dh, D, B);                       // (rho dO)_h^T Phat_h
+  gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.side = 1;
+  EP_REQUIRE(gemm_side_ok(gW2, false, false) && gemm_side_ok(gW1, false, false) && gemm_side_ok(gWp, false, false) &&
+             gemm_side_ok(gWv, false, false), EP_E_ALIGN, "cait: unaligned gradient contraction");
   // out = norm(c2)
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dout, w.c2, w.statf, pr.norm_w, (const float*)nullptr,
                      B, D, w.dc2);
@@ -407,10 +418,14 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
                      (float*)nullptr);
   EP_LAUNCH_CHECK("ep_cait final-norm backward kernels");
   if (!side_add_colsum(sd, w.dm2, B, D, D, acc, gr.fc2_b)) EP_TRY(colsum(w.dm2, B, D, D, acc, gr.fc2_b, st));
+  side_add_gemm(sd, gW2, 1);
+  EP_TRY(aux_side_fork(ax, sd));                     // dW2 = dm2^T h1
   EP_TRY(gemm(true, false, cgm(w.dm2, D, pr.fc2_w, Hd, w.dh1, Hd, B, Hd, D), 1, st));              // dh1 = dm2 W2
   hipLaunchKernelGGL(ep_gelu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.dh1);   // -> dpre
   EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
   if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
+  side_add_gemm(sd, gW1, 1);
+  EP_TRY(aux_side_fork(ax, sd));                     // dW1 = dpre^T h2
   EP_TRY(gemm(true, false, cgm(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.c1, w.stat2, pr.n2_w, w.dc2, B, D, w.dc1);
   EP_TRY(lnaffine_grad(w.dh2, w.c1, w.stat2, B, D, acc, gr.n2_w,
@@ -420,11 +435,16 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
                      w.dcsum);
   EP_LAUNCH_CHECK("ep_cait block backward kernels");
   if (!side_add_colsum(sd, w.dz1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
+  side_add_gemm(sd, gWp, 1);
+  EP_TRY(aux_side_fork(ax, sd));                     // dWp = dz1^T ya
   EP_TRY(gemm(true, false, cgm(w.dz1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                // dya = dz1 Wp
   EP_TRY(colsum(w.dya, B, D, D, 0, w.dbo, st));                                                    // d(Wv b1 + bv)
   EP_TRY(delta_rows(w.dya, w.ya, B * H, dh, w.ML2, st, w.bo, H));                                  // delta' = dO . (o - bias)
   hipLaunchKernelGGL(ep_cait_clsgrad_kernel, dim3((B * H + 3) / 4), dim3(256), 0, st, w.dya, w.vc, w.ML2, w.mix, B * H, dh, H,
                      w.dya0, w.csc);
+  side_add_gemm(sd, gWv, H);
+  EP_TRY(aux_side_fork(ax, sd));                     // dWv' = dya0^T Phat
+  EP_TRY(aux_side_rest(ax, sd));                     // the column sums, the statistics
   hipLaunchKernelGGL(ep_cait_dvc_kernel, dim3(cgrid), dim3(256), 0, st, w.dya, w.mix, B, D, dh, H, w.dvc);
   EP_LAUNCH_CHECK("ep_cait class-entry kernels");
   {
@@ -432,32 +452,12 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
     g.sAz = dh; g.sBz = (int64_t)dh * D; g.sCz = D; g.extB = D;
     EP_TRY(gemm(true, false, g, H, st));
   }
-  GemmParams gW2 = cgm(w.dm2, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;
-  GemmParams gW1 = cgm(w.dh1, Hd, w.h2, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;
-  GemmParams gWp = cgm(w.dz1, D, w.ya, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;
-  GemmParams gWv = cgm(w.dya0, D, w.P, (int64_t)H * D, w.dWvs, D, dh, D, B);                       // (rho dO)_h^T Phat_h
-  gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.side = 1;
-  EP_REQUIRE(gemm_side_ok(gW2, false, false) && gemm_side_ok(gW1, false, false) && gemm_side_ok(gWp, false, false) &&
-             gemm_side_ok(gWv, false, false), EP_E_ALIGN, "cait: unaligned gradient contraction");
-  side_add_gemm(sd, gW2, 1); side_add_gemm(sd, gW1, 1); side_add_gemm(sd, gWp, 1); side_add_gemm(sd, gWv, H);
   PoolParams p = cait_pool_params(d, x, x_dtype, bstride, index, tokstat, w);
   p.ML = w.ML2;                                       // the (N + 1)-entry softmax state
   p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-  {
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipStream_t side = aux ? aux : st;
-    if (side != st) {
-      EP_TRY(get_events(ev, 2));
-      EP_HIP(hipEventRecord(ev[0], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    }
-    EP_TRY(side_run_standalone(sd, side));
-    EP_TRY(pool_backward(p, w.dw, 0, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[1], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
-    }
-  }
+  EP_TRY(aux_side_before_pass(ax, sd));
+  EP_TRY(pool_backward(p, w.dw, 0, st));
+  EP_TRY(aux_side_join(ax));
   // class entry: dw += chat sum_b dS_c ; dchat ; dWv' += dvc chat^T
   hipLaunchKernelGGL(ep_cait_clsred_part_kernel, dim3((D + 31) / 32, CAIT_RS), dim3(1024), 0, st, w.csc, w.dP, (int64_t)B * H, D, w.cpart);
   hipLaunchKernelGGL(ep_cait_clsred_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.csc, w.cpart, CAIT_RS, w.wq, w.chat, B, H, D, w.dw,

@@ -657,7 +657,19 @@ static int cae_backward_core(const ep_cae_dims& d, const void* x, int x_dtype, i
   const int D = d.D, dh = D / d.H, B = d.B;
   const float scale = (float)pow((double)dh, -0.5);
   if (!tokstat) tokstat = w.stats;                                                     // left there by the forward
+  // the weight-gradient contractions: on the aux stream, each as early as its operands exist (AuxSide, ep_internal.h)
+  AuxSide ax;
+  EP_TRY(aux_side_begin(ax, st, aux));
+  GemmParams gWp = cg(dy, D, w.o, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;          // dWp = dy^T o
+  GemmParams gWv = cg(w.dO, D, w.P, (int64_t)d.H * D, w.dWvs, D, dh, D, B);                               // d(Wv gv)_h = dO_h^T Phat_h
+  gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.side = 1;
+  EP_REQUIRE(gemm_side_ok(gWp, false, false) && gemm_side_ok(gWv, false, false), EP_E_ALIGN, "cae: unaligned gradient contraction");
+  side_add_gemm(sd, gWp, 1);
+  EP_TRY(aux_side_fork(ax, sd));                                                        // the caller's dWc, dWp
   EP_TRY(gemm(true, false, cg(dy, D, pr.proj_w, D, w.dO, D, B, D, D), 1, st));         // dO = dy Wp
+  side_add_gemm(sd, gWv, d.H);
+  EP_TRY(aux_side_fork(ax, sd));
+  EP_TRY(aux_side_rest(ax, sd));
   EP_TRY(colsum(dy, B, D, D, acc, gr.proj_b, st));
   EP_TRY(colsum(w.dO, B, D, D, 0, w.dbo, st));                                          // d(Wv bv)
   EP_TRY(delta_rows(w.dO, w.o, B * d.H, dh, w.ML, st, w.bo, d.H));                      // dPhat . Phat (bias taken out)
@@ -666,28 +678,11 @@ static int cae_backward_core(const ep_cae_dims& d, const void* x, int x_dtype, i
     g.sAz = dh; g.sBz = (int64_t)dh * D; g.sCz = D; g.extB = D;
     EP_TRY(gemm(true, false, g, d.H, st));
   }
-  GemmParams gWp = cg(dy, D, w.o, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;          // dWp = dy^T o
-  GemmParams gWv = cg(w.dO, D, w.P, (int64_t)d.H * D, w.dWvs, D, dh, D, B);                               // d(Wv gv)_h = dO_h^T Phat_h
-  gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.side = 1;
-  EP_REQUIRE(gemm_side_ok(gWp, false, false) && gemm_side_ok(gWv, false, false), EP_E_ALIGN, "cae: unaligned gradient contraction");
-  side_add_gemm(sd, gWp, 1); side_add_gemm(sd, gWv, d.H);
   PoolParams p = cae_pool_params(d, x, x_dtype, bstride, index, tokstat, w);
   p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-  {
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipStream_t side = aux ? aux : st;
-    if (side != st) {
-      EP_TRY(get_events(ev, 2));
-      EP_HIP(hipEventRecord(ev[0], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    }
-    EP_TRY(side_run_standalone(sd, side));
-    EP_TRY(pool_backward(p, w.dw, 0, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[1], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
-    }
-  }
+  EP_TRY(aux_side_before_pass(ax, sd));
+  EP_TRY(pool_backward(p, w.dw, 0, st));
+  EP_TRY(aux_side_join(ax));
   hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.v_w, pr.nv_w, pr.nv_b, D, acc,
                      gr.v_w, gr.nv_w, gr.nv_b, gr.n2_w, gr.n2_b);
   hipLaunchKernelGGL(ep_cae_du_kernel, dim3((D + 255) / 256), dim3(256), 0, st, w.dw, w.u, pr.nk_w, D, d.H, acc, w.du, gr.nk_w,

@@ -183,6 +183,23 @@ void side_add_gemm(SideTasks& sd, const GemmParams& g, int batch);
 bool side_add_colsum(SideTasks& sd, const float* src, int B, int ncol, int ld, int accumulate, float* out);
 // run the side tasks as stand-alone launches on `st` (kernel families that cannot carry them)
 int side_run_standalone(const SideTasks& sd, hipStream_t st);
+// Side work of a head step whose token-pass kernel takes no side workgroups: on the aux stream, EARLY (round 4; EP_WGRAD_EARLY=0:
+// all of it beside the second pass) -- every contraction starts as soon as its operands exist, beside the chain of small
+// kernels and critical-path contractions in front of the pass that leaves most of the chip idle, instead of starting with the
+// HBM-bound pass (which fills every CU) and running on after it.  Usage: begin; after producing the operands of some
+// contractions: side_add_gemm(sd, ...) + fork; rest() once the column sums' sources exist; before_pass() in front of the
+// pass launch; join() in front of the first consumer of a side result.  aux == st or null: everything inline on `st`.
+struct AuxSide {
+  hipStream_t st = nullptr, side = nullptr;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool early = false, rest_done = false;
+  int launched = 0, nev = 0;
+};
+int aux_side_begin(AuxSide& a, hipStream_t st, hipStream_t aux);
+int aux_side_fork(AuxSide& a, const SideTasks& sd);        // early: aux waits for `st` so far, then runs sd.g[launched .. n_gemm)
+int aux_side_rest(AuxSide& a, const SideTasks& sd);        // early: the column sums and statistics of `sd`, now
+int aux_side_before_pass(AuxSide& a, const SideTasks& sd); // whatever of `sd` has not been launched (not early: all of it)
+int aux_side_join(AuxSide& a);                             // `st` waits for the aux stream
 int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
                     hipStream_t st, DeferredReduce* defer = nullptr);
 

@@ -322,25 +322,11 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   const float scale = (float)pow((double)dh, -0.5);
   const int64_t n4 = (int64_t)B * Hd / 4;
   if (!tokstat) tokstat = w.tstat;
-  // The weight-gradient contractions feed nothing before the optimizer (dWv: the small kernels behind the second pass).  The
-  // token-pass kernel of this head takes no side workgroups, so they run on the aux stream -- EARLY (round 4, default; EP_WGRAD_EARLY=0:
-  // all of them beside the second pass): each one starts as soon as its operands exist, beside the chain of small kernels and
-  // critical-path contractions below that leaves most of the chip idle, instead of all five starting with the second pass and
-  // running on for ~200 us after it has ended.
-  static int early_env = -1;
-  if (early_env < 0) { const char* e = getenv("EP_WGRAD_EARLY"); early_env = e ? atoi(e) : 1; }
-  hipStream_t side = aux ? aux : st;
-  const bool early = early_env && side != st;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (side != st) EP_TRY(get_events(ev, 6));
-  int launched = 0;                                  // contractions of `sd` already on the aux stream
-  auto fork = [&](int e, int upto) -> int {          // aux waits for everything enqueued on `st` so far, then runs sd.g[launched .. upto)
-    if (!early) return 0;
-    EP_HIP(hipEventRecord(ev[e], st));
-    EP_HIP(hipStreamWaitEvent(side, ev[e], 0));
-    for (; launched < upto; ++launched) EP_TRY(gemm(false, false, sd.g[launched], sd.gz[launched], side));
-    return 0;
-  };
+  // The weight-gradient contractions feed nothing before the optimizer (dWv: the small kernels behind the second pass); the
+  // token-pass kernel of this head takes no side workgroups: the aux stream, each contraction as early as its operands exist
+  // (AuxSide, ep_internal.h).  At 256 x 768, 1024 images: 1.367 -> 1.27 ms per step.
+  AuxSide ax;
+  EP_TRY(aux_side_begin(ax, st, aux));
   GemmParams gW2 = mkg(dout, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;
   GemmParams gW1 = mkg(w.dh1, Hd, w.h2, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;
   GemmParams gWp = mkg(w.dq1, D, w.ya, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;
@@ -348,17 +334,18 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.side = 1;
   EP_REQUIRE(gemm_side_ok(gW2, false, false) && gemm_side_ok(gW1, false, false) && gemm_side_ok(gWp, false, false) &&
              gemm_side_ok(gWv, false, false), EP_E_ALIGN, "jepa: unaligned gradient contraction");
-  const int n0 = sd.n_gemm;                          // the caller's contractions (the classifier's weight gradient): operands ready
-  side_add_gemm(sd, gW2, 1); side_add_gemm(sd, gW1, 1); side_add_gemm(sd, gWp, 1); side_add_gemm(sd, gWv, d.H);
-  EP_TRY(fork(0, n0 + 1));                           // dWc, dW2 = dout^T h1
+  side_add_gemm(sd, gW2, 1);
+  EP_TRY(aux_side_fork(ax, sd));                     // the caller's dWc, dW2 = dout^T h1
   // out = q1 + fc2(gelu(fc1(LN2(q1))))
   EP_TRY(gemm(true, false, mkg(dout, D, pr.fc2_w, Hd, w.dh1, Hd, B, Hd, D), 1, st));               // dh1 = dout W2
   hipLaunchKernelGGL(ep_gelu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.dh1);   // -> dpre
   EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
-  EP_TRY(fork(1, n0 + 2));                           // dW1 = dpre^T h2
+  side_add_gemm(sd, gW1, 1);
+  EP_TRY(aux_side_fork(ax, sd));                     // dW1 = dpre^T h2
   EP_TRY(gemm(true, false, mkg(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.q1, w.qstat, pr.n2_w, dout, B, D, w.dq1);
-  EP_TRY(fork(2, n0 + 3));                           // dWp = dq1^T ya
+  side_add_gemm(sd, gWp, 1);
+  EP_TRY(aux_side_fork(ax, sd));                     // dWp = dq1^T ya
   EP_TRY(lnaffine_grad(w.dh2, w.q1, w.qstat, B, D, acc, gr.n2_w,
                      gr.n2_b, st));
   EP_LAUNCH_CHECK("ep_jepa LN2 backward kernels");
@@ -366,14 +353,9 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
   if (!side_add_colsum(sd, w.dq1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dq1, B, D, D, acc, gr.proj_b, st));   // q1 = q0 + o Wp^T + bp
   EP_TRY(gemm(true, false, mkg(w.dq1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                 // dya = dq1 Wp
-  EP_TRY(fork(3, n0 + 4));                           // dWv = dya^T P
-  bool rest_done = false;
-  if (early) {                                       // ... and the column sums / statistics behind it: beside the second pass, which
-    SideTasks rest = sd;                             // fills every CU, one of these 8-us kernels took the whole pass (200 us)
-    rest.n_gemm = 0;
-    EP_TRY(side_run_standalone(rest, side));
-    rest_done = true;
-  }
+  side_add_gemm(sd, gWv, d.H);
+  EP_TRY(aux_side_fork(ax, sd));                     // dWv = dya^T P
+  EP_TRY(aux_side_rest(ax, sd));                     // (beside the pass one of these 8-us column sums took the whole pass: 200 us)
   EP_TRY(colsum(w.dya, B, D, D, 0, w.dbo, st));                                                     // d(Wv b1 + bv)
   EP_TRY(delta_rows(w.dya, w.ya, B * d.H, dh, w.ML, st, w.bo, d.H));
   {
@@ -383,18 +365,9 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   }
   PoolParams p = jepa_pool_params(d, x, x_dtype, bstride, index, tokstat, w);
   p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-  {
-    if (side != st && !rest_done) {
-      EP_HIP(hipEventRecord(ev[4], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[4], 0));
-    }
-    if (!rest_done) EP_TRY(side_run_standalone(sd, side));   // (not early: everything beside the second pass)
-    EP_TRY(pool_backward(p, w.dw, 0, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[5], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[5], 0));
-    }
-  }
+  EP_TRY(aux_side_before_pass(ax, sd));
+  EP_TRY(pool_backward(p, w.dw, 0, st));
+  EP_TRY(aux_side_join(ax));
   // value side: d kv.weight[D:], d kv.bias[D:], and the value-side parts of d norm1.weight / bias
   hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.kv_w + (int64_t)D * D, pr.n1_w,
                      pr.n1_b, D, acc, gr.kv_w + (int64_t)D * D, gr.n1_w, gr.n1_b, (float*)nullptr, (float*)nullptr);
