@@ -414,20 +414,12 @@ static int aim_backward_core(const ep_aim_dims& d, const void* x, int x_dtype, i
   p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
   if (pool_backward_takes_side(p)) {
     EP_TRY(pool_backward(p, w.dw, 0, st, &sd));
-  } else {
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipStream_t side = aux ? aux : st;
-    if (side != st) {
-      EP_TRY(get_events(ev, 2));
-      EP_HIP(hipEventRecord(ev[0], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    }
-    EP_TRY(side_run_standalone(sd, side));
+  } else {                                           // (kernel families without side workgroups: the aux stream)
+    AuxSide ax;
+    EP_TRY(aux_side_begin(ax, st, aux));
+    EP_TRY(aux_side_before_pass(ax, sd));
     EP_TRY(pool_backward(p, w.dw, 0, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[1], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
-    }
+    EP_TRY(aux_side_join(ax));
   }
   // dWv = d(Wv r) diag(r) + dbo nb^T   (the unused r / nb gradients of the shared kernel go to scratch)
   hipLaunchKernelGGL(ep_cae_dwv_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.dWvs, w.dbo, pr.v_w, w.r, w.nb, D, acc,

@@ -297,20 +297,12 @@ static int coca_backward_core(const ep_coca_dims& d, const void* x, int x_dtype,
   p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
   if (pool_backward_takes_side(p)) {
     EP_TRY(pool_backward(p, w.du, 0, st, &sd));
-  } else {
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipStream_t side = aux ? aux : st;
-    if (side != st) {
-      EP_TRY(get_events(ev, 2));
-      EP_HIP(hipEventRecord(ev[0], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    }
-    EP_TRY(side_run_standalone(sd, side));
+  } else {                                           // (kernel families without side workgroups: the aux stream)
+    AuxSide ax;
+    EP_TRY(aux_side_begin(ax, st, aux));
+    EP_TRY(aux_side_before_pass(ax, sd));
     EP_TRY(pool_backward(p, w.du, 0, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[1], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
-    }
+    EP_TRY(aux_side_join(ax));
   }
   // dWv = sum over heads of the partials -> rows dh..2dh-1 of d to_kv
   EP_TRY(reduce_partials(w.dWvp, d.H, d.dh * D, 1.0f, accumulate, gr.to_kv + (int64_t)d.dh * D, nullptr, st));

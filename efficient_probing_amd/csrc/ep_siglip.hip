@@ -131,26 +131,17 @@ static int sig_backward_core(const ep_siglip_dims& d, const void* x, int x_dtype
   const int D = d.D, dh = D / d.H, Hd = d.hidden, B = d.B;
   const float scale = (float)pow((double)dh, -0.5);
   const int64_t n4 = (int64_t)B * Hd / 4;
-  // MLP: out = z1 + fc2(gelu(fc1(z1)))
-  EP_TRY(gemm(true, false, mkg(dout, D, pr.fc2_w, Hd, w.dh1, Hd, B, Hd, D), 1, st));               // dh1 = dout W2
-  hipLaunchKernelGGL(ep_gelu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.dh1);   // -> dpre
-  EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
-  EP_HIP(hipMemcpyAsync(w.dz1, dout, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-  { GemmParams g = mkg(w.dh1, Hd, pr.fc1_w, D, w.dz1, D, B, D, Hd); g.accumulate = 1; EP_TRY(gemm(true, false, g, 1, st)); }   // dz1 = dout + dpre W1
-  EP_TRY(gemm(true, false, mkg(w.dz1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                 // dya = dz1 Wp
-  EP_TRY(delta_rows(w.dya, w.ya, B * d.H, dh, w.ML, st, pr.kv_b + D, d.H));                          // dP . P (bias taken out)
-  {
-    GemmParams g = mkg(w.dya, D, pr.kv_w + (int64_t)D * D, D, w.dP, (int64_t)d.H * D, B, D, dh);     // dP[b,h] = dya[b,h] Wv_h
-    g.sAz = dh; g.sBz = (int64_t)dh * D; g.sCz = D; g.extB = D;
-    EP_TRY(gemm(true, false, g, d.H, st));
-  }
-  // bias gradients (column sums over the batch)
-  // (nothing consumes them before the optimizer: side workgroups of the second pass, like the weight gradients)
-  if (!side_add_colsum(sd, dout, B, D, D, acc, gr.fc2_b)) EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
-  if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
-  if (!side_add_colsum(sd, w.dz1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
-  if (!side_add_colsum(sd, w.dya, B, D, D, acc, gr.kv_b + D)) EP_TRY(colsum(w.dya, B, D, D, acc, gr.kv_b + D, st));
-  // weight gradients: nothing consumes them before the optimizer -> side tasks of the second token pass
+  // Weight and bias gradients: nothing consumes them before the optimizer.  They ride in the second token pass as side
+  // workgroups where its kernel takes them; otherwise (or with EP_SIDE_AUX=1) on the aux stream, each contraction as early as
+  // its operands exist (AuxSide, ep_internal.h).
+  PoolParams p = sig_pool_params(d, x, x_dtype, bstride, index, w);
+  p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
+  static int aux_env = -1;
+  if (aux_env < 0) { const char* e = getenv("EP_SIDE_AUX"); aux_env = e ? atoi(e) : 0; }
+  const bool in_pass = pool_backward_takes_side(p) && !(aux_env && aux && aux != st);
+  AuxSide ax;
+  EP_TRY(aux_side_begin(ax, st, aux));
+  auto fork = [&]() -> int { return in_pass ? 0 : aux_side_fork(ax, sd); };
   GemmParams gW2 = mkg(dout, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;       // dW2 = dout^T h1
   GemmParams gW1 = mkg(w.dh1, Hd, w.z1, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;       // dW1 = dpre^T z1
   GemmParams gWp = mkg(w.dz1, D, w.ya, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;        // dWp = dz1^T o
@@ -158,25 +149,39 @@ static int sig_backward_core(const ep_siglip_dims& d, const void* x, int x_dtype
   gWv.sAz = dh; gWv.extA = dh; gWv.sBz = D; gWv.extB = D; gWv.sCz = (int64_t)dh * D; gWv.accumulate = acc; gWv.side = 1;
   EP_REQUIRE(gemm_side_ok(gW2, false, false) && gemm_side_ok(gW1, false, false) && gemm_side_ok(gWp, false, false) &&
              gemm_side_ok(gWv, false, false), EP_E_ALIGN, "siglip: unaligned gradient contraction");
-  side_add_gemm(sd, gW2, 1); side_add_gemm(sd, gW1, 1); side_add_gemm(sd, gWp, 1); side_add_gemm(sd, gWv, d.H);
-  PoolParams p = sig_pool_params(d, x, x_dtype, bstride, index, w);
-  p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-  if (pool_backward_takes_side(p)) {
+  side_add_gemm(sd, gW2, 1);
+  EP_TRY(fork());
+  // MLP: out = z1 + fc2(gelu(fc1(z1)))
+  EP_TRY(gemm(true, false, mkg(dout, D, pr.fc2_w, Hd, w.dh1, Hd, B, Hd, D), 1, st));               // dh1 = dout W2
+  hipLaunchKernelGGL(ep_gelu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.dh1);   // -> dpre
+  EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
+  side_add_gemm(sd, gW1, 1);
+  EP_TRY(fork());
+  EP_HIP(hipMemcpyAsync(w.dz1, dout, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  { GemmParams g = mkg(w.dh1, Hd, pr.fc1_w, D, w.dz1, D, B, D, Hd); g.accumulate = 1; EP_TRY(gemm(true, false, g, 1, st)); }   // dz1 = dout + dpre W1
+  side_add_gemm(sd, gWp, 1);
+  EP_TRY(fork());
+  EP_TRY(gemm(true, false, mkg(w.dz1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                 // dya = dz1 Wp
+  side_add_gemm(sd, gWv, d.H);
+  EP_TRY(fork());
+  // bias gradients (column sums over the batch)
+  if (!side_add_colsum(sd, dout, B, D, D, acc, gr.fc2_b)) EP_TRY(colsum(dout, B, D, D, acc, gr.fc2_b, st));
+  if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
+  if (!side_add_colsum(sd, w.dz1, B, D, D, acc, gr.proj_b)) EP_TRY(colsum(w.dz1, B, D, D, acc, gr.proj_b, st));
+  if (!side_add_colsum(sd, w.dya, B, D, D, acc, gr.kv_b + D)) EP_TRY(colsum(w.dya, B, D, D, acc, gr.kv_b + D, st));
+  if (!in_pass) EP_TRY(aux_side_rest(ax, sd));
+  EP_TRY(delta_rows(w.dya, w.ya, B * d.H, dh, w.ML, st, pr.kv_b + D, d.H));                          // dP . P (bias taken out)
+  {
+    GemmParams g = mkg(w.dya, D, pr.kv_w + (int64_t)D * D, D, w.dP, (int64_t)d.H * D, B, D, dh);     // dP[b,h] = dya[b,h] Wv_h
+    g.sAz = dh; g.sBz = (int64_t)dh * D; g.sCz = D; g.extB = D;
+    EP_TRY(gemm(true, false, g, d.H, st));
+  }
+  if (in_pass) {
     EP_TRY(pool_backward(p, w.du, 0, st, &sd));
   } else {
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipStream_t side = aux ? aux : st;
-    if (side != st) {
-      EP_TRY(get_events(ev, 2));
-      EP_HIP(hipEventRecord(ev[0], st));
-      EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    }
-    EP_TRY(side_run_standalone(sd, side));
+    EP_TRY(aux_side_before_pass(ax, sd));
     EP_TRY(pool_backward(p, w.du, 0, st));
-    if (side != st) {
-      EP_HIP(hipEventRecord(ev[1], side));
-      EP_HIP(hipStreamWaitEvent(st, ev[1], 0));
-    }
+    EP_TRY(aux_side_join(ax));
   }
   // query chain
   hipLaunchKernelGGL(ep_siglip_dq_kernel, dim3((D + 3) / 4), dim3(256), 0, st, w.du, pr.kv_w, D, dh, scale, acc, w.dq, gr.q_b);

@@ -139,7 +139,7 @@ def test_engine_lars_steps_vs_reference(case):
 
 def test_larger_batch_vs_oracle_and_determinism():
     """B = 32 images of 256 x 768 tokens (8192 token rows through every contraction, 256 batched attention products): pooled
-    output against the fp32 oracle; the fused step is deterministic; indexed batches are refused loudly."""
+    output against the fp32 oracle; the fused step is deterministic; an indexed batch equals the gathered one."""
     case = DinovitCase("big", B=32, N=256, D=768, C=100, seed=3, sharp=True)
     inp = make_dinovit_inputs(case)
     head, plist = native_head(case, inp)
@@ -159,5 +159,8 @@ def test_larger_batch_vs_oracle_and_determinism():
     e1.train_step(x, t, lr=0.5)
     e2.train_step(x.clone(), t, lr=0.5)
     assert torch.equal(e1.flat_p, e2.flat_p)                       # deterministic: same inputs -> same bits
-    with pytest.raises(NotImplementedError, match="gather"):
-        e1.train_step(x, t, lr=0.5, image_index=torch.arange(case.B, device=DEV, dtype=torch.int32))
+    # a batch of a resident store (image_index): this matrix-core-bound head gathers it into a contiguous tensor -- same bits
+    perm = torch.randperm(case.B, device=DEV).to(torch.int32)
+    e1.train_step(x, t[perm.long()], lr=0.5, image_index=perm)
+    e2.train_step(x[perm.long()].contiguous(), t[perm.long()], lr=0.5)
+    assert torch.equal(e1.flat_p, e2.flat_p)

@@ -131,5 +131,8 @@ def test_full_size_batch_vs_oracle_strided_bf16_and_determinism():
     e3 = make_engine(native_head(case, inp)[0], optimizer="lars"); e3.train_step(x.to(torch.bfloat16), t, lr=0.3)
     e4 = make_engine(native_head(case, inp)[0], optimizer="lars"); e4.train_step(x.to(torch.bfloat16).float(), t, lr=0.3)
     assert torch.equal(e3.flat_p, e4.flat_p)
-    with pytest.raises(NotImplementedError):
-        e4.train_step(x, t, lr=0.3, image_index=torch.arange(case.B, device=DEV, dtype=torch.int32))
+    # a batch of a resident store (image_index): this matrix-core-bound head gathers it into a contiguous tensor -- same bits
+    perm = torch.randperm(case.B, device=DEV).to(torch.int32)
+    e5 = make_engine(native_head(case, inp)[0], optimizer="lars"); e5.train_step(x, t[perm.long()], lr=0.3, image_index=perm)
+    e6 = make_engine(native_head(case, inp)[0], optimizer="lars"); e6.train_step(x[perm.long()].contiguous(), t[perm.long()], lr=0.3)
+    assert torch.equal(e5.flat_p, e6.flat_p)
