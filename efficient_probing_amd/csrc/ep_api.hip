@@ -366,6 +366,11 @@ int aux_side_before_pass(AuxSide& a, const SideTasks& sd) {
   }
   return 0;
 }
+int aux_side_gemm(AuxSide& a, const GemmParams& g, int batch) {
+  if (!a.early) return gemm(false, false, g, batch, a.st);
+  EP_TRY(aux_side_sync(a));
+  return gemm(false, false, g, batch, a.side);
+}
 int aux_side_join(AuxSide& a) {
   if (a.side == a.st) return 0;
   EP_HIP(hipEventRecord(a.ev[5], a.side));

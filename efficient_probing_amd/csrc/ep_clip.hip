@@ -361,7 +361,7 @@ static int clip_forward_core(const ep_clip_dims& d, const void* x, int x_dtype, 
 
 static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
                               const float* tokstat, const ep_clip_params& pr, const float* dy, const ep_clip_params& gr, int acc,
-                              const ClipWs& w, hipStream_t st) {
+                              const ClipWs& w, hipStream_t st, AuxSide* axp = nullptr) {
   const int D = d.D, dh = D / d.H, B = d.B, H = d.H, N = d.N, BH = B * H;
   const float scale = (float)pow((double)dh, -0.5);
   const float* pos0 = pr.pos_embed; const float* posN = pr.pos_embed + D;
@@ -371,16 +371,21 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   if (!tokstat) tokstat = w.tstat;
   const int64_t nhd = (int64_t)BH * D;
   const unsigned eh = (unsigned)((nhd + 255) / 256), cgrid = (D + CG - 1) / CG;
+  // The six parameter-gradient contractions feed nothing before the optimizer: in the fused step they go to the aux stream, each
+  // as soon as its operands exist (AuxSide, ep_internal.h); the caller joins.  Stand-alone: inline, in program order.
+  AuxSide inline_ax;
+  if (!axp) { EP_TRY(aux_side_begin(inline_ax, st, nullptr)); axp = &inline_ax; }
+  AuxSide& ax = *axp;
   // y = o Wp^T + bp
   EP_TRY(colsum(dy, B, D, D, acc, gr.proj_b, st));
-  { GemmParams g = kg(dy, D, w.o, D, gr.proj_w, D, D, D, B); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }
+  { GemmParams g = kg(dy, D, w.o, D, gr.proj_w, D, D, D, B); g.accumulate = acc; EP_TRY(aux_side_gemm(ax, g, 1)); }
   EP_TRY(gemm(true, false, kg(dy, D, pr.proj_w, D, w.dO, D, B, D, D), 1, st));                                        // dO = dy Wp
   // o_h = vin_h Wv_h^T + bv_h
   EP_TRY(colsum(w.dO, B, D, D, acc, gr.qkv_b + 2 * D, st));
   {
     GemmParams g = kg(w.dO, D, w.vin, (int64_t)H * D, dWv, D, dh, D, B);                                              // dWv_h = dO_h^T vin_h
     g.sAz = dh; g.extA = dh; g.sBz = D; g.extB = D; g.sCz = (int64_t)dh * D; g.accumulate = acc;
-    EP_TRY(gemm(false, false, g, H, st));
+    EP_TRY(aux_side_gemm(ax, g, H));
   }
   {
     GemmParams g = kg(w.dO, D, Wv, D, w.dvin, (int64_t)H * D, B, D, dh);                                              // dvin_h = dO_h Wv_h
@@ -395,7 +400,7 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   hipLaunchKernelGGL(ep_clip_dppr_kernel, dim3(eh), dim3(256), 0, st, w.dvin, pr.norm_w, nhd, D, w.dPpr);
   EP_LAUNCH_CHECK("ep_clip value backward kernels");
   // Apos = A pos[1:] :  d pos[1:] = A^T dvin ; dAp = dvin pos[1:]^T
-  { GemmParams g = kg(w.A, N, w.dvin, D, dposN, D, N, D, BH); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }
+  { GemmParams g = kg(w.A, N, w.dvin, D, dposN, D, N, D, BH); g.accumulate = acc; EP_TRY(aux_side_gemm(ax, g, 1)); }
   EP_TRY(gemm(true, true, kg(w.dvin, D, posN, D, w.dAp, N, BH, N, D), 1, st));
   hipLaunchKernelGGL(ep_clip_delta_kernel, dim3((BH + 3) / 4), dim3(256), 0, st, w.dPpr, w.Ppr, w.dvin, w.xbar, pos0, w.A, w.dAp,
                      w.mix, BH, H, D, N, w.ML2, w.ds0);
@@ -412,7 +417,7 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   EP_TRY(clip_colred(w.w, (const float*)nullptr, 1, w.ds0, 1, BH, D, 0,
                      (float*)nullptr, 1, dpos0, w.cpart, st));
   EP_LAUNCH_CHECK("ep_clip key backward kernels");
-  { GemmParams g = kg(w.dS, N, w.w, D, dposN, D, N, D, BH); g.accumulate = 1; EP_TRY(gemm(false, false, g, 1, st)); }
+  { GemmParams g = kg(w.dS, N, w.w, D, dposN, D, N, D, BH); g.accumulate = 1; EP_TRY(aux_side_gemm(ax, g, 1)); }   // (behind the first dposN term: same stream)
   // w_h = scale q0_h Wk_h :  dq0_h = scale dw_h Wk_h^T ; dWk_h = scale q0_h^T dw_h ; d bk = 0
   {
     GemmParams g = kg(w.dw, (int64_t)H * D, Wk, D, w.dq0, D, B, dh, D);
@@ -422,12 +427,12 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   {
     GemmParams g = kg(w.q0, D, w.dw, (int64_t)H * D, dWk, D, dh, D, B);
     g.sAz = dh; g.extA = dh; g.sBz = D; g.extB = D; g.sCz = (int64_t)dh * D; g.alpha = scale; g.accumulate = acc;
-    EP_TRY(gemm(false, false, g, H, st));
+    EP_TRY(aux_side_gemm(ax, g, H));
   }
   if (!acc) EP_HIP(hipMemsetAsync(gr.qkv_b + D, 0, (size_t)D * sizeof(float), st));
   // q0 = t0 Wq^T + bq ;  t0 = g * xbar + b + pos_0
   EP_TRY(colsum(w.dq0, B, D, D, acc, gr.qkv_b, st));
-  { GemmParams g = kg(w.dq0, D, w.t0, D, dWq, D, D, D, B); g.accumulate = acc; EP_TRY(gemm(false, false, g, 1, st)); }
+  { GemmParams g = kg(w.dq0, D, w.t0, D, dWq, D, D, D, B); g.accumulate = acc; EP_TRY(aux_side_gemm(ax, g, 1)); }
   EP_TRY(gemm(true, false, kg(w.dq0, D, Wq, D, w.dt0, D, B, D, D), 1, st));                                          // dt0 = dq0 Wq
   EP_TRY(clip_colred(w.dt0, w.xbar, 1, (const float*)nullptr, 0, B, D, 1,
                      gr.norm_w, 0, (float*)nullptr, w.cpart, st));
@@ -531,11 +536,20 @@ int ep_clip_head_train_step(const ep_clip_step* s, void* ws, size_t ws_bytes, ep
     EP_TRY(linear_forward(w.z, Wc, bc, d.B, d.D, d.C, w.logits, w.ldl, st));
     EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
     EP_TRY(ce_stats(w.rowstat, d.B, s->stats, st));
-    EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, s->grads + offs[7], s->grads + offs[8],
-                           s->accumulate, st));
+    AuxSide ax;
+    EP_TRY(aux_side_begin(ax, st, (hipStream_t)s->aux_stream));
+    if (ax.early) {                                  // the classifier's weight gradient: beside dz and the BatchNorm backward
+      EP_TRY(aux_side_gemm(ax, dwc_gemm(w.dlogits, w.ldl, w.z, d.B, d.D, d.C, s->grads + offs[7], s->accumulate), 1));
+      EP_TRY(colsum(w.dlogits, d.B, d.C, w.ldl, s->accumulate, s->grads + offs[8], ax.side));
+      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, nullptr, nullptr, 0, st));
+    } else {
+      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, s->grads + offs[7], s->grads + offs[8],
+                             s->accumulate, st));
+    }
     EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, d.D, w.dy, w.bnpart, st));
     EP_TRY(clip_backward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, s->token_stats, pr, w.dy, gr, s->accumulate, w,
-                              st));
+                              st, &ax));
+    EP_TRY(aux_side_join(ax));
   }
   if (s->phases & 2) {
     EP_REQUIRE(s->found_inf, EP_E_ARG, "optimizer phase needs found_inf");

@@ -200,6 +200,8 @@ int aux_side_fork(AuxSide& a, const SideTasks& sd);        // early: aux waits f
 int aux_side_rest(AuxSide& a, const SideTasks& sd);        // early: the column sums and statistics of `sd`, now
 int aux_side_before_pass(AuxSide& a, const SideTasks& sd); // whatever of `sd` has not been launched (not early: all of it)
 int aux_side_join(AuxSide& a);                             // `st` waits for the aux stream
+// one T/T contraction whose operands exist now: early -> on the aux stream behind everything enqueued on `st` so far; else inline
+int aux_side_gemm(AuxSide& a, const GemmParams& g, int batch);
 int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
                     hipStream_t st, DeferredReduce* defer = nullptr);
 
