@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
-EP_ABI_VERSION = 22        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
+EP_ABI_VERSION = 23        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
 
@@ -256,7 +256,7 @@ class EPClipParams(C.Structure):
 
 
 class EPClipStep(C.Structure):
-    _fields_ = [("dims", EPClipDims)] + list(EPCaeStep._fields_[1:])
+    _fields_ = [("dims", EPClipDims)] + list(EPCaeStep._fields_[1:]) + [("xhat_mean", C.c_void_p)]
 
 
 class EPDolgDims(C.Structure):

@@ -311,8 +311,16 @@ static PoolParams clip_pool_params(const ep_clip_dims& d, const void* x, int x_d
   return p;
 }
 
+// rows of a cached per-image table: out[b, :] = table[index[b], :]
+__global__ void ep_clip_gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ index, int64_t total, int rowlen,
+                                           float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = table[(int64_t)(index ? index[i / rowlen] : (int)(i / rowlen)) * rowlen + (i % rowlen)];
+}
+
 static int clip_forward_core(const ep_clip_dims& d, const void* x, int x_dtype, int64_t bstride, const int32_t* index,
-                             const float* tokstat, const ep_clip_params& pr, const ClipWs& w, float* y, hipStream_t st) {
+                             const float* tokstat, const ep_clip_params& pr, const ClipWs& w, float* y, hipStream_t st,
+                             const float* xbar_table = nullptr) {
   const int D = d.D, dh = D / d.H, B = d.B, H = d.H, N = d.N, BH = B * H;
   const float scale = (float)pow((double)dh, -0.5);                        // attention_pool2d.py:124
   const float* pos0 = pr.pos_embed; const float* posN = pr.pos_embed + D;  // row 0: the mean row; rows 1..N: the patch rows
@@ -325,6 +333,12 @@ static int clip_forward_core(const ep_clip_dims& d, const void* x, int x_dtype, 
     if (have_xbar) EP_TRY(token_image_stats(x, x_dtype, bstride, B, N, D, d.ln_eps, 1, w.tstat, w.xbar, st));
     else EP_TRY(token_stats(x, x_dtype == EP_DTYPE_BF16, bstride, B, N, D, d.ln_eps, w.tstat, st));
     tokstat = w.tstat;
+  }
+  if (!have_xbar && xbar_table) {                    // the store's cached table (ABI v23): the batch's rows, no token read
+    const int64_t nbd = (int64_t)B * D;
+    hipLaunchKernelGGL(ep_clip_gather_rows_kernel, dim3((unsigned)((nbd + 255) / 256)), dim3(256), 0, st, xbar_table, index, nbd, D, w.xbar);
+    EP_LAUNCH_CHECK("ep_clip_gather_rows_kernel");
+    have_xbar = true;
   }
   if (!have_xbar) EP_TRY(xhat_mean(x, x_dtype, bstride, index, tokstat, B, N, D, w.xbar, st));
   const int64_t nd = (int64_t)B * D, nhd = (int64_t)BH * D;
@@ -530,7 +544,8 @@ int ep_clip_head_train_step(const ep_clip_step* s, void* ws, size_t ws_bytes, ep
   if (s->phases & 1) {
     EP_REQUIRE(s->x && s->targets && s->running_mean && s->running_var && s->stats, EP_E_ARG, "train step: null input");
     EP_TRY(check_tokens(s->x, s->x_dtype, s->x_bstride, d.B, d.N, d.D, d.H));
-    EP_TRY(clip_forward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, s->token_stats, pr, w, w.y, st));
+    EP_REQUIRE(!s->xhat_mean || s->token_stats, EP_E_ARG, "clip: the xhat_mean table goes with the token_stats table it was made from");
+    EP_TRY(clip_forward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, s->token_stats, pr, w, w.y, st, s->xhat_mean));
     EP_TRY(bn_forward_train(w.y, d.B, d.D, s->bn_eps, s->bn_momentum, w.z, w.rstd, s->running_mean, s->running_var,
                             s->num_batches_tracked, w.bnpart, st));
     EP_TRY(linear_forward(w.z, Wc, bc, d.B, d.D, d.C, w.logits, w.ldl, st));

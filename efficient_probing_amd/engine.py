@@ -75,7 +75,7 @@ class ProbeHeadEngine:
     def _table_ptr(self, field: str) -> int:
         """Pointer for a step / eval struct: the caller's explicit per-call table, else the attached store's, else 0 (the
         library computes the statistics of the batch itself)."""
-        explicit = getattr(self, "_tokstat" if field == "token_stats" else "_imgstat", None)
+        explicit = getattr(self, {"token_stats": "_tokstat", "image_stats": "_imgstat"}.get(field, "_no_such_field"), None)
         if explicit is not None:
             return explicit.data_ptr()
         t = getattr(self, "_bound_tables", {}).get(field)
@@ -854,7 +854,7 @@ class CaitHeadEngine(CaeHeadEngine):
 class ClipHeadEngine(CaeHeadEngine):
     """Fused train / eval step of Sequential(AttentionPool2d (CLIP), BatchNorm1d, Linear) through ``ep_clip_head_train_step``."""
 
-    _store_kinds = {"token_stats": ("token_stats", F_.CLIP_LN_EPS)}
+    _store_kinds = {"token_stats": ("token_stats", F_.CLIP_LN_EPS), "xhat_mean": ("xhat_mean", F_.CLIP_LN_EPS)}
 
     def _check_head(self, head):
         from .probe_heads import is_native_clip_head
@@ -871,6 +871,7 @@ class ClipHeadEngine(CaeHeadEngine):
     def _new_step(self):
         s = N.EPClipStep()
         s.token_stats = self._table_ptr("token_stats")
+        s.xhat_mean = self._table_ptr("xhat_mean") if s.token_stats else 0      # (the table goes with the statistics it was made from)
         s.ln_eps = F_.CLIP_LN_EPS
         return s
 

@@ -664,6 +664,21 @@ def token_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     return out
 
 
+def token_xhat_mean(x: torch.Tensor, stats: torch.Tensor, image_index=None) -> torch.Tensor:
+    """(B, D) mean over the N tokens of the normalised rows (x - mean) * rstd, given ``stats`` = token_stats(x, eps): the CLIP
+    head's mean-row query input (reference poolings/clip/attention_pool2d.py:153-155).  A function of the frozen tokens only:
+    a resident store keeps it as a table (``ResidentTokenStore.table("xhat_mean", eps)``)."""
+    lib = N.load()
+    xv, bstride = as_token_view(x)
+    iptr, B = _index_arg(image_index, xv)
+    _, Nn, D = xv.shape
+    stats = _f32c(stats, "token_stats")
+    out = torch.empty((B, D), device=xv.device, dtype=torch.float32)
+    N.check(lib.ep_token_xhat_mean(xv.data_ptr(), token_dtype_code(xv), bstride, iptr, stats.data_ptr(), B, Nn, D, out.data_ptr(),
+                                   N.current_stream_ptr(xv.device)), "ep_token_xhat_mean")
+    return out
+
+
 def pool_forward_ln(x, cls_token, scale, stats, image_index=None):
     """EP pooling of the NORMALISED tokens xhat = (x - mean) * rstd without materialising them.
     Returns P (B,Q,D) = softmax_n(S) xhat, S (B,Q,N) = (cls*scale) . xhat, ML (B,Q,4)."""

@@ -164,18 +164,20 @@ class ResidentTokenStore:
         ``"token_stats"``: (n, N, 2) {mean, rstd} of a LayerNorm over D with ``eps`` (CAE / JEPA / CaiT / CLIP / SimPool heads;
         the reference applies that LayerNorm to the tokens in every forward, e.g. poolings/cae/cae_att.py:104,
         poolings/simpool.py:52), ``"channel_stats"``: (n, 2, D) per-image column mean and sum of squared deviations (AIM's token
-        BatchNorm, SimPool's mean-token query), ``"cbam_channel_table"``: (n, 3, D).  ``engine.attach_store(store)`` makes an
+        BatchNorm, SimPool's mean-token query), ``"cbam_channel_table"``: (n, 3, D), ``"xhat_mean"``: (n, D) mean normalised token
+        row (the CLIP head's query input; made from ``"token_stats"`` of the same ``eps``).  ``engine.attach_store(store)`` makes an
         engine look them up (``engine_finetune.train_one_epoch`` / ``evaluate`` do that for a ``StoreBatch``)."""
         from . import functional as F_
         key = (kind, None if eps is None else float(eps))
         cache = self.__dict__.setdefault("_tables", {})
         if key not in cache:
-            fn = {"token_stats": lambda t: F_.token_stats(t, eps), "channel_stats": F_.channel_stats,
-                  "cbam_channel_table": F_.cbam_channel_table}.get(kind)
+            fn = {"token_stats": lambda t, lo: F_.token_stats(t, eps), "channel_stats": lambda t, lo: F_.channel_stats(t),
+                  "cbam_channel_table": lambda t, lo: F_.cbam_channel_table(t),
+                  "xhat_mean": lambda t, lo: F_.token_xhat_mean(t, self.table("token_stats", eps)[lo:lo + t.shape[0]])}.get(kind)
             if fn is None:
                 raise ValueError(f"unknown store table {kind!r}")
             n = self.tokens.shape[0]
-            parts = [fn(self.tokens[lo:lo + 32768]) for lo in range(0, n, 32768)]      # bounded launch grids
+            parts = [fn(self.tokens[lo:lo + 32768], lo) for lo in range(0, n, 32768)]  # bounded launch grids
             cache[key] = parts[0] if len(parts) == 1 else torch.cat(parts)
         return cache[key]
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 22
+#define EP_ABI_VERSION 23
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -921,6 +921,10 @@ typedef struct ep_clip_step {
   int64_t opt_step;
   int32_t phases;
   ep_stream_t aux_stream;
+  /* ABI v23: optional (M, D) table of the mean normalised token row of every image of a resident store
+   * (ep_token_xhat_mean over the whole store, same ln eps; indexed like x through image_index; needs token_stats).  It
+   * depends on the frozen tokens only: with it a step reads the batch's tokens twice instead of three times.  NULL: computed. */
+  const float* xhat_mean;
 } ep_clip_step;
 
 int64_t ep_clip_head_param_offsets(const ep_clip_dims* dims, int64_t offsets[9]);
