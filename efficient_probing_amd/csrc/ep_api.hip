@@ -371,6 +371,15 @@ int aux_side_gemm(AuxSide& a, const GemmParams& g, int batch) {
   EP_TRY(aux_side_sync(a));
   return gemm(false, false, g, batch, a.side);
 }
+int classifier_backward(AuxSide& a, const float* dlogits, int ldl, const float* z, const float* Wc, int B, int D, int C, float* dz,
+                        float* dWc, float* dbc, int accumulate) {
+  if (!a.early) return linear_backward(dlogits, ldl, z, Wc, B, D, C, dz, dWc, dbc, accumulate, a.st);
+  GemmParams g = dwc_gemm(dlogits, ldl, z, B, D, C, dWc, accumulate);
+  g.side = 1;
+  EP_TRY(aux_side_gemm(a, g, 1));
+  EP_TRY(colsum(dlogits, B, C, ldl, accumulate, dbc, a.side));
+  return linear_backward(dlogits, ldl, z, Wc, B, D, C, dz, nullptr, nullptr, 0, a.st);
+}
 int aux_side_join(AuxSide& a) {
   if (a.side == a.st) return 0;
   EP_HIP(hipEventRecord(a.ev[5], a.side));

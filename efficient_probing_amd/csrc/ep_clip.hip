@@ -553,14 +553,8 @@ int ep_clip_head_train_step(const ep_clip_step* s, void* ws, size_t ws_bytes, ep
     EP_TRY(ce_stats(w.rowstat, d.B, s->stats, st));
     AuxSide ax;
     EP_TRY(aux_side_begin(ax, st, (hipStream_t)s->aux_stream));
-    if (ax.early) {                                  // the classifier's weight gradient: beside dz and the BatchNorm backward
-      EP_TRY(aux_side_gemm(ax, dwc_gemm(w.dlogits, w.ldl, w.z, d.B, d.D, d.C, s->grads + offs[7], s->accumulate), 1));
-      EP_TRY(colsum(w.dlogits, d.B, d.C, w.ldl, s->accumulate, s->grads + offs[8], ax.side));
-      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, nullptr, nullptr, 0, st));
-    } else {
-      EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, s->grads + offs[7], s->grads + offs[8],
-                             s->accumulate, st));
-    }
+    EP_TRY(classifier_backward(ax, w.dlogits, w.ldl, w.z, Wc, d.B, d.D, d.C, w.dz, s->grads + offs[7], s->grads + offs[8],
+                               s->accumulate));     // (the weight gradient: beside dz and the BatchNorm backward)
     EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, d.D, w.dy, w.bnpart, st));
     EP_TRY(clip_backward_core(d, s->x, s->x_dtype, s->x_bstride, s->image_index, s->token_stats, pr, w.dy, gr, s->accumulate, w,
                               st, &ax));

@@ -202,6 +202,10 @@ int aux_side_before_pass(AuxSide& a, const SideTasks& sd); // whatever of `sd` h
 int aux_side_join(AuxSide& a);                             // `st` waits for the aux stream
 // one T/T contraction whose operands exist now: early -> on the aux stream behind everything enqueued on `st` so far; else inline
 int aux_side_gemm(AuxSide& a, const GemmParams& g, int batch);
+// The classifier's backward (reference probe_heads.py:76 Linear and its autograd): dz = dlogits Wc on `st`; dWc = dlogits^T z
+// and dbc = column sums of dlogits feed nothing before the optimizer -- early on the aux stream (AuxSide) or inline.
+int classifier_backward(AuxSide& a, const float* dlogits, int ldl, const float* z, const float* Wc, int B, int D, int C, float* dz,
+                        float* dWc, float* dbc, int accumulate);
 int reduce_partials(const float* parts, int nparts, int n, float scale, int accumulate, float* out, float* stage,
                     hipStream_t st, DeferredReduce* defer = nullptr);
 
