@@ -339,10 +339,19 @@ static int aux_side_sync(AuxSide& a) {                // aux waits for everythin
   EP_HIP(hipStreamWaitEvent(a.side, e, 0));
   return 0;
 }
+// An early contraction runs beside the chain in front of the pass, not beside the pass: the `side` hint (which keeps a
+// contraction beside a vector-issue-bound stream on the exact-f32 kernel, ep_gemm.hip: gemm_b3_ok) does not apply.  EP_AUX_B3=0 keeps it.
+static GemmParams aux_early_params(const GemmParams& g) {
+  static int b3 = -1;
+  if (b3 < 0) { const char* e = getenv("EP_AUX_B3"); b3 = e ? atoi(e) : 1; }
+  GemmParams q = g;
+  if (b3) q.side = 0;
+  return q;
+}
 int aux_side_fork(AuxSide& a, const SideTasks& sd) {
   if (!a.early || a.launched >= sd.n_gemm) return 0;
   EP_TRY(aux_side_sync(a));
-  for (; a.launched < sd.n_gemm; ++a.launched) EP_TRY(gemm(false, false, sd.g[a.launched], sd.gz[a.launched], a.side));
+  for (; a.launched < sd.n_gemm; ++a.launched) EP_TRY(gemm(false, false, aux_early_params(sd.g[a.launched]), sd.gz[a.launched], a.side));
   return 0;
 }
 int aux_side_rest(AuxSide& a, const SideTasks& sd) {
@@ -369,7 +378,7 @@ int aux_side_before_pass(AuxSide& a, const SideTasks& sd) {
 int aux_side_gemm(AuxSide& a, const GemmParams& g, int batch) {
   if (!a.early) return gemm(false, false, g, batch, a.st);
   EP_TRY(aux_side_sync(a));
-  return gemm(false, false, g, batch, a.side);
+  return gemm(false, false, aux_early_params(g), batch, a.side);
 }
 int classifier_backward(AuxSide& a, const float* dlogits, int ldl, const float* z, const float* Wc, int B, int D, int C, float* dz,
                         float* dWc, float* dbc, int accumulate) {
