@@ -123,3 +123,30 @@ def test_resident_store_epoch_equals_gathered_batches(name):
     ev_gath = EF.evaluate([(t[i.long()].contiguous(), y) for t, i, y in store.batches(B, epoch=1, shuffle=False, drop_last=False)],
                           models[0], torch.device(DEV))
     assert abs(ev_store["loss"] - ev_gath["loss"]) <= 1e-5 * max(1.0, abs(ev_gath["loss"])) and ev_store["acc1"] == ev_gath["acc1"]
+
+
+@pytest.mark.parametrize("name", ["ep", "cae", "simpool", "clip", "aim", "cbam"])
+def test_bf16_resident_store_epoch_equals_gathered_batches(name):
+    """The same with the tokens STORED as bf16 (the protocol's dump format for the large encoders): the store's tables are then
+    computed from the bf16 tokens, exactly what a step computes for a gathered bf16 batch."""
+    from efficient_probing_amd import engine_finetune as EF
+    from efficient_probing_amd import token_store as TS
+    from efficient_probing_amd.util.lars import LARS
+    from efficient_probing_amd.util.misc import NativeScalerWithGradNormCount
+    g = torch.Generator().manual_seed(13)
+    n_img = 2 * B + 5
+    tokens = torch.randn(n_img, N_TOK, D, generator=g).to(DEV).to(torch.bfloat16)
+    labels = torch.randint(0, C, (n_img,), generator=g).to(DEV)
+    store = TS.ResidentTokenStore.from_tensors(tokens, labels, seed=4)
+    assert store.dtype == "bfloat16"
+    gathered = [(t[i.long()].contiguous(), y) for t, i, y in store.batches(B, epoch=0)]
+    args = Namespace(accum_iter=1, amp="none", lr=0.2, min_lr=0.0, warmup_epochs=0, epochs=2, output_dir="", suffix="t", resume="")
+    models = []
+    for feed in ("store", "gathered"):
+        model = fix_grid(make_model(name))
+        opt = LARS(model.head.parameters(), lr=0.0, weight_decay=0.0)
+        data = store.loader(B, epoch=0) if feed == "store" else gathered
+        EF.train_one_epoch(model, torch.nn.CrossEntropyLoss(), data, opt, torch.device(DEV), 0, NativeScalerWithGradNormCount(), args=args)
+        models.append(model)
+    for (k, a), (_, b) in zip(models[0].head.state_dict().items(), models[1].head.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=2e-5, atol=2e-6), f"{name}: {k} differs by {float((a.float() - b.float()).abs().max()):.3e}"
