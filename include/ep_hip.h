@@ -274,8 +274,13 @@ typedef struct ep_head_step {
   int64_t opt_step;
   int32_t phases;
   ep_stream_t aux_stream; /* optional second caller-owned stream: the weight-gradient contractions
-                             (dWc, dWv, dbc) that nothing else in the step depends on run there,
-                             concurrently with the second token pass; NULL = everything on `stream` */
+                             (dWc, dWv, dbc) that nothing else in the step depends on run there where
+                             the second token pass cannot carry them as side workgroups; the call
+                             forks and joins with events, `stream` is complete when it returns to
+                             the caller's queue order; NULL = everything on `stream`.  The other
+                             heads' step structs have the same field: since round 4 their
+                             parameter-gradient contractions start there as soon as their operands
+                             exist (csrc/ep_internal.h: AuxSide). */
   /* Split phases for communication overlap (ABI v7).  phases bit 2 (4): only the first token pass
    * (needs nothing but cls_token); bit 3 (8): everything of phase 1 after it.  1 == 4|8.
    * The optimizer phase updates parameter tensors [opt_first_segment, opt_first_segment +
