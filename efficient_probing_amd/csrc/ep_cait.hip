@@ -398,8 +398,12 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   const unsigned cgrid = (D + CG - 1) / CG;
   if (!tokstat) tokstat = w.tstat;
   // the weight-gradient contractions: on the aux stream, each as early as its operands exist (AuxSide, ep_internal.h)
+  PoolParams p = cait_pool_params(d, x, x_dtype, bstride, index, tokstat, w);
+  p.ML = w.ML2;                                       // the (N + 1)-entry softmax state
+  p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
+  const bool in_pass = pool_backward_takes_side(p);   // side workgroups of the second pass where its kernel takes them
   AuxSide ax;
-  EP_TRY(aux_side_begin(ax, st, aux));
+  EP_TRY(aux_side_begin(ax, st, in_pass ? nullptr : aux));
   EP_TRY(aux_side_fork(ax, sd));                     // the caller's (the classifier's weight gradient)
   GemmParams gW2 = cgm(w.dm2, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;
   GemmParams gW1 = cgm(w.dh1, Hd, w.h2, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;
@@ -452,12 +456,13 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
     g.sAz = dh; g.sBz = (int64_t)dh * D; g.sCz = D; g.extB = D;
     EP_TRY(gemm(true, false, g, H, st));
   }
-  PoolParams p = cait_pool_params(d, x, x_dtype, bstride, index, tokstat, w);
-  p.ML = w.ML2;                                       // the (N + 1)-entry softmax state
-  p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
-  EP_TRY(aux_side_before_pass(ax, sd));
-  EP_TRY(pool_backward(p, w.dw, 0, st));
-  EP_TRY(aux_side_join(ax));
+  if (in_pass) {
+    EP_TRY(pool_backward(p, w.dw, 0, st, &sd));
+  } else {
+    EP_TRY(aux_side_before_pass(ax, sd));
+    EP_TRY(pool_backward(p, w.dw, 0, st));
+    EP_TRY(aux_side_join(ax));
+  }
   // class entry: dw += chat sum_b dS_c ; dchat ; dWv' += dvc chat^T
   hipLaunchKernelGGL(ep_cait_clsred_part_kernel, dim3((D + 31) / 32, CAIT_RS), dim3(1024), 0, st, w.csc, w.dP, (int64_t)B * H, D, w.cpart);
   hipLaunchKernelGGL(ep_cait_clsred_kernel, dim3((D + 31) / 32), dim3(1024), 0, st, w.csc, w.cpart, CAIT_RS, w.wq, w.chat, B, H, D, w.dw,

@@ -463,7 +463,11 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
 bool pool_backward_takes_side(const PoolParams& p) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_SIDE"); allow = e ? atoi(e) : 1; }
-  if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || force_generic()) return false;
+  // (LayerNorm-of-tokens mode of the vector-ALU kernel: since round 4 -- CaiT's five weight gradients in its pass, 1.167 ->
+  // 1.158 ms against their early start on the aux stream; EP_POOL_SIDE_LN=0 keeps them there)
+  static int allow_ln = -1;
+  if (allow_ln < 0) { const char* e = getenv("EP_POOL_SIDE_LN"); allow_ln = e ? atoi(e) : 1; }
+  if (!allow || needs_generic(p) || (p.tokstat && !allow_ln) || use_wide(p) || force_generic()) return false;
   if (use_mb(p)) return mb_takes_side(p.D);          // bf16 tokens: the two-workgroup matrix-core pass carries them too
   if (use_mm(p, true) || use_mf(p, true)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
