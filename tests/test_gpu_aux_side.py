@@ -41,6 +41,11 @@ eng = make_engine(head.to("cuda:0").train(), optimizer="lars", lr=0.2, weight_de
 g = torch.Generator().manual_seed(5)
 for s in range(3):
     x = torch.randn(B, N, D, generator=g).to("cuda:0")
+    tok = os.environ.get("EP_TEST_TOKENS", "f32")
+    if tok == "bf16":
+        x = x.to(torch.bfloat16)                       # bf16-STORED tokens
+    elif tok == "bf16_as_f32":
+        x = x.to(torch.bfloat16).float()               # the same values held as fp32
     t = torch.randint(0, C, (B,), generator=g).to("cuda:0")
     eng.train_step(x, t)
 torch.cuda.synchronize()
@@ -67,3 +72,18 @@ def test_schedules_agree(name):
             assert np.allclose(other[k], base[k], rtol=2e-4, atol=2e-5 * scale), \
                 f"{name} {env} {k}: max diff {float(np.abs(other[k] - base[k]).max()):.3e} (scale {scale:.3e})"
         assert abs(other["stats"][0] - base["stats"][0]) <= 1e-4 * abs(base["stats"][0])
+
+
+def test_cait_bf16_tokens_in_pass_side_work_agrees():
+    """CaiT on bf16-stored tokens: its weight gradients ride in the LayerNorm-mode second pass as side workgroups (default),
+    start early on the aux stream (EP_POOL_SIDE_LN=0) or run on one stream -- and equal the step on fp32 tokens holding the
+    same rounded values."""
+    base = run("cait", {"EP_TEST_TOKENS": "bf16"})
+    assert np.isfinite(base["p"]).all() and base["stats"][3] == 0
+    for env in ({"EP_TEST_TOKENS": "bf16", "EP_POOL_SIDE_LN": "0"}, {"EP_TEST_TOKENS": "bf16", "EP_AUX_STREAM": "0"},
+                {"EP_TEST_TOKENS": "bf16_as_f32"}):
+        other = run("cait", env)
+        for k in ("p", "mu"):
+            scale = float(np.abs(base[k]).max())
+            assert np.allclose(other[k], base[k], rtol=2e-4, atol=2e-5 * scale), \
+                f"cait {env} {k}: max diff {float(np.abs(other[k] - base[k]).max()):.3e} (scale {scale:.3e})"
