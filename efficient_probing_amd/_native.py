@@ -375,6 +375,7 @@ SIGNATURES = {
                                             c_float, c_f32p, c_int, c_void, c_size, c_void]),
     "ep_l2_normalize": (c_int, [c_f32p, c_i64, c_int, c_float, c_f32p, c_void]),
     "ep_knn_workspace_bytes": (c_size, [c_int, c_int]),
+    "ep_knn_workspace_bytes_ex": (c_size, [c_int, c_int, c_int]),
     "ep_knn_topk": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_void, c_int, c_void, c_size, c_void]),
     "ep_knn_vote": (c_int, [c_f32p, c_void, c_int, c_void, c_int, c_int, c_float, c_int, c_void, c_void, c_f32p, c_void]),
     "ep_siglip_pool_workspace_bytes": (c_size, [C.POINTER(EPSiglipDims)]),

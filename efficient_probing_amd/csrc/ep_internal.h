@@ -78,6 +78,8 @@ struct GemmParams {
   const float* cs_z; float* cs_out;
   // ep_planes.hip: the B operand as pre-split bf16 planes (weights; see planes_split) -- [term][row][ldbp], K contiguous
   const uint16_t* Bpl; int64_t pl_term, ldbp, sBpz;   // plane base, term stride, row stride, batch offset (elements)
+  int m_fast;                       // planes kernel: M-tiles fastest in the launch order (few M-tiles against a very long N: the
+                                    // workgroups that share a weight tile then run together and it is fetched from HBM once)
 };
 
 // a row-major weight matrix W (R x K, leading dimension ldw) and where its planes go (ep_planes.hip); either may be null

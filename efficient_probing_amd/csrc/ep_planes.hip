@@ -197,7 +197,17 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 multiply, 8..11 only move data
   const int i16 = lane & 15, kk = lane >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * (16 * NB);
+  int mt_ = blockIdx.y, nt_ = blockIdx.x;
+  if (p.m_fast) {
+    // 1-D launch, M-tiles fastest, XCD-aware: workgroup L runs on XCD L % 8, so XCD c walks the contiguous range of tile
+    // numbers [c per, (c + 1) per) -- the M-tiles of one weight tile are neighbours in time on ONE XCD's L2
+    const int mtn = (p.M + 63) / 64, ntn = (p.N + 16 * NB - 1) / (16 * NB);
+    const unsigned per = gridDim.x / 8u, L = blockIdx.x;
+    const unsigned V = (L % 8u) * per + L / 8u;
+    if (V >= (unsigned)mtn * (unsigned)ntn) return;
+    mt_ = (int)(V % (unsigned)mtn); nt_ = (int)(V / (unsigned)mtn);
+  }
+  const int m0 = mt_ * 64, n0 = nt_ * (16 * NB);
   const int z = blockIdx.z;
   const int nk = (p.K + BK - 1) / BK;
   const bool ktail = (p.K % BK) != 0;
@@ -359,7 +369,10 @@ static void planes_launch(const GemmParams& p, int batch, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   dim3 grid((p.N + 16 * NB - 1) / (16 * NB), (p.M + 63) / 64, batch);
-  hipLaunchKernelGGL(ep_gemm_planes_kernel<NB>, grid, dim3(768), lds, st, p);
+  GemmParams q = p;
+  if (batch != 1) q.m_fast = 0;                      // (the 1-D tile numbering is for single contractions)
+  if (q.m_fast) grid = dim3(8u * (unsigned)(((size_t)grid.x * grid.y + 7) / 8), 1, 1);
+  hipLaunchKernelGGL(ep_gemm_planes_kernel<NB>, grid, dim3(768), lds, st, q);
 }
 // 64 x 128 tiles when they fill the chip at least twice (EP_PLANES_WIDE=0 / 1 forces)
 static bool planes_wide(const GemmParams& p, int batch) {

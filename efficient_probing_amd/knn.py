@@ -51,7 +51,7 @@ def knn_search(train_features: torch.Tensor, test_features: torch.Tensor, k: int
         raise ValueError(f"features must be (n, D) with equal D, got {tuple(tr.shape)} and {tuple(te.shape)}")
     M, D = te.shape
     n_train = tr.shape[0]
-    nbytes = lib.ep_knn_workspace_bytes(M, n_train)
+    nbytes = lib.ep_knn_workspace_bytes_ex(M, n_train, D)
     ws = torch.empty(nbytes, device=te.device, dtype=torch.uint8)
     sims = torch.empty((M, k), device=te.device, dtype=torch.float32)
     idx = torch.empty((M, k), device=te.device, dtype=torch.int32)

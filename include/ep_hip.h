@@ -468,6 +468,9 @@ int ep_abmilp_head_eval_forward(const ep_abmilp_dims* dims, const void* x, int x
  * ------------------------------------------------------------------------------------------ */
 int ep_l2_normalize(const float* x, int64_t rows, int D, float eps, float* out, ep_stream_t stream);
 size_t ep_knn_workspace_bytes(int M, int n_train);
+/* the same for features of width D (round 4: the gallery's bf16 planes live in the workspace too -- they are split once per
+ * search and every query chunk's similarities run on the planes kernel; ep_knn_workspace_bytes sizes them for D <= 1536) */
+size_t ep_knn_workspace_bytes_ex(int M, int n_train, int D);
 int ep_knn_topk(const float* test, const float* train, int M, int n_train, int D, int k, float* sims,
                 int32_t* idx, int out_ld, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_knn_vote(const float* sims, const int32_t* idx, int ld, const int64_t* train_labels, int M, int k,

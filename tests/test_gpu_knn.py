@@ -96,3 +96,48 @@ def test_full_size_search_is_fast_and_consistent():
     assert (sims[:, :-1] >= sims[:, 1:]).all()
     ref = (test[:64] @ train.t()).topk(200, dim=1).values            # stock fp32 GEMM + topk as an independent check
     np.testing.assert_allclose(sims[:64].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=3e-6)
+
+
+def test_fast_select_path_ties_fallback_and_ordered_rows():
+    """Rows long enough for the two-pass selection (group maxima -> threshold -> gather; csrc/ep_knn.hip): the same exact
+    result and tie rule (value descending, lowest index first) as the radix passes it replaces, which still take over when
+    the candidates do not come together."""
+    from efficient_probing_amd import knn
+    rng = np.random.default_rng(11)
+    # (1) every gallery row 16 times: exact ties everywhere, also across the k-th place
+    base = rng.standard_normal((4096, 16)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)              # unit rows: a row's best match is itself
+    train = np.tile(base, (16, 1))                                   # row j + 4096 c == row j
+    test = base[:32].copy()
+    k = 50
+    sims, idx = knn.knn_search(dev(train), dev(test), k)
+    s, i = sims.cpu().numpy(), idx.cpu().numpy()
+    for r in range(32):
+        assert list(i[r, :16]) == [r + 4096 * c for c in range(16)]
+        order = np.lexsort((i[r], -s[r]))
+        assert (order == np.arange(k)).all()                         # sorted by (value descending, index ascending)
+        # tie groups: complete ones hold all 16 copies, the cut one the LOWEST copies
+        for v in np.unique(s[r]):
+            grp = i[r][s[r] == v]
+            j = grp[0] % 4096
+            assert (grp == j + 4096 * np.arange(len(grp))).all()
+    true = np.einsum("md,mkd->mk", test, train[i])
+    np.testing.assert_allclose(s, true, rtol=0, atol=2e-5)
+    ref = (dev(test) @ dev(train).t()).topk(k, dim=1).values.cpu().numpy()
+    np.testing.assert_allclose(s, ref, rtol=0, atol=2e-5)
+    # (2) all-equal similarities: no element above any threshold -> the radix passes, lowest indices
+    ones = np.ones((40000, 8), np.float32)
+    sims, idx = knn.knn_search(dev(ones), dev(np.ones((3, 8), np.float32)), 10)
+    assert (idx.cpu().numpy() == np.arange(10)[None, :]).all() and (sims.cpu().numpy() == 8.0).all()
+    # (3) similarities increasing along the row: the top k sit at its very end
+    ramp = np.linspace(-1.0, 1.0, 70001, dtype=np.float32)[:, None] * np.ones((1, 4), np.float32)
+    sims, idx = knn.knn_search(dev(ramp), dev(np.ones((2, 4), np.float32)), 200)
+    assert (idx.cpu().numpy() == np.arange(70000, 70000 - 200, -1)[None, :]).all()
+    # (4) k at the capacity of the neighbour list
+    g = torch.Generator(device=DEV).manual_seed(2)
+    tr = knn.l2_normalize(torch.randn(100_000, 64, device=DEV, generator=g))
+    te = knn.l2_normalize(torch.randn(16, 64, device=DEV, generator=g))
+    sims, idx = knn.knn_search(tr, te, 1024)
+    ref = (te @ tr.t()).topk(1024, dim=1)
+    np.testing.assert_allclose(sims.cpu().numpy(), ref.values.cpu().numpy(), rtol=0, atol=2e-6)
+    assert (idx.long() == ref.indices).float().mean() > 0.98        # (near-ties may swap between the two contractions)
