@@ -325,7 +325,10 @@ __global__ __launch_bounds__(64) void ep_knn_vote_kernel(const float* __restrict
 
 static int64_t knn_ld(int n_train) { return ((int64_t)n_train + 3) / 4 * 4; }
 static int knn_chunk_rows(int M, int n_train) {
-  int64_t rows = (int64_t)(1LL << 31) / (knn_ld(n_train) * 4);       // <= 2 GiB of similarities at a time
+  static int64_t cap = -1;                                            // EP_KNN_CHUNK_GIB (default 4): similarities held at a time
+  if (cap < 0) { const char* e = getenv("EP_KNN_CHUNK_GIB"); cap = (int64_t)(e ? atoi(e) : 4) << 30; if (cap < (1LL << 28)) cap = 1LL << 28; }
+  int64_t rows = cap / (knn_ld(n_train) * 4);
+  if (rows >= 128) rows -= rows % 64;                                 // whole 64-row tiles of the similarity contraction
   if (rows < 16) rows = 16;
   if (rows > M) rows = M;
   return (int)rows;
