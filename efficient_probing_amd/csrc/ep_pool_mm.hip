@@ -28,6 +28,9 @@ namespace ep {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
+#ifndef EP_MM_ABLATE
+#define EP_MM_ABLATE 0                // diagnostic builds of the forward (tools/build_variant.sh): 1 ring + barriers only,
+#endif                                // 2 + score MFMAs, 3 + gather / softmax (no pooling MFMAs); results are then wrong
 constexpr int MM_TT = 16;             // tokens per tile
 constexpr int MM_NW = 8;              // waves per workgroup (one workgroup per CU)
 constexpr float MM_LOG2E = 1.4426950408889634f;
@@ -102,6 +105,9 @@ __device__ __forceinline__ void mm_dma_tile(const char* src, unsigned limit, cha
   }
 }
 
+__device__ __forceinline__ void continue_tile(int& ctile, int& cimg, int tiles_per_img) {   // (ablation builds only)
+  if (ctile == tiles_per_img - 1) { ctile = 0; ++cimg; } else ++ctile;
+}
 // step 1: 16 tokens x 16 queries over this wave's D-slice -> LDS scratch; `mid` (the ring refill) is
 // issued in the shadow of the first MFMAs.  Two accumulators halve the dependent-chain latency.
 template <int NG, typename F>
@@ -255,8 +261,10 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
 #pragma unroll
       for (int blk = 0; blk < NG; ++blk) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (EP_MM_ABLATE == 1) { produce(); mm_barrier(); continue_tile(ctile, cimg, tiles_per_img); continue; }
     mm_scores<NG>(tile, aoff, bq, spart, w, lane, produce);
     mm_barrier();                                   // all partial score blocks are in the scratch
+    if constexpr (EP_MM_ABLATE == 2) { continue_tile(ctile, cimg, tiles_per_img); continue; }
     float sc[4], ue[4];
     mm_gather(spart, j, kk, sc);
     float tm[4], tr[4];
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(MM_NW * 64, 2) void ep_pool_mm_fwd_kernel(PoolParam
       for (int s = 0; s < 4; ++s)
         if ((4 * s + kk) < nvalid) p.S[((int64_t)b * QS + j) * N + (unsigned)(n0 + 4 * s + kk)] = sc[s];
     }
-    mm_pool<NG>(tile, plane, w, wgt, acc);
+    if constexpr (EP_MM_ABLATE != 3) mm_pool<NG>(tile, plane, w, wgt, acc);
     if (ctile == tiles_per_img - 1) {
       const float l = q4_sum(lsum);
       const float inv = 1.0f / l;
