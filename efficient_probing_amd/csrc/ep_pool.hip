@@ -396,7 +396,11 @@ static int query_chunk(const PoolParams& p, bool bwd) {
     if (use_mb(q)) return 16;
   }
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
-  if (c.ok && stream_takes(p)) return 0;
+  // The vector-ALU kernel takes up to 32 queries in one pass, but beyond 16 its FORWARD is slower than two 16-query chunks on
+  // the all-matrix-core kernel (256 x 768, Q = 32: 445 -> 385 us; the backward 407 -> 417 us, so it stays): round 4, default.
+  // EP_POOL_QCHUNK=2: both directions in chunks; 3: neither.
+  const bool prefer_chunks = p.Q > 16 && on != 3 && (on == 2 || !bwd);
+  if (c.ok && stream_takes(p) && !prefer_chunks) return 0;
   for (int qc = 16; qc >= 8; qc -= 8) {
     if (p.Q <= qc) continue;
     PoolParams q = p;
