@@ -67,7 +67,11 @@ class ProbeHeadEngine:
         st = getattr(self, "_store", None)
         if st is None or image_index is None or not self._store_kinds:
             return
-        if xv.data_ptr() != st.tokens.data_ptr() or xv.shape[0] != st.tokens.shape[0]:
+        # the tables are indexed [image][token] with the STORE's token count: a view with the same base pointer but another
+        # token count / row width / batch stride (store.tokens[:, :K]) must not bind them (it would read them with the wrong
+        # stride) -- unbound, an indexed batch of the heads that need a table fails loudly instead
+        if (xv.data_ptr() != st.tokens.data_ptr() or tuple(xv.shape) != tuple(st.tokens.shape)
+                or xv.stride() != st.tokens.stride() or xv.dtype != st.tokens.dtype):
             return
         for field, (kind, eps) in self._store_kinds.items():
             self._bound_tables[field] = st.table(kind, eps)
@@ -170,6 +174,7 @@ class ProbeHeadEngine:
 
     def sync_buffers(self):
         self.flush()
+        self.invalidate_planes()          # an epoch boundary: re-split once rather than trust a p.data write nobody could see
         if self.world > 1:
             for b in (self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked):
                 dist.broadcast(b, src=0, group=self.group)
@@ -450,7 +455,10 @@ class ProbeHeadEngine:
                 if id(p) not in skip:
                     seg = self.flat_p[o:o + p.numel()]
                     seg.copy_(r16(seg))
-            out = self.eval_logits(x16, None, precision="fp32")
+            # the base-class forward, NOT the virtual one: the callers that override eval_logits (AbMILP / DINOv2-block / DOLG)
+            # have already applied their token selection (`_tokens`: content == "patch" drops token 0, poolings/abmilp.py:56-57)
+            # before they come here -- going through their override again would drop a second token
+            out = ProbeHeadEngine.eval_logits(self, x16, None, precision="fp32")
         finally:
             self.flat_p.copy_(keep)
         return r16(out)

@@ -180,7 +180,8 @@ def get_engine(model, optimizer=None, args=None):
             raise RuntimeError(f"the fused engine of this model was built for {eng.optimizer_name}; got a "
                                f"{type(optimizer).__name__} optimizer (build a new model / head for another optimizer)")
         else:
-            eng.weight_decay = kw["weight_decay"]
+            eng.invalidate_planes()                     # re-entry (every epoch): parameter writes through p.data are invisible
+            eng.weight_decay = kw["weight_decay"]       # to the version counters the cached weight planes are checked against
             if name == "lars":
                 eng.momentum, eng.trust_coefficient = kw["momentum"], kw["trust_coefficient"]
             if name == "adamw":

@@ -164,9 +164,15 @@ def native_head_kind(head: nn.Module):
     if len(head) == 2 and isinstance(head[0], nn.BatchNorm1d) and not head[0].affine and isinstance(head[1], nn.Linear):
         return "lp"
     if len(head) == 3 and isinstance(head[1], nn.BatchNorm1d) and isinstance(head[2], nn.Linear):
-        entry = NATIVE_HEADS.get(type(head[0]))
+        entry = _native_entry(head[0])
         return entry[1] if entry else None
     return None
+
+
+def _native_entry(pool: nn.Module):
+    """NATIVE_HEADS entry of a pooling module, resolved along its MRO: a user subclass (``class MyEP(EfficientProbing)``)
+    stays on the fused path of its base class instead of silently dropping to the module path."""
+    return next((NATIVE_HEADS[c] for c in type(pool).__mro__ if c in NATIVE_HEADS), None)
 
 
 def native_engine_name(head: nn.Module):
@@ -174,7 +180,7 @@ def native_engine_name(head: nn.Module):
     kind = native_head_kind(head)
     if kind == "lp":
         return "LinearProbeEngine"
-    return NATIVE_HEADS[type(head[0])][0] if kind else None
+    return _native_entry(head[0])[0] if kind else None
 
 
 def is_native_head(head: nn.Module) -> bool:

@@ -45,6 +45,9 @@ CASES = [
     Case("vit7b_q8", B=4, N=196, D=4096, Q=8, C=1000, seed=3, full=False, steps=1, sub_rows=128),   # BASELINE config 5
     # a batch large enough that BatchNorm's 1/sigma no longer amplifies fp32 rounding: the tight post-BN tolerances
     Case("vitb14_b64", B=64, N=256, D=768, Q=8, C=1000, seed=4, full=False, steps=3),
+    # the published protocol's query count (main_linprobe.py:113 --ep_queries 32) on DINOv2 ViT-B/14 tokens: the f32 / D <= 768 /
+    # Q > 16 kernel dispatch (round 5)
+    Case("vitb14_q32", B=8, N=256, D=768, Q=32, C=1000, seed=5, full=False, steps=3),
 ]
 CASE_BY_NAME = {c.name: c for c in CASES}
 
@@ -263,6 +266,9 @@ class AbmilpCase:
 ABMILP_CASES = [
     AbmilpCase("tiny", B=4, N=17, D=64, C=10, seed=0, weight_decay=1e-4),
     AbmilpCase("tiny_sharp_patch", B=3, N=21, D=64, C=7, seed=1, content="patch", sharp=True, steps=1),
+    # content == "patch" with ordinary weights: the fp16-autocast evaluation is pinned on this one (the sharp one cannot be,
+    # tests/test_gpu_abmilp.py), which catches a token dropped twice on that path (round 4 advisor finding)
+    AbmilpCase("tiny_patch", B=5, N=23, D=64, C=9, seed=3, content="patch", steps=1),
     AbmilpCase("n197", B=5, N=197, D=128, C=10, seed=2, full=False, steps=1),
     AbmilpCase("vitb14", B=6, N=256, D=768, C=1000, seed=0, full=False, steps=1, sharp=True),
     AbmilpCase("so400m", B=4, N=256, D=1152, C=1000, seed=1, full=False, steps=1, sharp=True),   # BASELINE config 4

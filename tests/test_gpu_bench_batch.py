@@ -23,6 +23,11 @@ IDS = ["c2_b1024", "c2_b1025", "ns_b1024", "ns_b1025"]
 # families (the matrix-core token passes), the same B = 1024 the `configs` object of bench.py times
 WIDE = [(1024, 196, 1024, 8), (1024, 256, 1152, 8)]
 WIDE_IDS = ["c3_b1024", "c4_b1024"]
+# round 5: the two BASELINE configurations that were only step-checked below the bench batch -- configs[0] (196x384, Q = 1:
+# the one-query template of the vector-ALU pass) and configs[4] (196x4096: four workgroup rounds of the wide-row kernel,
+# the bf16x3 weight-gradient kernel over 1024 rows)
+EDGE = [(1024, 196, 384, 1), (1024, 196, 4096, 8)]
+EDGE_IDS = ["c1_b1024", "c5_b1024"]
 
 
 def fp64_reference(x, cls, scale, dP, chunk=128):
@@ -44,7 +49,7 @@ def fp64_reference(x, cls, scale, dP, chunk=128):
     return P, S, dcls
 
 
-@pytest.mark.parametrize("shape", SHAPES + WIDE, ids=IDS + WIDE_IDS)
+@pytest.mark.parametrize("shape", SHAPES + WIDE + EDGE, ids=IDS + WIDE_IDS + EDGE_IDS)
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_token_passes_at_bench_batch_vs_fp64(shape, storage):
     from efficient_probing_amd import functional as F_, _native
@@ -94,7 +99,7 @@ def _heads(Nn, D, Q, Cc):
 
 
 @pytest.mark.parametrize("one_call", [False, True], ids=["two_calls", "one_call"])
-@pytest.mark.parametrize("shape", SHAPES + WIDE, ids=IDS + WIDE_IDS)
+@pytest.mark.parametrize("shape", SHAPES + WIDE + EDGE, ids=IDS + WIDE_IDS + EDGE_IDS)
 def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
     """Two full iterations at the bench configuration (lr = blr * B / 256 as main_linprobe.py:572-573) against the
     torch-CPU port of the reference step: loss, every gradient (incl. the side-task weight gradients over 1024 / 1025
@@ -104,11 +109,12 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
     from efficient_probing_amd.engine import ProbeHeadEngine
     from oracle import torch_port
     B, Nn, D, Q = shape
-    if one_call and (B != 1024 or D != 768):
-        pytest.skip("the one-call form is compared at the two benchmarked 768-wide shapes")
-    if not one_call and shape == SHAPES[2]:
-        pytest.skip("197x768 at B = 1024: covered by the one-call form (and B = 1025 by this one)")
-    Cc = 1000
+    if one_call and (B != 1024 or (D != 768 and shape not in EDGE)):
+        pytest.skip("the one-call form is compared at the two benchmarked 768-wide shapes and the two round-5 ones")
+    if not one_call and (shape == SHAPES[2] or shape in EDGE):
+        pytest.skip("197x768 at B = 1024: covered by the one-call form (and B = 1025 by this one); c1 / c5: the one-call form")
+    Cc = 100 if D == 384 else 1000
+    nsteps = 1 if D >= 4096 else 2       # (the torch-CPU port of the 196x4096 step is ~20 TFLOP: one iteration)
     head, port = _heads(Nn, D, Q, Cc)
     lr = 0.1 * B / 256
     eng = ProbeHeadEngine(head, optimizer="lars", lr=lr, weight_decay=0.0)
@@ -118,7 +124,7 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
     mus = [torch.zeros_like(p) for p in pparams]
     g = torch.Generator().manual_seed(77)
     names = ["cls_token", "v.weight", "fc.weight", "fc.bias"]
-    for step in range(2):
+    for step in range(nsteps):
         x = torch.randn(B, Nn, D, generator=g)
         t = torch.randint(0, Cc, (B,), generator=g)
         xd, td = x.to(DEV), t.to(DEV)
@@ -170,9 +176,11 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
 PATHS = [((256, 196, 4096, 8), "f32"), ((256, 196, 4096, 8), "bf16"), ((1024, 256, 768, 8), "bf16"), ((1024, 197, 768, 8), "bf16"),
          ((1024, 196, 1024, 8), "bf16"), ((512, 196, 384, 1), "bf16"),
          # the published protocol's 32 queries (README.md:133-134) on the chunked passes (csrc/ep_pool.hip: query_chunk)
-         ((256, 196, 1024, 32), "f32"), ((256, 256, 768, 32), "bf16")]
+         ((256, 196, 1024, 32), "f32"), ((256, 256, 768, 32), "bf16"),
+         # round 5: DINOv2 ViT-B/14 with the protocol's 32 queries on fp32 tokens -- what configs.c2_q32 of the bench line times
+         ((1024, 256, 768, 32), "f32"), ((256, 256, 768, 32), "f32"), ((1024, 256, 768, 32), "bf16")]
 PATH_IDS = ["c5_b256_f32_planes", "c5_b256_bf16", "c2_b1024_bf16", "ns_b1024_bf16", "c3_b1024_bf16", "c1_b512_bf16",
-            "c3_b256_q32_f32_chunked", "c2_b256_q32_bf16_chunked"]
+            "c3_b256_q32_f32_chunked", "c2_b256_q32_bf16_chunked", "c2_b1024_q32_f32", "c2_b256_q32_f32", "c2_b1024_q32_bf16"]
 
 
 @pytest.mark.parametrize("path", PATHS, ids=PATH_IDS)
@@ -189,7 +197,7 @@ def test_fused_lars_steps_on_the_benchmarked_paths_vs_torch_port(path):
     lib = _native.load()
     kname = lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, 1 if storage == "bf16" else 0).decode()
     assert "generic" not in kname, kname
-    if storage == "bf16" and D <= 1024:
+    if storage == "bf16" and D <= 1024 and Q <= 16:
         assert "mb2" in kname, kname                                   # the matrix-core pass (Q = 8: it carries the side tasks)
     byname = dict(port.named_parameters())
     pparams = [byname["0.cls_token"], byname["0.v.weight"], byname["2.weight"], byname["2.bias"]]
@@ -234,6 +242,7 @@ def test_fused_lars_steps_on_the_benchmarked_paths_vs_torch_port(path):
 # is more queries than one launch of the fast kernel families takes: the passes then run in chunks of 16 (8 for the wide-row
 # kernels) with the memory stride of all 32 (csrc/ep_pool.hip: query_chunk) -- not on the generic kernel.
 Q32 = [((64, 196, 1024, 32), "f32"), ((64, 196, 1024, 32), "bf16"), ((48, 256, 1152, 32), "f32"), ((24, 50, 4096, 32), "f32"),
+       ((72, 256, 768, 32), "f32"), ((40, 197, 768, 32), "f32"), ((40, 197, 768, 32), "bf16"), ((33, 77, 384, 32), "f32"), ((33, 77, 512, 24), "f32"),
        ((24, 50, 4096, 32), "bf16"), ((48, 100, 768, 32), "bf16"), ((40, 64, 1152, 24), "f32"), ((16, 40, 2048, 20), "f32")]
 
 

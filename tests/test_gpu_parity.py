@@ -145,6 +145,54 @@ def test_streaming_and_generic_kernels_agree(case):
                                        err_msg=f"{which} {name}")
 
 
+# The query-chunk dispatch (csrc/ep_pool.hip: query_chunk) is chosen per process from EP_POOL_QCHUNK: 1 = the default (f32 tokens at
+# D <= 768 and Q > 16: forward as 16-query chunks on the all-matrix-core kernel, backward ONE pass on the vector-ALU kernel --
+# two kernel families sharing S / ML), 2 = both directions chunked, 3 = neither.  Every setting in a fresh process against the
+# generic kernel on the two Q = 32 reference cases, and the default against the reference's golden pooled vector / attention.
+_QCHUNK_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ["EP_TEST_ROOT"], "tests", "golden")); sys.path.insert(0, os.environ["EP_TEST_ROOT"])
+from cases import CASE_BY_NAME, make_inputs
+from efficient_probing_amd import functional as F_, _native
+lib = _native.load()
+for name in ("vitb14_q32", "vitl_q32_dout2"):
+    case = CASE_BY_NAME[name]
+    inp = make_inputs(case)
+    x = torch.from_numpy(inp["x_buf"]).cuda()
+    for storage in ("f32", "bf16"):
+        xs = x.to(torch.bfloat16) if storage == "bf16" else x
+        cls = torch.from_numpy(inp["cls_token"]).cuda()[0] * (40.0 if storage == "f32" else 25.0)     # a sharp softmax
+        dP = torch.from_numpy(np.random.default_rng(5).standard_normal((case.B, case.Q, case.D), dtype=np.float32)).cuda()
+        outs = []
+        for mode in (1, 0):
+            lib.ep_debug_force_generic_pool(mode)
+            P, S, ML = F_.pool_forward(xs, cls, case.D ** -0.5)
+            ML2 = ML.clone(); ML2[:, :, 2] = 0.25
+            dcls = F_.pool_backward(xs, S, ML2, dP, case.D ** -0.5)
+            torch.cuda.synchronize()
+            outs.append([t.cpu().numpy() for t in (P, S, dcls)])
+        lib.ep_debug_force_generic_pool(0)
+        fams = [lib.ep_pool_kernel_name_ex(case.B, case.N, case.D, case.Q, b, 1 if storage == "bf16" else 0).decode() for b in (0, 1)]
+        for a, b, n in zip(outs[1], outs[0], ("P", "S", "dcls")):
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1e-3, float(np.abs(b).max())), err_msg=f"{name} {storage} {n} {fams}")
+        print("FAMILY", name, storage, fams[0], fams[1])
+print("QCHUNK_OK")
+"""
+
+
+@pytest.mark.parametrize("qchunk", ["1", "2", "3"])
+def test_query_chunk_dispatch_agrees_with_generic_in_fresh_process(qchunk):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EP_POOL_QCHUNK=qchunk, EP_TEST_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _QCHUNK_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "QCHUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    fam = {tuple(l.split()[1:3]): l.split()[3:5] for l in r.stdout.splitlines() if l.startswith("FAMILY")}
+    assert all("generic" not in k for v in fam.values() for k in v), fam
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
 def test_module_forward_backward_golden(case):
     """Drop-in path: Sequential(EfficientProbing, BatchNorm1d, Linear) under autograd."""
