@@ -347,6 +347,14 @@ static int mf_grid(int B) { int g = cu_count(); return g < B ? g : B; }
 // all-matrix-core kernel: forced with mode 3; chosen automatically where it measured fastest: more than 8 queries
 // (16 heads at 256x768: 223 / 228 us against 250 / 266 us of the mixed kernel; at 256x1152: 332 us against 511 us of the
 // vector-ALU kernel), and the backward at D = 1152, where the other two kernels run short of LDS / registers
+// 17 .. 32 queries on fp32 tokens: both 16-query blocks against one read of the tokens (ep_pool_mm2.hip; EP_POOL_MM2=0: the
+// round-4 dispatch -- forward in two chunks, backward on the vector-ALU kernel)
+static bool use_mm2(const PoolParams& p, bool bwd) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_POOL_MM2"); on = e ? atoi(e) : 1; }
+  if (!on || needs_generic(p) || p.tokstat || p.x_bf16 || (pool_mode() != 0 && pool_mode() != 3)) return false;
+  return mm2_supported(p.D, p.Q, p.cls_bstride, bwd);
+}
 static bool use_mm(const PoolParams& p, bool bwd) {
   if (needs_generic(p)) return false;
   static int ln_mm = -1;                 // LayerNorm-of-tokens mode on the all-matrix-core kernel (EP_POOL_LN_MM=0: vector-ALU kernel)
@@ -363,6 +371,16 @@ static bool use_mb(const PoolParams& p) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_POOL_MB"); on = e ? atoi(e) : 1; }
   return on && p.x_bf16 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mb_supported(p.D, p.Q, p.cls_bstride);
+}
+
+// bf16 tokens, 17 .. 32 queries: both 16-query blocks against one read of the tokens (second half of ep_pool_mb.hip;
+// EP_POOL_MBQ=0: two 16-query launches as in round 4)
+static bool use_mbq(const PoolParams& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_POOL_MBQ"); on = e ? atoi(e) : 1; }
+  static int mb = -1;
+  if (mb < 0) { const char* e = getenv("EP_POOL_MB"); mb = e ? atoi(e) : 1; }
+  return on && mb && p.x_bf16 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mbq_supported(p.D, p.Q, p.cls_bstride);
 }
 
 // what the vector-ALU streaming kernels can take (LayerNorm-of-tokens mode on bf16 tokens: where a tile's scores and
@@ -386,14 +404,17 @@ static bool use_wide(const PoolParams& p) {
 // Returns the chunk size, 0 = no chunking.
 static int query_chunk(const PoolParams& p, bool bwd) {
   if (needs_generic(p) || p.tokstat || force_generic() || pool_mode() != 0 || p.Q <= 8) return 0;
-  if (use_wide(p) || use_mb(p) || use_mm(p, bwd) || use_mf(p, bwd)) return 0;
+  if (use_wide(p) || use_mb(p) || use_mbq(p) || use_mm2(p, bwd) || use_mm(p, bwd) || use_mf(p, bwd)) return 0;
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_POOL_QCHUNK"); on = e ? atoi(e) : 1; }
   if (!on) return 0;
   if (p.x_bf16 && p.Q > 16) {            // bf16 tokens: two reads on the matrix-core pass beat one on the widening vector-ALU kernel
     PoolParams q = p;                    // (256 x 768, Q = 32: 500 / 454 us per pass on the vector-ALU kernel)
-    q.Q = 16;
-    if (use_mb(q)) return 16;
+    const int n = (p.Q + 15) / 16, sz = (p.Q + n - 1) / n;     // even split: every chunk on the same (stride-aware) family
+    q.Q = sz;
+    PoolParams r = p;
+    r.Q = p.Q - sz * (n - 1);
+    if (use_mb(q) && use_mb(r)) return sz;
   }
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   // The vector-ALU kernel takes up to 32 queries in one pass, but beyond 16 its FORWARD is slower than two 16-query chunks on
@@ -401,11 +422,19 @@ static int query_chunk(const PoolParams& p, bool bwd) {
   // EP_POOL_QCHUNK=2: both directions in chunks; 3: neither.
   const bool prefer_chunks = p.Q > 16 && on != 3 && (on == 2 || !bwd);
   if (c.ok && stream_takes(p) && !prefer_chunks) return 0;
-  for (int qc = 16; qc >= 8; qc -= 8) {
-    if (p.Q <= qc) continue;
+  // EVERY chunk -- the last, smaller one too -- must land on a family that honours the memory stride Qs (the vector-ALU and
+  // the generic kernels do not): the queries are split evenly over ceil(Q / cap) chunks and both chunk sizes are checked
+  // (round 5: Q = 24 at D = 512 used to run 16 + 8, and the 8-query remainder fell to the vector-ALU kernel, which wrote its
+  // rows with stride 8 -- tests/test_gpu_bench_batch.py 33x77x512_q24)
+  auto aware = [&](int qn) {
     PoolParams q = p;
-    q.Q = qc;
-    if (use_wide(q) || use_mb(q) || use_mm(q, bwd) || use_mf(q, bwd)) return qc;
+    q.Q = qn;
+    return use_wide(q) || use_mb(q) || use_mm(q, bwd) || use_mf(q, bwd);
+  };
+  for (int cap = 16; cap >= 8; cap -= 8) {
+    if (p.Q <= cap) continue;
+    const int n = (p.Q + cap - 1) / cap, sz = (p.Q + n - 1) / n, last = p.Q - sz * (n - 1);
+    if (last >= 1 && aware(sz) && aware(last)) return sz;
   }
   return 0;
 }
@@ -416,6 +445,8 @@ const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) 
   if (const int qc = query_chunk(p, bwd != 0)) p.Q = qc;          // (the family the chunks run on)
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
   if (use_mb(p)) return mb_kernel_name(D, bwd != 0);
+  if (use_mbq(p)) return bwd ? "ep_pool_mbq_bwd_kernel" : "ep_pool_mbq_fwd_kernel";
+  if (use_mm2(p, bwd != 0)) return bwd ? "ep_pool_mm2_bwd_kernel" : "ep_pool_mm2_fwd_kernel";
   if (use_mm(p, bwd != 0)) return bwd ? "ep_pool_mm_bwd_kernel" : "ep_pool_mm_fwd_kernel";
   if (use_mf(p, bwd != 0)) return bwd ? "ep_pool_mf_bwd_kernel" : "ep_pool_mf_fwd_kernel";
   if (stream_plan(B, N, D, Q).ok && !force_generic() && stream_takes(p)) return bwd ? "ep_pool_bwd_kernel" : "ep_pool_fwd_kernel";
@@ -448,8 +479,12 @@ int pool_forward(const PoolParams& p0, hipStream_t st) {
     if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
     return mb_launch(false, p, mb_grid(p.D, p.B), st);
   }
+  if (use_mbq(p)) return mbq_launch(false, p, mbq_grid(p.B), st);
+  if (use_mm2(p, false)) return mm2_launch(false, p, mf_grid(p.B), st);
   if (use_mm(p, false)) return mm_launch(false, p, mf_grid(p.B), st);
   if (use_mf(p, false)) return mf_launch(false, p, mf_grid(p.B), st);
+  // (the kernels below index P / S / ML with Q as the per-image row stride)
+  EP_REQUIRE(!p.Qs || p.Qs == p.Q, EP_E_UNSUPPORTED, "pool_forward: a %d-query chunk of %d has no stride-aware kernel at D=%d", p.Q, p.Qs, p.D);
   StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (c.ok && !force_generic() && !needs_generic(p) && stream_takes(p)) {
     if (const char* e = getenv("EP_POOL_ABLATE")) p.ablate = atoi(e);
@@ -473,7 +508,8 @@ bool pool_backward_takes_side(const PoolParams& p) {
   if (allow_ln < 0) { const char* e = getenv("EP_POOL_SIDE_LN"); allow_ln = e ? atoi(e) : 1; }
   if (!allow || needs_generic(p) || (p.tokstat && !allow_ln) || use_wide(p) || force_generic()) return false;
   if (use_mb(p)) return mb_takes_side(p.D);          // bf16 tokens: the two-workgroup matrix-core pass carries them too
-  if (use_mm(p, true) || use_mf(p, true)) return false;
+  if (use_mbq(p)) return false;
+  if (use_mm2(p, true) || use_mm(p, true) || use_mf(p, true)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   return c.ok && c.nw == 4;
 }
@@ -485,7 +521,8 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
   if (allow < 0) { const char* e = getenv("EP_POOL_DELTA"); allow = e ? atoi(e) : 1; }
   if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || force_generic()) return false;
   if (use_mb(p)) return mb_takes_delta(p.D, p.Q, Dv);
-  if (use_mm(p, true) || use_mf(p, true)) return false;
+  if (use_mbq(p)) return mbq_takes_delta(p.D, p.Q, Dv);
+  if (use_mm2(p, true) || use_mm(p, true) || use_mf(p, true)) return false;
   const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
   if (!c.ok || !stream_takes(p) || Dv <= 0 || Dv % (4 * p.Q) != 0) return false;
   // ring slot of the kernel that will run = (tokens per tile) * D * (bytes per stored element).  A bf16 tile holds TWICE
@@ -585,6 +622,12 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
   } else if (use_mb(p)) {
     nparts = mb_grid(p.D, p.B);
     EP_TRY(mb_launch(true, p, nparts, st, side));
+  } else if (use_mbq(p)) {
+    nparts = mbq_grid(p.B);
+    EP_TRY(mbq_launch(true, p, nparts, st));
+  } else if (use_mm2(p, true)) {
+    nparts = mf_grid(p.B);
+    EP_TRY(mm2_launch(true, p, nparts, st));
   } else if (use_mm(p, true)) {
     nparts = mf_grid(p.B);
     EP_TRY(mm_launch(true, p, nparts, st));
@@ -592,6 +635,10 @@ int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t
     const int grid = mf_grid(p.B);
     nparts = 2 * grid;                         // one partial per token half of every workgroup
     EP_TRY(mf_launch(true, p, grid, st));
+  } else if (p.Qs && p.Qs != p.Q) {
+    // (the kernels below index S / ML / dP with Q as the per-image row stride)
+    set_error("pool_backward: a %d-query chunk of %d has no stride-aware kernel at D=%d", p.Q, p.Qs, p.D);
+    return EP_E_UNSUPPORTED;
   } else if (p.tick) {
     // ticketed form (ep_pool_bwd2.hip): one gradient partial per IMAGE; `first` pooling workgroups in front of the side tasks
     static int first_env = -1;

@@ -1091,6 +1091,388 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
   }
 }
 
+// =======================================================================================
+// 17 .. 32 queries in ONE read of the bf16 tokens (round 5): the reference's default --ep_queries 32 (reference
+// main_linprobe.py:113) used to run as two 16-query launches of the form above.  Here one 8-wave workgroup per CU shares the
+// ring: wave w = (qb, kq) is wave kq of the two-workgroup form for query block qb (queries 16 qb .. 16 qb + 15) -- the same
+// D-quarter, the same MFMAs, the same registers -- and the two blocks' waves (w, w + 4: one SIMD) read the same tile.  D = 256 NK'
+// (even NK: the 8 waves split a tile's DMA pieces evenly).  Like ep_pool_mm2.hip the halves run staggered: waves 4-7 carry the
+// pooling MFMAs of a tile into the next iteration, their operands taken into registers before the tile's slot is released.
+// =======================================================================================
+constexpr int MBQ_NW = 8;
+#ifndef EP_MBQ_STAGGER
+#define EP_MBQ_STAGGER 1
+#endif
+#ifndef EP_MBQ_ABLATE
+#define EP_MBQ_ABLATE 0               // diagnostic builds of the forward: 1 ring + barriers only, 2 no pooling (loads + MFMAs), 3 no softmax
+#endif                                // arithmetic / operand split (constant weights), 4 no score MFMAs; results are wrong
+
+template <int NK>
+struct MbqCfg {
+  static constexpr int D = 128 * NK;
+  static constexpr int ROWB = 2 * D;
+  static constexpr int NCH = D / 8;
+  static constexpr int SLOT = MB2_TT * ROWB;
+  static constexpr int KDMA = SLOT / (MBQ_NW * 1024);   // = NK / 2
+  static constexpr int SPART = MBQ_NW * 1024;
+  static constexpr int LDS_TOTAL = 160 * 1024;
+  static constexpr int nslot() {
+    int ns = (LDS_TOTAL - SPART) / SLOT;
+    ns = ns > 6 ? 6 : ns;
+    while (ns > 3 && (ns - 2) * KDMA > 16) --ns;        // (mb_wait_vmcnt counts up to 16)
+    return ns;
+  }
+  static constexpr int NSLOT = nslot();
+  static constexpr int LDS = NSLOT * SLOT + SPART;
+  static_assert(NK % 2 == 0 && SLOT % (MBQ_NW * 1024) == 0, "the two-block form needs D = 256 k");
+};
+// pooling A operands of a 16-token tile -> registers (mb2_pool's reads, detached from its MFMAs)
+template <int NK>
+__device__ __forceinline__ void mbq_pool_load(const char* tile, const int (&poff)[4], const int (&pseg)[NK], unsigned (&xr)[NK][4]) {
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xr[dg][e] = *reinterpret_cast<const unsigned*>(tile + poff[e] + pseg[dg]);
+}
+template <int NK>
+__device__ __forceinline__ void mbq_pool_mfma(const unsigned (&xr)[NK][4], const u2 (&bw)[3], f4 (&accE)[NK], f4 (&accO)[NK]) {
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) {
+    u2 ae, ao;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ae[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x05040100u);
+      ao[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x07060302u);
+    }
+#pragma unroll
+    for (int term = 2; term >= 0; --term) {
+      accE[dg] = mb2_mfma16(ae, bw[term], accE[dg]);
+      accO[dg] = mb2_mfma16(ao, bw[term], accO[dg]);
+    }
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_fwd_kernel(PoolParams p) {
+  using C = MbqCfg<NK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* ring = lds;
+  char* spart = lds + NSLOT * SLOT;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int qb = w >> 2, kq = w & 3;
+  const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;
+  const bool n4 = (N & 3) == 0;
+  const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * tiles_per_img;
+  if (n_items <= 0) return;
+  const int j = lane & 15, g = lane >> 4;
+  const int qj = 16 * qb + j;
+  const bool late = qb != 0 && EP_MBQ_STAGGER != 0;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+  char* sblk = spart + qb * (MB2_NW * 1024);         // the four records of this wave's query block
+
+  u4 bq[NK][3];
+  int aoff[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (qj < Q) {
+      const float* src = p.cls + (int64_t)qj * D + 32 * NK * kq + 32 * ks + 8 * g;
+      const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+      v[0] = a.x * p.scale; v[1] = a.y * p.scale; v[2] = a.z * p.scale; v[3] = a.w * p.scale;
+      v[4] = b.x * p.scale; v[5] = b.y * p.scale; v[6] = b.z * p.scale; v[7] = b.w * p.scale;
+    }
+    mb_split8(v, bq[ks]);
+    aoff[ks] = j * ROWB + (((4 * NK * kq + 4 * ks + g) ^ j) << 4);
+  }
+  unsigned soff[KDMA];
+  mb_source_offsets<NCH, MBQ_NW, KDMA>(w, lane, soff);
+  int poff[4], pseg[NK];
+  mb_pool_offsets<NK, MB2_NW>(kq, j, g, poff, pseg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+  const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
+  auto produce = [&]() {
+    if (pi < n_items) {
+      const int left = N - ptile * MB2_TT;
+      const unsigned limit = (unsigned)((left < MB2_TT ? left : MB2_TT) * ROWB - 16);
+      mb_dma_tile<MBQ_NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
+      ++pi;
+      pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+      if (++ptile == tiles_per_img) {
+        ptile = 0; ++pimg;
+        psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+      } else {
+        psrc += SLOT;
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+  f4 accE[NK], accO[NK];
+  float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;
+  u2 bw[3] = {u2{0u, 0u}, u2{0u, 0u}, u2{0u, 0u}};   // the tile's weights as three bf16 terms (late half: of the pending tile)
+  unsigned xr[NK][4];                                 // pooling operands (late half: of the pending tile)
+  int cslot = 0, it = 0;
+  for (int img = 0; img < n_img; ++img) {
+    const int b = wg + img * G;
+    for (int t = 0; t < tiles_per_img; ++t, ++it) {
+      mb_wait_vmcnt((pi - 1 - it) * KDMA);
+      mb_barrier();                                  // tile `it` landed everywhere; the slot of tile it-1 is free
+      const int n0 = t * MB2_TT;
+      const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+      const char* tile = ring + cslot * SLOT;
+      cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+      if constexpr (EP_MBQ_ABLATE == 1) { produce(); mb_barrier(); continue; }
+      if constexpr (EP_MBQ_ABLATE == 4) { produce(); } else
+      mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+      mb_barrier();                                  // all partial score blocks are in the scratch
+      if constexpr (EP_MBQ_ABLATE != 2) if (late && t > 0) mbq_pool_mfma<NK>(xr, bw, accE, accO);
+      __builtin_amdgcn_sched_barrier(0);
+      float sc[4], ue[4];
+      mb2_gather(sblk, lane, sc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (EP_MBQ_ABLATE != 2) mbq_pool_load<NK>(tile, poff, pseg, xr);       // in flight under the softmax arithmetic; complete before the next barrier
+      if constexpr (EP_MBQ_ABLATE == 3) { bw[0] = u2{0x3f803f80u + lane, 0x3f803f80u}; bw[1] = bw[0]; bw[2] = bw[0]; if (!late) mbq_pool_mfma<NK>(xr, bw, accE, accO); continue; }
+      if (t == 0) {
+        m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
+#pragma unroll
+        for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ue[e] = (4 * g + e) < nvalid ? sc[e] : -INFINITY;
+        mx = fmaxf(mx, ue[e]);
+      }
+      if (__builtin_amdgcn_ballot_w64(mx > m_j + MB_LAZY_MAX_THR) != 0ull) {
+        const float mn = fmaxf(m_j, mb_q4_max(mx));
+        const float f = __builtin_amdgcn_exp2f((m_j - mn) * MB_LOG2E);
+        m_j = mn; mL_j = mn * MB_LOG2E;
+        lsum *= f;
+#pragma unroll
+        for (int dg = 0; dg < NK; ++dg) { accE[dg] *= f; accO[dg] *= f; }
+      }
+      float wgt[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));
+        lsum += wgt[e];
+      }
+      mb2_split4(wgt, bw);
+      if (kq == (t & 3) && qj < Q) {                 // the four waves of a block hold the same scores: they take turns writing them
+        float* Srow = p.S + ((int64_t)b * QS + qj) * N + n0 + 4 * g;
+        if (n4) {
+          if (4 * g < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[0], sc[1], sc[2], sc[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g + r < nvalid) Srow[r] = sc[r];
+        }
+      }
+      if constexpr (EP_MBQ_ABLATE != 2) if (!late) mbq_pool_mfma<NK>(xr, bw, accE, accO);
+    }
+    if constexpr (EP_MBQ_ABLATE != 2) if (late) mbq_pool_mfma<NK>(xr, bw, accE, accO);
+    const float l = mb_q4_sum(lsum);
+    const float inv = 1.0f / l;
+    if (qj < Q) {
+      float* Pq = p.P + ((int64_t)b * QS + qj) * D + 32 * NK * kq + 8 * g;
+#pragma unroll
+      for (int dg = 0; dg < NK; ++dg) mb_store8(Pq + 32 * dg, accE[dg], accO[dg], inv);
+      if (kq == 0 && g == 0) {
+        const f4 rec = {m_j, l, 0.f, 0.f};
+        *reinterpret_cast<f4*>(p.ML + ((int64_t)b * QS + qj) * 4) = rec;
+      }
+    }
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolParams p) {
+  using C = MbqCfg<NK>;
+  constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* ring = lds;
+  char* spart = lds + NSLOT * SLOT;
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int qb = w >> 2, kq = w & 3;
+  const int N = p.N, Q = p.Q;
+  const int QS = p.Qs ? p.Qs : p.Q;
+  const bool n4 = (N & 3) == 0;
+  const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int n_img = (p.B - wg + G - 1) / G;
+  const int n_items = n_img * tiles_per_img;
+  const int j = lane & 15, g = lane >> 4;
+  const int qj = 16 * qb + j;
+  const bool live = qj < Q;
+  const int jq = live ? qj : Q - 1;
+  const bool late = qb != 0 && EP_MBQ_STAGGER != 0;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
+  char* sblk = spart + qb * (MB2_NW * 1024);
+
+  f4 gE[NK], gO[NK];
+#pragma unroll
+  for (int dg = 0; dg < NK; ++dg) { gE[dg] = f4{0.f, 0.f, 0.f, 0.f}; gO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
+
+  if (n_items > 0) {
+    int aoff[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) aoff[ks] = j * ROWB + (((4 * NK * kq + 4 * ks + g) ^ j) << 4);
+    unsigned soff[KDMA];
+    mb_source_offsets<NCH, MBQ_NW, KDMA>(w, lane, soff);
+    int poff[4], pseg[NK];
+    mb_pool_offsets<NK, MB2_NW>(kq, j, g, poff, pseg);
+
+    float sv[4];
+    auto load_scores = [&](int img, int tl) {
+      const int b = wg + img * G;
+      const float* Srow = p.S + ((int64_t)b * QS + jq) * N;
+      int t0 = tl * MB2_TT + 4 * g;
+      if (n4) {
+        t0 = t0 < N ? t0 : N - 4;
+        const f4 v = *reinterpret_cast<const f4*>(Srow + t0);
+        sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = Srow[(t0 + r) < N ? (t0 + r) : N - 1];
+      }
+    };
+    load_scores(0, 0);
+    int pi = 0, pimg = 0, ptile = 0, pslot = 0;
+    const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
+    auto produce = [&]() {
+      if (pi < n_items) {
+        const int left = N - ptile * MB2_TT;
+        const unsigned limit = (unsigned)((left < MB2_TT ? left : MB2_TT) * ROWB - 16);
+        mb_dma_tile<MBQ_NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
+        ++pi;
+        pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+        if (++ptile == tiles_per_img) {
+          ptile = 0; ++pimg;
+          psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, (wg + pimg * G) < p.B ? (wg + pimg * G) : wg));
+        } else {
+          psrc += SLOT;
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s) produce();
+
+    u4 bq[NK][3];
+    float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
+    u2 bw[3] = {u2{0u, 0u}, u2{0u, 0u}, u2{0u, 0u}};
+    unsigned xr[NK][4];
+    int cslot = 0, it = 0;
+    for (int img = 0; img < n_img; ++img) {
+      const int b = wg + img * G;
+      for (int t = 0; t < tiles_per_img; ++t, ++it) {
+        mb_wait_vmcnt((pi - 1 - it) * KDMA);
+        mb_barrier();
+        const int n0 = t * MB2_TT;
+        const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+        const char* tile = ring + cslot * SLOT;
+        cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+        if (t == 0) {                                // new image: its dP rows (this wave's slice) and ML row
+          const float* src = p.dP + ((int64_t)b * QS + jq) * D + 32 * NK * kq + 8 * g;
+          const f4 hml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * QS + jq) * 4);
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const f4 a = *reinterpret_cast<const f4*>(src + 32 * ks), c = *reinterpret_cast<const f4*>(src + 32 * ks + 4);
+            float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            if (!live) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            mb_split8(v, bq[ks]);
+          }
+          mL_j = hml.x * MB_LOG2E; il_j = 1.0f / hml.y; dl_j = hml.z;
+          if (p.dyv) {                               // delta[b, qj] = dy[b, qj-slice] . y[b, qj-slice] (see ep_pool_mb2_bwd_kernel)
+            const int Dq = p.Dv / Q;
+            const float* dyr = p.dyv + (int64_t)b * p.Dv + jq * Dq;
+            const float* yr = p.yv + (int64_t)b * p.Dv + jq * Dq;
+            float acc = 0.f;
+            for (int c = 4 * g; c < Dq; c += 16) {
+              const f4 a = *reinterpret_cast<const f4*>(dyr + c), y4 = *reinterpret_cast<const f4*>(yr + c);
+              acc = fmaf(a.x, y4.x, acc); acc = fmaf(a.y, y4.y, acc); acc = fmaf(a.z, y4.z, acc); acc = fmaf(a.w, y4.w, acc);
+            }
+            dl_j = mb_q4_sum(acc);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // keeps the counted waits below exact
+        }
+        float cur[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur[e] = sv[e];
+        {
+          int nimg = img, ntile = t + 1;
+          if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
+          if (nimg < n_img) load_scores(nimg, ntile);
+        }
+        mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+        mb_barrier();
+        if (late && t > 0) mbq_pool_mfma<NK>(xr, bw, gE, gO);
+        __builtin_amdgcn_sched_barrier(0);
+        float u[4], wgt[4];
+        mb2_gather(sblk, lane, u);
+        __builtin_amdgcn_sched_barrier(0);
+        mbq_pool_load<NK>(tile, poff, pseg, xr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
+          wgt[e] = ((4 * g + e) < nvalid && live) ? a * (u[e] - dl_j) : 0.f;
+        }
+        mb2_split4(wgt, bw);
+        if (!late) mbq_pool_mfma<NK>(xr, bw, gE, gO);
+      }
+      if (late) mbq_pool_mfma<NK>(xr, bw, gE, gO);
+    }
+  }
+  if (live) {
+    float* Gq = p.Gpart + ((int64_t)wg * Q + qj) * D + 32 * NK * kq + 8 * g;
+#pragma unroll
+    for (int dg = 0; dg < NK; ++dg) mb_store8(Gq + 32 * dg, gE[dg], gO[dg], 1.0f);
+  }
+}
+
+template <int NK>
+static int mbq_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  using C = MbqCfg<NK>;
+  const size_t lds = C::LDS;
+  auto kf = ep_pool_mbq_fwd_kernel<NK>;
+  auto kb = ep_pool_mbq_bwd_kernel<NK>;
+  const void* fn = bwd ? (const void*)kb : (const void*)kf;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+  if (bwd) hipLaunchKernelGGL(kb, dim3(grid), dim3(MBQ_NW * 64), lds, st, p);
+  else hipLaunchKernelGGL(kf, dim3(grid), dim3(MBQ_NW * 64), lds, st, p);
+  EP_LAUNCH_CHECK(bwd ? "ep_pool_mbq_bwd_kernel" : "ep_pool_mbq_fwd_kernel");
+  return 0;
+}
+// bf16 tokens, shared query rows, 17 .. 32 queries: D in {256, 512, 768} (D = 1024: 256 registers + 147 spilled -- stays on two
+// 16-query launches of the form above)
+bool mbq_supported(int D, int Q, int64_t cls_bstride) {
+  return cls_bstride == 0 && Q > 16 && Q <= 32 && (D == 256 || D == 512 || D == 768);
+}
+bool mbq_takes_delta(int D, int Q, int Dv) { return mbq_supported(D, Q, 0) && Dv > 0 && Dv % (4 * Q) == 0; }
+int mbq_grid(int B) { const int g = cu_count(); return g < B ? g : B; }
+int mbq_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  switch (p.D) {
+    case 256: return mbq_launch_one<2>(bwd, p, grid, st);
+    case 512: return mbq_launch_one<4>(bwd, p, grid, st);
+    case 768: return mbq_launch_one<6>(bwd, p, grid, st);
+  }
+  set_error("no 32-query bf16 matrix-core pooling kernel for D=%d", p.D);
+  return EP_E_UNSUPPORTED;
+}
+
 static thread_local int* g_mb_occ_query = nullptr;
 
 template <int NK, int NS = 3>

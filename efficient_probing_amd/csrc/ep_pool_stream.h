@@ -68,6 +68,9 @@ int mf_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // all-matrix-core variant (ep_pool_mm.hip)
 bool mm_supported(int D, int Q, int64_t cls_bstride);
 int mm_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
+// ... with 17 .. 32 queries in one read of the tokens (ep_pool_mm2.hip): two 16-query blocks against the resident tile
+bool mm2_supported(int D, int Q, int64_t cls_bstride, bool bwd);
+int mm2_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // bf16-token matrix-core variant (ep_pool_mb.hip): bf16-stored tokens, D in {256, 384, 512, 768, 1024, 1152}, Q <= 16
 bool mb_supported(int D, int Q, int64_t cls_bstride);
 int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side = nullptr);
@@ -75,6 +78,11 @@ bool mb_takes_side(int D);                       // the second pass of this D ca
 bool mb_takes_delta(int D, int Q, int Dv);
 bool mb_takes_inpass_dp(const PoolParams& p);     // ... and run the dP contraction in front of its stream (ep_inpass.h)       // ... and compute the delta rows itself (PoolParams.dyv / yv / Dv)
 int mb_grid(int D, int B);
+// ... with 17 .. 32 queries in one read of the tokens (second half of ep_pool_mb.hip): D in {256, 512, 768}
+bool mbq_supported(int D, int Q, int64_t cls_bstride);
+bool mbq_takes_delta(int D, int Q, int Dv);
+int mbq_grid(int B);
+int mbq_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 const char* mb_kernel_name(int D, bool bwd);
 // wide-row variant (ep_pool_wide.hip): D = 2048 / 4096, Q <= 8, row split across the waves
 bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16 = 0);
