@@ -673,9 +673,19 @@ def main():
         for name in ("c1", "c3", "c4", "c5"):
             cN, cD, cQ, cC, cdesc = WORKLOADS[name]
             torch.cuda.empty_cache()
-            line = secondary(cN, cD, cQ, "f32", 20, sC=cC)
+            line = secondary(cN, cD, cQ, "f32", 20, sC=cC, passes=(name == "c5"))
             line["workload"] = cdesc
             line["classes"] = cC
+            if name == "c5":
+                # a co-bound step: its six dense contractions (y, dP, dWv: 2 B D D each; logits, dz, dWc: 2 B D C each) run on the
+                # bf16 matrix cores as six bf16 products per fp32 product (csrc/ep_planes.hip, ep_wgrad3.h); their time is the step
+                # minus the two token passes (an upper bound: BatchNorm / CE / optimizer launches are in it too)
+                flop = 3 * 2.0 * B * cD * cD + 3 * 2.0 * B * cD * cC
+                t_us = line["ms_per_step"] * 1e3 - line["in_step"]["fwd_us"] - line["in_step"]["bwd_us"]
+                line["mfma"] = {"kernel": "ep_gemm_planes_kernel + ep_gemm_b3_kernel", "flop_per_step": flop, "time_us": round(t_us, 1),
+                                "achieved": round(flop / t_us / 1e6, 1), "peak": round(2500.0 / 6.0, 1), "unit": "TFLOP/s",
+                                "frac": round(flop / t_us / 1e6 / (2500.0 / 6.0), 4),
+                                "peak_note": "fp32-accurate product = six bf16 products: 2.5 PFLOP/s / 6; time = step - token passes"}
             configs[name] = line
         # the headline shape at the per-GPU batches a fixed global batch gives on more GPUs (the published protocol's effective
         # batch is 4096 -- reference README.md:119-120 -- i.e. 512 per GPU on 8): what a --global-batch point is read against
@@ -688,10 +698,20 @@ def main():
         # the headline shape, f32 and bf16-stored tokens -- BASELINE.json's configurations say q = 8, these say what the README's
         # own commands would run at (beyond D = 768 and for bf16 tokens the passes run in chunks of 16 queries)
         for stor in ("f32", "bf16"):
-            line = secondary(Nn, D, 32, stor, 20, toks=xs)
+            line = secondary(Nn, D, 32, stor, 20, toks=xs, passes=True)
             line["workload"] = desc.replace("EP q=8", "EP q=32") + (" [tokens stored as bf16]" if stor == "bf16" else "")
+            # co-bound passes at 32 queries: priced on the matrix axis as well (2 contractions x 2 B N D Q FLOP per pass; fp32
+            # tokens on v_mfma_f32_16x16x4_f32: 157.3 TFLOP/s; bf16 tokens as three bf16 products per fp32 product: 2500 / 3)
+            flop = 4.0 * B * Nn * D * 32
+            peak = F32_MFMA_PEAK_TFLOPS if stor == "f32" else 2500.0 / 3.0
+            ins = line["in_step"]
+            line["mfma"] = {"kernel": line["kernel"], "flop_per_pass": flop, "peak": round(peak, 1), "unit": "TFLOP/s",
+                            "fwd_achieved": round(flop / ins["fwd_us"] / 1e6, 1), "bwd_achieved": round(flop / ins["bwd_us"] / 1e6, 1),
+                            "fwd_frac": round(flop / ins["fwd_us"] / 1e6 / peak, 4), "bwd_frac": round(flop / ins["bwd_us"] / 1e6 / peak, 4),
+                            "peak_note": ("exact fp32 matrix instruction" if stor == "f32" else
+                                          "bf16 tokens x fp32 operand as three bf16 terms: 2.5 PFLOP/s / 3")}
             configs[f"{args.workload}_q32" + ("_bf16" if stor == "bf16" else "")] = line
-        # configs[4] as it fits 8 x 288 GB: the pre-dumped ViT-7B tokens stored as bf16 (DESIGN section 3), both passes in the step
+        # configs[4] as it fits 8 x 288 GB: the pre-dumped ViT-7B tokens stored as bf16 (DESIGN.md section 3), both passes in the step
         torch.cuda.empty_cache()
         cN, cD, cQ, cC, cdesc = WORKLOADS["c5"]
         line = secondary(cN, cD, cQ, "bf16", 20, sC=cC, passes=True)
@@ -715,6 +735,12 @@ def main():
                                               "workload": d["config"]["workload"], "bound": d["roofline"]["bound"],
                                               "step_frac": d["roofline"].get("step_frac"),
                                               "mean_loss_over_timed_steps": d["check"]["mean_loss_over_timed_steps"]}
+                    if d["roofline"]["bound"] == "mfma":
+                        r_ = d["roofline"]
+                        step_tf = d["value"] * r_["step_flop_per_image"] / 1e12
+                        configs["c4_" + hname]["mfma"] = {"kernel": r_["kernel"], "achieved_tflops": r_["achieved"], "peak": r_["peak"],
+                                                          "frac": r_["frac"], "step_achieved_tflops": round(step_tf, 1),
+                                                          "step_frac": r_.get("step_frac"), "peak_note": r_.get("peak_note")}
                 except Exception as e:                          # a secondary never takes the headline line down with it
                     configs["c4_" + hname] = {"error": f"{type(e).__name__}: {e}"[:200]}
         torch.cuda.empty_cache()

@@ -1093,28 +1093,28 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
 
 // =======================================================================================
 // 17 .. 32 queries in ONE read of the bf16 tokens (round 5): the reference's default --ep_queries 32 (reference
-// main_linprobe.py:113) used to run as two 16-query launches of the form above.  Here one 8-wave workgroup per CU shares the
-// ring: wave w = (qb, kq) is wave kq of the two-workgroup form for query block qb (queries 16 qb .. 16 qb + 15) -- the same
-// D-quarter, the same MFMAs, the same registers -- and the two blocks' waves (w, w + 4: one SIMD) read the same tile.  D = 256 NK'
-// (even NK: the 8 waves split a tile's DMA pieces evenly).  Like ep_pool_mm2.hip the halves run staggered: waves 4-7 carry the
-// pooling MFMAs of a tile into the next iteration, their operands taken into registers before the tile's slot is released.
+// main_linprobe.py:113) used to run as two 16-query launches of the form above.  Here one 8-wave workgroup per CU shares a ring of
+// 32-token tiles: wave w = (qb, kq) owns query block qb = w >> 2 (queries 16 qb .. 16 qb + 15) and D-quarter kq = w & 3 for both
+// contractions -- the arithmetic of the 8-wave form at the top of this file (two 16-token MFMA blocks per tile, the pooling
+// contraction on v_mfma_f32_16x16x32_bf16 with K = the 32 tokens of the tile) with the waves split over query blocks instead of
+// all waves holding all queries: the cross-wave score exchange is 4 records per block, the softmax / operand-split work per
+// wave covers ITS block only.  (A first version with 16-token tiles ran 165 / 159 us per pass at 1024 x 256 x 768: its ring alone,
+// two barriers per 24 KiB tile on one workgroup per CU, moved 4.4 TB/s; 32-token tiles halve the rendezvous per byte.)
+// D = 128 k (k = 2, 3, 4, 6).
 // =======================================================================================
-constexpr int MBQ_NW = 8;
-#ifndef EP_MBQ_STAGGER
-#define EP_MBQ_STAGGER 1
-#endif
+constexpr int MBQ_NW = 8, MBQ_KQ = 4;
 #ifndef EP_MBQ_ABLATE
-#define EP_MBQ_ABLATE 0               // diagnostic builds of the forward: 1 ring + barriers only, 2 no pooling (loads + MFMAs), 3 no softmax
-#endif                                // arithmetic / operand split (constant weights), 4 no score MFMAs; results are wrong
+#define EP_MBQ_ABLATE 0               // diagnostic builds of the forward: 1 ring + barriers only, 2 no pooling, 4 no score MFMAs; results are wrong
+#endif
 
-template <int NK>
+template <int NK>                     // D = 128 * NK: a wave's D-quarter is 32 * NK channels (NK k-steps of the score MFMAs)
 struct MbqCfg {
   static constexpr int D = 128 * NK;
   static constexpr int ROWB = 2 * D;
   static constexpr int NCH = D / 8;
-  static constexpr int SLOT = MB2_TT * ROWB;
-  static constexpr int KDMA = SLOT / (MBQ_NW * 1024);   // = NK / 2
-  static constexpr int SPART = MBQ_NW * 1024;
+  static constexpr int SLOT = MB_TT * ROWB;
+  static constexpr int KDMA = SLOT / (MBQ_NW * 1024);   // = NK
+  static constexpr int SPART = 2 * MBQ_NW * 1024;       // partial score records [query block][token block][wave of the block][lane] f4
   static constexpr int LDS_TOTAL = 160 * 1024;
   static constexpr int nslot() {
     int ns = (LDS_TOTAL - SPART) / SLOT;
@@ -1124,33 +1124,8 @@ struct MbqCfg {
   }
   static constexpr int NSLOT = nslot();
   static constexpr int LDS = NSLOT * SLOT + SPART;
-  static_assert(NK % 2 == 0 && SLOT % (MBQ_NW * 1024) == 0, "the two-block form needs D = 256 k");
+  static_assert(SLOT % (MBQ_NW * 1024) == 0 && NSLOT >= 3, "the two-block form needs D = 128 k and a ring of three tiles");
 };
-// pooling A operands of a 16-token tile -> registers (mb2_pool's reads, detached from its MFMAs)
-template <int NK>
-__device__ __forceinline__ void mbq_pool_load(const char* tile, const int (&poff)[4], const int (&pseg)[NK], unsigned (&xr)[NK][4]) {
-#pragma unroll
-  for (int dg = 0; dg < NK; ++dg)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) xr[dg][e] = *reinterpret_cast<const unsigned*>(tile + poff[e] + pseg[dg]);
-}
-template <int NK>
-__device__ __forceinline__ void mbq_pool_mfma(const unsigned (&xr)[NK][4], const u2 (&bw)[3], f4 (&accE)[NK], f4 (&accO)[NK]) {
-#pragma unroll
-  for (int dg = 0; dg < NK; ++dg) {
-    u2 ae, ao;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      ae[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x05040100u);
-      ao[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x07060302u);
-    }
-#pragma unroll
-    for (int term = 2; term >= 0; --term) {
-      accE[dg] = mb2_mfma16(ae, bw[term], accE[dg]);
-      accO[dg] = mb2_mfma16(ao, bw[term], accO[dg]);
-    }
-  }
-}
 
 template <int NK>
 __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_fwd_kernel(PoolParams p) {
@@ -1165,17 +1140,17 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_fwd_kernel(PoolPar
   const int N = p.N, Q = p.Q;
   const int QS = p.Qs ? p.Qs : p.Q;
   const bool n4 = (N & 3) == 0;
-  const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
+  const int tiles_per_img = (N + MB_TT - 1) / MB_TT;
   const int G = gridDim.x, wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * tiles_per_img;
   if (n_items <= 0) return;
   const int j = lane & 15, g = lane >> 4;
   const int qj = 16 * qb + j;
-  const bool late = qb != 0 && EP_MBQ_STAGGER != 0;
   const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
-  char* sblk = spart + qb * (MB2_NW * 1024);         // the four records of this wave's query block
+  char* sblk = spart + qb * (2 * MBQ_KQ * 1024);     // the 2 x 4 records of this wave's query block
 
+  // B operand of the score MFMAs: query qj over the wave's D-quarter, pre-scaled like the reference (ep.py:39), three bf16 terms
   u4 bq[NK][3];
   int aoff[NK];
 #pragma unroll
@@ -1193,15 +1168,15 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_fwd_kernel(PoolPar
   unsigned soff[KDMA];
   mb_source_offsets<NCH, MBQ_NW, KDMA>(w, lane, soff);
   int poff[4], pseg[NK];
-  mb_pool_offsets<NK, MB2_NW>(kq, j, g, poff, pseg);
+  mb_pool_offsets<NK, MBQ_KQ>(kq, j, g, poff, pseg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int pi = 0, pimg = 0, ptile = 0, pslot = 0;
   const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
   auto produce = [&]() {
     if (pi < n_items) {
-      const int left = N - ptile * MB2_TT;
-      const unsigned limit = (unsigned)((left < MB2_TT ? left : MB2_TT) * ROWB - 16);
+      const int left = N - ptile * MB_TT;
+      const unsigned limit = (unsigned)((left < MB_TT ? left : MB_TT) * ROWB - 16);
       mb_dma_tile<MBQ_NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
       ++pi;
       pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
@@ -1217,69 +1192,63 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_fwd_kernel(PoolPar
   for (int s = 0; s < NSLOT - 1; ++s) produce();
 
   f4 accE[NK], accO[NK];
-  float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;
-  u2 bw[3] = {u2{0u, 0u}, u2{0u, 0u}, u2{0u, 0u}};   // the tile's weights as three bf16 terms (late half: of the pending tile)
-  unsigned xr[NK][4];                                 // pooling operands (late half: of the pending tile)
+  float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;     // per lane: running max / partial sum of query qj
   int cslot = 0, it = 0;
   for (int img = 0; img < n_img; ++img) {
     const int b = wg + img * G;
+    m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
+#pragma unroll
+    for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
     for (int t = 0; t < tiles_per_img; ++t, ++it) {
       mb_wait_vmcnt((pi - 1 - it) * KDMA);
       mb_barrier();                                  // tile `it` landed everywhere; the slot of tile it-1 is free
-      const int n0 = t * MB2_TT;
-      const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+      const int n0 = t * MB_TT;
+      const int nvalid = (N - n0) < MB_TT ? (N - n0) : MB_TT;
       const char* tile = ring + cslot * SLOT;
       cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
       if constexpr (EP_MBQ_ABLATE == 1) { produce(); mb_barrier(); continue; }
       if constexpr (EP_MBQ_ABLATE == 4) { produce(); } else
-      mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+      mb_scores<NK, MBQ_KQ, false>(tile, aoff, bq, sblk, kq, lane, produce);
       mb_barrier();                                  // all partial score blocks are in the scratch
-      if constexpr (EP_MBQ_ABLATE != 2) if (late && t > 0) mbq_pool_mfma<NK>(xr, bw, accE, accO);
-      __builtin_amdgcn_sched_barrier(0);
-      float sc[4], ue[4];
-      mb2_gather(sblk, lane, sc);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (EP_MBQ_ABLATE != 2) mbq_pool_load<NK>(tile, poff, pseg, xr);       // in flight under the softmax arithmetic; complete before the next barrier
-      if constexpr (EP_MBQ_ABLATE == 3) { bw[0] = u2{0x3f803f80u + lane, 0x3f803f80u}; bw[1] = bw[0]; bw[2] = bw[0]; if (!late) mbq_pool_mfma<NK>(xr, bw, accE, accO); continue; }
-      if (t == 0) {
-        m_j = -INFINITY; mL_j = -INFINITY; lsum = 0.f;
-#pragma unroll
-        for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
-      }
+      float sc[8], ue[8];
+      mb_gather<MBQ_KQ, false>(sblk, lane, sc);
       float mx = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ue[e] = (4 * g + e) < nvalid ? sc[e] : -INFINITY;
+      for (int e = 0; e < 8; ++e) {
+        ue[e] = (16 * (e >> 2) + 4 * g + (e & 3)) < nvalid ? sc[e] : -INFINITY;
         mx = fmaxf(mx, ue[e]);
       }
-      if (__builtin_amdgcn_ballot_w64(mx > m_j + MB_LAZY_MAX_THR) != 0ull) {
+      if (__builtin_amdgcn_ballot_w64(mx > m_j + MB_LAZY_MAX_THR) != 0ull) {    // rare
         const float mn = fmaxf(m_j, mb_q4_max(mx));
-        const float f = __builtin_amdgcn_exp2f((m_j - mn) * MB_LOG2E);
+        const float f = __builtin_amdgcn_exp2f((m_j - mn) * MB_LOG2E);           // m = -inf -> 0
         m_j = mn; mL_j = mn * MB_LOG2E;
         lsum *= f;
 #pragma unroll
-        for (int dg = 0; dg < NK; ++dg) { accE[dg] *= f; accO[dg] *= f; }
+        for (int dg = 0; dg < NK; ++dg) { accE[dg] *= f; accO[dg] *= f; }       // my column is query qj
       }
-      float wgt[4];
+      float wgt[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));
+      for (int e = 0; e < 8; ++e) {
+        wgt[e] = __builtin_amdgcn_exp2f(fmaf(ue[e], MB_LOG2E, -mL_j));          // invalid tokens: 0
         lsum += wgt[e];
       }
-      mb2_split4(wgt, bw);
-      if (kq == (t & 3) && qj < Q) {                 // the four waves of a block hold the same scores: they take turns writing them
-        float* Srow = p.S + ((int64_t)b * QS + qj) * N + n0 + 4 * g;
-        if (n4) {
-          if (4 * g < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[0], sc[1], sc[2], sc[3]};
-        } else {
+      // the four waves of a block hold the same scores: wave kq writes token group kq of both token blocks
+      if (g == kq && qj < Q) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * g + r < nvalid) Srow[r] = sc[r];
+        for (int blk = 0; blk < 2; ++blk) {
+          const int t0 = 16 * blk + 4 * g;
+          float* Srow = p.S + ((int64_t)b * QS + qj) * N + n0 + t0;
+          if (n4) {
+            if (t0 < nvalid) *reinterpret_cast<f4*>(Srow) = f4{sc[4 * blk], sc[4 * blk + 1], sc[4 * blk + 2], sc[4 * blk + 3]};
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t0 + r < nvalid) Srow[r] = sc[4 * blk + r];
+          }
         }
       }
-      if constexpr (EP_MBQ_ABLATE != 2) if (!late) mbq_pool_mfma<NK>(xr, bw, accE, accO);
+      if constexpr (EP_MBQ_ABLATE != 2) mb_pool<NK, MBQ_KQ>(tile, poff, pseg, wgt, accE, accO);
     }
-    if constexpr (EP_MBQ_ABLATE != 2) if (late) mbq_pool_mfma<NK>(xr, bw, accE, accO);
     const float l = mb_q4_sum(lsum);
     const float inv = 1.0f / l;
     if (qj < Q) {
@@ -1294,6 +1263,9 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_fwd_kernel(PoolPar
   }
 }
 
+// backward: the same pair with dP in place of the queries and A*(dA-delta) in place of the softmax weights.  The dP rows of
+// an image (this wave's D-quarter of its query block: read straight from global memory at the image's first tile -- the ring keeps
+// streaming meanwhile) are split into bf16 terms once per image; the saved scores of a tile are fetched one tile ahead.
 template <int NK>
 __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolParams p) {
   using C = MbqCfg<NK>;
@@ -1307,7 +1279,7 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolPar
   const int N = p.N, Q = p.Q;
   const int QS = p.Qs ? p.Qs : p.Q;
   const bool n4 = (N & 3) == 0;
-  const int tiles_per_img = (N + MB2_TT - 1) / MB2_TT;
+  const int tiles_per_img = (N + MB_TT - 1) / MB_TT;
   const int G = gridDim.x, wg = blockIdx.x;
   const int n_img = (p.B - wg + G - 1) / G;
   const int n_items = n_img * tiles_per_img;
@@ -1315,9 +1287,8 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolPar
   const int qj = 16 * qb + j;
   const bool live = qj < Q;
   const int jq = live ? qj : Q - 1;
-  const bool late = qb != 0 && EP_MBQ_STAGGER != 0;
   const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x);
-  char* sblk = spart + qb * (MB2_NW * 1024);
+  char* sblk = spart + qb * (2 * MBQ_KQ * 1024);
 
   f4 gE[NK], gO[NK];
 #pragma unroll
@@ -1330,20 +1301,25 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolPar
     unsigned soff[KDMA];
     mb_source_offsets<NCH, MBQ_NW, KDMA>(w, lane, soff);
     int poff[4], pseg[NK];
-    mb_pool_offsets<NK, MB2_NW>(kq, j, g, poff, pseg);
+    mb_pool_offsets<NK, MBQ_KQ>(kq, j, g, poff, pseg);
 
-    float sv[4];
+    // saved scores of tile (img, tile): S[b, qj, n0 + 16 blk + 4 g + r]
+    float sv[8];
     auto load_scores = [&](int img, int tl) {
       const int b = wg + img * G;
       const float* Srow = p.S + ((int64_t)b * QS + jq) * N;
-      int t0 = tl * MB2_TT + 4 * g;
-      if (n4) {
-        t0 = t0 < N ? t0 : N - 4;
-        const f4 v = *reinterpret_cast<const f4*>(Srow + t0);
-        sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
-      } else {
+      const int n0 = tl * MB_TT;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = Srow[(t0 + r) < N ? (t0 + r) : N - 1];
+      for (int blk = 0; blk < 2; ++blk) {
+        int t0 = n0 + 16 * blk + 4 * g;
+        if (n4) {
+          t0 = t0 < N ? t0 : N - 4;
+          const f4 v = *reinterpret_cast<const f4*>(Srow + t0);
+          sv[4 * blk] = v.x; sv[4 * blk + 1] = v.y; sv[4 * blk + 2] = v.z; sv[4 * blk + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[4 * blk + r] = Srow[(t0 + r) < N ? (t0 + r) : N - 1];
+        }
       }
     };
     load_scores(0, 0);
@@ -1351,8 +1327,8 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolPar
     const char* psrc = reinterpret_cast<const char*>(xb + EP_IMG_OFF(p, wg));
     auto produce = [&]() {
       if (pi < n_items) {
-        const int left = N - ptile * MB2_TT;
-        const unsigned limit = (unsigned)((left < MB2_TT ? left : MB2_TT) * ROWB - 16);
+        const int left = N - ptile * MB_TT;
+        const unsigned limit = (unsigned)((left < MB_TT ? left : MB_TT) * ROWB - 16);
         mb_dma_tile<MBQ_NW, KDMA>(psrc, limit, ring + pslot * SLOT, w, soff);
         ++pi;
         pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
@@ -1369,16 +1345,14 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolPar
 
     u4 bq[NK][3];
     float mL_j = 0.f, il_j = 0.f, dl_j = 0.f;
-    u2 bw[3] = {u2{0u, 0u}, u2{0u, 0u}, u2{0u, 0u}};
-    unsigned xr[NK][4];
     int cslot = 0, it = 0;
     for (int img = 0; img < n_img; ++img) {
       const int b = wg + img * G;
       for (int t = 0; t < tiles_per_img; ++t, ++it) {
         mb_wait_vmcnt((pi - 1 - it) * KDMA);
         mb_barrier();
-        const int n0 = t * MB2_TT;
-        const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
+        const int n0 = t * MB_TT;
+        const int nvalid = (N - n0) < MB_TT ? (N - n0) : MB_TT;
         const char* tile = ring + cslot * SLOT;
         cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
         if (t == 0) {                                // new image: its dP rows (this wave's slice) and ML row
@@ -1408,31 +1382,25 @@ __global__ __launch_bounds__(MBQ_NW * 64, 1) void ep_pool_mbq_bwd_kernel(PoolPar
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // keeps the counted waits below exact
         }
-        float cur[4];
+        float cur[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cur[e] = sv[e];
-        {
+        for (int e = 0; e < 8; ++e) cur[e] = sv[e];
+        {                                            // scores of the next tile, in front of the ring refill (the counted wait covers them)
           int nimg = img, ntile = t + 1;
           if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
           if (nimg < n_img) load_scores(nimg, ntile);
         }
-        mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+        mb_scores<NK, MBQ_KQ, false>(tile, aoff, bq, sblk, kq, lane, produce);      // dA partial blocks
         mb_barrier();
-        if (late && t > 0) mbq_pool_mfma<NK>(xr, bw, gE, gO);
-        __builtin_amdgcn_sched_barrier(0);
-        float u[4], wgt[4];
-        mb2_gather(sblk, lane, u);
-        __builtin_amdgcn_sched_barrier(0);
-        mbq_pool_load<NK>(tile, poff, pseg, xr);
+        float u[8], wgt[8];
+        mb_gather<MBQ_KQ, false>(sblk, lane, u);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
           const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
-          wgt[e] = ((4 * g + e) < nvalid && live) ? a * (u[e] - dl_j) : 0.f;
+          wgt[e] = ((16 * (e >> 2) + 4 * g + (e & 3)) < nvalid && live) ? a * (u[e] - dl_j) : 0.f;
         }
-        mb2_split4(wgt, bw);
-        if (!late) mbq_pool_mfma<NK>(xr, bw, gE, gO);
+        mb_pool<NK, MBQ_KQ>(tile, poff, pseg, wgt, gE, gO);
       }
-      if (late) mbq_pool_mfma<NK>(xr, bw, gE, gO);
     }
   }
   if (live) {
@@ -1456,16 +1424,17 @@ static int mbq_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t s
   EP_LAUNCH_CHECK(bwd ? "ep_pool_mbq_bwd_kernel" : "ep_pool_mbq_fwd_kernel");
   return 0;
 }
-// bf16 tokens, shared query rows, 17 .. 32 queries: D in {256, 512, 768} (D = 1024: 256 registers + 147 spilled -- stays on two
-// 16-query launches of the form above)
+// bf16 tokens, shared query rows, 17 .. 32 queries: D in {256, 384, 512, 768} (D = 1024 would spill and hold a ring of two
+// tiles only -- it stays on two 16-query launches of the form above)
 bool mbq_supported(int D, int Q, int64_t cls_bstride) {
-  return cls_bstride == 0 && Q > 16 && Q <= 32 && (D == 256 || D == 512 || D == 768);
+  return cls_bstride == 0 && Q > 16 && Q <= 32 && (D == 256 || D == 384 || D == 512 || D == 768);
 }
 bool mbq_takes_delta(int D, int Q, int Dv) { return mbq_supported(D, Q, 0) && Dv > 0 && Dv % (4 * Q) == 0; }
 int mbq_grid(int B) { const int g = cu_count(); return g < B ? g : B; }
 int mbq_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   switch (p.D) {
     case 256: return mbq_launch_one<2>(bwd, p, grid, st);
+    case 384: return mbq_launch_one<3>(bwd, p, grid, st);
     case 512: return mbq_launch_one<4>(bwd, p, grid, st);
     case 768: return mbq_launch_one<6>(bwd, p, grid, st);
   }

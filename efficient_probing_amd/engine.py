@@ -160,6 +160,8 @@ class ProbeHeadEngine:
         self.defer_update = False
         self._defer_event = None
         self._deferred = False
+        self._fs = None                                      # persistent step struct of the one-call step (see _fast_one_call)
+        self._fast_ok = type(self).__name__ == "ProbeHeadEngine" and os.environ.get("EP_FAST_STEP", "1") != "0"
         if broadcast_from_rank0 and self.world > 1:
             dist.broadcast(self.flat_p, src=0, group=self.group)     # what DDP does at wrap time
             self.sync_buffers()
@@ -342,13 +344,67 @@ class ProbeHeadEngine:
     def _can_defer(self) -> bool:
         import os
         # EP_DEFER_OPT=1 to use it: measured SLOWER on MI355X / ROCm 7.2 (0.452 against 0.433 ms per step at 256x768) -- a
-        # dependency between two HIP streams costs 8-12 us of idle queue on each side
+        # dependency between two HIP streams costs 8-12 us of idle queue on each side (EXPERIMENTS.md section 4, round 3)
         return (self.defer_update and self.aux_stream is not None and self.loss_scale == 1.0
                 and os.environ.get("EP_DEFER_OPT", "0") == "1")
+
+    # ---- the one-call step with a PERSISTENT step struct (round 5): the ~40 fields of ep_head_step are written once; a call
+    # rewrites the handful that change from step to step (token / target / index pointers, batch geometry, lr, the optimizer's
+    # hyper-parameters and step counter, planes_valid) and checks the tokens with plain attribute reads -- 100 -> ~35 us of
+    # Python per step (tools/host_overhead.py), which is what a B = 256 .. 512 per-GPU step of the 8-GPU protocol point is
+    # measured against (0.2 .. 0.26 ms of device time).  Anything unusual (tokens that need a copy, a dtype conversion, a
+    # changed stream) falls back to the general path below.
+    def _fast_one_call(self, x, targets, lr, image_index) -> bool:
+        if (x.dim() != 3 or not x.is_cuda or targets.dtype is not torch.int64 or targets.device != self.device
+                or self._pending is not None or self._deferred):
+            return False
+        B, Nn, D = x.shape
+        dt = x.dtype
+        if dt is torch.float32:
+            code, al = N.EP_DTYPE_F32, 4
+        elif dt is torch.bfloat16 and D % 8 == 0:
+            code, al = N.EP_DTYPE_BF16, 8
+        else:
+            return False
+        st0, st1, st2 = x.stride()
+        xp = x.data_ptr()
+        if st2 != 1 or st1 != D or (B > 1 and (st0 < Nn * D or st0 % al != 0)) or xp % 16 != 0:
+            return False
+        if image_index is not None:
+            if image_index.dtype is not torch.int32 or not image_index.is_cuda or not image_index.is_contiguous():
+                return False
+            iptr, B = image_index.data_ptr(), image_index.numel()
+        else:
+            iptr = 0
+        self._bind_store_tables(x, image_index)
+        fs = self._fs
+        if fs is None:
+            fs = self._fs = self._step_struct(None, 0, None, 3, False, None)
+            self._fs_ref = C.byref(fs)
+        ws = self._ws if self._ws_key == (B, Nn) else self._workspace(B, Nn)
+        self.opt_step += 1
+        fs.dims.B = B; fs.dims.N = Nn
+        fs.x = xp; fs.x_dtype = code; fs.x_bstride = st0 if B > 1 else Nn * D
+        fs.image_index = iptr
+        fs.targets = targets.data_ptr()
+        fs.lr = self.lr if lr is None else lr
+        fs.weight_decay = self.weight_decay; fs.momentum = self.momentum; fs.trust_coefficient = self.trust_coefficient
+        fs.beta1, fs.beta2 = self.betas; fs.adam_eps = self.adam_eps
+        fs.grad_scale = self.loss_scale; fs.inv_scale = 1.0 / self.loss_scale       # (one rank, no accumulation: _one_call_step)
+        fs.opt_step = self.opt_step
+        fs.planes_valid = int(self._planes_current())
+        rc = self.lib.ep_head_train_step(self._fs_ref, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            N.check(rc, "head train step")
+        self._planes_token = self._param_versions()          # phases = 3 established / rewrote the planes
+        self._micro = 0
+        return True
 
     def _train_step_one_call(self, x, targets, lr, image_index) -> None:
         if self._can_defer():
             return self._train_step_deferred(x, targets, lr, image_index)
+        if self._fast_ok and self._fast_one_call(x, targets, lr, image_index):
+            return
         self.flush()
         xv, bstride = F_.as_token_view(x)
         _, Nn, D = xv.shape

@@ -244,7 +244,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     if engine is not None and hasattr(engine, "defer_update"):
         # inside this loop nothing reads the head's parameters between two steps, so the engine MAY let the large update of a
         # step run beside the next step's first token pass (flushed below, before anything can read them) -- it only does
-        # with EP_DEFER_OPT=1: measured slower on this stack (engine._can_defer)
+        # with EP_DEFER_OPT=1: measured slower on this stack (engine._can_defer, EXPERIMENTS.md section 4 round 3)
         engine.defer_update = True
     optimizer.zero_grad()
     pending = pending_images = 0                  # fused steps (and their images) whose statistics are still on the GPU

@@ -15,7 +15,7 @@ keeps the head kernels fed.  This module provides
     drawn as an int32 index vector -- the pooling kernels read the selected images IN PLACE
     (``image_index`` of the C ABI), so an epoch never copies or re-uploads a token;
   * ``StreamingTokenLoader``: for stores larger than HBM, double-buffered pinned-host -> device
-    copies on a side stream (PCIe-bound, ~80 k img/s at 256x768 fp32).
+    copies on a side stream (PCIe-bound, ~80 k img/s at 256x768 fp32; see EXPERIMENTS.md section 3).
 """
 from __future__ import annotations
 

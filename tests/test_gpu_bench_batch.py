@@ -169,7 +169,7 @@ def test_fused_lars_steps_at_bench_batch_vs_torch_port(shape, one_call):
 
 # what else bench.py times (round 4): BASELINE configs[4] on its default path -- D >= 2048 and B >= 128 puts all six
 # contractions on the bf16-plane kernel (csrc/ep_planes.hip) and the token passes on the wide-row kernels -- at the B = 256
-# row of DESIGN section 4, and the bf16-STORED tokens of the `bf16_token_storage` / `c5_bf16` objects (matrix-core token
+# row of EXPERIMENTS.md section 4, and the bf16-STORED tokens of the `bf16_token_storage` / `c5_bf16` objects (matrix-core token
 # passes that carry the weight-gradient side tasks, csrc/ep_pool_mb.hip) at the bench batch.  Against the torch-CPU port of
 # the reference step -- fed the ROUNDED tokens for bf16 storage (the contract of that mode: fp32 arithmetic on the stored
 # values) -- not against other kernels of this library.
