@@ -251,11 +251,15 @@ GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int
   return g;
 }
 
+bool project_dp_thin_ok(int D, int Dp, int Q);           // ep_tail.hip: thin query slices (Dq <= 32)
+int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
 static int project_backward(const float* dy, const float* y, const float* P, const float* Wv, int B, int D, int Dp,
                             int Q, float* dP, float* dWv, float* ML, int accumulate, hipStream_t st) {
   const int Dq = Dp / Q;
   if (ML && y) EP_TRY(delta_rows(dy, y, B * Q, Dq, ML, st));
-  if (dP) {
+  if (dP && project_dp_thin_ok(D, Dp, Q)) {
+    EP_TRY(project_dp_thin(dy, Wv, B, D, Dp, Q, dP, st));
+  } else if (dP) {
     GemmParams g{};
     g.A = dy; g.lda = Dp; g.sAz = Dq;
     g.B = Wv; g.ldb = D; g.sBz = (int64_t)Dq * D; g.extB = D;
@@ -824,11 +828,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       if (plw) EP_TRY(wgrad_dwv_pl(w, d, s->grads + offs[1], s->accumulate, side));
       else EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
                                    s->accumulate, side));
+      // the softmax-correction rows dy_q . y_q inside the second pass where its kernel can (the 32-query bf16 pass): one launch less
+      const bool in_pass2 = pool_backward_takes_delta(p, Dp);
+      if (in_pass2) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
       if (pl) {
-        EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
+        if (!in_pass2) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));
       } else {
-        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, w.ML, 0, st));
+        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, w.dP, nullptr, in_pass2 ? nullptr : w.ML, 0, st));
       }
       mark_pass(2, st);
       EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, nullptr, (s->phases & 2) ? &red : nullptr));

@@ -602,6 +602,48 @@ int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hip
   EP_LAUNCH_CHECK("ep_delta_kernel");
   return 0;
 }
+// dP[b, q, :] = sum_{c < DQ} dy[b, q DQ + c] Wv[q DQ + c, :]  (autograd of the value projection, reference poolings/ep.py:40)
+// for THIN query slices, DQ = D' / Q <= 32 -- the published protocol's 32 queries at D <= 1024.  As a batched contraction on
+// the matrix kernels (K = 24 at 256 x 768) it ran 84 us for 1.2 GFLOP (round 5 timeline, profiles/r05); it is bound by the 100 MB
+// it writes.  One workgroup per (query, block of images): a thread keeps the DQ x 4 weights of its four output channels in
+// registers, the dy slice of an image is wave-uniform (scalar loads), every output row is one coalesced float4 store per lane.
+template <int DQ>
+__global__ __launch_bounds__(256) void ep_dp_thin_kernel(const float* __restrict__ dy, const float* __restrict__ Wv, int B, int D, int Dp,
+                                                        int Q, int rows_per_block, float* __restrict__ dP) {
+  const int q = blockIdx.x, b0 = blockIdx.y * rows_per_block;
+  const int c4 = threadIdx.x;
+  if (4 * c4 >= D) return;
+  f4 w[DQ];
+#pragma unroll
+  for (int c = 0; c < DQ; ++c) w[c] = *reinterpret_cast<const f4*>(Wv + (int64_t)(q * DQ + c) * D + 4 * c4);
+  const int b1 = (b0 + rows_per_block) < B ? (b0 + rows_per_block) : B;
+  for (int b = b0; b < b1; ++b) {
+    const float* dyr = dy + (int64_t)b * Dp + q * DQ;
+    f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < DQ; ++c) a += dyr[c] * w[c];
+    *reinterpret_cast<f4*>(dP + ((int64_t)b * Q + q) * D + 4 * c4) = a;
+  }
+}
+bool project_dp_thin_ok(int D, int Dp, int Q) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_DP_THIN"); on = e ? atoi(e) : 1; }
+  const int Dq = Dp / Q;
+  return on && D % 4 == 0 && D <= 1024 && Dp % Q == 0 && (Dq == 8 || Dq == 12 || Dq == 16 || Dq == 24 || Dq == 32);
+}
+int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st) {
+  const int Dq = Dp / Q;
+  const int rpb = 32;
+  const dim3 grid(Q, (B + rpb - 1) / rpb), block(256);
+#define EP_DPT(N_) case N_: hipLaunchKernelGGL(ep_dp_thin_kernel<N_>, grid, block, 0, st, dy, Wv, B, D, Dp, Q, rpb, dP); break;
+  switch (Dq) {
+    EP_DPT(8) EP_DPT(12) EP_DPT(16) EP_DPT(24) EP_DPT(32)
+    default: set_error("project_dp_thin: Dq = %d", Dq); return EP_E_UNSUPPORTED;
+  }
+#undef EP_DPT
+  EP_LAUNCH_CHECK("ep_dp_thin_kernel");
+  return 0;
+}
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
                   float* loss_rows, float* dlogits, float* rowstat, hipStream_t st) {
   if (ldl <= 64 * CE_RPT)
