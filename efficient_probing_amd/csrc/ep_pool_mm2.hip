@@ -15,7 +15,7 @@
 // gather reads and 8 exponentials per lane and tile, redundantly on 8 waves) the vector-ALU / LDS work between the two MFMA
 // phases of a tile is a quarter; the MFMA count per wave is the same (D/8 per tile), each A operand is read from LDS by the
 // two waves that share a SIMD (w and w + 4).
-// The two halves run STAGGERED (waves 4-7 carry the pooling MFMAs of a tile into the next iteration, see the forward kernel).
+// (Two alternative tile schedules -- staggered halves, pipelined pooling -- are kept behind EP_MM2_STAGGER: measured equal.)
 // The pass is matrix-pipe bound: 2 * 2 * N * D * 32 FLOP per image, 25.8 GFLOP at 1024 x 256 x 768 = 164 us at the 157 TFLOP/s
 // fp32-matrix peak -- within 1.3 x of the HBM time of the fp32 tokens (805 MB at 6.3 TB/s = 128 us).
 // The backward is the same pair with dP in place of the queries (two header items per image) and A*(dA-delta) in place of
@@ -33,8 +33,12 @@ typedef const __attribute__((address_space(1))) void* m2_gptr_t;
 #define EP_MM2_ABLATE 0               // diagnostic builds of the forward (tools/build_variant_one.sh): 1 ring + barriers only, 4 all MFMAs
 #endif                                // but no gather / softmax, 5 = 4 without ring refills; results are wrong
 #ifndef EP_MM2_STAGGER
-#define EP_MM2_STAGGER 1              // 0 (A/B builds): both halves of the workgroup in lockstep
-#endif
+#define EP_MM2_STAGGER 0              // tile schedule: 0 (shipped) every wave finishes a tile inside its iteration; 1 waves 4-7 carry the
+#endif                                // pooling MFMAs of a tile into the next iteration (stagger); 2 ALL waves do, and issue them right behind
+                                      // the score MFMAs of the next tile: one matrix and one vector phase per tile (pipe).  Measured EQUAL
+                                      // at 256 x 768 (fwd / bwd alone: 301 / 272, 305 / 270, 307 / 278 us) and at D = 384 / 512: the exact-fp32
+                                      // MFMA runs at the fp32 VECTOR rate and, as measured here, does not overlap the SIMD partner's vector
+                                      // instructions, so re-ordering phases between the two waves of a SIMD is zero-sum (EXPERIMENTS.md r5)
 #ifndef EP_MM2_PRIO
 #define EP_MM2_PRIO 0                 // static s_setprio of waves 4-7, the younger wave of every SIMD (A/B builds; measured zero-sum)
 #endif
@@ -249,7 +253,7 @@ __device__ __forceinline__ void m2_pool_mfma(const float (&xa)[4][NB], const f4&
 __device__ __forceinline__ float m2_sel(const f4& v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
 
 // ---------------------------------------------------------------------------------------
-// forward.  The two halves of the workgroup run STAGGERED: waves 0-3 ("early") finish a tile inside its iteration --
+// forward.  With EP_MM2_STAGGER = 1 the two halves of the workgroup run STAGGERED: waves 0-3 ("early") finish a tile inside its iteration --
 // scores | barrier | softmax | pooling MFMAs -- while waves 4-7 ("late", the SIMD partners of 0-3) carry the pooling
 // MFMAs of a tile into the NEXT iteration -- scores | barrier | pooling MFMAs of the previous tile | softmax of this one.
 // Between two barriers one wave of every SIMD is then on the matrix pipe while its partner gathers and exponentiates,
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_fwd_kernel(PoolPara
   if (n_items <= 0) return;
   const int j = lane & 15, kk = lane >> 4;
   const int qj = 16 * qb + j;                // this lane's query (column of the wave's score / pooled blocks)
-  const bool late = qb != 0 && EP_MM2_STAGGER != 0;
+  const bool late = (EP_MM2_STAGGER == 2 || (EP_MM2_STAGGER == 1 && qb != 0)) && NG <= 6;   // (D >= 896: the carried pooling operands would spill; lockstep there)
+  constexpr bool PIPE = EP_MM2_STAGGER == 2 && NG <= 6;
   unsigned long long clk0 = 0, rt0 = 0;
   if constexpr (EP_MM2_CLK != 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
@@ -388,9 +393,10 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_fwd_kernel(PoolPara
       if constexpr (EP_MM2_ABLATE == 1) { produce(); m2_barrier(); continue; }
       m2_scores<NB>(tile, aoff, bq, spart, w, lane, produce);
       M2_STAMP(1)
+      if constexpr (PIPE) { if (t > 0) m2_pool_mfma<NB>(xa, wgt, acc); }       // the pending tile: one matrix phase per iteration
       m2_barrier();                                 // all partial score blocks are in the scratch
       M2_STAMP(2)
-      if (late && t > 0) m2_pool_mfma<NB>(xa, wgt, acc);
+      if constexpr (!PIPE) { if (late && t > 0) m2_pool_mfma<NB>(xa, wgt, acc); }
       __builtin_amdgcn_sched_barrier(0);
       M2_STAMP(3)
       if constexpr (EP_MM2_ABLATE == 4 || EP_MM2_ABLATE == 5) {
@@ -457,7 +463,8 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_bwd_kernel(PoolPara
   const int j = lane & 15, kk = lane >> 4;
   const int qj = 16 * qb + j;
   const bool live = qj < Q;
-  const bool late = qb != 0 && EP_MM2_STAGGER != 0;
+  const bool late = (EP_MM2_STAGGER == 2 || (EP_MM2_STAGGER == 1 && qb != 0)) && NG <= 6;   // (D >= 896: the carried pooling operands would spill; lockstep there)
+  constexpr bool PIPE = EP_MM2_STAGGER == 2 && NG <= 6;
 
   f4 gacc[NB];
 #pragma unroll
@@ -545,8 +552,9 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_bwd_kernel(PoolPara
         const int n0 = t * M2_TT;
         const int nvalid = (N - n0) < M2_TT ? (N - n0) : M2_TT;
         m2_scores<NB>(tile, aoff, bq, spart, w, lane, produce);      // dA partial blocks
+        if constexpr (PIPE) { if (t > 0) m2_pool_mfma<NB>(xa, wgt, gacc); }
         m2_barrier();
-        if (late && t > 0) m2_pool_mfma<NB>(xa, wgt, gacc);
+        if constexpr (!PIPE) { if (late && t > 0) m2_pool_mfma<NB>(xa, wgt, gacc); }
         __builtin_amdgcn_sched_barrier(0);
         const f4 u = m2_gather(spart, qb, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -618,12 +626,12 @@ static int mm2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t s
   return 0;
 }
 
-// fp32 tokens, shared query rows, 17 .. 32 queries, D = 128 k up to 896 (two ring slots + the per-slot score / statistics
+// fp32 tokens, shared query rows, 17 .. 32 queries, D = 128 k up to 1024 (two ring slots + the per-slot score / statistics
 // pieces must fit the 160 KiB, the register budget is 256 per wave at two waves per SIMD)
 bool mm2_supported(int D, int Q, int64_t cls_bstride, bool bwd) {
   (void)bwd;
   if (cls_bstride != 0 || Q <= 16 || Q > 32 || D % 128 != 0 || D < 256) return false;
-  return D <= 896;                     // (D = 1024: 256 registers + 27 / 53 spilled)
+  return D <= 1024;
 }
 
 int mm2_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
@@ -634,6 +642,7 @@ int mm2_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
     case 5: return mm2_launch_one<5>(bwd, p, grid, st);
     case 6: return mm2_launch_one<6>(bwd, p, grid, st);
     case 7: return mm2_launch_one<7>(bwd, p, grid, st);
+    case 8: return mm2_launch_one<8>(bwd, p, grid, st);
   }
   set_error("no 32-query matrix-core pooling kernel for D=%d", p.D);
   return EP_E_UNSUPPORTED;
