@@ -579,7 +579,7 @@ def main():
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
     traffic, traffic_source = None, None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"{args.workload}_hbm_traffic_pmc.json")
         if traffic is None and os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
             try:

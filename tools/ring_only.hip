@@ -27,7 +27,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // NW waves; a tile = NW * KPW pieces of 1 KiB (one global_load_lds of 16 B per lane each); nslot ring slots; `nbar` barriers per tile
 template <int NW, int KPW>
-__global__ __launch_bounds__(NW * 64) void ring_kernel(const char* x, long img_bytes, int B, int nslot, int nbar, int aux, float* sink) {
+__global__ __launch_bounds__(NW * 64) void ring_kernel(const char* x, long img_bytes, int B, int nslot, int nbar, int aux, float* sink, int rowb) {
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   constexpr int TILE = NW * KPW * 1024;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -45,6 +45,10 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const char* x, long img_b
 #pragma unroll
       for (int k = 0; k < KPW; ++k) {
         unsigned off = (unsigned)((w + NW * k) * 1024 + lane * 16);
+        if (rowb) {                                    // the passes' source-side swizzle: LDS chunk (t, c') <- source chunk c' ^ (t & 15) of row t
+          const unsigned nch = (unsigned)rowb >> 4, pos = off >> 4, t = pos / nch, c = pos - t * nch;
+          off = t * (unsigned)rowb + ((c ^ (t & 15u)) << 4);
+        }
         off = off < limit ? off : limit;
         if (aux) __builtin_amdgcn_global_load_lds((gptr_t)(psrc + off), (lds_ptr_t)(ring + pslot * TILE + (w + NW * k) * 1024), 16, 0, 2);
         else __builtin_amdgcn_global_load_lds((gptr_t)(psrc + off), (lds_ptr_t)(ring + pslot * TILE + (w + NW * k) * 1024), 16, 0, 0);
@@ -77,9 +81,9 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const char* x, long img_b
 struct Geo { int nw, kpw, wgs, nslot, nbar, aux; };
 
 template <int NW, int KPW>
-static float run(const Geo& g, const std::vector<char*>& xs, long img_bytes, int B, int cus, float* sink) {
+static float run(const Geo& g, const std::vector<char*>& xs, long img_bytes, int B, int cus, float* sink, int rowb = 0, int lds_pad = 0) {
   const int tile = NW * KPW * 1024;
-  const size_t lds = (size_t)g.nslot * tile;
+  const size_t lds = (size_t)g.nslot * tile + lds_pad;
   auto k = ring_kernel<NW, KPW>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1.f;
   int grid = cus * g.wgs; if (grid > B) grid = B;
@@ -87,7 +91,7 @@ static float run(const Geo& g, const std::vector<char*>& xs, long img_bytes, int
   std::vector<float> ts;
   for (int it = 0; it < 25; ++it) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, xs[it % xs.size()], img_bytes, B, g.nslot, g.nbar, g.aux, sink);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, xs[it % xs.size()], img_bytes, B, g.nslot, g.nbar, g.aux, sink, rowb);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -131,5 +135,17 @@ int main(int argc, char** argv) {
           fflush(stdout);
         }
       }
+  // the matrix-core passes' geometry (8 waves, 48 KiB tiles, one workgroup per CU, 3 slots) with the source-side row swizzle of
+  // the passes, for fp32 rows (D x 4 bytes) and bf16 rows (D x 2 bytes), one and two barriers per tile
+  for (int rowb : {0, D * 4, D * 2})
+    for (int nbar : {1, 2}) {
+      Geo g{8, 6, 1, 3, nbar, 1};
+      const float us = run<8, 6>(g, xs, img_bytes, B, cus, sink, rowb);
+      printf("swizzled-source: 8 waves 48 KiB 1 WG/CU 3 slots, row bytes %d, %d barrier(s) per tile | %7.1f | %.2f\n", rowb, nbar, us, gb / us * 1e3);
+      if (nbar == 2) {
+        const float us2 = run<8, 6>(g, xs, img_bytes, B, cus, sink, rowb, 16384);
+        printf("   ... with the whole 160 KiB of LDS allocated (ring + 16 KiB)                          | %7.1f | %.2f\n", us2, gb / us2 * 1e3);
+      }
+    }
   return 0;
 }
