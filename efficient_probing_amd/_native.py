@@ -13,9 +13,10 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
-EP_ABI_VERSION = 23        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
+EP_ABI_VERSION = 24        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
+EP_DTYPE_F16 = 2          # fp16-stored tokens: forward entry points of the EP head only (ABI v24)
 
 c_f32p = C.c_void_p       # device pointers travel as integers (tensor.data_ptr())
 c_i64 = C.c_int64

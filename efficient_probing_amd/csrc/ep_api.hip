@@ -55,6 +55,30 @@ int check_tokens(const void* x, int x_dtype, int64_t x_bstride, int B, int N, in
   return 0;
 }
 
+// A second side queue of the library's own (created on first use, one per device and host thread, like the event pool): the
+// 32-query step has two weight-gradient contractions of ~50 us each that feed nothing before the optimizer; on ONE side stream
+// they are serialised (dWc, then dWv) and the second one runs into the second token pass, whose persistent workgroups starve
+// it (measured: dWv 307 us instead of 50, the step waits 40 us for it -- profiles/r05).  With dWv on its own queue both start
+// as soon as their operands exist and are done when the pass starts.
+static int get_side2_stream(hipStream_t* out) {
+  constexpr int MAX_DEV = 16;
+  static thread_local hipStream_t pool[MAX_DEV] = {};
+  int dev = 0;
+  EP_HIP(hipGetDevice(&dev));
+  EP_REQUIRE(dev >= 0 && dev < MAX_DEV, EP_E_ARG, "get_side2_stream: device %d not supported", dev);
+  if (!pool[dev]) EP_HIP(hipStreamCreateWithFlags(&pool[dev], hipStreamNonBlocking));
+  *out = pool[dev];
+  return 0;
+}
+
+// forward entry points also take fp16-STORED tokens (EP_DTYPE_F16, ABI v24): same layout rules as bf16
+static int check_tokens_fwd(const void* x, int x_dtype, int64_t x_bstride, int B, int N, int D, int Q) {
+  return check_tokens(x, x_dtype == EP_DTYPE_F16 ? EP_DTYPE_BF16 : x_dtype, x_bstride, B, N, D, Q);
+}
+
+bool project_dp_thin_ok(int D, int Dp, int Q);           // ep_tail.hip: thin query slices (Dq <= 32)
+int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
+
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
   float* ypart;                                // in-pass value projection: IP_YPARTS K-quarter partials of y (ep_inpass.h)
@@ -219,7 +243,7 @@ static int check_dims(const ep_head_dims& d) {
 
 PoolParams pool_params(const void* x, int64_t x_bstride, int B, int N, int D, int Q, float scale, int x_dtype) {
   PoolParams p{};
-  p.x = static_cast<const float*>(x); p.x_bf16 = x_dtype == EP_DTYPE_BF16 ? 1 : 0; p.x_bstride = x_bstride; p.B = B; p.N = N; p.D = D; p.Q = Q; p.scale = scale;
+  p.x = static_cast<const float*>(x); p.x_bf16 = x_dtype == EP_DTYPE_BF16 ? 1 : (x_dtype == EP_DTYPE_F16 ? 2 : 0); p.x_bstride = x_bstride; p.B = B; p.N = N; p.D = D; p.Q = Q; p.scale = scale;
   return p;
 }
 
@@ -251,8 +275,6 @@ GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int
   return g;
 }
 
-bool project_dp_thin_ok(int D, int Dp, int Q);           // ep_tail.hip: thin query slices (Dq <= 32)
-int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
 static int project_backward(const float* dy, const float* y, const float* P, const float* Wv, int B, int D, int Dp,
                             int Q, float* dP, float* dWv, float* ML, int accumulate, hipStream_t st) {
   const int Dq = Dp / Q;
@@ -425,15 +447,16 @@ const char* ep_linear_kernel_name(int M, int N, int K) {
   return gemm_kernel_name(true, true, g, 1);
 }
 const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype) {
-  return pool_kernel_family(B, N, D, Q, backward, x_dtype == EP_DTYPE_BF16);
+  return pool_kernel_family(B, N, D, Q, backward, x_dtype == EP_DTYPE_BF16 ? 1 : (x_dtype == EP_DTYPE_F16 ? 2 : 0));
 }
 
 int ep_pool_forward(const void* x, int x_dtype, int64_t x_bstride, const int32_t* image_index, int B, int N, int D,
                     const float* cls_token, int64_t cls_bstride, int Q, float scale, float* P, float* S, float* ML,
                     void* workspace, size_t workspace_bytes, ep_stream_t stream) {
   (void)workspace; (void)workspace_bytes;
-  EP_TRY(check_tokens(x, x_dtype, x_bstride, B, N, D, Q));
+  EP_TRY(check_tokens_fwd(x, x_dtype, x_bstride, B, N, D, Q));
   EP_REQUIRE(cls_token && P && S && ML, EP_E_ARG, "ep_pool_forward: null pointer");
+  EP_REQUIRE(x_dtype != EP_DTYPE_F16 || cls_bstride == 0, EP_E_UNSUPPORTED, "fp16-stored tokens: shared query rows only");
   EP_REQUIRE(aligned16(cls_token) && aligned16(P) && aligned16(ML) && cls_bstride % 4 == 0, EP_E_ALIGN,
              "ep_pool_forward: cls_token / P / ML must be 16-byte aligned");
   PoolParams p = pool_params(x, x_bstride, B, N, D, Q, scale, x_dtype);
@@ -802,9 +825,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       mark_pass(3, st);
     } else {
       hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
-      hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+      hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+      // dWv on a queue of its own where the aux stream's work would otherwise push it into the second pass (EP_SIDE2=0: one side stream)
+      static int side2_on = -1;
+      if (side2_on < 0) { const char* e = getenv("EP_SIDE2"); side2_on = e ? atoi(e) : 1; }
+      hipStream_t side2 = side;
+      if (side != st && side2_on && !plw && d.Q > 16) EP_TRY(get_side2_stream(&side2));
       if (side != st) {
-        EP_TRY(get_events(ev, 3));
+        EP_TRY(get_events(ev, 4));
         EP_HIP(hipEventRecord(ev[0], st));
         EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
       }
@@ -821,13 +849,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       if (side != st) {
         EP_HIP(hipEventRecord(ev[1], st));
-        EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
+        EP_HIP(hipStreamWaitEvent(side2, ev[1], 0));
       }
       // (The weight gradient of v started only when dP is done, so that it runs beside the HBM-bound second pass instead of
       // beside dP: measured, the pass then takes 1070 instead of 555 us at 196 x 4096 -- the two kernels do not share CUs.)
       if (plw) EP_TRY(wgrad_dwv_pl(w, d, s->grads + offs[1], s->accumulate, side));
       else EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr,
-                                   s->accumulate, side));
+                                   s->accumulate, side2));
+      if (side2 != side) EP_HIP(hipEventRecord(ev[3], side2));
       // the softmax-correction rows dy_q . y_q inside the second pass where its kernel can (the 32-query bf16 pass): one launch less
       const bool in_pass2 = pool_backward_takes_delta(p, Dp);
       if (in_pass2) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
@@ -843,6 +872,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       if (side != st) {
         EP_HIP(hipEventRecord(ev[2], side));
         EP_HIP(hipStreamWaitEvent(st, ev[2], 0));           // join: grads complete on `stream`
+        if (side2 != side) EP_HIP(hipStreamWaitEvent(st, ev[3], 0));
       }
     }
   }
@@ -899,7 +929,7 @@ int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, i
   EP_REQUIRE(dims && x && params && running_mean && running_var && logits && ws, EP_E_ARG, "ep_head_eval_forward: null pointer");
   const ep_head_dims& d = *dims;
   EP_TRY(check_dims(d));
-  EP_TRY(check_tokens(x, x_dtype, x_bstride, d.B, d.N, d.D, d.Q));
+  EP_TRY(check_tokens_fwd(x, x_dtype, x_bstride, d.B, d.N, d.D, d.Q));
   HeadWs w = carve(d, ws);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_eval_forward: workspace %zu < %zu", ws_bytes, w.total);
   EP_REQUIRE(ldl >= d.C, EP_E_ARG, "ldl < C");

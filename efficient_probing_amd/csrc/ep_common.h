@@ -55,10 +55,18 @@ __device__ __forceinline__ f4 bf16x4_to_f4(uint2 v) {
   r.z = __uint_as_float(v.y << 16); r.w = __uint_as_float(v.y & 0xffff0000u);
   return r;
 }
-// tokens are fp32 or bf16 in memory; all arithmetic is fp32.  `e`: element index (multiple of 4)
+// ---- fp16 token storage (forward / evaluation only, ABI v24): four consecutive fp16 values widened to fp32 (exact) ----
+__device__ __forceinline__ f4 f16x4_to_f4(uint2 v) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const h2v a = __builtin_bit_cast(h2v, v.x), b = __builtin_bit_cast(h2v, v.y);
+  return f4{(float)a.x, (float)a.y, (float)b.x, (float)b.y};
+}
+// 16-bit stored tokens: bf16, or (f16 != 0, a wave-uniform run-time flag of the 16-bit instantiations) fp16
+__device__ __forceinline__ f4 h16x4_to_f4(uint2 v, int f16) { return f16 ? f16x4_to_f4(v) : bf16x4_to_f4(v); }
+// tokens are fp32 or 16-bit (bf16 / fp16) in memory; all arithmetic is fp32.  `e`: element index (multiple of 4)
 template <bool BF16>
-__device__ __forceinline__ f4 load_tok4(const void* base, int64_t e) {
-  if (BF16) return bf16x4_to_f4(*reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + e));
+__device__ __forceinline__ f4 load_tok4(const void* base, int64_t e, int f16 = 0) {
+  if (BF16) return h16x4_to_f4(*reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + e), f16);
   return *reinterpret_cast<const f4*>(static_cast<const float*>(base) + e);
 }
 

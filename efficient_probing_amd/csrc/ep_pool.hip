@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int D = p.D, N = p.N, Q = p.Q;
+  const int f16 = BF16 && p.x_bf16 == 2;     // fp16-stored tokens (forward only)
   const char* xb = reinterpret_cast<const char*>(p.x) + EP_IMG_OFF(p, b) * (BF16 ? 2 : 4);
   float* red = sm + N;
   // LayerNorm-of-tokens mode: per-token {mean, rstd}; scores q.xhat = rstd (q.x - mean sum(q))
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
     for (int n = w; n < N; n += 4) {
       float s = 0.f;
       for (int d = lane * 4; d < D; d += 256) {
-        f4 xv = load_tok4<BF16>(xb, (int64_t)n * D + d);
+        f4 xv = load_tok4<BF16>(xb, (int64_t)n * D + d, f16);
         f4 cv = *reinterpret_cast<const f4*>(cq + d) * p.scale;
         s = fmaf(cv.x, xv.x, s); s = fmaf(cv.y, xv.y, s); s = fmaf(cv.z, xv.z, s); s = fmaf(cv.w, xv.w, s);
       }
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void ep_pool_fwd_generic_kernel(PoolParams p) 
     }
     for (int d = threadIdx.x * 4; d < D; d += 1024) {
       f4 a = {0, 0, 0, 0};
-      for (int n = 0; n < N; ++n) a += sm[n] * load_tok4<BF16>(xb, (int64_t)n * D + d);
+      for (int n = 0; n < N; ++n) a += sm[n] * load_tok4<BF16>(xb, (int64_t)n * D + d, f16);
       *reinterpret_cast<f4*>(p.P + ((int64_t)b * Q + q) * D + d) = (a - shift) * inv;
     }
     if (threadIdx.x == 0) {
@@ -370,7 +371,7 @@ static bool use_mm(const PoolParams& p, bool bwd) {
 static bool use_mb(const PoolParams& p) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_POOL_MB"); on = e ? atoi(e) : 1; }
-  return on && p.x_bf16 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mb_supported(p.D, p.Q, p.cls_bstride);
+  return on && p.x_bf16 == 1 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mb_supported(p.D, p.Q, p.cls_bstride);
 }
 
 // bf16 tokens, 17 .. 32 queries: both 16-query blocks against one read of the tokens (second half of ep_pool_mb.hip;
@@ -380,7 +381,7 @@ static bool use_mbq(const PoolParams& p) {
   if (on < 0) { const char* e = getenv("EP_POOL_MBQ"); on = e ? atoi(e) : 1; }
   static int mb = -1;
   if (mb < 0) { const char* e = getenv("EP_POOL_MB"); mb = e ? atoi(e) : 1; }
-  return on && mb && p.x_bf16 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mbq_supported(p.D, p.Q, p.cls_bstride);
+  return on && mb && p.x_bf16 == 1 && !needs_generic(p) && !p.tokstat && pool_mode() == 0 && mbq_supported(p.D, p.Q, p.cls_bstride);
 }
 
 // what the vector-ALU streaming kernels can take (LayerNorm-of-tokens mode on bf16 tokens: where a tile's scores and
@@ -393,7 +394,7 @@ static bool stream_takes(const PoolParams& p) {
 
 // wide rows (D = 2048 / 4096): the row is split across the waves of a workgroup
 static bool use_wide(const PoolParams& p) {
-  return !needs_generic(p) && !p.tokstat && pool_mode() == 0 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
+  return !needs_generic(p) && !p.tokstat && pool_mode() == 0 && p.x_bf16 != 2 && wide_supported(p.D, p.Q, p.cls_bstride, p.x_bf16);
 }
 
 // More queries than the fast kernel families take at this row width -- Q > 16 beyond D = 768, Q > 8 for the wide-row kernels:
@@ -442,6 +443,7 @@ static int query_chunk(const PoolParams& p, bool bwd) {
 const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) {
   PoolParams p{};
   p.B = B; p.N = N; p.D = D; p.Q = Q; p.x_bf16 = x_bf16;
+  if (x_bf16 == 2) return bwd ? "(none: fp16-stored tokens are forward only)" : (stream_plan(B, N, D, Q).ok && !force_generic() ? "ep_pool_fwd_kernel" : "ep_pool_fwd_generic_kernel");
   if (const int qc = query_chunk(p, bwd != 0)) p.Q = qc;          // (the family the chunks run on)
   if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
   if (use_mb(p)) return mb_kernel_name(D, bwd != 0);
@@ -462,6 +464,18 @@ size_t pool_workspace_bytes(int B, int N, int D, int Q) {
 
 int pool_forward(const PoolParams& p0, hipStream_t st) {
   PoolParams p = p0;
+  if (p.x_bf16 == 2) {
+    // fp16-STORED tokens (ABI v24; what the reference's evaluate() hands the head under fp16 autocast, engine_finetune.py:131):
+    // the vector-ALU streaming kernel widens them in its ring like bf16 (exact), the generic kernel on load; forward only
+    EP_REQUIRE(!needs_generic(p) && !p.tokstat, EP_E_UNSUPPORTED, "fp16-stored tokens: plain shared-query forward only");
+    const StreamPlan c = stream_plan(p.B, p.N, p.D, p.Q);
+    if (c.ok && !force_generic()) return stream_launch(false, c, p, st);
+    const size_t lds = (size_t)(p.N + 8) * sizeof(float);
+    EP_REQUIRE(lds <= 64 * 1024, EP_E_UNSUPPORTED, "generic pooling kernel: N = %d tokens per image exceed its LDS row buffer (max 16376)", p.N);
+    hipLaunchKernelGGL(ep_pool_fwd_generic_kernel<true>, dim3(p.B), dim3(256), lds, st, p);
+    EP_LAUNCH_CHECK("ep_pool_fwd_generic_kernel");
+    return 0;
+  }
   if (const int qc = query_chunk(p, false)) {
     const int qs = p.Qs ? p.Qs : p.Q;
     for (int q0 = 0; q0 < p.Q; q0 += qc) {
@@ -600,6 +614,7 @@ StreamGridInfo pool_stream_grid(const PoolParams& p) {
 int pool_backward(const PoolParams& p0, float* dcls, int accumulate, hipStream_t st, const SideTasks* side,
                   DeferredReduce* defer) {
   PoolParams p = p0;
+  EP_REQUIRE(p.x_bf16 != 2, EP_E_UNSUPPORTED, "fp16-stored tokens are a forward / evaluation storage type (widen them for training)");
   if (const int qc = query_chunk(p, true)) {
     EP_REQUIRE(!side || side->total == 0, EP_E_UNSUPPORTED, "pool_backward: side tasks with a chunked pass");
     const int qs = p.Qs ? p.Qs : p.Q;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, (stream_waves_per_cu(QW, KP, NW) / 4)) voi
       for (int t0 = 0; t0 < TT; t0 += TB) {
         if (t0 >= nvalid) break;
         f4 xv[TB][KP];
-        load_rows<QW, KP, BF16>(tile + t0 * rowbytes, rowbytes, coff, xv);
+        load_rows<QW, KP, BF16>(tile + t0 * rowbytes, rowbytes, coff, xv, BF16 && p.x_bf16 == 2);     // (x_bf16 == 2: fp16-stored tokens)
         float part[QW][TB];
         partial_scores<QW, KP>(cq, xv, part);
         float u[QW];

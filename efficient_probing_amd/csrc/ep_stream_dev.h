@@ -132,12 +132,12 @@ __device__ __forceinline__ void butterfly(const float (&part)[QW][TB], float (&u
 }
 
 template <int QW, int KP, bool BF16>
-__device__ __forceinline__ void load_rows(const char* tile, int rowbytes, const int (&coff)[KP], f4 (&xv)[TB][KP]) {
+__device__ __forceinline__ void load_rows(const char* tile, int rowbytes, const int (&coff)[KP], f4 (&xv)[TB][KP], int f16 = 0) {
 #pragma unroll
   for (int t = 0; t < TB; ++t)
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-      if (BF16) xv[t][k] = bf16x4_to_f4(*reinterpret_cast<const uint2*>(tile + t * rowbytes + coff[k]));
+      if (BF16) xv[t][k] = h16x4_to_f4(*reinterpret_cast<const uint2*>(tile + t * rowbytes + coff[k]), f16);
       else xv[t][k] = *reinterpret_cast<const f4*>(tile + t * rowbytes + coff[k]);
     }
 }

@@ -470,10 +470,14 @@ class ProbeHeadEngine:
             return self._eval_logits_fp16_operands(x, image_index)
         self.flush()
         r16 = lambda t: t.to(torch.float16).to(torch.float32)
-        xv, _ = F_.as_token_view(x)
+        # k = x under autocast (ep.py:38,42): the tokens rounded to fp16.  They stay STORED as fp16 -- the forward pass widens them
+        # in its ring (EP_DTYPE_F16, exact) -- so fp16 tokens from an autocast backbone are read in place and fp32 ones cost one
+        # half-size copy instead of a rounded fp32 copy (round 5).
         if image_index is not None:
-            xv = xv[image_index.long()]
-        x16 = r16(xv)                                                        # k = x under autocast (ep.py:38,42)
+            xv, _ = F_.as_token_view(x, allow_f16=True)
+            x16 = xv[image_index.long()].to(torch.float16)
+        else:
+            x16 = x if x.dtype == torch.float16 else x.to(torch.float16)
         q16 = r16(self.pool.cls_token.detach()[0] * self.pool.scale)          # q = cls_token * scale, then the matmul cast
         P, _, _ = F_.pool_forward(x16, q16, 1.0)
         y16 = r16(F_.project_forward(P, r16(self.pool.v.weight.detach())))   # self.v under autocast, attn @ v
@@ -527,7 +531,7 @@ class ProbeHeadEngine:
         if precision != "fp32":
             raise ValueError("precision must be 'fp32' or 'fp16_autocast'")
         self.flush()
-        xv, bstride = F_.as_token_view(x)
+        xv, bstride = F_.as_token_view(x, allow_f16=type(self) is ProbeHeadEngine)   # (ep_head_eval_forward reads fp16 tokens in place)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
         self._bind_store_tables(xv, image_index)

@@ -27,20 +27,24 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def as_token_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
+def as_token_view(x: torch.Tensor, allow_f16: bool = False) -> Tuple[torch.Tensor, int]:
     """Return (x', batch_stride) with x' fp32 or bf16, inner two dims contiguous.  A view such as
     ``feat[:, 1:]`` (reference models_more.py:24) is passed through without a copy.  bf16 tokens (a bf16
     backbone's output, or a bf16 token store) are read as they are -- the token passes widen them to fp32 on the
-    fly and compute in fp32; fp16 is widened once here."""
+    fly and compute in fp32.  fp16 tokens (what the reference's ``evaluate()`` hands the head under its fp16 autocast,
+    engine_finetune.py:131) are read as they are by the FORWARD entry points of the EP head (``allow_f16``: ABI v24,
+    ``EP_DTYPE_F16``); everywhere else they are widened once here."""
     N.require_gpu_tensor(x, "tokens")
     if x.dim() != 3:
         raise ValueError(f"tokens must be (B, N, D), got {tuple(x.shape)}")
     B, Nn, D = x.shape
-    if x.dtype == torch.bfloat16 and D % 8 != 0:
+    if x.dtype in (torch.bfloat16, torch.float16) and D % 8 != 0:
         x = x.float()
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype == torch.float16 and not allow_f16:
         x = x.float()
-    al = 8 if x.dtype == torch.bfloat16 else 4
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        x = x.float()
+    al = 8 if x.dtype in (torch.bfloat16, torch.float16) else 4
     ok = x.stride(2) == 1 and x.stride(1) == D and (B == 1 or x.stride(0) >= Nn * D) \
         and x.stride(0) % al == 0 and x.data_ptr() % 16 == 0
     if not ok:
@@ -49,7 +53,7 @@ def as_token_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
 
 
 def token_dtype_code(x: torch.Tensor) -> int:
-    return N.EP_DTYPE_BF16 if x.dtype == torch.bfloat16 else N.EP_DTYPE_F32
+    return N.EP_DTYPE_BF16 if x.dtype == torch.bfloat16 else N.EP_DTYPE_F16 if x.dtype == torch.float16 else N.EP_DTYPE_F32
 
 
 def _index_arg(image_index, x):
@@ -68,7 +72,7 @@ def pool_forward(x: torch.Tensor, cls_token: torch.Tensor, scale: float,
     With ``image_index`` (int32, (B,)), x is a resident token store (M,N,D) and image b of the batch
     is x[image_index[b]], read in place."""
     lib = N.load()
-    x, bstride = as_token_view(x)
+    x, bstride = as_token_view(x, allow_f16=not per_image_queries)       # (fp16-stored tokens: shared query rows, forward only)
     _, Nn, D = x.shape
     iptr, B = _index_arg(image_index, x)
     cls = _f32c(cls_token, "cls_token")

@@ -33,10 +33,14 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 23
+#define EP_ABI_VERSION 24
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
+#define EP_DTYPE_F16 2     /* ABI v24: fp16-STORED tokens, FORWARD entry points only (ep_pool_forward, ep_head_eval_forward): what the
+                              reference's evaluate() hands the head under its fp16 autocast (engine_finetune.py:131); widened
+                              to fp32 in the token ring like bf16 -- exact -- and all arithmetic stays fp32.  Every other
+                              entry point rejects it (EP_E_UNSUPPORTED). */
 
 #define EP_OK 0
 #define EP_E_ARG (-1)         /* null pointer / non-positive size / bad enum            */
