@@ -257,6 +257,11 @@ static int project_forward(const float* P, const float* Wv, int B, int D, int Dp
   return gemm(true, true, g, Q, st);
 }
 
+// The `side` hint of the two weight-gradient contractions (GemmParams.side: "runs beside a vector-issue-bound token pass: keep to
+// the exact-f32 tile below 8 GFLOP", ep_gemm.hip).  The 32-query step runs them beside the small kernels between the passes and
+// the matrix-pipe-bound 32-query passes; there the bf16 x3 tile measured faster (0.7225 -> 0.714 ms fp32 tokens, 0.440 -> 0.435 ms
+// bf16, round 5), so that branch clears the hint for its calls.
+static thread_local int t_wgrad_side = 1;
 // dWv[q*Dq + c, d] (+)= sum_b dy[b, q*Dq + c] * P[b, q, d]   (Q batched T/T contractions over the batch)
 static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp, int Q, float* dWv, int accumulate) {
   const int Dq = Dp / Q;
@@ -264,14 +269,14 @@ static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp
   g.A = dy; g.lda = Dp; g.sAz = Dq; g.extA = Dq;
   g.B = P; g.ldb = (int64_t)Q * D; g.sBz = D; g.extB = D;
   g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
-  g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
+  g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = t_wgrad_side;
   return g;
 }
 // dWc[c, k] (+)= sum_b dlogits[b, c] * z[b, k]
 GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int C, float* dWc, int accumulate) {
   GemmParams g{};
   g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
-  g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = 1;
+  g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = t_wgrad_side;
   return g;
 }
 
@@ -837,6 +842,8 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
         EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
       }
       EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
+      struct SideHint { int old; explicit SideHint(int v) : old(t_wgrad_side) { t_wgrad_side = v; } ~SideHint() { t_wgrad_side = old; } };
+      const SideHint hint(d.Q > 16 ? 0 : 1);                // (restored when this branch is left, error returns included)
       if (plw) {
         EP_TRY(wgrad_dwc_pl(w, d, s->grads + offs[2], s->accumulate, side));
         EP_TRY(colsum(w.dlogits, d.B, d.C, w.ldl, s->accumulate, s->grads + offs[3], side));

@@ -623,7 +623,9 @@ bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
     // kernel only uses the otherwise idle matrix pipe: 196 x 1024 0.536 against 0.522 ms, 256 x 1152 0.733 against 0.726 ms
     // with it -- but 196 x 4096 (34 GFLOP of dWv beside the dP contraction, not beside a pass) 2.284 against 2.335 ms.
     // So: side contractions only from 8 GFLOP.
-    if (p.side && 2.0 * p.M * p.N * (double)p.K * batch < 8e9) return false;
+    static double side_min = -1.0;                             // (EP_GEMM_B3_SIDE_MIN_GFLOP: experiments)
+    if (side_min < 0) { const char* e = getenv("EP_GEMM_B3_SIDE_MIN_GFLOP"); side_min = e ? atof(e) * 1e9 : 8e9; }
+    if (p.side && 2.0 * p.M * p.N * (double)p.K * batch < side_min) return false;
     return true;
   }
   if (!a_k) return false;                                      // (T / K does not occur)

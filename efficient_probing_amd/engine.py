@@ -478,6 +478,8 @@ class ProbeHeadEngine:
             x16 = xv[image_index.long()].to(torch.float16)
         else:
             x16 = x if x.dtype == torch.float16 else x.to(torch.float16)
+        if not F_.f16_in_place_ok(x16.shape[-1]):
+            x16 = x16.float()                                                # (wide rows: the rounded values through the fp32 kernels)
         q16 = r16(self.pool.cls_token.detach()[0] * self.pool.scale)          # q = cls_token * scale, then the matmul cast
         P, _, _ = F_.pool_forward(x16, q16, 1.0)
         y16 = r16(F_.project_forward(P, r16(self.pool.v.weight.detach())))   # self.v under autocast, attn @ v
@@ -531,7 +533,7 @@ class ProbeHeadEngine:
         if precision != "fp32":
             raise ValueError("precision must be 'fp32' or 'fp16_autocast'")
         self.flush()
-        xv, bstride = F_.as_token_view(x, allow_f16=type(self) is ProbeHeadEngine)   # (ep_head_eval_forward reads fp16 tokens in place)
+        xv, bstride = F_.as_token_view(x, allow_f16=type(self) is ProbeHeadEngine and F_.f16_in_place_ok(x.shape[-1]))   # (ep_head_eval_forward reads fp16 tokens in place)
         _, Nn, D = xv.shape
         iptr, B = F_._index_arg(image_index, xv)
         self._bind_store_tables(xv, image_index)

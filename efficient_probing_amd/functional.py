@@ -52,6 +52,12 @@ def as_token_view(x: torch.Tensor, allow_f16: bool = False) -> Tuple[torch.Tenso
     return x, (x.stride(0) if B > 1 else Nn * D)
 
 
+def f16_in_place_ok(D: int) -> bool:
+    """fp16-stored tokens are worth reading in place where the streaming forward kernel takes the row width (D = 64 k <= 1536);
+    wider rows would fall to the library's generic kernel -- slower than one widening copy in front of the wide-row kernels."""
+    return D % 64 == 0 and D <= 1536
+
+
 def token_dtype_code(x: torch.Tensor) -> int:
     return N.EP_DTYPE_BF16 if x.dtype == torch.bfloat16 else N.EP_DTYPE_F16 if x.dtype == torch.float16 else N.EP_DTYPE_F32
 
@@ -72,7 +78,7 @@ def pool_forward(x: torch.Tensor, cls_token: torch.Tensor, scale: float,
     With ``image_index`` (int32, (B,)), x is a resident token store (M,N,D) and image b of the batch
     is x[image_index[b]], read in place."""
     lib = N.load()
-    x, bstride = as_token_view(x, allow_f16=not per_image_queries)       # (fp16-stored tokens: shared query rows, forward only)
+    x, bstride = as_token_view(x, allow_f16=not per_image_queries and f16_in_place_ok(x.shape[-1]))   # (fp16 tokens: shared queries, forward only)
     _, Nn, D = x.shape
     iptr, B = _index_arg(image_index, x)
     cls = _f32c(cls_token, "cls_token")

@@ -101,7 +101,7 @@ int ep_pool_backward_ln(const void* x, int x_dtype, int64_t x_bstride, const int
                         int D, int Q, float scale, const float* token_stats, const float* S, const float* ML,
                         const float* dP, float* dcls, int accumulate, void* workspace, size_t workspace_bytes,
                         ep_stream_t stream);
-/* same, for a given token storage type (EP_DTYPE_F32 / EP_DTYPE_BF16) */
+/* same, for a given token storage type (EP_DTYPE_F32 / EP_DTYPE_BF16 / EP_DTYPE_F16) */
 const char* ep_pool_kernel_name_ex(int B, int N, int D, int Q, int backward, int x_dtype);
 /* name of the device kernel a dense layer y = x W^T (x: M x K, W: N x K, both K-contiguous and 16-byte aligned) launches for
  * this shape: "ep_gemm_b3_kernel" (bf16 x3 at fp32 accuracy, csrc/ep_wgrad3.h: large contractions) or one of the exact-f32

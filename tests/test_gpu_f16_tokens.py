@@ -28,7 +28,13 @@ def test_pool_forward_reads_fp16_tokens_in_place(shape):
     assert name in ("ep_pool_fwd_kernel", "ep_pool_fwd_generic_kernel"), name
     if D % 8 == 0:
         assert F_.as_token_view(x16, allow_f16=True)[0].data_ptr() == x16.data_ptr()      # read in place, no copy
-    P16, S16, ML16 = F_.pool_forward(x16, cls, 1.0)
+    if F_.f16_in_place_ok(D):
+        P16, S16, ML16 = F_.pool_forward(x16, cls, 1.0)
+    else:                                                          # (the Python layer widens these; the C ABI still takes them)
+        xv, bs = F_.as_token_view(x16, allow_f16=True)
+        P16 = torch.empty(B, Q, D, device=DEV); S16 = torch.empty(B, Q, Nn, device=DEV); ML16 = torch.empty(B, Q, 4, device=DEV)
+        _native.check(lib.ep_pool_forward(xv.data_ptr(), F_.token_dtype_code(xv), bs, 0, B, Nn, D, cls.data_ptr(), 0, Q, 1.0, P16.data_ptr(),
+                                          S16.data_ptr(), ML16.data_ptr(), 0, 0, _native.current_stream_ptr(torch.device(DEV))), "ep_pool_forward")
     P32, S32, ML32 = F_.pool_forward(x16.float(), cls, 1.0)       # the widened copy through the fp32 kernels
     np.testing.assert_allclose(S16.cpu().numpy(), S32.cpu().numpy(), rtol=1e-5, atol=1e-5)       # (scores of magnitude ~20: one fp32 ulp is 2e-6)
     np.testing.assert_allclose(P16.cpu().numpy(), P32.cpu().numpy(), rtol=1e-5, atol=5e-6)       # (two kernel families: summation order)
