@@ -203,3 +203,21 @@ def test_shard_range():
     from efficient_probing_amd.parallel import shard_range
     assert shard_range(10, 2, 0) == (0, 5) and shard_range(10, 2, 1) == (5, 10)
     assert shard_range(11, 4, 3) == (6, 8)
+
+
+def test_subclass_of_a_native_pooling_keeps_the_fused_engine():
+    """Round 4 advisor finding: the class -> engine table was looked up by exact type, so ``class MyEP(EfficientProbing)`` fell
+    off the fused path silently.  The lookup walks the MRO now."""
+    import torch
+    from efficient_probing_amd import probe_heads
+    from efficient_probing_amd.poolings.ep import EfficientProbing
+
+    class MyEP(EfficientProbing):
+        pass
+
+    head = torch.nn.Sequential(MyEP(64, num_queries=4), torch.nn.BatchNorm1d(64, affine=False, eps=1e-6), torch.nn.Linear(64, 10))
+    assert probe_heads.native_head_kind(head) == "ep"
+    assert probe_heads.native_engine_name(head) == "ProbeHeadEngine"
+    assert probe_heads.is_native_ep_head(head)
+    plain = torch.nn.Sequential(torch.nn.Identity(), torch.nn.BatchNorm1d(64, affine=False), torch.nn.Linear(64, 10))
+    assert probe_heads.native_head_kind(plain) is None

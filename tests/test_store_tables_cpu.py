@@ -59,3 +59,19 @@ def test_tables_are_bound_only_for_in_place_batches_of_the_attached_store():
     eng._tokstat = None
     eng._bind_store_tables(st.tokens, None)                                   # the next contiguous call starts clean
     assert eng._table_ptr("token_stats") == 0
+
+
+def test_a_view_of_the_store_with_another_token_count_does_not_bind_the_tables():
+    """Round 4 advisor finding: a view with the store's base pointer and image count but fewer tokens (``store.tokens[:, :K]``)
+    used to bind the (n, N_store, 2) tables, which the kernels would then read with the view's token stride."""
+    st, eng = FakeStore(), FakeEngine()
+    eng.attach_store(st)
+    idx = torch.zeros(2, dtype=torch.int32)
+    view = st.tokens[:, :2]                                                   # same data_ptr, same shape[0], 2 of 3 tokens
+    assert view.data_ptr() == st.tokens.data_ptr() and view.shape[0] == st.tokens.shape[0]
+    eng._bind_store_tables(view, idx)
+    assert eng._table_ptr("token_stats") == 0 and st.asked == []
+    eng._bind_store_tables(st.tokens[:, :, :2], idx)                          # narrower rows
+    assert eng._table_ptr("token_stats") == 0 and st.asked == []
+    eng._bind_store_tables(st.tokens, idx)                                    # the store itself still binds
+    assert eng._table_ptr("token_stats") != 0
