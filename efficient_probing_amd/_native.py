@@ -13,10 +13,11 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
-EP_ABI_VERSION = 24        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
+EP_ABI_VERSION = 25        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
 EP_DTYPE_F16 = 2          # fp16-stored tokens: forward entry points of the EP head only (ABI v24)
+EP_ARITH_F32, EP_ARITH_BF16_AUTOCAST = 0, 1          # ep_head_step.arith (ABI v25)
 
 c_f32p = C.c_void_p       # device pointers travel as integers (tensor.data_ptr())
 c_i64 = C.c_int64
@@ -57,6 +58,7 @@ class EPHeadStep(C.Structure):
         ("opt_first_segment", C.c_int32), ("opt_num_segments", C.c_int32),
         ("defer_event", C.c_void_p),
         ("planes_valid", C.c_int32),
+        ("arith", C.c_int32),
     ]
 
 
@@ -345,6 +347,7 @@ SIGNATURES = {
     "ep_head_param_offsets": (c_i64, [C.POINTER(EPHeadDims), C.POINTER(c_i64)]),
     "ep_head_workspace_bytes": (c_size, [C.POINTER(EPHeadDims)]),
     "ep_head_workspace_flag_offset": (C.c_int64, [C.POINTER(EPHeadDims)]),
+    "ep_head_workspace_logits_offset": (C.c_int64, [C.POINTER(EPHeadDims), C.POINTER(C.c_int32)]),
     "ep_head_workspace_init": (c_int, [C.POINTER(EPHeadDims), c_void, c_size, c_void]),
     "ep_debug_set_pass_events": (c_int, [c_void, c_void, c_void, c_void]),
     "ep_head_train_step": (c_int, [C.POINTER(EPHeadStep), c_void, c_size, c_void]),

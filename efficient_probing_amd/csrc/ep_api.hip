@@ -108,7 +108,8 @@ static int head_planes_mode(const ep_head_dims& d) {
   // unset: all four contractions for wide rows; below, the classifier's two -- their planes come for free since round 4 (the
   // optimizer's update kernel writes them, ep_optim.hip: tile_update_emit; ep_head_step.planes_valid): 256 x 768, same box,
   // mode 0 against mode 2: 0.4343 -> 0.4285 ms (f32 tokens), 0.3141 -> 0.3060 ms (bf16-stored tokens)
-  const int mode = on >= 0 ? on : (d.D >= 2048 ? 1 : 2);
+  // the AMP-bf16 arithmetic mode (ep_head_step.arith, gemm_arith()) runs all four against the planes whatever the width
+  const int mode = gemm_arith() == 1 ? 1 : on >= 0 ? on : (d.D >= 2048 ? 1 : 2);
   if (!mode || d.D % 4 != 0 || Dp % 4 != 0) return 0;
   if (mode == 1) return (Dp / d.Q) % 32 == 0 ? 1 : 0;
   return 2;
@@ -270,6 +271,7 @@ static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp
   g.B = P; g.ldb = (int64_t)Q * D; g.sBz = D; g.extB = D;
   g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
   g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = t_wgrad_side;
+  g.nterms = gemm_arith() == 1 ? 1 : 0;            // (rides into the side tiles of the second token pass as well)
   return g;
 }
 // dWc[c, k] (+)= sum_b dlogits[b, c] * z[b, k]
@@ -277,6 +279,7 @@ GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int
   GemmParams g{};
   g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
   g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = t_wgrad_side;
+  g.nterms = gemm_arith() == 1 ? 1 : 0;
   return g;
 }
 
@@ -656,6 +659,14 @@ int64_t ep_head_workspace_flag_offset(const ep_head_dims* dims) {
   return reinterpret_cast<char*>(w.iperr) - base;
 }
 
+int64_t ep_head_workspace_logits_offset(const ep_head_dims* dims, int32_t* ldl) {
+  if (!dims || check_dims(*dims) != 0) return -1;
+  char* base = reinterpret_cast<char*>(uintptr_t(1) << 20);
+  const HeadWs w = carve(*dims, base);
+  if (ldl) *ldl = w.ldl;
+  return reinterpret_cast<char*>(w.logits) - base;
+}
+
 int ep_head_workspace_init(const ep_head_dims* dims, void* ws, size_t ws_bytes, ep_stream_t stream) {
   EP_REQUIRE(dims && ws, EP_E_ARG, "ep_head_workspace_init: null pointer");
   EP_TRY(check_dims(*dims));
@@ -674,6 +685,15 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   HeadWs w = carve(d, ws);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_train_step: workspace %zu < %zu", ws_bytes, w.total);
   EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_head_train_step: arith %d is neither EP_ARITH_F32 nor EP_ARITH_BF16_AUTOCAST", s->arith);
+  // the arithmetic mode of every contraction this call enqueues (restored on every return path)
+  struct ArithScope { int old; explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); } ~ArithScope() { gemm_set_arith(old); } };
+  const ArithScope arith_scope(s->arith);
+  if (s->arith == EP_ARITH_BF16_AUTOCAST) {
+    EP_REQUIRE(head_planes_mode(d) == 1, EP_E_UNSUPPORTED,
+               "ep_head_train_step: the AMP-bf16 arithmetic mode runs its contractions against the weight planes and needs (D / d_out / Q) %% 32 == 0 (D=%d d_out=%d Q=%d)", d.D, d.d_out, d.Q);
+    EP_REQUIRE((s->phases & (4 | 8 | 16 | 32)) == 0, EP_E_UNSUPPORTED, "ep_head_train_step: the AMP-bf16 arithmetic mode is implemented for whole steps (phases 1 | 2) only");
+  }
   hipStream_t st = (hipStream_t)stream;
   const int Dp = d.D / d.d_out;
   int64_t offs[4];
@@ -999,6 +1019,15 @@ int ep_lp_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream
   const LpWs w = lp_carve(d, ws);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_lp_train_step: workspace %zu < %zu", ws_bytes, w.total);
   EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_head_train_step: arith %d is neither EP_ARITH_F32 nor EP_ARITH_BF16_AUTOCAST", s->arith);
+  // the arithmetic mode of every contraction this call enqueues (restored on every return path)
+  struct ArithScope { int old; explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); } ~ArithScope() { gemm_set_arith(old); } };
+  const ArithScope arith_scope(s->arith);
+  if (s->arith == EP_ARITH_BF16_AUTOCAST) {
+    EP_REQUIRE(head_planes_mode(d) == 1, EP_E_UNSUPPORTED,
+               "ep_head_train_step: the AMP-bf16 arithmetic mode runs its contractions against the weight planes and needs (D / d_out / Q) %% 32 == 0 (D=%d d_out=%d Q=%d)", d.D, d.d_out, d.Q);
+    EP_REQUIRE((s->phases & (4 | 8 | 16 | 32)) == 0, EP_E_UNSUPPORTED, "ep_head_train_step: the AMP-bf16 arithmetic mode is implemented for whole steps (phases 1 | 2) only");
+  }
   hipStream_t st = (hipStream_t)stream;
   int64_t offs[2];
   const int64_t total = ep_lp_param_offsets(&d, offs);

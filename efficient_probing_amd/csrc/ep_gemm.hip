@@ -604,6 +604,9 @@ static void b3_launch(const GemmParams& p, int batch, bool m32, hipStream_t st) 
   if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), B3_KERNEL_LDS, st, p);
   else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), B3_KERNEL_LDS, st, p);
 }
+static thread_local int t_arith = 0;
+int gemm_arith() { return t_arith; }
+void gemm_set_arith(int a) { t_arith = a; }
 // EP_GEMM_B3=0: T / T contractions back on the exact-f32 kernels
 bool gemm_b3_on() {
   static int on = -1;
@@ -618,6 +621,7 @@ bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
   if (!vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) || !vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB)) return false;
   if (!a_k && !b_k) {
     if (p.bias) return false;
+    if (t_arith == 1 || p.nterms == 1) return true;            // AMP-bf16: this tile is the single-product kernel of the T / T layout
     // `side`: the contraction runs on a second queue BESIDE a token pass (shapes whose pass cannot carry it as side
     // workgroups).  The tile's split instructions then compete with a vector-issue-bound stream, where the exact-f32
     // kernel only uses the otherwise idle matrix pipe: 196 x 1024 0.536 against 0.522 ms, 256 x 1152 0.733 against 0.726 ms
@@ -654,9 +658,11 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
   if (gemm_b3_ok(p, a_k, b_k, batch)) {
     // 32-row tiles where 64-row ones would leave tiles half empty or the chip under-filled (as side_add_gemm)
     const bool m32 = !(p.M % 64 == 0 || p.M >= 256) || tiles64 < 2L * cu_count();
-    if (!a_k) b3_launch<false, false>(p, batch, m32, st);
-    else if (b_k) b3_launch<true, true>(p, batch, m32, st);
-    else b3_launch<true, false>(p, batch, m32, st);
+    GemmParams q3 = p;
+    if (t_arith == 1) q3.nterms = 1;
+    if (!a_k) b3_launch<false, false>(q3, batch, m32, st);
+    else if (b_k) b3_launch<true, true>(q3, batch, m32, st);
+    else b3_launch<true, false>(q3, batch, m32, st);
     EP_LAUNCH_CHECK("ep_gemm_b3_kernel");
     return 0;
   }

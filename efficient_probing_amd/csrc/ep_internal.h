@@ -78,6 +78,9 @@ struct GemmParams {
   const float* cs_z; float* cs_out;
   // ep_planes.hip: the B operand as pre-split bf16 planes (weights; see planes_split) -- [term][row][ldbp], K contiguous
   const uint16_t* Bpl; int64_t pl_term, ldbp, sBpz;   // plane base, term stride, row stride, batch offset (elements)
+  int nterms;                       // bf16 matrix-core kernels (planes, b3): 0 / 3 = three-term split at fp32 accuracy; 1 = ONE product of the
+                                    // operands rounded to bf16, fp32 accumulation (the AMP-bf16 arithmetic mode: gemm_arith())
+  int zn;                           // planes kernel: batch count of a 1-D (m_fast) launch, set by gemm_planes
   int m_fast;                       // planes kernel: M-tiles fastest in the launch order (few M-tiles against a very long N: the
                                     // workgroups that share a weight tile then run together and it is fetched from HBM once)
 };
@@ -88,11 +91,19 @@ struct PlaneSpec {
   uint16_t* pn;                     // planes of W   : 3 * R * round_up(K, 32) elements
   uint16_t* pt;                     // planes of W^T : 3 * K * round_up(R, 32) elements
 };
+// Arithmetic mode of the calling thread's contractions (ep_gemm.hip): 0 = fp32 results (default), 1 = AMP-bf16 -- every
+// contraction on the bf16 matrix-core kernels as ONE product of bf16-rounded operands with fp32 accumulation (what the
+// reference's --amp bfloat16 does inside autocast, engine_finetune.py:52-55, minus the bf16 rounding of the outputs).
+// Set for the duration of a train step by ep_head_train_step (ep_head_step.arith).
+int gemm_arith();
+void gemm_set_arith(int a);
 size_t planes_elems(int rows, int K);               // elements (uint16) of the planes of a rows x K matrix
 int planes_split(const PlaneSpec* specs, int n, hipStream_t st);
 bool gemm_planes_ok(const GemmParams& p);
 // C[z] (+)= alpha * A[z] W[z]^T (+ bias): A fp32 with K contiguous (lda), W given as planes (Bpl ...); fp32 accuracy
 int gemm_planes(const GemmParams& p, int batch, hipStream_t st);
+bool planes_big_wanted(const GemmParams& p, int batch);      // ep_planes_big.hip: 128 x 128 tiles (large contractions)
+void planes_big_launch(const GemmParams& p, int batch, hipStream_t st);
 // dst (C x R, ldd) = src (R x C, lds_)^T, fp32 (ep_planes.hip)
 int transpose_f32(const float* src, int R, int C, int64_t lds_, float* dst, int64_t ldd, hipStream_t st);
 

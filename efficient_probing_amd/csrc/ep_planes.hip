@@ -147,10 +147,14 @@ int transpose_f32(const float* src, int R, int C, int64_t lds_, float* dst, int6
 // 32 KiB) -- the wide tile halves the activation bytes and the split per matrix instruction: 48 instead of 24 matrix
 // instructions stand against one fragment split and 26 instead of 14 LDS reads; for contractions with enough 64 x 128 tiles
 // to fill the chip twice (planes_wide).
-template <int NB> struct PlGeom {
-  static constexpr int stb = 8192 + 3 * NB * 1024;   // bytes per ring stage
-  static constexpr int nst = NB == 8 ? 4 : 5;        // ring stages (128 / 100 KiB)
-  static constexpr int npc = (8 + 3 * NB) / 4;       // 1-KiB pieces per loader wave and K-tile (8 / 5)
+// NT = weight terms multiplied: 3 (fp32 accuracy: six products per block) or 1 (the AMP-bf16 arithmetic mode, GemmParams.nterms:
+// bf16(a) x bf16(w) with fp32 accumulation -- the hi plane IS the weight rounded to bf16, the activation fragment is rounded by
+// the first four instructions of the split; one product per block, a third of the plane bytes).
+template <int NB, int NT = 3> struct PlGeom {
+  static constexpr int npw = NB * NT;                // 1-KiB weight pieces per K-tile ([block][term])
+  static constexpr int stb = 8192 + npw * 1024;      // bytes per ring stage
+  static constexpr int nst = (NT == 3 && NB == 8) ? 4 : 5;   // ring stages (128 / 100 KiB; single term: 80 / 60 KiB)
+  static constexpr int npc = (8 + npw) / 4;          // 1-KiB pieces per loader wave and K-tile (8 / 5; single term 4 / 3)
 };
 
 // The split of one 8-value fragment as 44 single instructions (11 per value pair, pair index fastest so that neighbours are
@@ -189,26 +193,27 @@ __device__ __forceinline__ void pl_split_uops(PlSplit& s, const f4v (&x)[2], pl_
   if constexpr (U0 < U1) { pl_split_uop<U0>(s, x, a); pl_split_uops<U0 + 1, U1>(s, x, a); }
 }
 
-template <int NB>
+template <int NB, int NT>
 __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
-  constexpr int NST = PlGeom<NB>::nst, PLG_STB = PlGeom<NB>::stb, NPC = PlGeom<NB>::npc;
+  constexpr int NST = PlGeom<NB, NT>::nst, PLG_STB = PlGeom<NB, NT>::stb, NPC = PlGeom<NB, NT>::npc;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 multiply, 8..11 only move data
   const int i16 = lane & 15, kk = lane >> 4;
-  int mt_ = blockIdx.y, nt_ = blockIdx.x;
+  int mt_ = blockIdx.y, nt_ = blockIdx.x, z_ = blockIdx.z;
   if (p.m_fast) {
     // 1-D launch, M-tiles fastest, XCD-aware: workgroup L runs on XCD L % 8, so XCD c walks the contiguous range of tile
     // numbers [c per, (c + 1) per) -- the M-tiles of one weight tile are neighbours in time on ONE XCD's L2
     const int mtn = (p.M + 63) / 64, ntn = (p.N + 16 * NB - 1) / (16 * NB);
     const unsigned per = gridDim.x / 8u, L = blockIdx.x;
     const unsigned V = (L % 8u) * per + L / 8u;
-    if (V >= (unsigned)mtn * (unsigned)ntn) return;
-    mt_ = (int)(V % (unsigned)mtn); nt_ = (int)(V / (unsigned)mtn);
+    if (V >= (unsigned)mtn * (unsigned)ntn * (unsigned)p.zn) return;
+    const unsigned r = V / (unsigned)mtn;
+    mt_ = (int)(V % (unsigned)mtn); nt_ = (int)(r % (unsigned)ntn); z_ = (int)(r / (unsigned)ntn);    // batched: z slowest
   }
   const int m0 = mt_ * 64, n0 = nt_ * (16 * NB);
-  const int z = blockIdx.z;
+  const int z = z_;
   const int nk = (p.K + BK - 1) / BK;
   const bool ktail = (p.K % BK) != 0;
   // Barrier k (k = 0 .. nk): K-tile k has landed completely AND the reads of tile k-1 are done, so its stage may be refilled.
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
     int64_t srcW[NPC - 2];
 #pragma unroll
     for (int jj = 0; jj < NPC - 2; ++jj) {
-      const int pb = lw + 4 * jj, blk = pb / 3, term = pb - 3 * blk;
+      const int pb = lw + 4 * jj, blk = pb / NT, term = pb - NT * blk;
       const int r16 = lane >> 2, kq = (lane & 3) ^ (2 * (r16 >> 3));
       int row = n0 + 16 * blk + r16; row = row < p.N ? row : p.N - 1;
       srcW[jj] = term * p.pl_term + (int64_t)row * p.ldbp + 8 * kq;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   for (int bi = 0; bi < NB; ++bi) acc[bi] = f4v{0.f, 0.f, 0.f, 0.f};
   f4v xs[2];                                         // [g]: fp32 fragment of A block wm
   pl_u4 a3[3];                                       // [term]: its split
-  pl_u4 bs[NB][3];                                   // [block][term]: planes of the four W blocks
+  pl_u4 bs[NB][NT];                                  // [block][term]: planes of the W blocks
   PlSplit sp;
   // Between barriers k and k+1 the waves of tile k's parity read it and split their fragment; between k+1 and k+2 they issue
   // its 24 matrix instructions -- while the waves of the other parity read and split tile k+1.  One wave feeds a SIMD's matrix
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-      for (int tm = 0; tm < 3; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * 3 + tm) * 1024);
+      for (int tm = 0; tm < NT; ++tm) bs[bi][tm] = *reinterpret_cast<const pl_u4*>(st + fragW + (bi * NT + tm) * 1024);
     if (ktail && t == nk - 1) {                      // zero the positions at or past K (last tile of a ragged K only)
       const int klim = p.K - t * BK;
 #pragma unroll
@@ -309,15 +314,20 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) xs[g][j] = (16 * g + 4 * kk + j >= klim) ? 0.f : xs[g][j];
     }
-    pl_split_uops<0, 44>(sp, xs, a3);                // volatile: the split stays on this side of the barrier
+    pl_split_uops<0, NT == 3 ? 44 : 4>(sp, xs, a3);  // volatile: the split stays on this side of the barrier (single term: the four roundings)
   };
   auto phase_mfma = [&]() {
     // smallest terms first: lo x hi, hi x lo, mid x mid, then the 2^-8 pair, then hi x hi
+    if constexpr (NT == 1) {
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) acc[bi] = pl_mfma(a3[0], bs[bi][0], acc[bi]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 6 * NB; ++i) {
       const int pr = i / NB, bi = i % NB;
       const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
-      acc[bi] = pl_mfma(a3[ta], bs[bi][tb], acc[bi]);
+      acc[bi] = pl_mfma(a3[ta], bs[bi][tb < NT ? tb : 0], acc[bi]);
     }
   };
   unsigned long long t_b0 = 0, t_rd = 0, t_b1 = 0, t_mm = 0;   // diagnostic only (EP_PLANES_STAMP)
@@ -363,16 +373,21 @@ bool gemm_planes_ok(const GemmParams& p) {
          p.pl_term % 8 == 0 && p.sBpz % 8 == 0 && p.M > 0 && p.N > 0 && p.K > 0;
 }
 
-template <int NB>
+template <int NB, int NT>
 static void planes_launch(const GemmParams& p, int batch, hipStream_t st) {
-  constexpr int lds = PlGeom<NB>::nst * PlGeom<NB>::stb;
+  constexpr int lds = PlGeom<NB, NT>::nst * PlGeom<NB, NT>::stb;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_kernel<NB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   dim3 grid((p.N + 16 * NB - 1) / (16 * NB), (p.M + 63) / 64, batch);
   GemmParams q = p;
-  if (batch != 1) q.m_fast = 0;                      // (the 1-D tile numbering is for single contractions)
-  if (q.m_fast) grid = dim3(8u * (unsigned)(((size_t)grid.x * grid.y + 7) / 8), 1, 1);
-  hipLaunchKernelGGL(ep_gemm_planes_kernel<NB>, grid, dim3(768), lds, st, q);
+  q.zn = batch;
+  // EP_PLANES_MFAST=0 / 1 forces the launch order.  Default: the caller's m_fast for single contractions; batched launches keep
+  // the 3-D grid (measured at 196 x 4096, y and dP as 8 batches: the XCD-aware 1-D order 2.354 - 2.359 ms per step against 2.342)
+  static int mfast_env = -2;
+  if (mfast_env == -2) { const char* e = getenv("EP_PLANES_MFAST"); mfast_env = e ? atoi(e) : -1; }
+  if (mfast_env >= 0) q.m_fast = mfast_env; else if (batch != 1) q.m_fast = 0;
+  if (q.m_fast) grid = dim3(8u * (unsigned)(((size_t)grid.x * grid.y * batch + 7) / 8), 1, 1);
+  hipLaunchKernelGGL((ep_gemm_planes_kernel<NB, NT>), grid, dim3(768), lds, st, q);
 }
 // 64 x 128 tiles when they fill the chip at least twice (EP_PLANES_WIDE=0 / 1 forces)
 static bool planes_wide(const GemmParams& p, int batch) {
@@ -394,7 +409,7 @@ int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
     GemmParams q = p;
     q.skws = reinterpret_cast<float*>(dbg); q.ablate = 77;
     (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * 6 * sizeof(unsigned long long), st);
-    if (planes_wide(p, 1)) planes_launch<8>(q, 1, st); else planes_launch<4>(q, 1, st);
+    if (planes_wide(p, 1)) planes_launch<8, 3>(q, 1, st); else planes_launch<4, 3>(q, 1, st);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host, dbg, (size_t)nwg * 8 * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double a[6] = {0, 0, 0, 0, 0, 0};
@@ -406,7 +421,12 @@ int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
               p.M, p.N, p.K, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / (nwg * 8.0), a[5] / (nwg * 8.0) / 100.0, a[4] / a[5] / 10.0, nwg);
     return 0;
   }
-  if (planes_wide(p, batch)) planes_launch<8>(p, batch, st); else planes_launch<4>(p, batch, st);
+  if (p.nterms == 1 || gemm_arith() == 1) {                               // AMP-bf16: one product per block
+    if (planes_wide(p, batch)) planes_launch<8, 1>(p, batch, st); else planes_launch<4, 1>(p, batch, st);
+  }
+  else if (planes_big_wanted(p, batch)) planes_big_launch(p, batch, st);   // ep_planes_big.hip: 128 x 128 tiles for the large contractions
+  else if (planes_wide(p, batch)) planes_launch<8, 3>(p, batch, st);
+  else planes_launch<4, 3>(p, batch, st);
   EP_LAUNCH_CHECK("ep_gemm_planes_kernel");
   return 0;
 }

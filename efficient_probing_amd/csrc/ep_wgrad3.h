@@ -51,7 +51,7 @@ __device__ __forceinline__ void w3_load_T(const float* __restrict__ base, int64_
   }
 }
 // split and store this thread's 2 x 4 values into the three plane images of one operand (transposed: image rows = columns)
-__device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq) {
+__device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq, bool one = false) {
   const bool cok = c0 + 4 * mq < ext;
   const bool k0ok = cok && k0 + 2 * kp < K, k1ok = cok && k0 + 2 * kp + 1 < K;
 #pragma unroll
@@ -60,6 +60,7 @@ __device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext
     pl_split2(k0ok ? x[0][j] : 0.f, k1ok ? x[1][j] : 0.f, h, m, l);
     const int o = w3_off(4 * mq + j, kp >> 2) + 4 * (kp & 3);
     *reinterpret_cast<unsigned*>(img + o) = h;
+    if (one) continue;                               // AMP-bf16 (GemmParams.nterms == 1): the rounded operand only
     *reinterpret_cast<unsigned*>(img + W3_IMG + o) = m;
     *reinterpret_cast<unsigned*>(img + 2 * W3_IMG + o) = l;
   }
@@ -76,7 +77,7 @@ __device__ __forceinline__ void w3_load_K(const float* __restrict__ base, int64_
   }
 }
 template <int RT>
-__device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int rows, int K, int r0, int k0, int tid) {
+__device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int rows, int K, int r0, int k0, int tid, bool one = false) {
 #pragma unroll
   for (int r = 0; r < RT / 32; ++r) {
     const int idx = tid + 256 * r, lrow = idx >> 3, kq = idx & 7;
@@ -87,6 +88,7 @@ __device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int row
     typedef unsigned w3_u2 __attribute__((ext_vector_type(2)));
     const int o = w3_off(lrow, kq >> 1) + 8 * (kq & 1);
     *reinterpret_cast<w3_u2*>(img + o) = w3_u2{h0, h1};
+    if (one) continue;
     *reinterpret_cast<w3_u2*>(img + W3_IMG + o) = w3_u2{m0, m1};
     *reinterpret_cast<w3_u2*>(img + 2 * W3_IMG + o) = w3_u2{l0, l1};
   }
@@ -120,6 +122,7 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
     for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + 31) / 32;
+  const bool one = p.nterms == 1;
   f4v xa[2], xb[2];
   auto loadA = [&](int k0) {
     if constexpr (A_K) w3_load_K<BMT>(A, p.lda, p.M, p.K, m0, k0, tid, xa);
@@ -132,13 +135,24 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
   loadA(0); loadB(0);
   for (int it = 0; it < nk; ++it) {
     if (it > 0) __syncthreads();                     // every wave has read tile it-1's fragments
-    if constexpr (A_K) w3_stage_K<BMT>(imgA, xa, p.M, p.K, m0, it * 32, tid);
-    else { if (stA) w3_stage_T(imgA, xa, extA, p.K, m0, it * 32, kp, mq); }
-    if constexpr (B_K) w3_stage_K<64>(imgB, xb, p.N, p.K, n0, it * 32, tid);
-    else w3_stage_T(imgB, xb, extB, p.K, n0, it * 32, kp, mq);
+    if constexpr (A_K) w3_stage_K<BMT>(imgA, xa, p.M, p.K, m0, it * 32, tid, one);
+    else { if (stA) w3_stage_T(imgA, xa, extA, p.K, m0, it * 32, kp, mq, one); }
+    if constexpr (B_K) w3_stage_K<64>(imgB, xb, p.N, p.K, n0, it * 32, tid, one);
+    else w3_stage_T(imgB, xb, extB, p.K, n0, it * 32, kp, mq, one);
     if (it + 1 < nk) { loadA((it + 1) * 32); loadB((it + 1) * 32); }     // in flight while this tile is multiplied
     __syncthreads();                                 // the plane images are complete
     pl_u4 fa[MI][3], fb[2][3];
+    if (one) {                                       // AMP-bf16: bf16(a) x bf16(b), fp32 accumulation -- one product
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi][0] = *reinterpret_cast<const pl_u4*>(imgA + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[ni][0] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * 32 + ni * 16 + i16, kk));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
+      continue;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -100,10 +100,19 @@ class ProbeHeadEngine:
     def __init__(self, head: nn.Sequential, optimizer: str = "lars", lr: float = 0.0, weight_decay: float = 0.0,
                  momentum: float = 0.9, trust_coefficient: float = 0.001, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                  process_group=None, loss_scale: float = 1.0, accum_iter: int = 1, broadcast_from_rank0: bool = True,
-                 overlap: bool = True, overlap_comm=None):
+                 overlap: bool = True, overlap_comm=None, arithmetic: str = "fp32"):
         self._check_head(head)
         if optimizer not in OPTIMIZERS:
             raise ValueError(f"optimizer must be one of {sorted(OPTIMIZERS)}")
+        # arithmetic of the step's six contractions (include/ep_hip.h: ep_head_step.arith).  "fp32": fp32 results.
+        # "bf16_autocast": what the published runs' ``--amp bfloat16`` does inside autocast (reference engine_finetune.py:52-55)
+        # -- operands rounded to bf16, one matrix-core product, fp32 accumulation; softmax, BatchNorm statistics, the loss and
+        # the optimizer stay fp32, the token passes keep their arithmetic.  The EP head only; a secondary mode.
+        if arithmetic not in ("fp32", "bf16_autocast"):
+            raise ValueError("arithmetic must be 'fp32' or 'bf16_autocast'")
+        if arithmetic != "fp32" and type(self) is not ProbeHeadEngine:
+            raise ValueError(f"{type(self).__name__}: arithmetic='bf16_autocast' is implemented for the EP head (ProbeHeadEngine) only")
+        self.arithmetic = arithmetic
         self.head = head
         self.pool, self.bn, self.fc = head[0], head[1], head[2]
         dev = self.fc.weight.device
@@ -151,7 +160,7 @@ class ProbeHeadEngine:
         import os
         want = overlap_comm if overlap_comm is not None else (os.environ.get("EP_OVERLAP_COMM", "0") == "1")
         self._pipelined = bool(want) and self._supports_comm_overlap() and self.accum_iter == 1 \
-            and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force")
+            and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force") and self.arithmetic == "fp32"
         self._pending = None
         # Deferred large update (one rank): the step updates cls_token, then v.weight / fc.* on the aux stream BESIDE the
         # next step's first token pass (which reads cls_token only).  Off by default -- between a train_step() and the
@@ -222,6 +231,8 @@ class ProbeHeadEngine:
         s.aux_stream = self.aux_stream.cuda_stream if self.aux_stream is not None else 0
         if hasattr(s, "planes_valid"):
             s.planes_valid = int(self._planes_current())
+        if hasattr(s, "arith"):
+            s.arith = N.EP_ARITH_BF16_AUTOCAST if getattr(self, "arithmetic", "fp32") == "bf16_autocast" else N.EP_ARITH_F32
         return s
 
     # ---- bf16 weight planes kept in the workspace (csrc/ep_planes.hip; include/ep_hip.h: ep_head_step.planes_valid) ----
@@ -346,7 +357,7 @@ class ProbeHeadEngine:
         # EP_DEFER_OPT=1 to use it: measured SLOWER on MI355X / ROCm 7.2 (0.452 against 0.433 ms per step at 256x768) -- a
         # dependency between two HIP streams costs 8-12 us of idle queue on each side (EXPERIMENTS.md section 4, round 3)
         return (self.defer_update and self.aux_stream is not None and self.loss_scale == 1.0
-                and os.environ.get("EP_DEFER_OPT", "0") == "1")
+                and getattr(self, "arithmetic", "fp32") == "fp32" and os.environ.get("EP_DEFER_OPT", "0") == "1")
 
     # ---- the one-call step with a PERSISTENT step struct (round 5): the ~40 fields of ep_head_step are written once; a call
     # rewrites the handful that change from step to step (token / target / index pointers, batch geometry, lr, the optimizer's
@@ -543,6 +554,19 @@ class ProbeHeadEngine:
         out = torch.empty((B, ldl), device=self.device, dtype=torch.float32)
         N.check(self._call_eval(xv, bstride, iptr, out, ldl, ws), "head eval forward")
         return out[:, :Cc]
+
+    def last_train_logits(self) -> torch.Tensor:
+        """The train-mode logits (B, C) the last train step computed its loss from (a copy out of the step's workspace;
+        diagnostics and tests: the distance of the ``bf16_autocast`` arithmetic from the reference's bf16 head)."""
+        if type(self) is not ProbeHeadEngine or self._ws is None:
+            raise RuntimeError("last_train_logits: the EP head's engine after a train step only")
+        ldl = C.c_int32(0)
+        off = self.lib.ep_head_workspace_logits_offset(C.byref(self.dims), C.byref(ldl))      # (self.dims follows the workspace: _workspace)
+        if off < 0:
+            raise RuntimeError("ep_head_workspace_logits_offset failed")
+        B = self._ws_key[0]
+        flat = self._ws[off: off + 4 * B * ldl.value].view(torch.float32).view(B, ldl.value)
+        return flat[:, : self.dims.C].clone()
 
     def read_stats(self, reset: bool = True):
         """(mean loss summed over the steps since the last reset, #top-1 hits, #top-5 hits,

@@ -33,14 +33,16 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 24
+#define EP_ABI_VERSION 25
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
-#define EP_DTYPE_F16 2     /* ABI v24: fp16-STORED tokens, FORWARD entry points only (ep_pool_forward, ep_head_eval_forward): what the
+#define EP_DTYPE_F16 2        /* ABI v24: fp16-STORED tokens, FORWARD entry points only (ep_pool_forward, ep_head_eval_forward): what the
                               reference's evaluate() hands the head under its fp16 autocast (engine_finetune.py:131); widened
                               to fp32 in the token ring like bf16 -- exact -- and all arithmetic stays fp32.  Every other
                               entry point rejects it (EP_E_UNSUPPORTED). */
+#define EP_ARITH_F32 0            /* ep_head_step.arith (ABI v25) */
+#define EP_ARITH_BF16_AUTOCAST 1
 
 #define EP_OK 0
 #define EP_E_ARG (-1)         /* null pointer / non-positive size / bad enum            */
@@ -310,6 +312,14 @@ typedef struct ep_head_step {
    * them); 0 (the safe default) makes the step split them itself, as before.  engine.ProbeHeadEngine tracks it through the
    * parameters' torch version counter. */
   int32_t planes_valid;
+  /* ABI v25: arithmetic of the step's six contractions (y = P Wv^T, logits, dz, dP, dWv, dWc -- reference poolings/ep.py:40,
+   * probe_heads.py:76 and their autograd).  EP_ARITH_F32 (0): fp32 results (exact-fp32 or bf16 x3 matrix-core products).
+   * EP_ARITH_BF16_AUTOCAST (1): what the published runs' --amp bfloat16 does inside autocast (reference
+   * engine_finetune.py:52-55): both operands rounded to bf16, ONE matrix-core product, fp32 accumulation -- the outputs stay
+   * fp32 (autocast rounds them to bf16 as well), softmax / BatchNorm statistics / cross-entropy / the optimizer stay fp32, the
+   * token passes keep their arithmetic.  Needs (D / d_out / Q) % 32 == 0 (the contractions run against the weight planes);
+   * EP_E_UNSUPPORTED otherwise.  A secondary mode: never the default, never the headline number. */
+  int32_t arith;
 } ep_head_step;
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);
@@ -317,6 +327,9 @@ size_t ep_head_workspace_bytes(const ep_head_dims* dims);
 /* byte offset inside `ws` of an int32 that counts bounded flag waits of the in-pass contractions that gave up (always 0
  * in a correct run; a diagnostic for tests).  -1: bad dims. */
 int64_t ep_head_workspace_flag_offset(const ep_head_dims* dims);
+/* byte offset inside `ws` of the train-mode logits (B x ldl floats, *ldl = row stride) the last forward phase left there --
+ * what the loss of that step was computed from (a read-only view for tests and diagnostics; ABI v25).  -1: bad dims. */
+int64_t ep_head_workspace_logits_offset(const ep_head_dims* dims, int32_t* ldl);
 /* clear the counters the step keeps in `ws` (see "Workspace contract" above); asynchronous on `stream` */
 int ep_head_workspace_init(const ep_head_dims* dims, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_head_train_step(const ep_head_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);

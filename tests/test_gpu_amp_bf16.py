@@ -1,0 +1,125 @@
+"""The AMP-bf16 arithmetic mode of the EP head's fused step (ep_head_step.arith = EP_ARITH_BF16_AUTOCAST, ABI v25;
+ProbeHeadEngine(arithmetic="bf16_autocast")): the six contractions of a step as ONE bf16 matrix-core product with fp32
+accumulation -- what the published runs' ``--amp bfloat16`` does inside autocast (reference engine_finetune.py:52-55) minus the
+bf16 rounding of the outputs.  Pinned against the reference head's own bf16-autocast forward recorded in the EP goldens
+(``logits_bf16_autocast`` / ``loss_bf16_autocast``: cases.assert_amp_bf16_fidelity), against the fp32 mode on a short
+training run, and refused loudly where the contractions cannot run against the weight planes.  Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from cases import CASES, make_inputs, assert_amp_bf16_fidelity  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _capable(c):
+    return (c.D // c.d_out // c.Q) % 32 == 0
+
+
+def _head(case, inp):
+    from test_gpu_parity import build_head
+    return build_head(case, inp)
+
+
+def _tokens(case, buf):
+    from test_gpu_parity import tokens
+    return tokens(case, buf)
+
+
+AMP_CASES = [c for c in CASES if _capable(c)]
+
+
+@pytest.mark.parametrize("case", AMP_CASES, ids=lambda c: c.name)
+def test_train_logits_within_the_reference_bf16_heads_distance(case):
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    g = np.load(os.path.join(GOLD, f"ep_{case.name}.npz"))
+    if "logits_bf16_autocast" not in g.files:
+        pytest.skip("fixture without the bf16-autocast forward")
+    inp = make_inputs(case)
+    x = _tokens(case, inp["x_buf"])
+    t = torch.from_numpy(inp["targets"]).to(DEV)
+    out = {}
+    for mode in ("fp32", "bf16_autocast"):
+        eng = ProbeHeadEngine(_head(case, inp), optimizer="sgd", lr=0.0, arithmetic=mode)
+        eng.train_step(x, t, lr=0.0)                               # (lr = 0: the forward of the fixture's parameters)
+        loss, _, _, bad = eng.read_stats()
+        assert bad == 0 and int(eng.found_inf.item()) == 0
+        out[mode] = (eng.last_train_logits().cpu().numpy(), loss)
+    # the fp32 mode reproduces the fixture's fp32 logits; the AMP mode is a different arithmetic ...
+    np.testing.assert_allclose(out["fp32"][0], g["logits"], rtol=2e-4, atol=2e-4)
+    scale = float(np.abs(g["logits"]).max())
+    d = float(np.abs(out["bf16_autocast"][0] - out["fp32"][0]).max())
+    assert d > 1e-5 * scale, "the AMP mode returned the fp32 logits: single-product kernels not in use?"
+    # ... no further from the reference's bf16-autocast head than that head is from the reference's fp32 one
+    assert_amp_bf16_fidelity(out["bf16_autocast"][0], out["bf16_autocast"][1], g, err_msg=case.name)
+    assert d <= 4.0 * 2.0 ** -8 * scale
+
+
+def test_short_training_run_follows_the_fp32_mode():
+    """40 LARS steps at the published learning-rate scale on a learnable synthetic problem: the loss curve of the AMP mode
+    stays within 2 % of the fp32 mode's at every step and ends as low."""
+    from efficient_probing_amd import probe_heads
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    from argparse import Namespace
+    B, Nn, D, Q, Cc = 256, 64, 256, 8, 16
+    g = torch.Generator(device=DEV).manual_seed(11)
+    proto = torch.randn(Cc, D, device=DEV, generator=g)
+    targets = torch.randint(0, Cc, (B,), device=DEV, generator=g)
+    x = torch.randn(B, Nn, D, device=DEV, generator=g) + 0.7 * proto[targets][:, None, :]
+    curves = {}
+    for mode in ("fp32", "bf16_autocast"):
+        class Enc(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.head = torch.nn.Linear(D, Cc)
+        torch.manual_seed(3)
+        enc = Enc()
+        probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=Cc))
+        eng = ProbeHeadEngine(enc.head.to(DEV).train(), optimizer="lars", lr=0.4, arithmetic=mode)
+        losses = []
+        for _ in range(40):
+            eng.train_step(x, targets, lr=0.4)
+            loss, _, _, bad = eng.read_stats()
+            assert bad == 0
+            losses.append(loss)
+        curves[mode] = np.array(losses)
+    a, b = curves["fp32"], curves["bf16_autocast"]
+    assert b[-1] < 0.5 * b[0], b
+    np.testing.assert_allclose(b, a, rtol=2e-2, atol=2e-3)
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dims", [(1152, 8), (768, 32)], ids=["so400m_q8", "vitb_q32"])
+def test_unsupported_widths_are_refused(dims):
+    from efficient_probing_amd import probe_heads
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    from argparse import Namespace
+    D, Q = dims
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(D, 10)
+    enc = Enc()
+    probe_heads.build_probe_head(enc, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=10))
+    eng = ProbeHeadEngine(enc.head.to(DEV).train(), optimizer="sgd", lr=0.1, arithmetic="bf16_autocast")
+    x = torch.randn(8, 20, D, device=DEV)
+    t = torch.randint(0, 10, (8,), device=DEV)
+    with pytest.raises(RuntimeError, match="AMP-bf16"):
+        eng.train_step(x, t, lr=0.1)
+
+
+def test_other_heads_and_bad_names_are_refused_on_the_host():
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    from cases import CASES as _C
+    case = [c for c in _C if c.name == "tiny_q1"][0]
+    inp = make_inputs(case)
+    with pytest.raises(ValueError, match="arithmetic"):
+        ProbeHeadEngine(_head(case, inp), optimizer="sgd", arithmetic="fp8")

@@ -131,3 +131,18 @@ def test_matrix_core_heads_keep_their_f32_contractions(head):
                         "-k", "module_forward_backward or engine_lars_steps"], cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_big_tile_kernel_in_fresh_process():
+    """csrc/ep_planes_big.hip (128 x 128 tiles, taken on its own only by long contractions with >= 192 tiles) forced for EVERY
+    planes contraction (EP_PLANES_BIG=1, read once per process): the ragged shapes of the matmul test (row / column edges, K tail,
+    fewer K-tiles than ring stages) and the fused-step comparisons run through it in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, EP_PLANES_BIG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "matmul_against_planes or fused_step_with_and_without", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
