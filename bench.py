@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--buffers", type=int, default=4, help="distinct token buffers rotated through (HBM, not cache)")
     ap.add_argument("--tokens", default="f32", choices=["f32", "bf16"],
                     help="storage type of the tokens in HBM (arithmetic is fp32 either way)")
+    ap.add_argument("--arith", default="fp32", choices=["fp32", "bf16_autocast"],
+                    help="arithmetic of the EP step's six contractions (ep_head_step.arith): fp32 (default, the headline) or the "
+                         "AMP-bf16 mode of the published --amp bfloat16 runs (one bf16 product, fp32 accumulation) -- an explicit "
+                         "secondary mode: the line says so in `dtype` and `config`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-secondary", action="store_true", help="skip the bf16-token-storage line of the default EP run")
     ap.add_argument("--no-north-star", action="store_true", help="skip the north-star-shape (197x768) object of the default EP run")
@@ -361,7 +365,9 @@ def main():
                                                 model="capi_vitl14_in1k" if Nn == 256 else "vit_base_patch16"))
     head = enc.head.to(dev).train()
     lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
-    eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0)
+    if args.arith != "fp32" and args.head != "ep":
+        raise SystemExit("--arith bf16_autocast is implemented for the EP head only")
+    eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0, **({"arithmetic": args.arith} if args.arith != "fp32" else {}))
     if hasattr(eng, "defer_update"):
         eng.defer_update = True          # (takes effect only with EP_DEFER_OPT=1 -- measured slower, engine._can_defer; the loop
                                          # below calls flush() before it stops the clock, as train_one_epoch does)
@@ -594,7 +600,7 @@ def main():
     bwd_gbs = algo_bytes / t_bwd / 1e9
 
     # ---- secondary runs of the SAME step (never `value`): a fresh head + engine per run, the same timing protocol
-    def secondary(sN, sD, sQ, storage, steps, toks=None, sC=None, sB=None, passes=False):
+    def secondary(sN, sD, sQ, storage, steps, toks=None, sC=None, sB=None, passes=False, arithmetic="fp32"):
         sC = sC or Cc
         sB = sB or B
         torch.manual_seed(0)
@@ -608,7 +614,8 @@ def main():
                                                      model="vit_base_patch16"))
         ts = [(t % sC)[:sB].contiguous() for t in ts_all]
         h2 = enc2.head.to(dev).train()
-        eng2 = make_engine(h2, optimizer="lars", lr=0.1 * (sB * world) / 256, weight_decay=0.0)
+        eng2 = make_engine(h2, optimizer="lars", lr=0.1 * (sB * world) / 256, weight_decay=0.0,
+                           **({"arithmetic": arithmetic} if arithmetic != "fp32" else {}))
         if hasattr(eng2, "defer_update"):
             eng2.defer_update = True
         if toks is None:
@@ -638,7 +645,7 @@ def main():
         tf2 = time_kernel(lambda i: F_.pool_forward(toks[i % args.buffers], c2_, sc2), args.kernel_iters)
         v2 = sB * world * steps / el2
         line = {"value": round(v2, 1), "unit": "images/s", "n_gpus": world, "steps": steps, "ms_per_step": round(el2 / steps * 1e3, 4),
-                "tokens": sN, "dim": sD, "queries": sQ, "batch_per_gpu": sB, "token_storage": storage, "arithmetic": "f32",
+                "tokens": sN, "dim": sD, "queries": sQ, "batch_per_gpu": sB, "token_storage": storage, "arithmetic": "f32" if arithmetic == "fp32" else arithmetic,
                 "kernel": eng.lib.ep_pool_kernel_name_ex(sB, sN, sD, sQ, 0, 1 if storage == "bf16" else 0).decode(),
                 "us_per_launch": round(tf2 * 1e6, 2), "algorithmic_bytes": sB * sN * sD * es,
                 "frac": round(sB * sN * sD * es / tf2 / 1e9 / HBM_PEAK_GBS, 4),
@@ -653,11 +660,11 @@ def main():
                                "bwd_kernel": eng.lib.ep_pool_kernel_name_ex(sB, sN, sD, sQ, 1, 1 if storage == "bf16" else 0).decode()}
         return line
 
-    default_ep = args.head == "ep" and args.tokens == "f32" and args.workload == "c2"
+    default_ep = args.head == "ep" and args.tokens == "f32" and args.workload == "c2" and args.arith == "fp32"
     # (N = 1 only) the same tokens STORED as bf16 (fp32 arithmetic and results; the token passes run on the bf16
     # matrix cores, csrc/ep_pool_mb.hip)
     bf16_line = None
-    if world == 1 and args.head == "ep" and args.tokens == "f32" and not args.no_bf16_secondary:
+    if world == 1 and args.head == "ep" and args.tokens == "f32" and args.arith == "fp32" and not args.no_bf16_secondary:
         bf16_line = secondary(Nn, D, Q, "bf16", max(10, min(args.steps, 50)), toks=xs, passes=True)
     # the north-star shape (ViT-B/16 tokens 197x768, BASELINE.json north_star) beside the configs[1] headline
     ns_line = None
@@ -718,6 +725,34 @@ def main():
         line["workload"] = cdesc + " [tokens stored as bf16, fp32 arithmetic]"
         line["classes"] = cC
         configs["c5_bf16"] = line
+        # The published runs train under --amp bfloat16 (reference README.md:639-645, engine_finetune.py:52-55).  The same steps in
+        # the AMP-bf16 arithmetic mode (ep_head_step.arith = EP_ARITH_BF16_AUTOCAST: the six contractions as ONE bf16 matrix-core
+        # product with fp32 accumulation; token passes, softmax, BatchNorm, loss and optimizer unchanged) -- secondary objects,
+        # never `value`: a different arithmetic from the headline's fp32 (tests/test_gpu_amp_bf16.py pins its distance from the
+        # reference's bf16-autocast head)
+        amp = {}
+        try:
+            l1 = secondary(Nn, D, Q, "bf16", 20, toks=xs, passes=True, arithmetic="bf16_autocast")
+            l1["workload"] = desc + " [tokens stored as bf16, AMP-bf16 contractions]"
+            amp[args.workload + "_bf16"] = l1
+            l0 = secondary(Nn, D, Q, "f32", 20, toks=xs, passes=True, arithmetic="bf16_autocast")
+            l0["workload"] = desc + " [AMP-bf16 contractions]"
+            amp[args.workload] = l0
+            torch.cuda.empty_cache()
+            for stor in ("f32", "bf16"):
+                l5 = secondary(cN, cD, cQ, stor, 20, sC=cC, passes=True, arithmetic="bf16_autocast")
+                l5["workload"] = cdesc + (" [tokens stored as bf16, AMP-bf16 contractions]" if stor == "bf16" else " [AMP-bf16 contractions]")
+                l5["classes"] = cC
+                flop = 3 * 2.0 * B * cD * cD + 3 * 2.0 * B * cD * cC
+                t_us = l5["ms_per_step"] * 1e3 - l5["in_step"]["fwd_us"] - l5["in_step"]["bwd_us"]
+                l5["mfma"] = {"kernel": "ep_gemm_planes_kernel<NB, 1> + ep_gemm_b3_kernel (one product)", "flop_per_step": flop, "time_us": round(t_us, 1),
+                              "achieved": round(flop / t_us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flop / t_us / 1e6 / 2500.0, 4),
+                              "peak_note": "one bf16 product per multiply-add: 2.5 PFLOP/s; time = step - token passes"}
+                amp["c5" + ("_bf16" if stor == "bf16" else "")] = l5
+        except Exception as e:                                  # a secondary never takes the headline line down with it
+            amp["error"] = f"{type(e).__name__}: {e}"[:300]
+        configs["amp_bf16"] = amp
+        torch.cuda.empty_cache()
         # BASELINE configs[3] compares three heads on the SO400M tokens: the other two (CoCa pooler: HBM-bound like EP; AbMILP:
         # matrix-core-bound) as short child runs of this file, rank 0 at N = 1 only (their own engines and workspaces)
         if world == 1:
@@ -835,7 +870,9 @@ def main():
                        "cbam": "CBAM-head train images/sec"}[args.head], "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, **({"collective_backend": "gloo (EP_BENCH_SHARE_DEVICE=1: all ranks on one device, a test mode)"} if share else {}),
             "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32" if args.arith == "fp32" else "bf16_autocast (contractions: one bf16 product, fp32 accumulation; token passes, softmax, BatchNorm, loss, optimizer f32)",
+            "data": "synthetic",
             "step_ms_p10": pct(0.10), "step_ms_p50": pct(0.50), "step_ms_p90": pct(0.90), "step_ms_window": me,
             "config": {"workload": desc + ("" if args.tokens == "f32" else " [tokens stored as bf16, fp32 arithmetic]"),
                        "tokens": Nn, "dim": D, "queries": Q, "classes": Cc, "batch_per_gpu": B, "token_storage": args.tokens,

@@ -421,10 +421,10 @@ int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {
               p.M, p.N, p.K, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / (nwg * 8.0), a[5] / (nwg * 8.0) / 100.0, a[4] / a[5] / 10.0, nwg);
     return 0;
   }
-  if (p.nterms == 1 || gemm_arith() == 1) {                               // AMP-bf16: one product per block
+  if (planes_big_wanted(p, batch)) planes_big_launch(p, batch, st);        // ep_planes_big.hip: 128 x 128 tiles for the large contractions
+  else if (p.nterms == 1 || gemm_arith() == 1) {                           // AMP-bf16: one product per block
     if (planes_wide(p, batch)) planes_launch<8, 1>(p, batch, st); else planes_launch<4, 1>(p, batch, st);
   }
-  else if (planes_big_wanted(p, batch)) planes_big_launch(p, batch, st);   // ep_planes_big.hip: 128 x 128 tiles for the large contractions
   else if (planes_wide(p, batch)) planes_launch<8, 3>(p, batch, st);
   else planes_launch<4, 3>(p, batch, st);
   EP_LAUNCH_CHECK("ep_gemm_planes_kernel");

@@ -48,8 +48,12 @@
 
 namespace ep {
 
-constexpr int PBG_STB = 16384 + 24 * 1024;           // bytes per ring stage
-constexpr int PBG_NPC = 10;                          // DMA instructions per wave and K-tile
+// NT = weight terms multiplied: 3 (fp32 accuracy) or 1 (the AMP-bf16 arithmetic mode: bf16(a) x bf16(w), the hi plane only)
+template <int NT> struct PbgGeom {
+  static constexpr int stb = 16384 + 8 * NT * 1024;  // bytes per ring stage: fp32 A image + 8 NT plane pieces
+  static constexpr int npc = 4 + 2 * NT;             // DMA instructions per wave and K-tile
+  static constexpr int nm = NT == 3 ? 48 : 8;        // matrix instructions per wave and K-tile
+};
 #ifndef EP_PBG_NST
 #define EP_PBG_NST 3                                 // ring stages of 40 KiB (3 or 4)
 #endif
@@ -103,8 +107,9 @@ __device__ __forceinline__ void pbg_dma(const char* base, unsigned off, unsigned
 }
 #pragma clang diagnostic pop
 
-template <int NST>
+template <int NST, int NT>
 __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles) {
+  constexpr int PBG_STB = PbgGeom<NT>::stb, PBG_NPC = PbgGeom<NT>::npc, NM = PbgGeom<NT>::nm;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -136,11 +141,11 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
       offA[jj] = (unsigned)(((int64_t)row * p.lda + 4 * kqA) * 4);
     }
   }
-  unsigned offW[6];
-  int64_t termW[6];                                  // (uniform) term offsets, bytes
+  unsigned offW[2 * NT];
+  int64_t termW[2 * NT];                             // (uniform) term offsets, bytes
 #pragma unroll
-  for (int jj = 0; jj < 6; ++jj) {
-    const int pb = w + 4 * jj, blk = pb / 3, term = pb - 3 * blk;
+  for (int jj = 0; jj < 2 * NT; ++jj) {
+    const int pb = w + 4 * jj, blk = pb / NT, term = pb - NT * blk;
     const int r16 = lane >> 2, kq = (lane & 3) ^ (2 * (r16 >> 3));
     int row = 16 * blk + r16; row = n0 + row < p.N ? row : p.N - 1 - n0;
     offW[jj] = (unsigned)(((int64_t)row * p.ldbp + 8 * kq) * 2);
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
       __builtin_amdgcn_global_load_lds((pl_gptr_t)(Ab + o), (pl_lds_ptr_t)(st + (w + 4 * jj) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int jj = 0; jj < 6; ++jj)
+    for (int jj = 0; jj < 2 * NT; ++jj)
       __builtin_amdgcn_global_load_lds((pl_gptr_t)(Wb + termW[jj] + (int64_t)t * (BK * 2) + offW[jj]),
                                        (pl_lds_ptr_t)(st + 16384 + (w + 4 * jj) * 1024), 16, 0, 0);
   };
@@ -163,13 +168,14 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
   // ---- fragment addresses.  A: row 64 wm + 32 mb + i32, fp32 chunks (2 s + kh) and 4 + (2 s + kh); planes: 16-row block
   // 4 wn + 2 nb + (i32 >> 4), term, chunk 2 s + kh
   int fragA[2][2];                                   // [s][g]; + mb * 4096
-  int fragW[2];                                      // [s]; + nb * 6144 + term * 1024
+  int fragW[2];                                      // [s]; + nb * NBO + term * 1024
+  constexpr int NBO = 2 * NT * 1024;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int r = wm * 64 + i32, c = 2 * s + kh, sw = (i32 >> 1) & 7;
     fragA[s][0] = r * 128 + 16 * (c ^ sw);
     fragA[s][1] = r * 128 + 16 * ((4 + c) ^ sw);
-    fragW[s] = 16384 + (wn * 4 + (i32 >> 4)) * 3072 + (4 * i16 + (c ^ (2 * (i16 >> 3)))) * 16;
+    fragW[s] = 16384 + (wn * 4 + (i32 >> 4)) * (NT * 1024) + (4 * i16 + (c ^ (2 * (i16 >> 3)))) * 16;
   }
 
   pbg_f16v acc[2][2];
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
   // the lo planes of tile t+1 are read into the SAME registers after matrix instruction 7 and the mid planes after 23.
   // (The order of the six products inside a K-tile does not matter for the accuracy: from the second K-tile on the accumulator
   // holds the large partial sum anyway.)
-  pl_u4 a3[2][2][2][3];                              // [buffer][M block][s][term]
+  pl_u4 a3[2][2][2][NT];                             // [buffer][M block][s][term]
   pl_u4 bhi[2][2][2], bmid[2][2], blo[2][2];         // [N block][s]
 
   auto wait_tile = [&](int ahead) {                  // my DMA parts of a tile have landed, `ahead` = tiles issued behind it
@@ -198,10 +204,10 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) b[nb][s] = *reinterpret_cast<const pl_u4*>(st + fragW[s] + nb * 6144 + term * 1024);
+      for (int s = 0; s < 2; ++s) b[nb][s] = *reinterpret_cast<const pl_u4*>(st + fragW[s] + nb * NBO + term * 1024);
   };
   // fragments of A of the tile in stage `st`, zeroed at or past klim, split into a[mb][s][term] (plain form: prologue, tail)
-  auto read_split_plain = [&](const char* st, int klim, pl_u4 (&a)[2][2][3]) {
+  auto read_split_plain = [&](const char* st, int klim, pl_u4 (&a)[2][2][NT]) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -210,18 +216,23 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
         float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (16 * (e >> 2) + 4 * (2 * s + kh) + (e & 3) >= klim) ? 0.f : v[e];
-        pl_split8(v, a[mb][s]);
+        if constexpr (NT == 3) pl_split8(v, a[mb][s]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[mb][s][0][e] = pl_pack_rne(v[2 * e], v[2 * e + 1]);
+        }
       }
   };
   // matrix instruction i of a K-tile on register buffer `cur`: phase i >> 3 = product, then s, M block, N block
   auto mfma_at = [&](auto cur_c, auto i_c) __attribute__((always_inline)) {
     constexpr int cur = decltype(cur_c)::value, i = decltype(i_c)::value;
-    constexpr int ph = i >> 3, s = (i >> 2) & 1, mb = (i >> 1) & 1, nb = i & 1;
+    constexpr int ph = NT == 3 ? i >> 3 : 5, s = (i >> 2) & 1, mb = (i >> 1) & 1, nb = i & 1;
     constexpr int ta = ph == 0 ? 0 : ph == 1 ? 1 : ph == 2 ? 0 : ph == 3 ? 2 : ph == 4 ? 1 : 0;
-    if constexpr (EP_PBG_ABLATE & 8) { if constexpr (i < 4) acc[mb][nb][0] += __uint_as_float(a3[cur][mb][s][ta][0] ^ blo[nb][s][0] ^ bmid[nb][s][1] ^ bhi[cur][nb][s][2]); }
-    else if constexpr (ph == 0) acc[mb][nb] = pbg_mfma(a3[cur][mb][s][ta], blo[nb][s], acc[mb][nb]);
-    else if constexpr (ph <= 2) acc[mb][nb] = pbg_mfma(a3[cur][mb][s][ta], bmid[nb][s], acc[mb][nb]);
-    else acc[mb][nb] = pbg_mfma(a3[cur][mb][s][ta], bhi[cur][nb][s], acc[mb][nb]);
+    if constexpr (NT == 1) acc[mb][nb] = pbg_mfma(a3[cur][mb][s][0], bhi[cur][nb][s], acc[mb][nb]);
+    else if constexpr (EP_PBG_ABLATE & 8) { if constexpr (i < 4) acc[mb][nb][0] += __uint_as_float(a3[cur][mb][s][ta < NT ? ta : 0][0] ^ blo[nb][s][0] ^ bmid[nb][s][1] ^ bhi[cur][nb][s][2]); }
+    else if constexpr (ph == 0) acc[mb][nb] = pbg_mfma(a3[cur][mb][s][ta < NT ? ta : 0], blo[nb][s], acc[mb][nb]);
+    else if constexpr (ph <= 2) acc[mb][nb] = pbg_mfma(a3[cur][mb][s][ta < NT ? ta : 0], bmid[nb][s], acc[mb][nb]);
+    else acc[mb][nb] = pbg_mfma(a3[cur][mb][s][ta < NT ? ta : 0], bhi[cur][nb][s], acc[mb][nb]);
   };
 
   // prologue: the whole ring in flight; tile 0 -> buffer 0
@@ -231,7 +242,8 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
   wait_tile(nk - 1 < NST - 1 ? nk - 1 : NST - 1);
   pl_barrier();
   read_split_plain(lds, (ktail && nk == 1) ? p.K : BK, a3[0]);
-  read_planes(lds, bhi[0], 0); read_planes(lds, bmid, 1); read_planes(lds, blo, 2);
+  read_planes(lds, bhi[0], 0);
+  if constexpr (NT == 3) { read_planes(lds, bmid, 1); read_planes(lds, blo, 2); }
 
   // Iteration t: (barrier) tile t+1 has landed and the stage of tile t is free -> refill it with tile t + NST; read and split
   // tile t+1 while the matrix instructions of tile t issue.  STEADY: no branch in the body; group i = matrix instruction i
@@ -256,13 +268,33 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
       asm volatile("" : "+v"(bA[s_][0]), "+v"(bA[s_][1]), "+v"(bW[s_]));
     }
     f4v xs[4][2];                                    // [fragment f = 2 mb + s][g]
+    if constexpr (NT == 1) {
+      // single product: 8 matrix instructions per K-tile.  Group i = matrix instruction i + DMA instruction i (i < 6) + the two
+      // reads of A fragment i (i < 4) or one hi-plane read (i >= 4) + the four roundings of fragment i - 4 (i >= 4)
+      pbg_for_seq(std::make_integer_sequence<int, 8>{}, [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        mfma_at(cur_c, ic);
+        if constexpr (i < 4) pbg_dma(Ak, offA[i & 3], stio + (w + 4 * (i & 3)) * 1024);
+        else if constexpr (i < 6) pbg_dma(Wk + termW[i - 4], offW[i - 4], stio + 16384 + (w + 4 * (i - 4)) * 1024);
+        if constexpr (i < 4) {
+          xs[i][0] = *reinterpret_cast<const f4v*>(lds + bA[i & 1][0] + (i >> 1) * 4096);
+          xs[i][1] = *reinterpret_cast<const f4v*>(lds + bA[i & 1][1] + (i >> 1) * 4096);
+        } else {
+          bhi[nxt][(i - 4) >> 1][(i - 4) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 4) & 1] + ((i - 4) >> 1) * NBO);
+          constexpr int f = i - 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a3[nxt][f >> 1][f & 1][0][e] = pl_pack_rne(xs[f][e >> 1][2 * (e & 1)], xs[f][e >> 1][2 * (e & 1) + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else {
     PbgPair pr[4];                                   // pairs in flight
     pbg_for_seq(std::make_integer_sequence<int, 48>{}, [&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       mfma_at(cur_c, ic);
       if constexpr (EP_PBG_ABLATE & 4) {}
       else if constexpr (i < 4) pbg_dma(Ak, offA[i & 3], stio + (w + 4 * (i & 3)) * 1024);
-      else if constexpr (i < 10) pbg_dma(Wk + termW[(i - 4) % 6], offW[(i - 4) % 6], stio + 16384 + (w + 4 * ((i - 4) % 6)) * 1024);
+      else if constexpr (i < 10) pbg_dma(Wk + termW[(i - 4) % (2 * NT)], offW[(i - 4) % (2 * NT)], stio + 16384 + (w + 4 * ((i - 4) % 6)) * 1024);
       if constexpr (i < 4) {                         // fragment f = i: (mb = i >> 1, s = i & 1)
         if constexpr (EP_PBG_ABLATE & 16) { xs[i][0] = f4v{1.f, 2.f, 3.f, 4.f}; xs[i][1] = f4v{5.f, 6.f, 7.f, 8.f}; }
         else {
@@ -270,9 +302,9 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
           xs[i][1] = *reinterpret_cast<const f4v*>(lds + bA[i & 1][1] + (i >> 1) * 4096);
         }
       } else if constexpr (EP_PBG_ABLATE & 2) {}
-      else if constexpr (i < 8) bhi[nxt][(i - 4) >> 1][(i - 4) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 4) & 1] + ((i - 4) >> 1) * 6144 + 0 * 1024);
-      else if constexpr (i < 12) blo[(i - 8) >> 1][(i - 8) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 8) & 1] + ((i - 8) >> 1) * 6144 + 2 * 1024);
-      else if constexpr (i >= 24 && i < 28) bmid[(i - 24) >> 1][(i - 24) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 24) & 1] + ((i - 24) >> 1) * 6144 + 1 * 1024);
+      else if constexpr (i < 8) bhi[nxt][(i - 4) >> 1][(i - 4) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 4) & 1] + ((i - 4) >> 1) * NBO + 0 * 1024);
+      else if constexpr (i < 12) blo[(i - 8) >> 1][(i - 8) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 8) & 1] + ((i - 8) >> 1) * NBO + 2 * 1024);
+      else if constexpr (i >= 24 && i < 28) bmid[(i - 24) >> 1][(i - 24) & 1] = *reinterpret_cast<const pl_u4*>(lds + bW[(i - 24) & 1] + ((i - 24) >> 1) * NBO + 1 * 1024);
       // split stages placed in this group
       pbg_for_seq(std::make_integer_sequence<int, 48>{}, [&](auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value, pair = q / 3, stg = q % 3;
@@ -291,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+    }
   };
   // the last iterations: the same data flow in plain blocks (waits by the number of tiles still behind, no refill past the end,
   // the ragged last K-tile zeroed before its split)
@@ -305,10 +338,12 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
       read_planes(st, bhi[nxt], 0);
     }
     pbg_for_seq(std::make_integer_sequence<int, 8>{}, [&](auto ic) __attribute__((always_inline)) { mfma_at(cur_c, std::integral_constant<int, decltype(ic)::value>{}); });
-    if (more) read_planes(st, blo, 2);
-    pbg_for_seq(std::make_integer_sequence<int, 16>{}, [&](auto ic) __attribute__((always_inline)) { mfma_at(cur_c, std::integral_constant<int, 8 + decltype(ic)::value>{}); });
-    if (more) read_planes(st, bmid, 1);
-    pbg_for_seq(std::make_integer_sequence<int, 24>{}, [&](auto ic) __attribute__((always_inline)) { mfma_at(cur_c, std::integral_constant<int, 24 + decltype(ic)::value>{}); });
+    if constexpr (NT == 3) {
+      if (more) read_planes(st, blo, 2);
+      pbg_for_seq(std::make_integer_sequence<int, 16>{}, [&](auto ic) __attribute__((always_inline)) { mfma_at(cur_c, std::integral_constant<int, 8 + decltype(ic)::value>{}); });
+      if (more) read_planes(st, bmid, 1);
+      pbg_for_seq(std::make_integer_sequence<int, 24>{}, [&](auto ic) __attribute__((always_inline)) { mfma_at(cur_c, std::integral_constant<int, 24 + decltype(ic)::value>{}); });
+    }
     if (more) read_split_plain(st, (ktail && t + 1 == nk - 1) ? p.K - (t + 1) * BK : BK, a3[nxt]);
   };
   int t = 0;
@@ -372,14 +407,20 @@ bool planes_big_wanted(const GemmParams& p, int batch) {
   if (force == -2) { const char* e = getenv("EP_PLANES_BIG"); force = e ? atoi(e) : -1; }
   if (force >= 0) return force != 0;
   const long tiles = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * batch;
+  if (p.nterms == 1 || gemm_arith() == 1) {          // single product: bandwidth-bound -- the larger tile halves the operand traffic
+    static int amp_big = -1;
+    if (amp_big < 0) { const char* e = getenv("EP_PLANES_BIG_AMP"); amp_big = e ? atoi(e) : 1; }
+    return amp_big && tiles >= 192 && p.K >= 256;
+  }
   return tiles >= 192 && p.K >= 2048;
 }
 
-void planes_big_launch(const GemmParams& p, int batch, hipStream_t st) {
-  constexpr int NST = EP_PBG_NST;
-  constexpr int lds = NST * PBG_STB;
+template <int NT>
+static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st) {
+  constexpr int NST = NT == 1 ? 4 : EP_PBG_NST;      // (single term: 24 KiB stages, four of them)
+  constexpr int lds = NST * PbgGeom<NT>::stb;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_big_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_big_kernel<NST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   const int mtn = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
   const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
   const unsigned grid = 8u * ((ntiles + 7u) / 8u);
@@ -390,7 +431,7 @@ void planes_big_launch(const GemmParams& p, int batch, hipStream_t st) {
   GemmParams q = p;
   q.skws = reinterpret_cast<float*>(dbg);
   if (ntiles <= 8192) {
-    hipLaunchKernelGGL(ep_gemm_planes_big_kernel<NST>, dim3(grid), dim3(256), lds, st, q, mtn, ntn, ntiles);
+    hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, q, mtn, ntn, ntiles);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host, dbg, (size_t)ntiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double c = 0, r = 0;
@@ -402,7 +443,10 @@ void planes_big_launch(const GemmParams& p, int batch, hipStream_t st) {
     return;
   }
 #endif
-  hipLaunchKernelGGL(ep_gemm_planes_big_kernel<NST>, dim3(grid), dim3(256), lds, st, p, mtn, ntn, ntiles);
+  hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, p, mtn, ntn, ntiles);
+}
+void planes_big_launch(const GemmParams& p, int batch, hipStream_t st) {
+  if (p.nterms == 1 || gemm_arith() == 1) planes_big_launch_nt<1>(p, batch, st); else planes_big_launch_nt<3>(p, batch, st);
 }
 
 }  // namespace ep

@@ -196,6 +196,14 @@ def get_engine(model, optimizer=None, args=None):
             eng._eval_only = True
         else:
             name, kw = _optimizer_spec(optimizer)
+            # arithmetic of the EP step's contractions: fp32 unless asked for.  The reference's published command lines pass
+            # ``--amp bfloat16`` (README.md:639-645; engine_finetune.py:52-55 runs the head under autocast); here that flag keeps
+            # the fp32 arithmetic (a superset in accuracy) and the bf16 single-product mode is an explicit opt-in:
+            # ``args.ep_arithmetic = "bf16_autocast"`` or EP_ARITHMETIC=bf16_autocast (the EP head only).
+            import os
+            arith = getattr(args, "ep_arithmetic", None) or os.environ.get("EP_ARITHMETIC", "fp32")
+            if arith != "fp32":
+                kw = dict(kw, arithmetic=arith)
             eng = make_engine(head, optimizer=name, accum_iter=accum, **kw)
             eng._eval_only = False
             _alias_optimizer_state(eng, optimizer, name)
