@@ -707,6 +707,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   }
   PoolParams p = pool_params(s->x, s->x_bstride, d.B, d.N, d.D, d.Q, scale, s->x_dtype);
   p.cls = cls; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = s->image_index;
+  p.nterms = s->arith == EP_ARITH_BF16_AUTOCAST ? 1 : 0;   // (bf16-token matrix-core passes: single product; the others ignore it)
   // Weight planes of THIS step (ep_planes.hip).  (In front of the first pass on the same stream instead: 2.377 against 2.385 ms
   // at 196 x 4096 -- the same.)  With the whole step in one call and an aux stream the split runs BESIDE
   // the first token pass (it needs the weights only, the pass the queries only): fork before the pass is enqueued, join

@@ -9,6 +9,8 @@ struct PoolParams {
   int x_bf16;            // 1: tokens are stored as bf16 (widened to fp32 on load; all arithmetic stays fp32)
   int64_t x_bstride;     // elements between images
   int B, N, D, Q;
+  int nterms;            // bf16-token matrix-core passes (ep_pool_mb.hip: mb2): 0 / 3 = the fp32 operand as three bf16 terms (fp32 results);
+                         // 1 = AMP-bf16 arithmetic: the operand rounded to bf16, ONE product.  Other kernel families ignore it.
   int Qs;                // queries per image in MEMORY (batch stride of P / S / ML / dP in query rows); 0 = Q.  Larger than Q
                          // when a launch covers a chunk of the queries (ep_pool.hip: chunked passes for Q beyond a kernel family's limit)
   const float* cls;      // fwd: (Q,D) or (B,Q,D)

@@ -567,6 +567,10 @@ struct Mb2Cfg {
 __device__ __forceinline__ f4 mb2_mfma16(u2 a, u2 b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, a), __builtin_bit_cast(s4v, b), c, 0, 0, 0);
 }
+// NT (mb2_scores / mb2_pool / the mb2 kernels): terms of the fp32 operand that are multiplied -- 3: fp32 results; 1: the AMP-bf16
+// arithmetic mode (PoolParams.nterms: bf16(query) x token and bf16(weight) x token as ONE product with fp32 accumulation, what
+// the reference's q @ k^T and attn @ v do under --amp bfloat16, poolings/ep.py:41-44 inside engine_finetune.py:52-55's autocast)
+template <int NT = 3>
 __device__ __forceinline__ void mb2_split4(const float (&v)[4], u2 (&t)[3]) {
   unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -574,12 +578,14 @@ __device__ __forceinline__ void mb2_split4(const float (&v)[4], u2 (&t)[3]) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     t[0][e] = mb_pack_hi(h[2 * e], h[2 * e + 1]);
-    t[1][e] = mb_pack_hi(m[2 * e], m[2 * e + 1]);
-    t[2][e] = mb_pack_hi(l[2 * e], l[2 * e + 1]);
+    if constexpr (NT == 3) {
+      t[1][e] = mb_pack_hi(m[2 * e], m[2 * e + 1]);
+      t[2][e] = mb_pack_hi(l[2 * e], l[2 * e + 1]);
+    }
   }
 }
 // partial scores of the 16-token tile over this wave's slice -> its record in the scratch
-template <int NK, typename F>
+template <int NK, int NT = 3, typename F>
 __device__ __forceinline__ void mb2_scores(const char* tile, const int (&aoff)[NK], const u4 (&bq)[NK][3], char* spart,
                                            int w, int lane, F&& mid) {
   u4 xa[NK];
@@ -589,7 +595,7 @@ __device__ __forceinline__ void mb2_scores(const char* tile, const int (&aoff)[N
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
 #pragma unroll
-    for (int term = 2; term >= 0; --term) acc[ks & 1] = mb_mfma(xa[ks], bq[ks][term], acc[ks & 1]);
+    for (int term = NT - 1; term >= 0; --term) acc[ks & 1] = mb_mfma(xa[ks], bq[ks][term], acc[ks & 1]);
     if (ks == 0) mid();
   }
   *reinterpret_cast<f4*>(spart + (w * 64 + lane) * 16) = acc[0] + acc[1];
@@ -600,11 +606,11 @@ __device__ __forceinline__ void mb2_gather(const char* spart, int lane, float (&
   for (int ws = 1; ws < MB2_NW; ++ws) v += *reinterpret_cast<const f4*>(spart + (ws * 64 + lane) * 16);
   s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
 }
-template <int NK>
+template <int NK, int NT = 3>
 __device__ __forceinline__ void mb2_pool(const char* tile, const int (&poff)[4], const int (&pseg)[NK],
                                          const float (&wgt)[4], f4 (&accE)[NK], f4 (&accO)[NK]) {
   u2 bw[3];
-  mb2_split4(wgt, bw);
+  mb2_split4<NT>(wgt, bw);
   unsigned xr[NK][4];
 #pragma unroll
   for (int dg = 0; dg < NK; ++dg)
@@ -619,14 +625,14 @@ __device__ __forceinline__ void mb2_pool(const char* tile, const int (&poff)[4],
       ao[e] = __builtin_amdgcn_perm(xr[dg][2 * e + 1], xr[dg][2 * e], 0x07060302u);
     }
 #pragma unroll
-    for (int term = 2; term >= 0; --term) {
+    for (int term = NT - 1; term >= 0; --term) {
       accE[dg] = mb2_mfma16(ae, bw[term], accE[dg]);
       accO[dg] = mb2_mfma16(ao, bw[term], accO[dg]);
     }
   }
 }
 
-template <int NK, int NS>
+template <int NK, int NS, int NT = 3>
 __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolParams p) {
   using C = Mb2Cfg<NK, NS>;
   constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
@@ -711,9 +717,9 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       const int n0 = ctile * MB2_TT;
       const int nvalid = (N - n0) < MB2_TT ? (N - n0) : MB2_TT;
       const char* tile = ring + cslot * SLOT;
-      if (live) mb2_scores<NK>(tile, aoff, bq, spart, w, lane, [] {});
+      if (live) mb2_scores<NK, NT>(tile, aoff, bq, spart, w, lane, [] {});
       if (it > 0) {
-        mb2_pool<NK>(ptile_, poff, pseg, pwgt, accE, accO);
+        mb2_pool<NK, NT>(ptile_, poff, pseg, pwgt, accE, accO);
         if (w == ((it - 1) & 3) && j < Q) {         // every wave holds the same scores: one writes the tile
           float* Srow = p.S + ((int64_t)pb * QS + j) * N + pn0 + 4 * g;
           if (n4) {
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
       for (int dg = 0; dg < NK; ++dg) { accE[dg] = f4{0.f, 0.f, 0.f, 0.f}; accO[dg] = f4{0.f, 0.f, 0.f, 0.f}; }
     }
     if (MB_ABLATE && p.ablate == 1) { produce(); continue; }     // diagnostic: ring only
-    mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+    mb2_scores<NK, NT>(tile, aoff, bq, spart, w, lane, produce);
     float sc[4], ue[4];
     if (MB_ABLATE && p.ablate == 2) {               // diagnostic: no exchange
 #pragma unroll
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
           if (4 * g + r < nvalid) Srow[r] = sc[r];
       }
     }
-    if (!MB_ABLATE || p.ablate != 3) mb2_pool<NK>(tile, poff, pseg, wgt, accE, accO);
+    if (!MB_ABLATE || p.ablate != 3) mb2_pool<NK, NT>(tile, poff, pseg, wgt, accE, accO);
     if (ctile == tiles_per_img - 1) {
       const float l = mb_q4_sum(lsum);
       const float inv = 1.0f / l;
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_fwd_kernel(PoolPar
 // workgroups behind the pooling grid (ep_sidetask.h: the dispatcher places them as pooling workgroups retire, i.e. into
 // the tail of the pass -- no second stream, no cross-queue events).  A template flag because the contraction tile's
 // registers must not push the D <= 384 pooling kernels below four workgroups per CU when nothing rides along.
-template <int NK, int NS, bool SIDE>
+template <int NK, int NS, bool SIDE, int NT = 3>
 __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolParams p, SideTasks side) {
   using C = Mb2Cfg<NK, NS>;
   constexpr int D = C::D, ROWB = C::ROWB, SLOT = C::SLOT, NSLOT = C::NSLOT, KDMA = C::KDMA, NCH = C::NCH;
@@ -1000,8 +1006,8 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // keeps the counted waits below exact
         }
-        if (live) mb2_scores<NK>(tile, aoff, bq, spart, w, lane, [] {});      // dA partial blocks
-        if (it > 0) mb2_pool<NK>(ptile_, poff, pseg, pwgt, gE, gO);
+        if (live) mb2_scores<NK, NT>(tile, aoff, bq, spart, w, lane, [] {});      // dA partial blocks
+        if (it > 0) mb2_pool<NK, NT>(ptile_, poff, pseg, pwgt, gE, gO);
         if (!live) break;
         mb_barrier();                                  // partial blocks complete; the slot of tile it-1 is free
         float cur[4];
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
         if (ntile == tiles_per_img) { ntile = 0; ++nimg; }
         if (nimg < n_img) load_scores(nimg, ntile);
       }
-      mb2_scores<NK>(tile, aoff, bq, spart, w, lane, produce);
+      mb2_scores<NK, NT>(tile, aoff, bq, spart, w, lane, produce);
       mb_barrier();
       float u[4], wgt[4];
       mb2_gather(spart, lane, u);
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
         const float a = __builtin_amdgcn_exp2f(fmaf(cur[e], MB_LOG2E, -mL_j)) * il_j;
         wgt[e] = ((4 * g + e) < nvalid && j < Q) ? a * (u[e] - dl_j) : 0.f;
       }
-      mb2_pool<NK>(tile, poff, pseg, wgt, gE, gO);
+      mb2_pool<NK, NT>(tile, poff, pseg, wgt, gE, gO);
       if (++ctile == tiles_per_img) { ctile = 0; ++cimg; }
     }
   }
@@ -1465,6 +1471,20 @@ static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t s
     (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kq, MB2_NW * 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = -1; }
     *g_mb_occ_query = nb;
+    return 0;
+  }
+  if (p.nterms == 1) {                               // AMP-bf16 arithmetic: single-product passes (the step runs no in-pass dP then)
+    if (p.ip_dy) { set_error("the single-product (AMP-bf16) bf16-token passes carry no in-pass dP"); return EP_E_UNSUPPORTED; }
+    auto kf1 = ep_pool_mb2_fwd_kernel<NK, NS, 1>;
+    auto kb1 = ep_pool_mb2_bwd_kernel<NK, NS, false, 1>;
+    auto ks1 = ep_pool_mb2_bwd_kernel<NK, NS, true, 1>;
+    const void* fn1 = bwd ? (with_side ? (const void*)ks1 : (const void*)kb1) : (const void*)kf1;
+    hipError_t e1 = hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e1)); return (int)e1; }
+    if (with_side) hipLaunchKernelGGL(ks1, dim3(grid + sd.total), dim3(MB2_NW * 64), lds, st, p, sd);
+    else if (bwd) hipLaunchKernelGGL(kb1, dim3(grid), dim3(MB2_NW * 64), lds, st, p, sd);
+    else hipLaunchKernelGGL(kf1, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
+    EP_LAUNCH_CHECK(bwd ? "ep_pool_mb2_bwd_kernel (single product)" : "ep_pool_mb2_fwd_kernel (single product)");
     return 0;
   }
   auto kf = ep_pool_mb2_fwd_kernel<NK, NS>;

@@ -62,6 +62,45 @@ def test_train_logits_within_the_reference_bf16_heads_distance(case):
     assert d <= 4.0 * 2.0 ** -8 * scale
 
 
+MB2_CASES = [c for c in AMP_CASES if c.D in (256, 384, 512, 768, 1024) and c.Q <= 16 and not getattr(c, "strided", False)]
+
+
+@pytest.mark.parametrize("case", MB2_CASES, ids=lambda c: c.name)
+def test_bf16_stored_tokens_run_single_product_passes(case):
+    """bf16-STORED tokens are what autocast makes of the tokens inside the reference's matmuls, so this is the closest form of
+    the published arithmetic: the token passes (csrc/ep_pool_mb.hip, mb2 kernels with NT = 1) multiply bf16(query) x token and
+    bf16(weight) x token as one product as well.  Same bound against the reference's bf16-autocast head."""
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    from efficient_probing_amd import _native
+    g = np.load(os.path.join(GOLD, f"ep_{case.name}.npz"))
+    if "logits_bf16_autocast" not in g.files:
+        pytest.skip("fixture without the bf16-autocast forward")
+    inp = make_inputs(case)
+    x = _tokens(case, inp["x_buf"]).to(torch.bfloat16)
+    t = torch.from_numpy(inp["targets"]).to(DEV)
+    lib = _native.load()
+    assert "mb2" in lib.ep_pool_kernel_name_ex(case.B, x.shape[1], case.D, case.Q, 0, _native.EP_DTYPE_BF16).decode()
+    out = {}
+    for mode in ("fp32", "bf16_autocast"):
+        eng = ProbeHeadEngine(_head(case, inp), optimizer="sgd", lr=0.0, arithmetic=mode)
+        eng.train_step(x, t, lr=0.0)
+        loss, _, _, bad = eng.read_stats()
+        assert bad == 0 and int(eng.found_inf.item()) == 0
+        out[mode] = (eng.last_train_logits().cpu().numpy(), loss)
+    scale = float(np.abs(g["logits"]).max())
+    d = float(np.abs(out["bf16_autocast"][0] - out["fp32"][0]).max())
+    assert 1e-5 * scale < d <= 4.0 * 2.0 ** -8 * scale, d / (2.0 ** -8 * scale)
+    assert_amp_bf16_fidelity(out["bf16_autocast"][0], out["bf16_autocast"][1], g, err_msg=case.name)
+    # gradients: three steps of LARS in both modes stay close (the update is a trust-ratio-normalised direction)
+    e32 = ProbeHeadEngine(_head(case, inp), optimizer="lars", lr=0.1, arithmetic="fp32")
+    e16 = ProbeHeadEngine(_head(case, inp), optimizer="lars", lr=0.1, arithmetic="bf16_autocast")
+    for _ in range(3):
+        e32.train_step(x, t, lr=0.1); e16.train_step(x, t, lr=0.1)
+    for a, b in zip(e32.params_list, e16.params_list):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        assert float((a - b).norm() / a.norm()) < 2e-2
+
+
 def test_short_training_run_follows_the_fp32_mode():
     """40 LARS steps at the published learning-rate scale on a learnable synthetic problem: the loss curve of the AMP mode
     stays within 2 % of the fp32 mode's at every step and ends as low."""
