@@ -1108,6 +1108,8 @@ __global__ __launch_bounds__(MB2_NW * 64, 2) void ep_pool_mb2_bwd_kernel(PoolPar
 // two barriers per 24 KiB tile on one workgroup per CU, moved 4.4 TB/s; 32-token tiles halve the rendezvous per byte.)
 // D = 128 k (k = 2, 3, 4, 6).
 // =======================================================================================
+int mb2_launch_amp(int NK, bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side, size_t lds);
+#ifndef EP_MB_AMP_TU
 constexpr int MBQ_NW = 8, MBQ_KQ = 4;
 #ifndef EP_MBQ_ABLATE
 #define EP_MBQ_ABLATE 0               // diagnostic builds of the forward: 1 ring + barriers only, 2 no pooling, 4 no score MFMAs; results are wrong
@@ -1473,20 +1475,7 @@ static int mb2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t s
     *g_mb_occ_query = nb;
     return 0;
   }
-  if (p.nterms == 1) {                               // AMP-bf16 arithmetic: single-product passes (the step runs no in-pass dP then)
-    if (p.ip_dy) { set_error("the single-product (AMP-bf16) bf16-token passes carry no in-pass dP"); return EP_E_UNSUPPORTED; }
-    auto kf1 = ep_pool_mb2_fwd_kernel<NK, NS, 1>;
-    auto kb1 = ep_pool_mb2_bwd_kernel<NK, NS, false, 1>;
-    auto ks1 = ep_pool_mb2_bwd_kernel<NK, NS, true, 1>;
-    const void* fn1 = bwd ? (with_side ? (const void*)ks1 : (const void*)kb1) : (const void*)kf1;
-    hipError_t e1 = hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e1)); return (int)e1; }
-    if (with_side) hipLaunchKernelGGL(ks1, dim3(grid + sd.total), dim3(MB2_NW * 64), lds, st, p, sd);
-    else if (bwd) hipLaunchKernelGGL(kb1, dim3(grid), dim3(MB2_NW * 64), lds, st, p, sd);
-    else hipLaunchKernelGGL(kf1, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
-    EP_LAUNCH_CHECK(bwd ? "ep_pool_mb2_bwd_kernel (single product)" : "ep_pool_mb2_fwd_kernel (single product)");
-    return 0;
-  }
+  if (p.nterms == 1) return mb2_launch_amp(NK, bwd, p, grid, st, with_side ? &sd : nullptr, lds);   // single-product instances: ep_pool_mb_amp.hip
   auto kf = ep_pool_mb2_fwd_kernel<NK, NS>;
   auto kb = ep_pool_mb2_bwd_kernel<NK, NS, false>;
   auto ks = ep_pool_mb2_bwd_kernel<NK, NS, true>;
@@ -1606,5 +1595,38 @@ int mb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st, const Sid
   set_error("no bf16 matrix-core pooling kernel for D=%d, Q=%d", p.D, p.Q);
   return EP_E_UNSUPPORTED;
 }
+
+#else   // EP_MB_AMP_TU: the single-product (AMP-bf16, NT = 1) instances of the mb2 kernels, a translation unit of their own
+          // (ep_pool_mb_amp.hip) so that they compile beside this file instead of behind it
+template <int NK, int NS>
+static int mb2_launch_amp_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side, size_t lds) {
+  if (p.ip_dy) { set_error("the single-product (AMP-bf16) bf16-token passes carry no in-pass dP"); return EP_E_UNSUPPORTED; }
+  const bool with_side = bwd && side && side->total > 0;
+  SideTasks sd{};
+  if (with_side) sd = *side;                          // (first_block set by the caller)
+  auto kf1 = ep_pool_mb2_fwd_kernel<NK, NS, 1>;
+  auto kb1 = ep_pool_mb2_bwd_kernel<NK, NS, false, 1>;
+  auto ks1 = ep_pool_mb2_bwd_kernel<NK, NS, true, 1>;
+  const void* fn1 = bwd ? (with_side ? (const void*)ks1 : (const void*)kb1) : (const void*)kf1;
+  hipError_t e1 = hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e1 != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e1)); return (int)e1; }
+  if (with_side) hipLaunchKernelGGL(ks1, dim3(grid + sd.total), dim3(MB2_NW * 64), lds, st, p, sd);
+  else if (bwd) hipLaunchKernelGGL(kb1, dim3(grid), dim3(MB2_NW * 64), lds, st, p, sd);
+  else hipLaunchKernelGGL(kf1, dim3(grid), dim3(MB2_NW * 64), lds, st, p);
+  EP_LAUNCH_CHECK(bwd ? "ep_pool_mb2_bwd_kernel (single product)" : "ep_pool_mb2_fwd_kernel (single product)");
+  return 0;
+}
+int mb2_launch_amp(int NK, bool bwd, const PoolParams& p, int grid, hipStream_t st, const SideTasks* side, size_t lds) {
+  switch (NK) {
+    case 2: return mb2_launch_amp_one<2, 3>(bwd, p, grid, st, side, lds);
+    case 3: return mb2_launch_amp_one<3, 3>(bwd, p, grid, st, side, lds);
+    case 4: return mb2_launch_amp_one<4, 3>(bwd, p, grid, st, side, lds);
+    case 6: return mb2_launch_amp_one<6, 3>(bwd, p, grid, st, side, lds);
+    case 8: return mb2_launch_amp_one<8, 2>(bwd, p, grid, st, side, lds);
+  }
+  set_error("mb2_launch_amp: no instance for NK = %d", NK);
+  return EP_E_UNSUPPORTED;
+}
+#endif  // EP_MB_AMP_TU
 
 }  // namespace ep
