@@ -445,7 +445,10 @@ const char* pool_kernel_family(int B, int N, int D, int Q, int bwd, int x_bf16) 
   p.B = B; p.N = N; p.D = D; p.Q = Q; p.x_bf16 = x_bf16;
   if (x_bf16 == 2) return bwd ? "(none: fp16-stored tokens are forward only)" : (stream_plan(B, N, D, Q).ok && !force_generic() ? "ep_pool_fwd_kernel" : "ep_pool_fwd_generic_kernel");
   if (const int qc = query_chunk(p, bwd != 0)) p.Q = qc;          // (the family the chunks run on)
-  if (use_wide(p)) return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
+  if (use_wide(p)) {
+    if (wideb_supported(p.D, p.Q, p.cls_bstride, p.x_bf16, bwd) && !p.tokstat) return bwd ? "ep_pool_wideb_bwd_kernel" : "ep_pool_wideb_fwd_kernel";
+    return bwd ? "ep_pool_wide_bwd_kernel" : "ep_pool_wide_fwd_kernel";
+  }
   if (use_mb(p)) return mb_kernel_name(D, bwd != 0);
   if (use_mbq(p)) return bwd ? "ep_pool_mbq_bwd_kernel" : "ep_pool_mbq_fwd_kernel";
   if (use_mm2(p, bwd != 0)) return bwd ? "ep_pool_mm2_bwd_kernel" : "ep_pool_mm2_fwd_kernel";

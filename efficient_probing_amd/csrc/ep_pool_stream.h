@@ -88,6 +88,9 @@ const char* mb_kernel_name(int D, bool bwd);
 bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16 = 0);
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 int wide_grid(int D, int B, int x_bf16 = 0);
+// ep_pool_wideb.hip: bf16-stored wide rows, scores on the matrix cores (EP_POOL_WIDEB=1)
+bool wideb_supported(int D, int Q, int64_t cls_bstride, int x_bf16, bool bwd);
+int wideb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // LayerNorm-of-tokens mode (PoolParams.tokstat) in the vector-ALU streaming kernels
 bool stream_ln_supported(int D, int Q);
 bool stream_ln_bf16_supported(int D, int Q);

@@ -389,6 +389,7 @@ static int wide_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t 
 }
 
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
+  if (wideb_supported(p.D, p.Q, p.cls_bstride, p.x_bf16, bwd) && !p.tokstat) return wideb_launch(bwd, p, grid, st);
   if (p.x_bf16) {
     if (p.D == 2048) return wide_launch_one<2, 4, true>(bwd, p, grid, st);      // 4 waves x 512-element slices
     if (p.D == 4096) return wide_launch_one<2, 8, true>(bwd, p, grid, st);
