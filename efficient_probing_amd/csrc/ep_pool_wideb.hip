@@ -336,8 +336,12 @@ bool wideb_supported(int D, int Q, int64_t cls_bstride, int x_bf16, bool bwd) {
 int wideb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
   const void* fn = bwd ? (const void*)ep_pool_wideb_bwd_kernel : (const void*)ep_pool_wideb_fwd_kernel;
   const size_t lds = bwd ? WB_LDS_BWD : WB_LDS;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+  static bool attr_set[2] = {false, false};          // (once per kernel: the call is host-side state, not a stream operation)
+  if (!attr_set[bwd ? 1 : 0]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+    attr_set[bwd ? 1 : 0] = true;
+  }
   if (bwd) hipLaunchKernelGGL(ep_pool_wideb_bwd_kernel, dim3(grid), dim3(WB_NW * 64), lds, st, p);
   else hipLaunchKernelGGL(ep_pool_wideb_fwd_kernel, dim3(grid), dim3(WB_NW * 64), lds, st, p);
   EP_LAUNCH_CHECK(bwd ? "ep_pool_wideb_bwd_kernel" : "ep_pool_wideb_fwd_kernel");
