@@ -489,7 +489,12 @@ static bool gemm_kk96_ok(bool a_k, bool b_k, const GemmParams& p, int batch) {
   if (!on || !a_k || !b_k || p.N % 96 != 0 || p.N % 64 == 0 || p.K % BK != 0 || p.K < BK || p.M < 1) return false;
   // worth it where the 64x64 tiling wastes tiles and the 32-row grid still fills the chip
   const long tiles = (long)(p.N / 96) * ((p.M + 31) / 32) * batch;
-  return tiles >= cu_count();
+  // from a quarter of the CU count on (EP_GEMM_KK96_MIN_PCT; until round 5: all of it): the value projection of 512 / 256 images
+  // (128 / 64 tiles of 32 x 96) -- the per-GPU batches of the 8- and 16-GPU protocol points -- took 18.8 us on the 64-column
+  // kernel, a third of whose columns are padding there: 256 x 768 steps 0.2538 -> 0.2497 ms (B = 512), 0.1969 -> 0.1926 (B = 256)
+  static int min_pct = -1;
+  if (min_pct < 0) { const char* e = getenv("EP_GEMM_KK96_MIN_PCT"); min_pct = e ? atoi(e) : 25; }
+  return tiles * 100 >= (long)cu_count() * min_pct;
 }
 
 static void gemm_launch_dma(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
