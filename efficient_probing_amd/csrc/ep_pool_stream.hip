@@ -662,7 +662,7 @@ static int launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t st, c
     static int b3_env = -2;
     if (b3_env == -2) { const char* e = getenv("EP_SIDE_B3"); b3_env = e ? atoi(e) : -1; }
     if (b3_env >= 0) sd.b3 = sd.b3 && b3_env;
-    else if (sd.total <= 1024) sd.b3 = 0;
+    else if (sd.total <= 1024 && sd.g[0].nterms != 1) sd.b3 = 0;    // (AMP-bf16: the single-product tile has no split to pay for)
     if (lds < SIDE_LDS_BYTES) lds = SIDE_LDS_BYTES;
     static int early = -1;
     if (early < 0) { const char* e = getenv("EP_SIDE_EARLY"); early = e ? atoi(e) : 0; }
