@@ -164,6 +164,14 @@ def test_constructor_validation_and_no_cpu_fallback():
     probe_heads.build_probe_head(enc, _args(ep_queries=4, nb_classes=10))
     with pytest.raises(RuntimeError, match="GPU"):
         ProbeHeadEngine(enc.head)
+    # the arithmetic switch (ep_head_step.arith): two names, checked before anything touches a device
+    with pytest.raises(ValueError, match="arithmetic"):
+        ProbeHeadEngine(enc.head, arithmetic="fp8")
+    with pytest.raises(RuntimeError, match="GPU"):
+        ProbeHeadEngine(enc.head, arithmetic="bf16_autocast")
+    from efficient_probing_amd import _native
+    assert (_native.EP_ARITH_F32, _native.EP_ARITH_BF16_AUTOCAST) == (0, 1)
+    assert [n for n, _ in _native.EPHeadStep._fields_][-2:] == ["planes_valid", "arith"]      # ABI v25: appended, nothing moved
 
 
 def test_lr_schedule_matches_reference_table():
