@@ -58,8 +58,9 @@ __device__ __forceinline__ float wb_sum8(float v) {
 // The three bf16 terms of this wave's query slice as MFMA A operands: lane (row r = lane & 15, k-group kk) holds, for K-step
 // ks, the 8 columns 32 ks + 8 kk .. + 7 of row r: rows 0..7 = (query r, hi), rows 8..15 = (query r - 8, mid) in `hm`;
 // rows 0..7 = (query r, lo), rows 8..15 = 0 in `lo`.  `src` = the fp32 rows (row stride ld), scaled by `scale`.
+// `one` (PoolParams.nterms == 1, the AMP-bf16 arithmetic mode): the operand rounded to bf16 only -- rows 8..15 and `lo` are zero.
 __device__ __forceinline__ void wb_query_terms(const float* src, int64_t ld, int nrows, float scale, int sbase, int lane,
-                                               pl_u4 (&hm)[WB_KS], pl_u4 (&lo)[WB_KS]) {
+                                               pl_u4 (&hm)[WB_KS], pl_u4 (&lo)[WB_KS], bool one) {
   const int r = lane & 15, kk = lane >> 4, q = r & 7;
 #pragma unroll
   for (int ks = 0; ks < WB_KS; ++ks) {
@@ -72,14 +73,14 @@ __device__ __forceinline__ void wb_query_terms(const float* src, int64_t ld, int
     }
     pl_u4 t[3];
     pl_split8(v, t);
-    hm[ks] = r < 8 ? t[0] : t[1];
-    lo[ks] = r < 8 ? t[2] : pl_u4{0u, 0u, 0u, 0u};
+    hm[ks] = r < 8 ? t[0] : (one ? pl_u4{0u, 0u, 0u, 0u} : t[1]);
+    lo[ks] = (r < 8 && !one) ? t[2] : pl_u4{0u, 0u, 0u, 0u};
   }
 }
 
 // partial scores of this wave's slice for the 8 x 8 (query, token) pairs of the tile -> its 16 entries of the exchange buffer
 // (entry 8 h + t = queries 4 h .. 4 h + 3 of token t)
-__device__ __forceinline__ void wb_scores(const char* tile, const pl_u4 (&hm)[WB_KS], const pl_u4 (&lo)[WB_KS], char* scr_w, int lane) {
+__device__ __forceinline__ void wb_scores(const char* tile, const pl_u4 (&hm)[WB_KS], const pl_u4 (&lo)[WB_KS], char* scr_w, int lane, bool one) {
   const int t = lane & 7, kk = lane >> 4;            // (lanes 8..15 of a row repeat tokens 0..7: the MFMA has 16 columns)
   // One accumulator chain, the B operand of K-step ks + 1 fetched before the two matrix instructions of K-step ks (measured on
   // one box, 1024 x 196 x 4096: read -> wait -> multiply per K-step 455 us; two chains with two operands in flight 504 us and
@@ -94,10 +95,10 @@ __device__ __forceinline__ void wb_scores(const char* tile, const pl_u4 (&hm)[WB
 #pragma unroll
   for (int ks = 0; ks < WB_KS; ks += 2) {
     b1 = *reinterpret_cast<const pl_u4*>(bo + 64 * (ks + 1));
-    if constexpr (!(EP_WB_ABLATE & 2)) { tot = pl_mfma(lo[ks], b0, tot); tot = pl_mfma(hm[ks], b0, tot); }
+    if constexpr (!(EP_WB_ABLATE & 2)) { if (!one) tot = pl_mfma(lo[ks], b0, tot); tot = pl_mfma(hm[ks], b0, tot); }
     else tot[0] += __uint_as_float(b0[0] ^ lo[ks][1] ^ hm[ks][2]);
     if (ks + 2 < WB_KS) b0 = *reinterpret_cast<const pl_u4*>(be + 64 * (ks + 2));
-    if constexpr (!(EP_WB_ABLATE & 2)) { tot = pl_mfma(lo[ks + 1], b1, tot); tot = pl_mfma(hm[ks + 1], b1, tot); }
+    if constexpr (!(EP_WB_ABLATE & 2)) { if (!one) tot = pl_mfma(lo[ks + 1], b1, tot); tot = pl_mfma(hm[ks + 1], b1, tot); }
     else tot[1] += __uint_as_float(b1[0] ^ lo[ks + 1][1] ^ hm[ks + 1][2]);
   }
   // rows 0..7 (k-groups 0, 1) hold hi + lo, rows 8..15 (k-groups 2, 3) mid: add the two 32-lane halves
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(WB_NW * 64, 1) void ep_pool_wideb_fwd_kernel(PoolPa
   if (n_items <= 0) return;
 
   pl_u4 qhm[WB_KS], qlo[WB_KS];
-  wb_query_terms(p.cls, D, Q, p.scale, sbase, lane, qhm, qlo);
+  const bool one = p.nterms == 1;
+  wb_query_terms(p.cls, D, Q, p.scale, sbase, lane, qhm, qlo, one);
 
   int pi = 0, pimg = 0, ptile = 0;
   auto produce = [&]() {
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(WB_NW * 64, 1) void ep_pool_wideb_fwd_kernel(PoolPa
     }
     const char* tile = ring + (i & 1) * WB_SLOTB;
     char* sb = scr + (i & 1) * WB_SCR;
-    wb_scores(tile, qhm, qlo, sb + w * 256, lane);
+    wb_scores(tile, qhm, qlo, sb + w * 256, lane, one);
     float u;
     if constexpr (EP_WB_ABLATE & 4) u = *reinterpret_cast<const float*>(sb + w * 256 + (lane & 15) * 16);
     else { wb_barrier(); u = wb_gather(sb, lane); }
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(WB_NW * 64, 1) void ep_pool_wideb_bwd_kernel(PoolPa
   const int n_items = n_img * tiles_per_img;
   const int myq = lane >> 3, myt = lane & 7;
   const int sq = myq < Q ? myq : Q - 1;
+  const bool one = p.nterms == 1;
 
   f4 gacc[8][2];
 #pragma unroll
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(WB_NW * 64, 1) void ep_pool_wideb_bwd_kernel(PoolPa
       if (ctile == 0) {
         // image header: this wave's slice of dP[b] as matrix operands and the softmax statistics of my query (plain loads: the
         // wait for them also drains the DMA in flight -- one bubble per image)
-        wb_query_terms(p.dP + (int64_t)b * QS * D, D, Q, 1.0f, sbase, lane, ghm, glo);
+        wb_query_terms(p.dP + (int64_t)b * QS * D, D, Q, 1.0f, sbase, lane, ghm, glo, one);
         const f4 ml = *reinterpret_cast<const f4*>(p.ML + ((int64_t)b * QS + sq) * 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mLq = ml.x * WB_LOG2E; il = 1.0f / ml.y; dl = ml.z;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(WB_NW * 64, 1) void ep_pool_wideb_bwd_kernel(PoolPa
       const char* tile = ring + (i & 1) * WB_SLOTB;
       char* sb = scr + (i & 1) * WB_SCR;
       const float sraw = *reinterpret_cast<const float*>(sraw_ring + (i & 1) * WB_SRAW + lane * 4);
-      wb_scores(tile, ghm, glo, sb + w * 256, lane);
+      wb_scores(tile, ghm, glo, sb + w * 256, lane, one);
       wb_barrier();
       const float dA = wb_gather(sb, lane);
       const float a = __builtin_amdgcn_exp2f(fmaf(sraw, WB_LOG2E, -mLq)) * il;

@@ -101,6 +101,37 @@ def test_bf16_stored_tokens_run_single_product_passes(case):
         assert float((a - b).norm() / a.norm()) < 2e-2
 
 
+def test_wide_bf16_rows_in_the_amp_mode_against_the_vit7b_golden():
+    """196 x 4096 with bf16-stored tokens: the hybrid passes (csrc/ep_pool_wideb.hip) multiply bf16(query) x token only in this
+    mode; same bound against the reference's bf16-autocast head on the ViT-7B fixture."""
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    case = [c for c in CASES if c.name == "vit7b_q8"][0]
+    g = np.load(os.path.join(GOLD, f"ep_{case.name}.npz"))
+    if "logits_bf16_autocast" not in g.files:
+        pytest.skip("fixture without the bf16-autocast forward")
+    inp = make_inputs(case)
+    x = _tokens(case, inp["x_buf"]).to(torch.bfloat16)
+    t = torch.from_numpy(inp["targets"]).to(DEV)
+    out = {}
+    for mode in ("fp32", "bf16_autocast"):
+        eng = ProbeHeadEngine(_head(case, inp), optimizer="sgd", lr=0.0, arithmetic=mode)
+        eng.train_step(x, t, lr=0.0)
+        loss, _, _, bad = eng.read_stats()
+        assert bad == 0
+        out[mode] = (eng.last_train_logits().cpu().numpy(), loss)
+    scale = float(np.abs(g["logits"]).max())
+    d = float(np.abs(out["bf16_autocast"][0] - out["fp32"][0]).max())
+    assert 1e-5 * scale < d <= 4.0 * 2.0 ** -8 * scale, d / (2.0 ** -8 * scale)
+    assert_amp_bf16_fidelity(out["bf16_autocast"][0], out["bf16_autocast"][1], g, err_msg=case.name)
+    e32 = ProbeHeadEngine(_head(case, inp), optimizer="lars", lr=0.1, arithmetic="fp32")
+    e16 = ProbeHeadEngine(_head(case, inp), optimizer="lars", lr=0.1, arithmetic="bf16_autocast")
+    for _ in range(2):
+        e32.train_step(x, t, lr=0.1); e16.train_step(x, t, lr=0.1)
+    for a, b in zip(e32.params_list, e16.params_list):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        assert float((a - b).norm() / a.norm()) < 2e-2
+
+
 def test_short_training_run_follows_the_fp32_mode():
     """40 LARS steps at the published learning-rate scale on a learnable synthetic problem: the loss curve of the AMP mode
     stays within 2 % of the fp32 mode's at every step and ends as low."""
