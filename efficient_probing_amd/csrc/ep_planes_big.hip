@@ -412,7 +412,9 @@ bool planes_big_wanted(const GemmParams& p, int batch) {
     if (amp_big < 0) { const char* e = getenv("EP_PLANES_BIG_AMP"); amp_big = e ? atoi(e) : 1; }
     return amp_big && tiles >= 192 && p.K >= 256;
   }
-  return tiles >= 192 && p.K >= 2048;
+  // ... and the token-matrix contractions of the matrix-core-bound heads (65536 rows: >= 2048 tiles): 1167 -> 1099 us at
+  // 65536 x 1152 x 1152, 543 -> 501 us at N = 512, 2034 -> 1942 us at 65536 x 768 x 3072; 288 tiles of K = 1152: 90 -> 104 us (not taken)
+  return (tiles >= 192 && p.K >= 2048) || (tiles >= 2048 && p.K >= 512);
 }
 
 template <int NT>
