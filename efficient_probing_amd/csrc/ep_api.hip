@@ -804,6 +804,54 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     const GemmParams gWv = dwv_gemm(w.dy, w.P, d.B, d.D, Dp, d.Q, s->grads + offs[1], s->accumulate);
     p.dP = w.dP; p.Gpart = static_cast<float*>(w.pool_ws);
     if (ipmask) { p.ip_zero = w.ycnt; p.ip_nzero = w.nrb * 32; }            // the second pass clears the first pass's counters
+    // Round 6, the default wherever the classifier's contractions run on the planes kernel: the side work leaves the second token
+    // pass.  dWc = dlogits^T z, the bias column sum and the statistics fold ride in the launch of dz = dlogits Wc (their
+    // operands exist behind the loss kernel), dWv_q = dy_q^T P_q in the launch of dP = dy_q Wv_q (mode 1; otherwise it stays
+    // with the pass) -- ep_planes.hip: ep_gemm_planes_side_kernel.  The pass then streams alone.  EP_CHAIN=0: the round-5 schedule.
+    static int chain_on = -1;
+    if (chain_on < 0) { const char* e = getenv("EP_CHAIN"); chain_on = e ? atoi(e) : 1; }
+    if (chain_on && plc && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
+      SideTasks sd1{};
+      side_add_gemm(sd1, gWc, 1);
+      sd1.cs_src = w.dlogits; sd1.cs_out = s->grads + offs[3]; sd1.cs_B = d.B; sd1.cs_ncol = d.C; sd1.cs_ld = w.ldl;
+      sd1.cs_accumulate = s->accumulate; sd1.n_colsum = (d.C + 15) / 16;
+      sd1.rowstat = w.rowstat; sd1.stats = s->stats; sd1.rs_B = d.B; sd1.n_stats = 1;
+      sd1.total += sd1.n_colsum + sd1.n_stats;
+      EP_TRY(gemm_planes_side(planes_gemm(w.dlogits, w.ldl, 0, w.plWcT, Dp, d.C, 0, w.dz, Dp, 0, d.B, Dp, d.C, nullptr), 1, sd1, st));
+      EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
+      const bool in_pass = pool_backward_takes_delta(p, Dp);
+      const bool ip_dp = (ipmask & 2) != 0;                              // (mode 2 only: the mask is 0 when the projections run on the planes)
+      if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
+      if (ip_dp) { p.ip_dy = w.dy; p.ip_Wv = Wv; p.ip_dcnt = w.dcnt; }
+      if ((ipmask & 4) && in_pass) p.tick = w.tick;
+      SideTasks sd2{};
+      side_add_gemm(sd2, gWv, d.Q);
+      const bool pass_side = pool_backward_takes_side(p);
+      hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
+      hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+      if (pl) {
+        if (!in_pass) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
+        const int Dq = Dp / d.Q;
+        EP_TRY(gemm_planes_side(planes_gemm(w.dy, Dp, Dq, w.plWvT, d.D, Dp, Dq, w.dP, (int64_t)d.Q * d.D, d.D, d.B, d.D, Dq, nullptr), d.Q, sd2, st));
+      } else {
+        if (!pass_side) {                                                // dWv on the side queue, started in front of dP
+          if (side != st) {
+            EP_TRY(get_events(ev, 4));
+            EP_HIP(hipEventRecord(ev[1], st));
+            EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
+          }
+          EP_TRY(project_backward(w.dy, nullptr, w.P, Wv, d.B, d.D, Dp, d.Q, nullptr, s->grads + offs[1], nullptr, s->accumulate, side));
+        }
+        EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, ip_dp ? nullptr : w.dP, nullptr, in_pass ? nullptr : w.ML, 0, st));
+      }
+      mark_pass(2, st);
+      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, (!pl && pass_side) ? &sd2 : nullptr, (s->phases & 2) ? &red : nullptr));
+      mark_pass(3, st);
+      if (!pl && !pass_side && side != st) {
+        EP_HIP(hipEventRecord(ev[2], side));
+        EP_HIP(hipStreamWaitEvent(st, ev[2], 0));                        // join: grads complete on `stream`
+      }
+    } else
     if (pool_backward_takes_side(p) && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
       // the softmax-correction rows dy_q . y_q: inside the second pass where its kernel can (one launch less)
       const bool in_pass = pool_backward_takes_delta(p, Dp);

@@ -104,6 +104,9 @@ int planes_split(const PlaneSpec* specs, int n, hipStream_t st);
 bool gemm_planes_ok(const GemmParams& p);
 // C[z] (+)= alpha * A[z] W[z]^T (+ bias): A fp32 with K contiguous (lda), W given as planes (Bpl ...); fp32 accuracy
 int gemm_planes(const GemmParams& p, int batch, hipStream_t st);
+struct SideTasks;
+// ... with side tasks (ep_sidetask.h: weight-gradient contractions, column sums, the statistics fold) as extra workgroups of the launch
+int gemm_planes_side(const GemmParams& p, int batch, const SideTasks& sd, hipStream_t st);
 bool planes_big_wanted(const GemmParams& p, int batch);      // ep_planes_big.hip: 128 x 128 tiles (large contractions)
 void planes_big_launch(const GemmParams& p, int batch, hipStream_t st);
 // dst (C x R, ldd) = src (R x C, lds_)^T, fp32 (ep_planes.hip)

@@ -60,6 +60,7 @@
 // (planes of W^T, for the two backward contractions that sum over W's row index) is produced in the same launch through
 // an LDS transpose.
 #include "ep_planes_dev.h"
+#include "ep_sidetask.h"
 
 namespace ep {
 
@@ -193,25 +194,15 @@ __device__ __forceinline__ void pl_split_uops(PlSplit& s, const f4v (&x)[2], pl_
   if constexpr (U0 < U1) { pl_split_uop<U0>(s, x, a); pl_split_uops<U0 + 1, U1>(s, x, a); }
 }
 
-template <int NB, int NT>
-__global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
-  constexpr int NST = PlGeom<NB, NT>::nst, PLG_STB = PlGeom<NB, NT>::stb, NPC = PlGeom<NB, NT>::npc;
-  extern __shared__ __attribute__((aligned(1024))) char lds[];
+// The tile body: one 64 x (16 NB) output tile (mt_, nt_) of batch entry z_, all 12 waves of the workgroup (the loader waves
+// and the odd-parity multiply waves leave through `return`: the callers do nothing behind it).  NST = ring stages.
+template <int NB, int NT, int NST>
+__device__ __forceinline__ void pl_tile_body(const GemmParams& p, char* lds, int mt_, int nt_, int z_) {
+  constexpr int PLG_STB = PlGeom<NB, NT>::stb, NPC = PlGeom<NB, NT>::npc;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 multiply, 8..11 only move data
   const int i16 = lane & 15, kk = lane >> 4;
-  int mt_ = blockIdx.y, nt_ = blockIdx.x, z_ = blockIdx.z;
-  if (p.m_fast) {
-    // 1-D launch, M-tiles fastest, XCD-aware: workgroup L runs on XCD L % 8, so XCD c walks the contiguous range of tile
-    // numbers [c per, (c + 1) per) -- the M-tiles of one weight tile are neighbours in time on ONE XCD's L2
-    const int mtn = (p.M + 63) / 64, ntn = (p.N + 16 * NB - 1) / (16 * NB);
-    const unsigned per = gridDim.x / 8u, L = blockIdx.x;
-    const unsigned V = (L % 8u) * per + L / 8u;
-    if (V >= (unsigned)mtn * (unsigned)ntn * (unsigned)p.zn) return;
-    const unsigned r = V / (unsigned)mtn;
-    mt_ = (int)(V % (unsigned)mtn); nt_ = (int)(r % (unsigned)ntn); z_ = (int)(r / (unsigned)ntn);    // batched: z slowest
-  }
   const int m0 = mt_ * 64, n0 = nt_ * (16 * NB);
   const int z = z_;
   const int nk = (p.K + BK - 1) / BK;
@@ -368,6 +359,50 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
   store_acc_blocks<NB>(p, C, z, rb, cb, acc, kk, i16);
 }
 
+template <int NB, int NT>
+__global__ __launch_bounds__(768) void ep_gemm_planes_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  int mt_ = blockIdx.y, nt_ = blockIdx.x, z_ = blockIdx.z;
+  if (p.m_fast) {
+    // 1-D launch, M-tiles fastest, XCD-aware: workgroup L runs on XCD L % 8, so XCD c walks the contiguous range of tile
+    // numbers [c per, (c + 1) per) -- the M-tiles of one weight tile are neighbours in time on ONE XCD's L2
+    const int mtn = (p.M + 63) / 64, ntn = (p.N + 16 * NB - 1) / (16 * NB);
+    const unsigned per = gridDim.x / 8u, L = blockIdx.x;
+    const unsigned V = (L % 8u) * per + L / 8u;
+    if (V >= (unsigned)mtn * (unsigned)ntn * (unsigned)p.zn) return;
+    const unsigned r = V / (unsigned)mtn;
+    mt_ = (int)(V % (unsigned)mtn); nt_ = (int)(r % (unsigned)ntn); z_ = (int)(r / (unsigned)ntn);    // batched: z slowest
+  }
+  pl_tile_body<NB, NT, PlGeom<NB, NT>::nst>(p, lds, mt_, nt_, z_);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same contraction with SIDE WORK in its launch (round 6): the weight-gradient contractions of a head step (dWc =
+// dlogits^T z, dWv_q = dy_q^T P_q), the bias column sum and the statistics fold feed nothing before the optimizer.  Until
+// round 5 they rode in the launch of the second token pass (extra workgroups behind the pooling grid), where they cost the
+// HBM-bound pass 30 - 35 us (256 x 768: 173 - 197 us in the step against 143 us alone) -- or ran on aux streams beside it,
+// which costs more.  The critical-path contractions between the passes are one latency-bound 64 x 64 tile per CU with a
+// quarter of the chip idle: their launches carry the side work instead.  1-D grid: blocks [0, main) are the tiles of the
+// contraction (N-tiles fastest, then M-tiles, then the batch), blocks behind them run `side` with their first four waves
+// (ep_sidetask.h: 256-thread bodies; the other eight waves leave at once).  Four ring stages (80 KiB) so that two workgroups
+// -- a tile and a side block, or two side blocks -- share a CU.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PLS_NST = 4;
+template <int NB, int NT>
+__global__ __launch_bounds__(768) void ep_gemm_planes_side_kernel(GemmParams p, SideTasks side) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int mtn = (p.M + 63) / 64, ntn = (p.N + 16 * NB - 1) / (16 * NB);
+  const int main_blocks = mtn * ntn * p.zn;
+  const int L = blockIdx.x;
+  if (L >= main_blocks) {
+    if (threadIdx.x >= 256) return;
+    run_side_task(side, L - main_blocks, lds);
+    return;
+  }
+  const int r = L / ntn;
+  pl_tile_body<NB, NT, PLS_NST>(p, lds, r % mtn, L % ntn, r / mtn);
+}
+
 bool gemm_planes_ok(const GemmParams& p) {
   return p.Bpl && aligned16(p.A) && aligned16(p.Bpl) && p.lda % 4 == 0 && p.sAz % 4 == 0 && p.ldbp % 32 == 0 &&
          p.pl_term % 8 == 0 && p.sBpz % 8 == 0 && p.M > 0 && p.N > 0 && p.K > 0;
@@ -395,6 +430,27 @@ static bool planes_wide(const GemmParams& p, int batch) {
   if (force == -2) { const char* e = getenv("EP_PLANES_WIDE"); force = e ? atoi(e) : -1; }
   if (force >= 0) return force != 0;
   return (long)((p.N + 127) / 128) * ((p.M + 63) / 64) * batch >= 2 * 256;
+}
+
+template <int NB, int NT>
+static void planes_side_launch(const GemmParams& p, int batch, const SideTasks& sd, hipStream_t st) {
+  constexpr size_t ring = (size_t)PLS_NST * PlGeom<NB, NT>::stb;
+  constexpr int lds = (int)(ring > SIDE_LDS_BYTES ? ring : SIDE_LDS_BYTES);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_side_kernel<NB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  GemmParams q = p;
+  q.zn = batch; q.m_fast = 0;
+  const int main_blocks = ((p.N + 16 * NB - 1) / (16 * NB)) * ((p.M + 63) / 64) * batch;
+  hipLaunchKernelGGL((ep_gemm_planes_side_kernel<NB, NT>), dim3(main_blocks + sd.total), dim3(768), lds, st, q, sd);
+}
+// C[z] (+)= alpha * A[z] W[z]^T (+ bias) as gemm_planes, with the side tasks `sd` as extra workgroups of the same launch
+int gemm_planes_side(const GemmParams& p, int batch, const SideTasks& sd, hipStream_t st) {
+  EP_REQUIRE(gemm_planes_ok(p), EP_E_ALIGN, "gemm_planes_side: operands must be 16-byte aligned (A: lda %% 4; planes: row stride %% 32)");
+  if (sd.total <= 0) return gemm_planes(p, batch, st);
+  if (p.nterms == 1 || gemm_arith() == 1) planes_side_launch<4, 1>(p, batch, sd, st);
+  else planes_side_launch<4, 3>(p, batch, sd, st);
+  EP_LAUNCH_CHECK("ep_gemm_planes_side_kernel");
+  return 0;
 }
 
 int gemm_planes(const GemmParams& p, int batch, hipStream_t st) {

@@ -369,7 +369,8 @@ class ProbeHeadEngine:
         if (x.dim() != 3 or not x.is_cuda or targets.dtype is not torch.int64 or targets.device != self.device
                 or self._pending is not None or self._deferred):
             return False
-        B, Nn, D = x.shape
+        M, Nn, D = x.shape                                   # M = images in the token buffer (a store when image_index is given)
+        B = M
         dt = x.dtype
         if dt is torch.float32:
             code, al = N.EP_DTYPE_F32, 4
@@ -379,7 +380,7 @@ class ProbeHeadEngine:
             return False
         st0, st1, st2 = x.stride()
         xp = x.data_ptr()
-        if st2 != 1 or st1 != D or (B > 1 and (st0 < Nn * D or st0 % al != 0)) or xp % 16 != 0:
+        if st2 != 1 or st1 != D or (M > 1 and (st0 < Nn * D or st0 % al != 0)) or xp % 16 != 0:
             return False
         if image_index is not None:
             if image_index.dtype is not torch.int32 or not image_index.is_cuda or not image_index.is_contiguous():
@@ -395,9 +396,17 @@ class ProbeHeadEngine:
         ws = self._ws if self._ws_key == (B, Nn) else self._workspace(B, Nn)
         self.opt_step += 1
         fs.dims.B = B; fs.dims.N = Nn
-        fs.x = xp; fs.x_dtype = code; fs.x_bstride = st0 if B > 1 else Nn * D
+        # the stride belongs to the BUFFER (as functional.as_token_view): a one-element index batch into a strided store must
+        # still step by the store's stride
+        fs.x = xp; fs.x_dtype = code; fs.x_bstride = st0 if M > 1 else Nn * D
         fs.image_index = iptr
         fs.targets = targets.data_ptr()
+        # the BatchNorm buffers can be rebound between steps (load_state_dict(assign=True), head.to(...)): never step through a
+        # cached pointer
+        bn = self.bn
+        fs.running_mean = bn.running_mean.data_ptr(); fs.running_var = bn.running_var.data_ptr()
+        fs.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+        fs.bn_eps = bn.eps; fs.bn_momentum = bn.momentum
         fs.lr = self.lr if lr is None else lr
         fs.weight_decay = self.weight_decay; fs.momentum = self.momentum; fs.trust_coefficient = self.trust_coefficient
         fs.beta1, fs.beta2 = self.betas; fs.adam_eps = self.adam_eps

@@ -121,3 +121,33 @@ def test_extract_features_from_a_dumped_store_feeds_knn(tmp_path):
     top1, top5 = knn.knn_classifier(st["features"].to(DEV), st["targets"].to(DEV), st2["features"].to(DEV), st2["targets"].to(DEV),
                                     k=5, T=0.07, num_classes=5)
     assert top1 == 100.0                                                          # every image finds itself
+
+
+def test_one_image_index_batch_into_a_strided_store():
+    """the fast one-call step took the batch stride from the INDEX count -- a one-element index batch into a store
+    whose image stride is not N * D (the `tokens[:, 1:]` view) then stepped by N * D and trained on the wrong image."""
+    from efficient_probing_amd import probe_heads
+    from efficient_probing_amd.engine import ProbeHeadEngine
+    Nn, D, Q, C, M = 20, 256, 8, 12, 6
+    g = torch.Generator().manual_seed(11)
+    full = torch.randn(M, Nn + 1, D, generator=g).to(DEV)
+    store = full[:, 1:]                                      # image stride (Nn + 1) * D
+    tgt = torch.tensor([5], dtype=torch.int64, device=DEV)
+
+    def make():
+        class Enc(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.head = torch.nn.Linear(D, C)
+        torch.manual_seed(0)
+        e = Enc()
+        probe_heads.build_probe_head(e, Namespace(cls_features="ep", ep_queries=Q, d_out=1, nb_classes=C))
+        return ProbeHeadEngine(e.head.to(DEV).train(), optimizer="sgd", lr=0.3)
+    e1, e2 = make(), make()
+    for i in (4, 2):
+        idx = torch.tensor([i], dtype=torch.int32, device=DEV)
+        e1.train_step(store, tgt, image_index=idx)
+        e2.train_step(store[i:i + 1].contiguous(), tgt)
+    for a, b in zip(e1.params_list, e2.params_list):
+        assert torch.equal(a, b)
+    assert e1.read_stats() == e2.read_stats()
