@@ -111,9 +111,14 @@ static int head_planes_mode(const ep_head_dims& d) {
   // the AMP-bf16 arithmetic mode (ep_head_step.arith, gemm_arith()) runs all four against the planes whatever the width
   const int mode = gemm_arith() == 1 ? 1 : on >= 0 ? on : (d.D >= 2048 ? 1 : 2);
   if (!mode || d.D % 4 != 0 || Dp % 4 != 0) return 0;
-  if (mode == 1) return (Dp / d.Q) % 32 == 0 ? 1 : 0;
+  // mode 1 at any slice width since round 6: only dP = dy_q Wv_q contracts over a query's SLICE of the planes' permuted k-order
+  // (it needs the slice to start and end on a group of 32: head_planes_dp) -- elsewhere it falls back to the thin-slice /
+  // exact-f32 kernels while y, logits, dz (and in the AMP-bf16 mode the single-product weight gradients) stay on the planes.
+  // The fp32 mode keeps the round-5 choice (no planes at all) for such widths unless asked by EP_GEMM_PLANES=1.
+  if (mode == 1) return ((Dp / d.Q) % 32 == 0 || gemm_arith() == 1 || on == 1) ? 1 : 0;
   return 2;
 }
+static bool head_planes_dp(const ep_head_dims& d) { return ((d.D / d.d_out) / d.Q) % 32 == 0; }
 static bool head_planes_ok(const ep_head_dims& d) { return head_planes_mode(d) != 0; }
 // The weight gradients dWv = dy^T P and dWc = dlogits^T z (sums over the batch index) on the planes kernel as well
 // (EP_PLANES_WGRAD, default on in mode 1): the activation that plays the weight -- P, z -- is split into planes of its
@@ -682,16 +687,18 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   const ep_head_dims& d = s->dims;
   EP_TRY(check_dims(d));
   EP_REQUIRE(aligned16(ws), EP_E_ALIGN, "workspace must be 16-byte aligned");
-  HeadWs w = carve(d, ws);
-  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_train_step: workspace %zu < %zu", ws_bytes, w.total);
   EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
   EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_head_train_step: arith %d is neither EP_ARITH_F32 nor EP_ARITH_BF16_AUTOCAST", s->arith);
-  // the arithmetic mode of every contraction this call enqueues (restored on every return path)
+  // the arithmetic mode of every contraction this call enqueues (restored on every return path) -- set BEFORE the workspace
+  // is carved: which plane buffers exist depends on it when EP_GEMM_PLANES=0
   struct ArithScope { int old; explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); } ~ArithScope() { gemm_set_arith(old); } };
   const ArithScope arith_scope(s->arith);
+  HeadWs w = carve(d, ws);
+  EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_train_step: workspace %zu < %zu%s", ws_bytes, w.total,
+             s->arith == EP_ARITH_BF16_AUTOCAST ? " (the AMP-bf16 mode needs the weight planes: size the workspace with EP_GEMM_PLANES unset)" : "");
   if (s->arith == EP_ARITH_BF16_AUTOCAST) {
-    EP_REQUIRE(head_planes_mode(d) == 1, EP_E_UNSUPPORTED,
-               "ep_head_train_step: the AMP-bf16 arithmetic mode runs its contractions against the weight planes and needs (D / d_out / Q) %% 32 == 0 (D=%d d_out=%d Q=%d)", d.D, d.d_out, d.Q);
+    EP_REQUIRE(head_planes_mode(d) == 1 && w.plWv && w.plWc, EP_E_UNSUPPORTED,
+               "ep_head_train_step: the AMP-bf16 arithmetic mode runs its contractions against the weight planes (D and D / d_out multiples of 4; D=%d d_out=%d Q=%d)", d.D, d.d_out, d.Q);
     EP_REQUIRE((s->phases & (4 | 8 | 16 | 32)) == 0, EP_E_UNSUPPORTED, "ep_head_train_step: the AMP-bf16 arithmetic mode is implemented for whole steps (phases 1 | 2) only");
   }
   hipStream_t st = (hipStream_t)stream;
@@ -715,6 +722,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   // lands between phase 4 and phase 8, so the split runs in phase 8 on the main stream.
   const bool plc = head_planes_ok(d) && (s->phases & (1 | 8));           // classifier contractions on the planes kernel
   const bool pl = plc && head_planes_mode(d) == 1;                        // ... and the two projections
+  const bool pl_dp = pl && head_planes_dp(d);                             // dP against the planes of Wv^T (slices of whole k-groups only)
   hipEvent_t pev[2] = {nullptr, nullptr};
   bool split_done = false;
   if (plc && s->planes_valid) {
@@ -809,7 +817,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     // operands exist behind the loss kernel), dWv_q = dy_q^T P_q in the launch of dP = dy_q Wv_q (mode 1; otherwise it stays
     // with the pass) -- ep_planes.hip: ep_gemm_planes_side_kernel.  The pass then streams alone.  EP_CHAIN=0: the round-5 schedule.
     static int chain_on = -1;
-    if (chain_on < 0) { const char* e = getenv("EP_CHAIN"); chain_on = e ? atoi(e) : 1; }
+    if (chain_on < 0) { const char* e = getenv("EP_CHAIN"); chain_on = e ? atoi(e) : 0; }
     if (chain_on && plc && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
       SideTasks sd1{};
       side_add_gemm(sd1, gWc, 1);
@@ -829,7 +837,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       const bool pass_side = pool_backward_takes_side(p);
       hipStream_t side = s->aux_stream ? (hipStream_t)s->aux_stream : st;
       hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-      if (pl) {
+      if (pl_dp) {
         if (!in_pass) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         const int Dq = Dp / d.Q;
         EP_TRY(gemm_planes_side(planes_gemm(w.dy, Dp, Dq, w.plWvT, d.D, Dp, Dq, w.dP, (int64_t)d.Q * d.D, d.D, d.B, d.D, Dq, nullptr), d.Q, sd2, st));
@@ -845,9 +853,9 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
         EP_TRY(project_backward(w.dy, w.y, w.P, Wv, d.B, d.D, Dp, d.Q, ip_dp ? nullptr : w.dP, nullptr, in_pass ? nullptr : w.ML, 0, st));
       }
       mark_pass(2, st);
-      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, (!pl && pass_side) ? &sd2 : nullptr, (s->phases & 2) ? &red : nullptr));
+      EP_TRY(pool_backward(p, s->grads + offs[0], s->accumulate, st, (!pl_dp && pass_side) ? &sd2 : nullptr, (s->phases & 2) ? &red : nullptr));
       mark_pass(3, st);
-      if (!pl && !pass_side && side != st) {
+      if (!pl_dp && !pass_side && side != st) {
         EP_HIP(hipEventRecord(ev[2], side));
         EP_HIP(hipStreamWaitEvent(st, ev[2], 0));                        // join: grads complete on `stream`
       }
@@ -880,7 +888,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       if (in_pass) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
       if (ip_dp) { p.ip_dy = w.dy; p.ip_Wv = Wv; p.ip_dcnt = w.dcnt; }   // dP rows by the pooling workgroups themselves
       if ((ipmask & 4) && in_pass) p.tick = w.tick;                      // ... in the ticketed form (ep_pool_bwd2.hip)
-      if (pl) {
+      if (pl_dp) {
         if (!in_pass) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));
       } else {
@@ -936,7 +944,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       // the softmax-correction rows dy_q . y_q inside the second pass where its kernel can (the 32-query bf16 pass): one launch less
       const bool in_pass2 = pool_backward_takes_delta(p, Dp);
       if (in_pass2) { p.dyv = w.dy; p.yv = w.y; p.Dv = Dp; }
-      if (pl) {
+      if (pl_dp) {
         if (!in_pass2) EP_TRY(delta_rows(w.dy, w.y, d.B * d.Q, Dp / d.Q, w.ML, st));
         EP_TRY(project_backward_dP_pl(w, d, st));
       } else {
@@ -1072,11 +1080,8 @@ int ep_lp_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream
   // the arithmetic mode of every contraction this call enqueues (restored on every return path)
   struct ArithScope { int old; explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); } ~ArithScope() { gemm_set_arith(old); } };
   const ArithScope arith_scope(s->arith);
-  if (s->arith == EP_ARITH_BF16_AUTOCAST) {
-    EP_REQUIRE(head_planes_mode(d) == 1, EP_E_UNSUPPORTED,
-               "ep_head_train_step: the AMP-bf16 arithmetic mode runs its contractions against the weight planes and needs (D / d_out / Q) %% 32 == 0 (D=%d d_out=%d Q=%d)", d.D, d.d_out, d.Q);
-    EP_REQUIRE((s->phases & (4 | 8 | 16 | 32)) == 0, EP_E_UNSUPPORTED, "ep_head_train_step: the AMP-bf16 arithmetic mode is implemented for whole steps (phases 1 | 2) only");
-  }
+  // (BatchNorm + Linear on pooled features: the plain linear probe has no planes and runs fp32 only)
+  EP_REQUIRE(s->arith == EP_ARITH_F32, EP_E_UNSUPPORTED, "ep_lp_train_step: the AMP-bf16 arithmetic mode is implemented for the EP head's fused step only");
   hipStream_t st = (hipStream_t)stream;
   int64_t offs[2];
   const int64_t total = ep_lp_param_offsets(&d, offs);

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(768) void ep_gemm_planes_side_kernel(GemmParams p, 
   const int L = blockIdx.x;
   if (L >= main_blocks) {
     if (threadIdx.x >= 256) return;
-    run_side_task(side, L - main_blocks, lds);
+    run_side_task<true>(side, L - main_blocks, lds);
     return;
   }
   const int r = L / ntn;
@@ -435,7 +435,8 @@ static bool planes_wide(const GemmParams& p, int batch) {
 template <int NB, int NT>
 static void planes_side_launch(const GemmParams& p, int batch, const SideTasks& sd, hipStream_t st) {
   constexpr size_t ring = (size_t)PLS_NST * PlGeom<NB, NT>::stb;
-  constexpr int lds = (int)(ring > SIDE_LDS_BYTES ? ring : SIDE_LDS_BYTES);
+  constexpr size_t side_lds = SIDE_LDS_BYTES > w3d_lds_bytes<64>() ? SIDE_LDS_BYTES : w3d_lds_bytes<64>();
+  constexpr int lds = (int)(ring > side_lds ? ring : side_lds);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_side_kernel<NB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   GemmParams q = p;
@@ -447,8 +448,17 @@ static void planes_side_launch(const GemmParams& p, int batch, const SideTasks& 
 int gemm_planes_side(const GemmParams& p, int batch, const SideTasks& sd, hipStream_t st) {
   EP_REQUIRE(gemm_planes_ok(p), EP_E_ALIGN, "gemm_planes_side: operands must be 16-byte aligned (A: lda %% 4; planes: row stride %% 32)");
   if (sd.total <= 0) return gemm_planes(p, batch, st);
-  if (p.nterms == 1 || gemm_arith() == 1) planes_side_launch<4, 1>(p, batch, sd, st);
-  else planes_side_launch<4, 3>(p, batch, sd, st);
+  // EP_SIDE_DMA=0: the side contractions on the register-prefetch tile (gemm_tile_b3g) instead of the LDS-ring one
+  static int dma_on = -1;
+  if (dma_on < 0) { const char* e = getenv("EP_SIDE_DMA"); dma_on = e ? atoi(e) : 1; }
+  SideTasks sq = sd;
+  if (dma_on && sq.b3 == 1) {
+    bool ok = true;
+    for (int i = 0; i < sq.n_gemm; ++i) ok &= sq.g[i].K >= 64 && sq.g[i].lda % 4 == 0 && sq.g[i].ldb % 4 == 0;
+    if (ok) sq.b3 = 2;
+  }
+  if (p.nterms == 1 || gemm_arith() == 1) planes_side_launch<4, 1>(p, batch, sq, st);
+  else planes_side_launch<4, 3>(p, batch, sq, st);
   EP_LAUNCH_CHECK("ep_gemm_planes_side_kernel");
   return 0;
 }

@@ -537,6 +537,9 @@ bool pool_backward_takes_delta(const PoolParams& p, int Dv) {
   static int allow = -1;
   if (allow < 0) { const char* e = getenv("EP_POOL_DELTA"); allow = e ? atoi(e) : 1; }
   if (!allow || needs_generic(p) || p.tokstat || use_wide(p) || force_generic()) return false;
+  // a chunked second pass (pool_backward asks query_chunk first) runs one launch per chunk with the chunk's Q: no launch sees
+  // the whole dy . y row -- the delta rows then come from ep_delta_kernel (the two predicates must agree)
+  if (query_chunk(p, true) != 0) return false;
   if (use_mb(p)) return mb_takes_delta(p.D, p.Q, Dv);
   if (use_mbq(p)) return mbq_takes_delta(p.D, p.Q, Dv);
   if (use_mm2(p, true) || use_mm(p, true) || use_mf(p, true)) return false;

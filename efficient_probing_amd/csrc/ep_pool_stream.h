@@ -78,7 +78,7 @@ bool mb_takes_side(int D);                       // the second pass of this D ca
 bool mb_takes_delta(int D, int Q, int Dv);
 bool mb_takes_inpass_dp(const PoolParams& p);     // ... and run the dP contraction in front of its stream (ep_inpass.h)       // ... and compute the delta rows itself (PoolParams.dyv / yv / Dv)
 int mb_grid(int D, int B);
-// ... with 17 .. 32 queries in one read of the tokens (second half of ep_pool_mb.hip): D in {256, 512, 768}
+// ... with 17 .. 32 queries in one read of the tokens (second half of ep_pool_mb.hip): D in {256, 384, 512, 768}
 bool mbq_supported(int D, int Q, int64_t cls_bstride);
 bool mbq_takes_delta(int D, int Q, int Dv);
 int mbq_grid(int B);
@@ -88,7 +88,7 @@ const char* mb_kernel_name(int D, bool bwd);
 bool wide_supported(int D, int Q, int64_t cls_bstride, int x_bf16 = 0);
 int wide_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 int wide_grid(int D, int B, int x_bf16 = 0);
-// ep_pool_wideb.hip: bf16-stored wide rows, scores on the matrix cores (EP_POOL_WIDEB=1)
+// ep_pool_wideb.hip: bf16-stored wide rows, scores on the matrix cores (the default; EP_POOL_WIDEB=0 switches it off)
 bool wideb_supported(int D, int Q, int64_t cls_bstride, int x_bf16, bool bwd);
 int wideb_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st);
 // LayerNorm-of-tokens mode (PoolParams.tokstat) in the vector-ALU streaming kernels

@@ -12,6 +12,8 @@ namespace ep {
 // otherwise drain; none of them feeds anything before the optimizer.  All T/T-layout vector GEMMs.
 constexpr size_t SIDE_LDS_BYTES = sizeof(float) * 2 * 2 * LDS_OPERAND > W3_LDS_BYTES ? sizeof(float) * 2 * 2 * LDS_OPERAND : W3_LDS_BYTES;
 
+// DMA_OK: the launch has the LDS of the ring form (w3d_lds_bytes) and may run SideTasks.b3 == 2
+template <bool DMA_OK = false>
 __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* lds_raw) {
   auto lds = reinterpret_cast<float (*)[2][LDS_OPERAND]>(lds_raw);
   const int tglob = t;
@@ -28,6 +30,13 @@ __device__ __forceinline__ void run_side_task(const SideTasks& s, int t, char* l
       const int by = r % s.gy[i], bz = r / s.gy[i];
       // (round 3: the LDS-DMA tile body of ep_gemm_dma.h as the side body -- 3 stages, 4 symmetric waves, 64-row tiles --
       // measured SLOWER inside the pass: second pass 181 -> 192 us at 256x768, 155 -> 166 us at 197x768; removed again)
+      if constexpr (DMA_OK) {
+        if (s.b3 == 2) {                               // ... with the rows prefetched into an LDS ring (few tiles per CU: ep_wgrad3.h)
+          if (s.bm[i] == 64) gemm_tile_b3d<64>(s.g[i], bx, by, bz, lds_raw);
+          else gemm_tile_b3d<32>(s.g[i], bx, by, bz, lds_raw);
+          return;
+        }
+      }
       if (s.b3) {                                      // bf16 x3 at fp32 accuracy: 96 instead of 256 matrix cycles per block
         if (s.bm[i] == 64) gemm_tile_b3<64>(s.g[i], bx, by, bz, lds_raw);
         else gemm_tile_b3<32>(s.g[i], bx, by, bz, lds_raw);

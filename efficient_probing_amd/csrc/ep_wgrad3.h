@@ -271,6 +271,128 @@ __device__ __forceinline__ void gemm_tile_b3g2(const GemmParams& p, int bx, int 
   store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
 }
 
+// The LATENCY-PROOF form for SMALL weight gradients (round 6): the two forms above keep one K-tile of rows in flight in
+// registers and rely on 3 - 5 resident workgroups per CU to cover the rest of the memory latency.  The weight gradients of the
+// EP step at B = 1024 are 192 - 384 tiles -- one or two workgroups per CU -- and every K-tile then costs a full round trip:
+// rocprofv3, stand-alone on a side queue at 1024 x 256 x 768: dWc = dlogits^T z (1.6 GFLOP) 38.8 us, dWv (1.2 GFLOP) 47.4 us,
+// i.e. ~1.2 us per K-tile for ~0.3 us of instructions.  Here the raw fp32 K-tiles (32 batch rows x BMT / 64 columns, whole
+// 128- / 256-byte row segments) come in by LDS-DMA into a ring of three stages, two K-tiles ahead of their use and at no
+// register cost; the waves then read their k-pair x 4 columns from the ring instead of from memory and split / transpose /
+// multiply exactly as gemm_tile_b3g does (same plane images, same matrix-instruction order: bit-identical results).
+// LDS: 3 x (4 | 8 + 8) KiB ring + 30 KiB images = 66 / 78 KiB.  Both operands T layout, 16-byte aligned, ld % 4 == 0.
+constexpr int W3D_NSTG = 3;
+template <int BMT> constexpr size_t w3d_lds_bytes() { return (size_t)W3D_NSTG * (32 * BMT * 4 + 32 * 64 * 4) + W3_LDS_BYTES; }
+template <int BMT>
+__device__ __forceinline__ void gemm_tile_b3d(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  constexpr int MI = BMT / 32;
+  constexpr int RAW_A = 32 * BMT * 4, RAW_B = 32 * 64 * 4, RAW = RAW_A + RAW_B;
+  constexpr int NDA = RAW_A / 1024, ND = NDA + 8, PW = ND / 4;        // 1-KiB DMA pieces per K-tile: 12 / 16, 3 / 4 per wave
+  constexpr int CPA = BMT / 4, RPA = 64 / CPA;                        // A: 16-byte chunks per k-row, k-rows per piece
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * BMT, n0 = bx * 64;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  char* ring = lds;
+  char* imgA = lds + W3D_NSTG * RAW;
+  char* imgB = imgA + 3 * W3_IMG;
+  const int mq = tid & 15, kp = tid >> 4;
+  const bool stA = 4 * mq < BMT;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  const int nk = (p.K + 31) / 32;
+  const bool one = p.nterms == 1;
+  // this wave's DMA pieces: piece i = w + 4 j; i < NDA: k-rows RPA i .. of the A tile, else k-rows 4 (i - NDA) .. of the B tile
+  const float* src[PW]; int krow[PW]; int64_t ldp[PW]; int dst[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int i = w + 4 * j;
+    if (i < NDA) {
+      const int c = m0 + 4 * (lane % CPA);
+      krow[j] = RPA * i + lane / CPA; ldp[j] = p.lda; src[j] = A + (c < extA ? c : 0); dst[j] = i * 1024;
+    } else {
+      const int c = n0 + 4 * (lane & 15);
+      krow[j] = 4 * (i - NDA) + (lane >> 4); ldp[j] = p.ldb; src[j] = B + (c < extB ? c : 0); dst[j] = RAW_A + (i - NDA) * 1024;
+    }
+  }
+  auto issue = [&](int t, int slot) {                 // K-tile t (clamped: redundant, never out of range) into ring stage `slot`
+    const int tt = t < nk ? t : nk - 1;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      int k = tt * 32 + krow[j];
+      k = k < p.K ? k : p.K - 1;
+      __builtin_amdgcn_global_load_lds((pl_gptr_t)(src[j] + (int64_t)k * ldp[j]), (pl_lds_ptr_t)(ring + slot * RAW + dst[j]), 16, 0, 0);
+    }
+  };
+  f4v acc[MI][2];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  issue(1, 1);
+  int slot = 0;
+  for (int it = 0; it < nk; ++it) {
+    pl_dma_wait<PW>();                                // my pieces of tile `it` (tile it+1 may still be in flight)
+    // (raw barriers: with LDS-DMA in flight __syncthreads() drains vmcnt(0) -- its workgroup-scope release covers the copies)
+    pl_barrier();                                     // everybody's pieces; and every wave has read tile it-1's fragments
+    issue(it + 2, slot == 0 ? 2 : slot - 1);          // the stage tile it-1 left (its rows were read before the barrier below, last round)
+    const char* raw = ring + slot * RAW;
+    f4v xa[2], xb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      xa[h] = *reinterpret_cast<const f4v*>(raw + (2 * kp + h) * (BMT * 4) + (stA ? mq : 0) * 16);
+      xb[h] = *reinterpret_cast<const f4v*>(raw + RAW_A + (2 * kp + h) * 256 + mq * 16);
+    }
+    if (stA) w3_stage_T(imgA, xa, extA, p.K, m0, it * 32, kp, mq, one);
+    w3_stage_T(imgB, xb, extB, p.K, n0, it * 32, kp, mq, one);
+    pl_barrier();                                     // the plane images are complete; the ring stage is free
+    slot = slot == 2 ? 0 : slot + 1;
+    pl_u4 fa[MI][3], fb[2][3];
+    if (one) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi][0] = *reinterpret_cast<const pl_u4*>(imgA + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[ni][0] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * 32 + ni * 16 + i16, kk));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
+      continue;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fa[mi][t] = *reinterpret_cast<const pl_u4*>(imgA + t * W3_IMG + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3_IMG + w3_off(wn * 32 + ni * 16 + i16, kk));
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+    }
+  }
+  pl_dma_wait<0>();                                   // the redundant tail pieces have landed: the ring may be reused
+  f4v blk[MI * 2]; int rb[MI * 2], cb[MI * 2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
+    }
+  store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
+  __syncthreads();                                    // LDS free for the caller's next tile
+}
+
 // the weight-gradient form (both operands T layout): what the token passes run as side work
 template <int BMT>
 __device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by, int bz, char* lds) {

@@ -151,3 +151,9 @@ def test_one_image_index_batch_into_a_strided_store():
     for a, b in zip(e1.params_list, e2.params_list):
         assert torch.equal(a, b)
     assert e1.read_stats() == e2.read_stats()
+    # a batch of one leaves no gradient behind the BatchNorm (z = 0): what tells the images apart is the running mean
+    assert torch.equal(e1.bn.running_mean, e2.bn.running_mean) and float(e1.bn.running_mean.abs().max()) > 0
+    wrong = make()
+    wrong.train_step(store[0:1].contiguous(), tgt)
+    wrong.train_step(store[0:1].contiguous(), tgt)
+    assert not torch.equal(wrong.bn.running_mean, e1.bn.running_mean)
