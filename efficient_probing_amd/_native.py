@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EP_HIP_LIB") or os.path.join(_HERE, "libep_hip.so")   # EP_HIP_LIB: A/B builds only
 
-EP_ABI_VERSION = 25        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
+EP_ABI_VERSION = 26        # include/ep_hip.h EP_ABI_VERSION the ctypes structs below are written for (checked in load())
 EP_DTYPE_F32 = 0
 EP_DTYPE_BF16 = 1
 EP_DTYPE_F16 = 2          # fp16-stored tokens: forward entry points of the EP head only (ABI v24)
@@ -59,6 +59,10 @@ class EPHeadStep(C.Structure):
         ("defer_event", C.c_void_p),
         ("planes_valid", C.c_int32),
         ("arith", C.c_int32),
+        ("scaler_state", C.c_void_p),
+        ("scaler_slot", C.c_int32),
+        ("scaler_growth", C.c_float), ("scaler_backoff", C.c_float),
+        ("scaler_interval", C.c_int32),
     ]
 
 

@@ -701,6 +701,17 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
                "ep_head_train_step: the AMP-bf16 arithmetic mode runs its contractions against the weight planes (D and D / d_out multiples of 4; D=%d d_out=%d Q=%d)", d.D, d.d_out, d.Q);
     EP_REQUIRE((s->phases & (4 | 8 | 16 | 32)) == 0, EP_E_UNSUPPORTED, "ep_head_train_step: the AMP-bf16 arithmetic mode is implemented for whole steps (phases 1 | 2) only");
   }
+  ScalerDev scd{};
+  const ScalerDev* scaler = nullptr;
+  if (s->scaler_state) {
+    EP_REQUIRE(s->scaler_slot == 0 || s->scaler_slot == 1, EP_E_ARG, "ep_head_train_step: scaler_slot %d", s->scaler_slot);
+    EP_REQUIRE(s->opt_num_segments == 0 && (s->phases & (16 | 32)) == 0, EP_E_UNSUPPORTED,
+               "ep_head_train_step: the device-resident loss scale needs whole-tensor, undeferred optimizer phases");
+    EP_REQUIRE(s->scaler_interval > 0 && s->scaler_growth > 0.f && s->scaler_backoff > 0.f, EP_E_ARG, "ep_head_train_step: scaler growth / backoff / interval must be positive");
+    scd = ScalerDev{s->scaler_state, s->scaler_slot, s->scaler_growth, s->scaler_backoff, s->scaler_interval};
+    scaler = &scd;
+  }
+  const float* scale_dev = scaler ? s->scaler_state + 2 * s->scaler_slot : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int Dp = d.D / d.d_out;
   int64_t offs[4];
@@ -802,7 +813,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
                             s->num_batches_tracked, w.bnpart, st));
     if (plc) EP_TRY(linear_forward_pl(w, d, bc, st));
     else EP_TRY(linear_forward(w.z, Wc, bc, d.B, Dp, d.C, w.logits, w.ldl, st));
-    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st));
+    EP_TRY(cross_entropy(w.logits, w.ldl, s->targets, d.B, d.C, s->grad_scale, nullptr, w.dlogits, w.rowstat, st, scale_dev));
     // The weight gradients dWc / dbc / dWv and the statistics feed nothing before the optimizer.
     // Preferred: they ride in the launch of the second token pass as extra workgroups, which the
     // dispatcher places as pooling workgroups retire (the tail of the pass) -- no second stream, no
@@ -1001,7 +1012,7 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     EP_TRY(optim_step(s->optimizer, s->params, s->grads, s->opt_state0, s->opt_state1, total,
                       use, nuse, s->lr, s->weight_decay,
                       s->momentum, s->trust_coefficient, s->inv_scale, s->beta1, s->beta2, s->adam_eps, s->opt_step,
-                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat, emit, n_emit));
+                      s->found_inf, s->grad_norm, w.opt_ws, w.opt_ws_bytes, st, &red, w.iperr, abort_stat, emit, n_emit, scaler));
   }
   return 0;
 }

@@ -183,8 +183,13 @@ int colsum(const float* src, int B, int ncol, int ld, int accumulate, float* out
 // delta[r] = sum_c dy[r,c] * (y[r,c] - bias[(r % Q)*Dq + c]) -> ML[r,2]   (bias may be null; rows = B*Q)
 int delta_rows(const float* dy, const float* y, int rows, int Dq, float* ML, hipStream_t st,
                const float* bias = nullptr, int Q = 1);
+// Device-resident GradScaler state (ABI v26: ep_head_step.scaler_state): two slots of {scale, growth tracker}; a step READS
+// slot `slot` (cross entropy: grad_scale * scale; optimizer: inv_scale / scale) and its optimizer phase WRITES the other one
+// (torch.cuda.amp.GradScaler.update: backoff on a non-finite gradient, growth after `interval` clean steps) -- no host sync.
+struct ScalerDev { float* state; int slot; float growth, backoff; int interval; };
+// scale_dev (optional): one device float the gradient scale is multiplied with
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
-                  float* loss_rows, float* dlogits, float* rowstat, hipStream_t st);
+                  float* loss_rows, float* dlogits, float* rowstat, hipStream_t st, const float* scale_dev = nullptr);
 int ce_stats(const float* rowstat, int B, float* stats, hipStream_t st);
 
 // shared host helpers (ep_api.hip)
@@ -233,7 +238,8 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
                hipStream_t st, const DeferredReduce* red = nullptr,    // red: finish that reduction into g first (g is written)
                const int* abort_flag = nullptr, float* abort_stat = nullptr,   // nonzero *abort_flag: skip the update, set found_inf, bump *abort_stat
-               const PlaneSpec* emit = nullptr, int n_emit = 0);   // weight matrices (whole segments) whose planes the update writes (<= 2)
+               const PlaneSpec* emit = nullptr, int n_emit = 0,    // weight matrices (whole segments) whose planes the update writes (<= 2)
+               const ScalerDev* scaler = nullptr);                 // device-resident loss scale: unscale by it, update it
 // how many of `emit` optim_step will really serve for this segment list (the others need planes_split)
 int optim_emits(const float* p, const ep_segment* segs, int nseg, const PlaneSpec* emit, int n_emit);
 

@@ -44,7 +44,11 @@ struct OptParams {
   // opt_scalars sums them -- instead of by every workgroup of the update (5094 chunks at 196 x 4096 tokens: 80 KB of
   // partials re-read from L2 per 64 KB of payload, and a serial latency chain in front of every workgroup's stores)
   const float* final_;
+  // device-resident loss scale (ScalerDev): gradients are unscaled by inv_scale / *sc_in; the thread that publishes found_inf
+  // also writes the NEXT state {scale, tracker} to sc_out (torch.cuda.amp.GradScaler.update)
+  const float* sc_in; float* sc_out; float sc_growth, sc_backoff; int sc_interval;
 };
+__device__ __forceinline__ float opt_inv_scale(const OptParams& o) { return o.sc_in ? o.inv_scale / o.sc_in[0] : o.inv_scale; }
 constexpr int OPT_FINAL_MIN = 1024;
 
 __device__ __forceinline__ int seg_of_chunk(const OptSegs& s, int chunk) {
@@ -86,8 +90,9 @@ __device__ __forceinline__ f4 chunk_norms(const OptParams& o, const OptSegs& seg
   const int64_t end = segs.off[k] + segs.numel[k];
   const bool decay = (o.mode == 0) ? (segs.trust[k] != 0) : (o.mode == 1);
   float pp = 0.f, uu = 0.f, gg = 0.f, bad = 0.f;
+  const float inv_scale = opt_inv_scale(o);
   auto acc1 = [&](float pv, float graw) {
-    const float gv = graw * o.inv_scale;
+    const float gv = graw * inv_scale;
     const float u = decay ? fmaf(o.wd, pv, gv) : gv;
     pp = fmaf(pv, pv, pp); uu = fmaf(u, u, uu); gg = fmaf(gv, gv, gg);
     bad += (fabsf(gv) <= 3.4028234664e38f) ? 0.f : 1.f;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void ep_opt_norms_kernel(OptParams o, OptSegs 
 
 // one element's update: LARS (util/lars.py:21-37), SGD without momentum (main_linprobe.py:407), AdamW (torch defaults)
 __device__ __forceinline__ float opt_update_elem(const OptParams& o, bool decay, float q, float pv, float graw, float& s0v, float& s1v) {
-  const float gv = graw * o.inv_scale;
+  const float gv = graw * o.inv_scale;          // (callers with a device-resident loss scale pass a copy of `o` whose inv_scale is resolved)
   if (o.mode == 0) {
     float dp = decay ? fmaf(o.wd, pv, gv) : gv;
     dp *= q;
@@ -189,6 +194,12 @@ __device__ __forceinline__ OptScalars opt_scalars(const OptParams& o, const OptS
     *o.found_inf = bad > 0.f ? 1 : 0;
     if (o.grad_norm) *o.grad_norm = sqrtf(gg);
     if (aborted && o.abort_stat) *o.abort_stat += 1.f;
+    if (o.sc_out) {                                   // GradScaler.update(): the next step reads this slot
+      float sc = o.sc_in[0], tr = o.sc_in[1];
+      if (bad > 0.f) { sc *= o.sc_backoff; tr = 0.f; }
+      else { tr += 1.f; if (tr >= (float)o.sc_interval) { sc *= o.sc_growth; tr = 0.f; } }
+      o.sc_out[0] = sc; o.sc_out[1] = tr;
+    }
   }
   float q = 1.0f;
   if (ratio) {
@@ -200,8 +211,10 @@ __device__ __forceinline__ OptScalars opt_scalars(const OptParams& o, const OptS
 
 // update of one chunk: the body of ep_opt_update_kernel.  `partial`: the per-chunk sums (global memory, or the LDS copy of
 // the small-segment kernel).
-__device__ __forceinline__ void chunk_update(const OptParams& o, const OptSegs& segs, int chunk, int tid, float* sm,
+__device__ __forceinline__ void chunk_update(const OptParams& o_, const OptSegs& segs, int chunk, int tid, float* sm,
                                              const float* partial, bool active) {
+  OptParams o = o_;
+  o.inv_scale = opt_inv_scale(o_);
   const int k = seg_of_chunk(segs, chunk);
   const int64_t base = segs.off[k] + (int64_t)(chunk - segs.first_chunk[k]) * OPT_CHUNK;
   const int64_t end = segs.off[k] + segs.numel[k];
@@ -281,8 +294,10 @@ struct PlaneEmit {
   int n;
 };
 
-__device__ __forceinline__ void tile_update_emit(const OptParams& o, const OptSegs& segs, const PlaneEmit& pe, int job, int t,
+__device__ __forceinline__ void tile_update_emit(const OptParams& o_, const OptSegs& segs, const PlaneEmit& pe, int job, int t,
                                                  int tid, float* sm, float (*tile)[65]) {
+  OptParams o = o_;
+  o.inv_scale = opt_inv_scale(o_);
   const PlaneJob& jb = pe.j[job];
   const int k = pe.seg[job];
   const int r0 = (t / pe.tiles_x[job]) * 64, c0 = (t % pe.tiles_x[job]) * 64;
@@ -399,7 +414,7 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
                int nseg, float lr, float wd, float momentum, float tc, float inv_scale, float beta1, float beta2,
                float eps, int64_t step, int32_t* found_inf, float* grad_norm, void* ws, size_t ws_bytes,
                hipStream_t st, const DeferredReduce* red, const int* abort_flag, float* abort_stat,
-               const PlaneSpec* emit, int n_emit) {
+               const PlaneSpec* emit, int n_emit, const ScalerDev* scaler) {
   EP_REQUIRE(p && g && found_inf && ws, EP_E_ARG, "optimizer: null pointer");
   EP_REQUIRE(mode != 0 || s0, EP_E_ARG, "LARS needs the momentum buffer");
   EP_REQUIRE(mode != 2 || (s0 && s1), EP_E_ARG, "AdamW needs exp_avg and exp_avg_sq");
@@ -418,6 +433,11 @@ int optim_step(int mode, float* p, const float* g, float* s0, float* s1, int64_t
   }
   o.partial = (float*)ws; o.nchunks = nchunks; o.found_inf = found_inf; o.grad_norm = grad_norm;
   o.abort_flag = abort_flag; o.abort_stat = abort_stat;
+  if (scaler && scaler->state) {
+    EP_REQUIRE(scaler->slot == 0 || scaler->slot == 1, EP_E_ARG, "optimizer: scaler slot %d", scaler->slot);
+    o.sc_in = scaler->state + 2 * scaler->slot; o.sc_out = scaler->state + 2 * (1 - scaler->slot);
+    o.sc_growth = scaler->growth; o.sc_backoff = scaler->backoff; o.sc_interval = scaler->interval;
+  }
   if (red && red->stage) {
     // the range must be one whole segment of whole float4s (the norms kernel decides per chunk)
     const int64_t off = red->out - g;

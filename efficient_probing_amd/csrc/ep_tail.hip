@@ -427,7 +427,9 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void ep_ce_kernel(const float* __restrict__ logits, int ldl,
                                                   const int64_t* __restrict__ targets, int B, int C,
                                                   float grad_scale, float* __restrict__ loss_rows,
-                                                  float* __restrict__ dlogits, float* __restrict__ rowstat) {
+                                                  float* __restrict__ dlogits, float* __restrict__ rowstat,
+                                                  const float* __restrict__ scale_dev) {
+  if (scale_dev) grad_scale *= *scale_dev;            // device-resident loss scale (GradScaler.scale(loss))
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
@@ -645,13 +647,13 @@ int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int 
   return 0;
 }
 int cross_entropy(const float* logits, int ldl, const int64_t* targets, int B, int C, float grad_scale,
-                  float* loss_rows, float* dlogits, float* rowstat, hipStream_t st) {
+                  float* loss_rows, float* dlogits, float* rowstat, hipStream_t st, const float* scale_dev) {
   if (ldl <= 64 * CE_RPT)
     hipLaunchKernelGGL(ep_ce_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, st, logits, ldl, targets, B, C,
-                       grad_scale, loss_rows, dlogits, rowstat);
+                       grad_scale, loss_rows, dlogits, rowstat, scale_dev);
   else
     hipLaunchKernelGGL(ep_ce_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, st, logits, ldl, targets, B, C,
-                       grad_scale, loss_rows, dlogits, rowstat);
+                       grad_scale, loss_rows, dlogits, rowstat, scale_dev);
   EP_LAUNCH_CHECK("ep_ce_kernel");
   return 0;
 }

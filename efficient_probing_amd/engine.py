@@ -170,6 +170,10 @@ class ProbeHeadEngine:
         self._defer_event = None
         self._deferred = False
         self._fs = None                                      # persistent step struct of the one-call step (see _fast_one_call)
+        # device-resident GradScaler (attach_scaler): (scaler object, (4,) float tensor {scale, tracker} x 2 slots, slot the next step reads)
+        self._scaler = None
+        self._scaler_state = None
+        self._scaler_slot = 0
         self._fast_ok = type(self).__name__ == "ProbeHeadEngine" and os.environ.get("EP_FAST_STEP", "1") != "0"
         if broadcast_from_rank0 and self.world > 1:
             dist.broadcast(self.flat_p, src=0, group=self.group)     # what DDP does at wrap time
@@ -203,6 +207,56 @@ class ProbeHeadEngine:
             self._planes_token = None
         return self._ws
 
+    # ---- GradScaler state on the device (include/ep_hip.h, ABI v26: ep_head_step.scaler_state) ----
+    def attach_scaler(self, scaler) -> None:
+        """Drive ``scaler`` (util.misc.NativeScalerWithGradNormCount: torch.cuda.amp.GradScaler semantics, reference
+        util/misc.py:260-286) from the fused step: the loss gradient is scaled by its scale, the optimizer unscales, skips the
+        update on a non-finite gradient and halves the scale, doubles it after ``growth_interval`` clean steps -- all inside
+        the step's kernels, on a 4-float device state; no host read per step.  ``sync_scaler()`` (called by
+        ``train_one_epoch`` at the end of an epoch and by ``scaler.state_dict()``) brings the host object up to date."""
+        if scaler is None or not getattr(scaler, "_enabled", False):
+            self._scaler = self._scaler_state = None
+            return
+        if self._pipelined or type(self) is not ProbeHeadEngine:
+            raise RuntimeError("attach_scaler: the device-resident loss scale is implemented for the EP head's undeferred, "
+                               "non-pipelined step (overlap_comm off)")
+        if self._scaler is scaler:
+            return
+        self.flush()
+        if self.loss_scale != 1.0:
+            raise RuntimeError("attach_scaler: the engine already applies a fixed loss_scale")
+        self._scaler = scaler
+        sc, tr = float(scaler._scale), float(scaler._growth_tracker)
+        self._scaler_state = torch.tensor([sc, tr, sc, tr], device=self.device, dtype=torch.float32)
+        self._scaler_slot = 0
+        scaler._device_sync = self.sync_scaler                # state_dict() / get_scale() of the host object read through
+        scaler._device_push = self.push_scaler
+
+    def push_scaler(self) -> None:
+        """The host scaler changed (load_state_dict, a step through the module path): upload its state."""
+        if self._scaler is None:
+            return
+        sc, tr = float(self._scaler._scale), float(self._scaler._growth_tracker)
+        self._scaler_state.copy_(torch.tensor([sc, tr, sc, tr], dtype=torch.float32), non_blocking=False)
+
+    def sync_scaler(self) -> None:
+        """Copy the device-resident scale / growth tracker back into the attached host scaler (one small read)."""
+        if self._scaler is None:
+            return
+        vals = self._scaler_state.tolist()
+        self._scaler._scale = float(vals[2 * self._scaler_slot])
+        self._scaler._growth_tracker = int(vals[2 * self._scaler_slot + 1])
+
+    def _scaler_fields(self, s) -> None:
+        if self._scaler is None or not hasattr(s, "scaler_state"):
+            if hasattr(s, "scaler_state"):
+                s.scaler_state = 0
+            return
+        sc = self._scaler
+        s.scaler_state = self._scaler_state.data_ptr()
+        s.scaler_slot = self._scaler_slot
+        s.scaler_growth = sc._growth_factor; s.scaler_backoff = sc._backoff_factor; s.scaler_interval = sc._growth_interval
+
     def _step_struct(self, x, bstride, targets, phases, accumulate, lr):
         s = self._new_step()
         s.dims = self.dims
@@ -220,6 +274,7 @@ class ProbeHeadEngine:
         s.bn_eps = self.bn.eps; s.bn_momentum = self.bn.momentum
         s.grad_scale = self.loss_scale / self.accum_iter
         s.inv_scale = 1.0 / (self.loss_scale * self.world)
+        self._scaler_fields(s)
         s.accumulate = int(accumulate)
         s.optimizer = OPTIMIZERS[self.optimizer_name]
         s.lr = self.lr if lr is None else lr
@@ -300,6 +355,8 @@ class ProbeHeadEngine:
         if num_segs:
             s.opt_first_segment, s.opt_num_segments = first_seg, num_segs
         N.check(self._call_train(s, ws), "head train step (optimizer)")
+        if self._scaler is not None:
+            self._scaler_slot ^= 1                            # the optimizer phase wrote the other slot
         self._planes_after_call(2, first_seg, num_segs)
 
     def optimizer_step(self, lr: Optional[float] = None) -> None:
@@ -356,7 +413,7 @@ class ProbeHeadEngine:
         import os
         # EP_DEFER_OPT=1 to use it: measured SLOWER on MI355X / ROCm 7.2 (0.452 against 0.433 ms per step at 256x768) -- a
         # dependency between two HIP streams costs 8-12 us of idle queue on each side (EXPERIMENTS.md section 4, round 3)
-        return (self.defer_update and self.aux_stream is not None and self.loss_scale == 1.0
+        return (self.defer_update and self.aux_stream is not None and self.loss_scale == 1.0 and self._scaler is None
                 and getattr(self, "arithmetic", "fp32") == "fp32" and os.environ.get("EP_DEFER_OPT", "0") == "1")
 
     # ---- the one-call step with a PERSISTENT step struct (round 5): the ~40 fields of ep_head_step are written once; a call
@@ -413,9 +470,13 @@ class ProbeHeadEngine:
         fs.grad_scale = self.loss_scale; fs.inv_scale = 1.0 / self.loss_scale       # (one rank, no accumulation: _one_call_step)
         fs.opt_step = self.opt_step
         fs.planes_valid = int(self._planes_current())
+        if self._scaler is not None or fs.scaler_state:
+            self._scaler_fields(fs)
         rc = self.lib.ep_head_train_step(self._fs_ref, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
             N.check(rc, "head train step")
+        if self._scaler is not None:
+            self._scaler_slot ^= 1
         self._planes_token = self._param_versions()          # phases = 3 established / rewrote the planes
         self._micro = 0
         return True
@@ -436,6 +497,8 @@ class ProbeHeadEngine:
         s = self._step_struct(xv, bstride, targets, 3, False, lr)
         s.image_index = iptr
         N.check(self._call_train(s, ws), "head train step")
+        if self._scaler is not None:
+            self._scaler_slot ^= 1
         self._planes_after_call(3)
         self._micro = 0
 

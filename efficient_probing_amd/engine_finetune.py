@@ -254,6 +254,14 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         # step run beside the next step's first token pass (flushed below, before anything can read them) -- it only does
         # with EP_DEFER_OPT=1: measured slower on this stack (engine._can_defer, EXPERIMENTS.md section 4 round 3)
         engine.defer_update = True
+    # the reference steps its GradScaler in every iteration, bf16 and fp32 runs included (util/misc.py:260-286): the fused step
+    # does the same on a device-resident state (scale(loss), unscale, skip on inf / nan, update) -- the host object is brought up to
+    # date at the end of the epoch and whenever its state_dict() / get_scale() is asked for
+    if engine is not None and hasattr(engine, "attach_scaler") and hasattr(loss_scaler, "_growth_tracker"):
+        try:
+            engine.attach_scaler(loss_scaler)
+        except RuntimeError:
+            pass                                  # (pipelined / other heads: the fused step keeps its fixed scale, as before)
     optimizer.zero_grad()
     pending = pending_images = 0                  # fused steps (and their images) whose statistics are still on the GPU
 
@@ -338,6 +346,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     eng = getattr(model.module if hasattr(model, "module") else model, "_ep_engine", None)
     if eng is not None:
         eng.flush()                       # a pipelined / deferred step leaves its large update half a step behind
+        if hasattr(eng, "sync_scaler"):
+            eng.sync_scaler()
         if hasattr(eng, "defer_update"):
             eng.defer_update = False
     metric_logger.synchronize_between_processes()

@@ -41,8 +41,12 @@ class NativeScalerWithGradNormCount:
         self._growth_interval = growth_interval
         self._growth_tracker = 0
         self._enabled = enabled
+        self._device_sync = None          # set by engine.attach_scaler: the state lives on the GPU while a fused engine drives it
+        self._device_push = None          # ... and host-side changes (load_state_dict, a module-path step) go back up through this
 
     def get_scale(self) -> float:
+        if self._device_sync is not None:
+            self._device_sync()
         return self._scale
 
     def update(self, found_inf: bool) -> None:
@@ -58,6 +62,8 @@ class NativeScalerWithGradNormCount:
                 self._growth_tracker = 0
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        if self._device_sync is not None:
+            self._device_sync()
         (loss * self._scale).backward(create_graph=create_graph)
         if not update_grad:
             return None
@@ -79,9 +85,13 @@ class NativeScalerWithGradNormCount:
             if not found:
                 optimizer.step()
         self.update(found)
+        if self._device_push is not None:
+            self._device_push()
         return norm
 
     def state_dict(self):
+        if self._device_sync is not None:
+            self._device_sync()
         return {"scale": self._scale, "growth_factor": self._growth_factor,
                 "backoff_factor": self._backoff_factor, "growth_interval": self._growth_interval,
                 "_growth_tracker": self._growth_tracker}
@@ -92,6 +102,8 @@ class NativeScalerWithGradNormCount:
         self._backoff_factor = state_dict.get("backoff_factor", self._backoff_factor)
         self._growth_interval = state_dict.get("growth_interval", self._growth_interval)
         self._growth_tracker = int(state_dict.get("_growth_tracker", 0))
+        if self._device_push is not None:
+            self._device_push()
 
 
 def is_dist_avail_and_initialized() -> bool:

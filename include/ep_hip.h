@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EP_ABI_VERSION 25
+#define EP_ABI_VERSION 26
 
 #define EP_DTYPE_F32 0
 #define EP_DTYPE_BF16 1
@@ -320,6 +320,18 @@ typedef struct ep_head_step {
    * token passes keep their arithmetic.  Needs (D / d_out / Q) % 32 == 0 (the contractions run against the weight planes);
    * EP_E_UNSUPPORTED otherwise.  A secondary mode: never the default, never the headline number. */
   int32_t arith;
+  /* ABI v26: device-resident loss scale -- torch.cuda.amp.GradScaler (reference util/misc.py:260-286: scale(loss), unscale_,
+   * step skipped on inf / nan, update()) without a host read per step.  scaler_state (device, 4 floats, NULL = off): two slots
+   * of {scale, growth tracker}.  A step READS slot scaler_slot: the loss gradient is scaled by grad_scale * scale, the
+   * optimizer unscales by inv_scale / scale (grad_scale / inv_scale then carry only 1 / accum_iter and 1 / world); its
+   * optimizer phase WRITES the other slot: scale * scaler_backoff and tracker 0 when a gradient was non-finite (the update is
+   * skipped, *found_inf = 1), else tracker + 1, and scale * scaler_growth with tracker 0 once it reaches scaler_interval.  The
+   * caller flips scaler_slot after every optimizer phase and reads the state back when it needs it (checkpoints).  Whole-tensor
+   * optimizer phases only (opt_num_segments == 0, no deferred update): EP_E_UNSUPPORTED otherwise. */
+  float* scaler_state;
+  int32_t scaler_slot;
+  float scaler_growth, scaler_backoff;
+  int32_t scaler_interval;
 } ep_head_step;
 
 int64_t ep_head_param_offsets(const ep_head_dims* dims, int64_t offsets[4]);

@@ -171,7 +171,9 @@ def test_constructor_validation_and_no_cpu_fallback():
         ProbeHeadEngine(enc.head, arithmetic="bf16_autocast")
     from efficient_probing_amd import _native
     assert (_native.EP_ARITH_F32, _native.EP_ARITH_BF16_AUTOCAST) == (0, 1)
-    assert [n for n, _ in _native.EPHeadStep._fields_][-2:] == ["planes_valid", "arith"]      # ABI v25: appended, nothing moved
+    names = [n for n, _ in _native.EPHeadStep._fields_]
+    assert names[-7:-5] == ["planes_valid", "arith"]                                          # ABI v25: appended, nothing moved
+    assert names[-5:] == ["scaler_state", "scaler_slot", "scaler_growth", "scaler_backoff", "scaler_interval"]   # ABI v26: likewise
 
 
 def test_lr_schedule_matches_reference_table():
