@@ -180,7 +180,10 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
     probe_heads.build_probe_head(enc, Namespace(cls_features=args.head, nb_classes=Cc, abmilp_sa="both", abmilp_act="tanh",
                                                 abmilp_depth=2, abmilp_cond=None, abmilp_content="all"))
     head = enc.head.to(dev).train()
-    eng = make_engine(head, optimizer="lars", lr=0.1 * (B * world) / 256, weight_decay=0.0)
+    if args.arith != "fp32" and args.head != "abmilp":
+        raise SystemExit("--arith bf16_autocast is implemented for the EP, CoCa and AbMILP heads only")
+    eng = make_engine(head, optimizer="lars", lr=0.1 * (B * world) / 256, weight_decay=0.0,
+                      **({"arithmetic": args.arith} if args.arith != "fp32" else {}))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     nbuf = min(args.buffers, 2)
     xs = [torch.randn(B, Nn, D, device=dev, generator=gen) for _ in range(nbuf)]
@@ -235,7 +238,9 @@ def bench_abmilp(args, torch, dist, dev, world, rank, Nn, D, Cc, desc, B):
         out = {
             "metric": label + "-head train images/sec", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "higher_is_better": True, "scaling": getattr(args, "_scaling", "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": getattr(args, "_scaling", "weak"), "vs_baseline": None,
+            "dtype": "f32" if args.arith == "fp32" else "bf16_autocast (contractions: one bf16 product, fp32 accumulation; softmax, tanh, BatchNorm, loss, optimizer f32)",
+            "data": "synthetic",
             "config": {"workload": desc.split(",")[0] + (f", DOLG spatial attention (1x1 conv, BatchNorm2d, softplus), {Cc} classes" if dolg
                                                           else f", DINOv2 block (8-head self-attention + GELU MLP) and token mean, {Cc} classes" if dino
                                                           else f", AbMILP head (self-attention + tanh predictor), {Cc} classes"),
@@ -365,8 +370,8 @@ def main():
                                                 model="capi_vitl14_in1k" if Nn == 256 else "vit_base_patch16"))
     head = enc.head.to(dev).train()
     lr = 0.1 * (B * world) / 256                           # blr * eff_batch / 256 (main_linprobe.py:572-573)
-    if args.arith != "fp32" and args.head != "ep":
-        raise SystemExit("--arith bf16_autocast is implemented for the EP head only")
+    if args.arith != "fp32" and args.head not in ("ep", "coca", "abmilp"):
+        raise SystemExit("--arith bf16_autocast is implemented for the EP, CoCa and AbMILP heads only")
     eng = make_engine(head, optimizer="lars", lr=lr, weight_decay=0.0, **({"arithmetic": args.arith} if args.arith != "fp32" else {}))
     if hasattr(eng, "defer_update"):
         eng.defer_update = True          # (takes effect only with EP_DEFER_OPT=1 -- measured slower, engine._can_defer; the loop
@@ -770,14 +775,15 @@ def main():
         if world == 1:
             import subprocess
             torch.cuda.empty_cache()
-            for hname in ("coca", "abmilp"):
+            for hname, harith in (("coca", "fp32"), ("abmilp", "fp32"), ("coca", "bf16_autocast"), ("abmilp", "bf16_autocast")):
                 cmd = [sys.executable, os.path.abspath(__file__), "--head", hname, "--workload", "c4", "--steps", "10", "--warmup", "3",
                        "--spinup", "5", "--no-cpu-baseline", "--no-configs", "--no-north-star", "--no-bf16-secondary",
-                       "--no-through-engine", "--kernel-iters", "3"]
+                       "--no-through-engine", "--kernel-iters", "3", "--arith", harith]
+                dest = configs if harith == "fp32" else configs.setdefault("amp_bf16", {})
                 try:
                     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                     d = json.loads(r.stdout.strip().splitlines()[-1])
-                    configs["c4_" + hname] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "n_gpus": 1, "steps": d["steps"],
+                    dest["c4_" + hname] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "n_gpus": 1, "steps": d["steps"],
                                               "ms_per_step": d["ms_per_step"], "batch_per_gpu": d["config"]["batch_per_gpu"],
                                               "workload": d["config"]["workload"], "bound": d["roofline"]["bound"],
                                               "step_frac": d["roofline"].get("step_frac"),
@@ -785,11 +791,11 @@ def main():
                     if d["roofline"]["bound"] == "mfma":
                         r_ = d["roofline"]
                         step_tf = d["value"] * r_["step_flop_per_image"] / 1e12
-                        configs["c4_" + hname]["mfma"] = {"kernel": r_["kernel"], "achieved_tflops": r_["achieved"], "peak": r_["peak"],
+                        dest["c4_" + hname]["mfma"] = {"kernel": r_["kernel"], "achieved_tflops": r_["achieved"], "peak": r_["peak"],
                                                           "frac": r_["frac"], "step_achieved_tflops": round(step_tf, 1),
                                                           "step_frac": r_.get("step_frac"), "peak_note": r_.get("peak_note")}
                 except Exception as e:                          # a secondary never takes the headline line down with it
-                    configs["c4_" + hname] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                    dest["c4_" + hname] = {"error": f"{type(e).__name__}: {e}"[:200]}
         torch.cuda.empty_cache()
     # the same workload through the reference's loop surface (engine_finetune.train_one_epoch, reference
     # engine_finetune.py:22-103): a resident token store, adjust_learning_rate every iteration, meters every 20

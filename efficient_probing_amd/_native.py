@@ -95,6 +95,7 @@ class EPCocaStep(C.Structure):
         ("opt_step", C.c_int64),
         ("phases", C.c_int32),
         ("aux_stream", C.c_void_p),
+        ("arith", C.c_int32),
     ]
 
 
@@ -123,6 +124,7 @@ class EPAbmilpStep(C.Structure):
         ("trust_coefficient", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("opt_step", C.c_int64),
         ("phases", C.c_int32),
+        ("arith", C.c_int32),
     ]
 
 
@@ -370,6 +372,7 @@ SIGNATURES = {
     "ep_coca_attention": (c_int, [C.POINTER(EPCocaDims), c_void, c_f32p, c_void]),
     "ep_coca_head_param_offsets": (c_i64, [C.POINTER(EPCocaDims), C.POINTER(c_i64)]),
     "ep_coca_head_workspace_bytes": (c_size, [C.POINTER(EPCocaDims)]),
+    "ep_coca_head_workspace_logits_offset": (C.c_int64, [C.POINTER(EPCocaDims), C.POINTER(C.c_int32)]),
     "ep_coca_head_train_step": (c_int, [C.POINTER(EPCocaStep), c_void, c_size, c_void]),
     "ep_abmilp_pool_workspace_bytes": (c_size, [C.POINTER(EPAbmilpDims)]),
     "ep_abmilp_pool_forward": (c_int, [C.POINTER(EPAbmilpDims), c_void, c_int, c_i64, C.POINTER(EPAbmilpParams),
@@ -378,6 +381,7 @@ SIGNATURES = {
                                         c_f32p, C.POINTER(EPAbmilpParams), c_int, c_void, c_size, c_void]),
     "ep_abmilp_head_param_offsets": (c_i64, [C.POINTER(EPAbmilpDims), C.POINTER(c_i64)]),
     "ep_abmilp_head_workspace_bytes": (c_size, [C.POINTER(EPAbmilpDims)]),
+    "ep_abmilp_head_workspace_logits_offset": (C.c_int64, [C.POINTER(EPAbmilpDims), C.POINTER(C.c_int32)]),
     "ep_abmilp_head_train_step": (c_int, [C.POINTER(EPAbmilpStep), c_void, c_size, c_void]),
     "ep_abmilp_head_eval_forward": (c_int, [C.POINTER(EPAbmilpDims), c_void, c_int, c_i64, c_f32p, c_f32p, c_f32p,
                                             c_float, c_f32p, c_int, c_void, c_size, c_void]),

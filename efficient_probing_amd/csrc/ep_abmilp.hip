@@ -465,6 +465,14 @@ size_t ep_abmilp_head_workspace_bytes(const ep_abmilp_dims* dims) {
   return ab_carve(*dims, nullptr, true).total;
 }
 
+int64_t ep_abmilp_head_workspace_logits_offset(const ep_abmilp_dims* dims, int32_t* ldl) {
+  if (!dims || ab_check(*dims, nullptr, 0, 0, true) != 0) return -1;
+  char* base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // ab_carve() only does address arithmetic on a non-null base
+  const AbWs w = ab_carve(*dims, base, true);
+  if (ldl) *ldl = w.ldl;
+  return reinterpret_cast<char*>(w.logits) - base;
+}
+
 int ep_abmilp_head_train_step(const ep_abmilp_step* s, void* ws, size_t ws_bytes, ep_stream_t stream) {
   EP_REQUIRE(s && ws, EP_E_ARG, "ep_abmilp_head_train_step: null pointer");
   const ep_abmilp_dims& d = s->dims;
@@ -473,6 +481,8 @@ int ep_abmilp_head_train_step(const ep_abmilp_step* s, void* ws, size_t ws_bytes
   const AbWs w = ab_carve(d, ws, true);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_abmilp_head_train_step: workspace %zu < %zu", ws_bytes, w.total);
   EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_abmilp_head_train_step: arith %d", s->arith);
+  const ArithScope arith_scope(s->arith);            // AMP-bf16: every contraction below as one bf16 product (ep_gemm.hip: gemm_b3_ok, ep_planes.hip)
   hipStream_t st = (hipStream_t)stream;
   int64_t offs[9];
   const int64_t total = ab_offsets(d, offs);

@@ -691,7 +691,6 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
   EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_head_train_step: arith %d is neither EP_ARITH_F32 nor EP_ARITH_BF16_AUTOCAST", s->arith);
   // the arithmetic mode of every contraction this call enqueues (restored on every return path) -- set BEFORE the workspace
   // is carved: which plane buffers exist depends on it when EP_GEMM_PLANES=0
-  struct ArithScope { int old; explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); } ~ArithScope() { gemm_set_arith(old); } };
   const ArithScope arith_scope(s->arith);
   HeadWs w = carve(d, ws);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_head_train_step: workspace %zu < %zu%s", ws_bytes, w.total,
@@ -1089,7 +1088,6 @@ int ep_lp_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stream
   EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
   EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_head_train_step: arith %d is neither EP_ARITH_F32 nor EP_ARITH_BF16_AUTOCAST", s->arith);
   // the arithmetic mode of every contraction this call enqueues (restored on every return path)
-  struct ArithScope { int old; explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); } ~ArithScope() { gemm_set_arith(old); } };
   const ArithScope arith_scope(s->arith);
   // (BatchNorm + Linear on pooled features: the plain linear probe has no planes and runs fp32 only)
   EP_REQUIRE(s->arith == EP_ARITH_F32, EP_E_UNSUPPORTED, "ep_lp_train_step: the AMP-bf16 arithmetic mode is implemented for the EP head's fused step only");

@@ -369,6 +369,14 @@ size_t ep_coca_head_workspace_bytes(const ep_coca_dims* dims) {
   return coca_carve(*dims, nullptr, true).total;
 }
 
+int64_t ep_coca_head_workspace_logits_offset(const ep_coca_dims* dims, int32_t* ldl) {
+  if (!dims || coca_check(*dims, true) != 0) return -1;
+  char* base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // coca_carve() only does address arithmetic on a non-null base
+  const CocaWs w = coca_carve(*dims, base, true);
+  if (ldl) *ldl = w.ldl;
+  return reinterpret_cast<char*>(w.logits) - base;
+}
+
 static ep_coca_params coca_views(float* base, const int64_t offs[7], const float* beta) {
   ep_coca_params p;
   p.gamma = base + offs[0]; p.beta = beta; p.img_queries = base + offs[1]; p.to_q = base + offs[2];
@@ -384,6 +392,8 @@ int ep_coca_head_train_step(const ep_coca_step* s, void* ws, size_t ws_bytes, ep
   const CocaWs w = coca_carve(d, ws, true);
   EP_REQUIRE(ws_bytes >= w.total, EP_E_WORKSPACE, "ep_coca_head_train_step: workspace %zu < %zu", ws_bytes, w.total);
   EP_REQUIRE(s->params && s->grads, EP_E_ARG, "params / grads null");
+  EP_REQUIRE(s->arith == EP_ARITH_F32 || s->arith == EP_ARITH_BF16_AUTOCAST, EP_E_ARG, "ep_coca_head_train_step: arith %d", s->arith);
+  const ArithScope arith_scope(s->arith);            // AMP-bf16: the contractions below as one bf16 product (ep_gemm.hip: gemm_b3_ok)
   hipStream_t st = (hipStream_t)stream;
   int64_t offs[7];
   const int64_t total = coca_offsets(d, offs);

@@ -638,6 +638,9 @@ bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
     return true;
   }
   if (!a_k) return false;                                      // (T / K does not occur)
+  // AMP-bf16 (round 6: the CoCa / AbMILP steps and the EP step's dP at odd slice widths): this tile is the single-product
+  // kernel of the K / K and K / T layouts too, whatever the size
+  if (t_arith == 1 || p.nterms == 1) return true;
   static long min_tiles = -1;
   if (min_tiles < 0) { const char* e = getenv("EP_GEMM_B3_MIN_TILES"); min_tiles = e ? atol(e) : 512; }
   const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;

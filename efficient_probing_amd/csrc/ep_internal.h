@@ -99,6 +99,14 @@ struct PlaneSpec {
 // Set for the duration of a train step by ep_head_train_step (ep_head_step.arith).
 int gemm_arith();
 void gemm_set_arith(int a);
+// sets the mode for the calls a step function enqueues, restores the previous one on every return path
+struct ArithScope {
+  int old;
+  explicit ArithScope(int a) : old(gemm_arith()) { gemm_set_arith(a); }
+  ~ArithScope() { gemm_set_arith(old); }
+  ArithScope(const ArithScope&) = delete;
+  ArithScope& operator=(const ArithScope&) = delete;
+};
 size_t planes_elems(int rows, int K);               // elements (uint16) of the planes of a rows x K matrix
 int planes_split(const PlaneSpec* specs, int n, hipStream_t st);
 bool gemm_planes_ok(const GemmParams& p);

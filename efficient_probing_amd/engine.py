@@ -110,8 +110,9 @@ class ProbeHeadEngine:
         # the optimizer stay fp32, the token passes keep their arithmetic.  The EP head only; a secondary mode.
         if arithmetic not in ("fp32", "bf16_autocast"):
             raise ValueError("arithmetic must be 'fp32' or 'bf16_autocast'")
-        if arithmetic != "fp32" and type(self) is not ProbeHeadEngine:
-            raise ValueError(f"{type(self).__name__}: arithmetic='bf16_autocast' is implemented for the EP head (ProbeHeadEngine) only")
+        if arithmetic != "fp32" and type(self).__name__ not in ("ProbeHeadEngine", "CocaHeadEngine", "AbmilpHeadEngine"):
+            raise ValueError(f"{type(self).__name__}: arithmetic='bf16_autocast' is implemented for the EP, CoCa and AbMILP heads "
+                             "(BASELINE configs[3]'s three) only")
         self.arithmetic = arithmetic
         self.head = head
         self.pool, self.bn, self.fc = head[0], head[1], head[2]
@@ -630,10 +631,12 @@ class ProbeHeadEngine:
     def last_train_logits(self) -> torch.Tensor:
         """The train-mode logits (B, C) the last train step computed its loss from (a copy out of the step's workspace;
         diagnostics and tests: the distance of the ``bf16_autocast`` arithmetic from the reference's bf16 head)."""
-        if type(self) is not ProbeHeadEngine or self._ws is None:
-            raise RuntimeError("last_train_logits: the EP head's engine after a train step only")
+        fn = {"ProbeHeadEngine": "ep_head_workspace_logits_offset", "CocaHeadEngine": "ep_coca_head_workspace_logits_offset",
+              "AbmilpHeadEngine": "ep_abmilp_head_workspace_logits_offset"}.get(type(self).__name__)
+        if fn is None or self._ws is None:
+            raise RuntimeError("last_train_logits: the EP / CoCa / AbMILP engines after a train step only")
         ldl = C.c_int32(0)
-        off = self.lib.ep_head_workspace_logits_offset(C.byref(self.dims), C.byref(ldl))      # (self.dims follows the workspace: _workspace)
+        off = getattr(self.lib, fn)(C.byref(self.dims), C.byref(ldl))      # (self.dims follows the workspace: _workspace)
         if off < 0:
             raise RuntimeError("ep_head_workspace_logits_offset failed")
         B = self._ws_key[0]

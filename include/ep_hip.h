@@ -409,10 +409,15 @@ typedef struct ep_coca_step {
   int64_t opt_step;
   int32_t phases;
   ep_stream_t aux_stream;
+  int32_t arith;         /* ABI v26: EP_ARITH_F32 / EP_ARITH_BF16_AUTOCAST, as ep_head_step.arith -- the step's contractions (to_out,
+                            the per-head value projection, the classifier and their gradients) as ONE bf16 product with fp32
+                            accumulation; the token passes, LayerNorm, softmax, BatchNorm, loss, optimizer stay fp32 */
 } ep_coca_step;
 
 int64_t ep_coca_head_param_offsets(const ep_coca_dims* dims, int64_t offsets[7]);
 size_t ep_coca_head_workspace_bytes(const ep_coca_dims* dims);
+/* as ep_head_workspace_logits_offset: where the last forward phase left its train-mode logits inside `ws` (ABI v26) */
+int64_t ep_coca_head_workspace_logits_offset(const ep_coca_dims* dims, int32_t* ldl);
 int ep_coca_head_train_step(const ep_coca_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_coca_head_eval_forward(const ep_coca_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
                               const int32_t* image_index, const float* params, const float* ln_beta,
@@ -474,10 +479,15 @@ typedef struct ep_abmilp_step {
   float lr, weight_decay, momentum, trust_coefficient, beta1, beta2, adam_eps;
   int64_t opt_step;
   int32_t phases;
+  int32_t arith;         /* ABI v26: EP_ARITH_F32 / EP_ARITH_BF16_AUTOCAST -- every contraction of the step (qkv, q k^T, A v, proj,
+                            predictor, classifier and all their gradients) as ONE bf16 matrix-core product with fp32 accumulation
+                            (reference engine_finetune.py:52-55: the published runs' --amp bfloat16); softmax, tanh, pooling,
+                            BatchNorm, loss and optimizer stay fp32, outputs are not rounded */
 } ep_abmilp_step;
 
 int64_t ep_abmilp_head_param_offsets(const ep_abmilp_dims* dims, int64_t offsets[9]);
 size_t ep_abmilp_head_workspace_bytes(const ep_abmilp_dims* dims);
+int64_t ep_abmilp_head_workspace_logits_offset(const ep_abmilp_dims* dims, int32_t* ldl);   /* (ABI v26, as for the EP head) */
 int ep_abmilp_head_train_step(const ep_abmilp_step* step, void* ws, size_t ws_bytes, ep_stream_t stream);
 int ep_abmilp_head_eval_forward(const ep_abmilp_dims* dims, const void* x, int x_dtype, int64_t x_bstride,
                                 const float* params, const float* running_mean, const float* running_var,

@@ -153,7 +153,7 @@ def assert_mu_close(got, want, err_msg="", gaps=None, factor_tol=2e-3, rtol=1e-4
     np.testing.assert_allclose(got64, c * want64, rtol=rtol, atol=atol_k * float(np.abs(want64).max()), err_msg=err_msg)
 
 
-def assert_amp_bf16_fidelity(logits, loss, g, err_msg=""):
+def assert_amp_bf16_fidelity(logits, loss, g, err_msg="", slack=1.25):
     """Fidelity against the PUBLISHED protocol (reference README.md:639-645: every published run trains under --amp bfloat16,
     engine_finetune.py:52-55): the fixture's ``logits_bf16_autocast`` / ``loss_bf16_autocast`` are the reference head's own
     train-mode forward under bf16 autocast on the same inputs.  An fp32 head cannot reproduce bf16 roundings bit for bit;
@@ -165,8 +165,15 @@ def assert_amp_bf16_fidelity(logits, loss, g, err_msg=""):
     want = np.asarray(g["logits_bf16_autocast"], np.float64)
     got = np.asarray(logits, np.float64)
     ulp = 2.0 ** -8 * float(np.abs(want).max())
-    assert float(np.abs(got - want).max()) <= 4.0 * ulp, f"{err_msg}: {np.abs(got - want).max() / ulp:.2f} bf16 ulps of the logits' scale"
-    assert abs(float(loss) - float(g["loss_bf16_autocast"])) <= 1.5e-3 * abs(float(g["loss_bf16_autocast"])), err_msg
+    # (round 6: the CoCa / AbMILP fixtures -- sharper attention, four chained Linears -- have a larger gap of their own, up to 11
+    # ulps / 1.8e-3 on the loss: the bound is `slack` x the fixture's own fp32-to-bf16 distance, never below the EP figures above.
+    # Two DIFFERENT bf16 realisations of one fp32 head -- the reference's rounds every output to bf16, the mode under test
+    # none -- can be as far apart as the sum of their distances from the fp32 head: those heads' tests pass slack = 2)
+    own = float(np.abs(np.asarray(g["logits"], np.float64) - want).max()) / ulp
+    own_loss = abs(float(g["loss"]) - float(g["loss_bf16_autocast"])) / abs(float(g["loss_bf16_autocast"]))
+    lim, lim_loss = max(4.0, slack * own), max(1.5e-3, slack * own_loss)
+    assert float(np.abs(got - want).max()) <= lim * ulp, f"{err_msg}: {np.abs(got - want).max() / ulp:.2f} bf16 ulps of the logits' scale (limit {lim:.2f})"
+    assert abs(float(loss) - float(g["loss_bf16_autocast"])) <= lim_loss * abs(float(g["loss_bf16_autocast"])), err_msg
     assert (got.argmax(1) != want.argmax(1)).sum() <= max(1, got.shape[0] // 32), err_msg   # near-ties at an untrained head
 
 

@@ -204,6 +204,21 @@ def run_case(case, optimizer_name="lars"):
     return out
 
 
+
+def bf16_autocast_forward(head, x, t, crit, pool_fn=None):
+    """The same head, same inputs, train mode, under CPU bf16 autocast (the published runs' --amp bfloat16, README.md:639-645;
+    engine_finetune.py:52-55) -- BatchNorm buffers restored afterwards.  Returns (logits fp32 view, loss)."""
+    with torch.no_grad():
+        bn = head[1]
+        rm, rv, nb = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            pooled = pool_fn(x) if pool_fn is not None else head[0](x)
+            lg16 = head[2](head[1](pooled))
+            ls16 = crit(lg16, t)
+        bn.running_mean.copy_(rm); bn.running_var.copy_(rv); bn.num_batches_tracked.copy_(nb)
+    return lg16.float().numpy(), np.float32(ls16.float().item())
+
+
 def run_epcls_case(case):
     """EfficientProbing.forward(x, cls=...) of the real reference (poolings/ep.py:32-33): pooled vector, and the gradients
     of the per-image queries and of v.weight under the upstream gradient ``dy`` (the learned cls_token takes none)."""
@@ -264,6 +279,8 @@ def run_coca_case(case):
         loss = crit(logits, t)
         loss.backward()
         if step == 0:
+            # round 6: the head under bf16 autocast -- the fidelity fixture of the AMP-bf16 arithmetic mode (as for EP)
+            out["logits_bf16_autocast"], out["loss_bf16_autocast"] = bf16_autocast_forward(head, x, t, crit)
             a1, a5 = topk_acc(logits, t)
             # attention of image query 0, restated from coca_pytorch.py:307-330
             pool = head[0]
@@ -1101,6 +1118,7 @@ def run_abmilp_case(case):
         loss = crit(logits, t)
         loss.backward()
         if step == 0:
+            out["logits_bf16_autocast"], out["loss_bf16_autocast"] = bf16_autocast_forward(head, x, t, crit)
             a1, a5 = topk_acc(logits, t)
             out.update(pooled=pooled.detach().numpy(), attn_map=amap.detach().numpy(), z=z.detach().numpy(),
                        logits=logits.detach().numpy(), loss=np.float32(loss.item()), acc1=np.float32(a1),

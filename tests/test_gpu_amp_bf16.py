@@ -211,3 +211,61 @@ def test_other_heads_and_bad_names_are_refused_on_the_host():
     inp = make_inputs(case)
     with pytest.raises(ValueError, match="arithmetic"):
         ProbeHeadEngine(_head(case, inp), optimizer="sgd", arithmetic="fp8")
+
+
+# ---- round 6: the two heads BASELINE configs[3] compares EP with run the mode as well (reference engine_finetune.py:52-55 wraps
+# every head in the same autocast; poolings/abmilp.py:53-71, poolings/coca_pytorch.py:250-343) ----
+def _other_head(fam, case):
+    if fam == "coca":
+        import test_gpu_coca as T
+        from cases import make_coca_inputs as mk
+        from efficient_probing_amd.engine import CocaHeadEngine as E
+    else:
+        import test_gpu_abmilp as T
+        from cases import make_abmilp_inputs as mk
+        from efficient_probing_amd.engine import AbmilpHeadEngine as E
+    inp = mk(case)
+    x = T.tokens(case, inp["x_buf"]) if fam == "coca" else torch.from_numpy(inp["x_buf"]).to(DEV)
+    return T, E, inp, x, torch.from_numpy(inp["targets"]).to(DEV)
+
+
+def _other_cases():
+    from cases import COCA_CASES, ABMILP_CASES
+    return [("coca", c) for c in COCA_CASES] + [("abmilp", c) for c in ABMILP_CASES]
+
+
+@pytest.mark.parametrize("fam_case", _other_cases(), ids=lambda fc: f"{fc[0]}_{fc[1].name}")
+def test_coca_and_abmilp_heads_in_the_amp_mode(fam_case):
+    fam, case = fam_case
+    T, E, inp, x, t = _other_head(fam, case)
+    g = T.load(case)
+    if "logits_bf16_autocast" not in g.files:
+        pytest.skip("fixture without the bf16-autocast forward")
+    out = {}
+    for mode in ("fp32", "bf16_autocast"):
+        head, _ = T.native_head(case, inp)
+        eng = E(head, optimizer="sgd", lr=0.0, arithmetic=mode)
+        eng.train_step(x, t, lr=0.0)
+        loss, _, _, bad = eng.read_stats()
+        assert bad == 0 and int(eng.found_inf.item()) == 0
+        out[mode] = (eng.last_train_logits().cpu().numpy(), loss)
+    np.testing.assert_allclose(out["fp32"][0], g["logits"], rtol=2e-4, atol=2e-4)
+    scale = float(np.abs(g["logits"]).max())
+    d = float(np.abs(out["bf16_autocast"][0] - out["fp32"][0]).max())
+    assert d > 1e-5 * scale, "the AMP mode returned the fp32 logits: single-product kernels not in use?"
+    assert_amp_bf16_fidelity(out["bf16_autocast"][0], out["bf16_autocast"][1], g, err_msg=f"{fam}_{case.name}", slack=2.0)
+    # ... and no further from the fp32 mode than the reference's bf16 head is from its fp32 one (the other leg of the triangle)
+    ulp = 2.0 ** -8 * scale
+    own = float(np.abs(np.asarray(g["logits"], np.float64) - np.asarray(g["logits_bf16_autocast"], np.float64)).max()) / ulp
+    assert d <= max(4.0, 1.25 * own) * ulp, (d / ulp, own)
+    # three LARS steps in both modes stay close
+    heads = [T.native_head(case, inp)[0] for _ in range(2)]
+    e32, e16 = E(heads[0], optimizer="lars", lr=0.1, arithmetic="fp32"), E(heads[1], optimizer="lars", lr=0.1, arithmetic="bf16_autocast")
+    for _ in range(3):
+        e32.train_step(x, t, lr=0.1); e16.train_step(x, t, lr=0.1)
+    for a, b in zip(e32.params_list, e16.params_list):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        if float(a.norm()) > 0:
+            # (LARS steps the 1-D tensors by lr x gradient without a trust ratio, and several of this head's bias gradients are
+            # sums of cancelling terms -- tests/test_gpu_abmilp.py CANCELLING: their drift is not normalised)
+            assert float((a - b).norm() / a.norm()) < (3e-2 if a.dim() > 1 else 1e-1)
