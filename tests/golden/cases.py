@@ -48,6 +48,10 @@ CASES = [
     # the published protocol's query count (main_linprobe.py:113 --ep_queries 32) on DINOv2 ViT-B/14 tokens: the f32 / D <= 768 /
     # Q > 16 kernel dispatch (round 5)
     Case("vitb14_q32", B=8, N=256, D=768, Q=32, C=1000, seed=5, full=False, steps=3),
+    # round 6: the published `ep_all` ViT-7B row's shape -- [CLS] + 196 patch tokens of 4096 (reference README.md:68,
+    # util/cls_features.py:29-37) at the protocol's 32 queries (main_linprobe.py:113): an odd token count on the wide-row kernels,
+    # in query chunks
+    Case("vit7b_all_q32", B=8, N=197, D=4096, Q=32, C=1000, seed=6, full=False, steps=1, sub_rows=128),
 ]
 CASE_BY_NAME = {c.name: c for c in CASES}
 

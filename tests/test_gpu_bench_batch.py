@@ -26,8 +26,10 @@ WIDE_IDS = ["c3_b1024", "c4_b1024"]
 # round 5: the two BASELINE configurations that were only step-checked below the bench batch -- configs[0] (196x384, Q = 1:
 # the one-query template of the vector-ALU pass) and configs[4] (196x4096: four workgroup rounds of the wide-row kernel,
 # the bf16x3 weight-gradient kernel over 1024 rows)
-EDGE = [(1024, 196, 384, 1), (1024, 196, 4096, 8)]
-EDGE_IDS = ["c1_b1024", "c5_b1024"]
+# round 6: the published `ep_all` ViT-7B row's shape, [CLS] + 196 patch tokens of 4096 (reference README.md:68): an odd token
+# count on the wide-row kernels (f32) and the hybrid ones (bf16-stored)
+EDGE = [(1024, 196, 384, 1), (1024, 196, 4096, 8), (1024, 197, 4096, 8)]
+EDGE_IDS = ["c1_b1024", "c5_b1024", "c5all_b1024"]
 
 
 def fp64_reference(x, cls, scale, dP, chunk=128):
