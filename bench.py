@@ -589,16 +589,29 @@ def main():
     kname_b = "ep_imgqf_kernel (backward)" if rowq else "ep_cbam_chan_kernel (pass A)" if cbam else "ep_imgq_kernel (backward)" if imgq else eng.lib.ep_pool_kernel_name_ex(B, Nn, D, Q, 1, dt).decode()
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the
     # committed profile of this same command -- rocprofv3 counters cannot be read from inside the run
-    traffic, traffic_source = None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    traffic, traffic_source, traffic_stale = None, None, False
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):           # (the newest round that has one: it is current or it is stale)
         tpath = os.path.join(ROOT, "profiles", rnd, f"{args.workload}_hbm_traffic_pmc.json")
-        if traffic is None and os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
+        if traffic is None and not traffic_stale and os.path.exists(tpath) and B == 1024 and args.tokens == "f32" and args.head == "ep":
             try:
-                pk = json.load(open(tpath))["per_kernel"]
-                # (of the dominant kernel: the second pass; the counters average its in-step and stand-alone launches)
-                traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pk.items() if k.startswith(kname_b)), None)
-                if traffic is not None:
-                    traffic_source = f"profiles/{rnd}/{args.workload}_hbm_traffic_pmc.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
+                prof = json.load(open(tpath))
+                pk = prof["per_kernel"]
+                # Counters are a citation of a committed profile, never of this run -- and only of THESE kernel sources: the
+                # profile carries the sha256 of csrc/ + include/ it was taken on (tools/src_hash.py, written by
+                # tools/make_profiles.sh); any other tree makes the number stale and it is withheld.
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from src_hash import source_hash
+                if prof.get("source_hash") != source_hash(ROOT):
+                    traffic_stale = True
+                    traffic_source = (f"profiles/{rnd}/{args.workload}_hbm_traffic_pmc.json was taken on other kernel sources "
+                                      f"(source_hash {str(prof.get('source_hash'))[:12]} != {source_hash(ROOT)[:12]}): withheld")
+                    break
+                # of the dominant kernel (the second pass), its launches INSIDE train steps only where the profile separates them
+                ent = next((v for k, v in pk.items() if k.startswith(kname_b)), None)
+                if ent is not None:
+                    traffic = round(ent.get("in_step", ent)["hbm_bytes_per_launch"])
+                    traffic_source = (f"profiles/{rnd}/{args.workload}_hbm_traffic_pmc.json (committed rocprofv3 --pmc passes of this command on "
+                                      f"these sources{', in-step launches only' if 'in_step' in ent else ''}; not re-measured in this run)")
             except Exception:
                 traffic = None
     fwd_gbs = algo_bytes / t_fwd / 1e9
@@ -872,7 +885,7 @@ def main():
             dom_how, fwd_us = alone["note"], None
         dom_gbs = algo_bytes / (dom_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                     "us_per_launch": round(dom_us, 2), "algorithmic_bytes": algo_bytes, "measured": dom_how,
                     "step_frac": step_frac, "alone": alone}
         if fwd_us is not None:

@@ -1035,8 +1035,23 @@ int ep_head_eval_forward(const ep_head_dims* dims, const void* x, int x_dtype, i
   PoolParams p = pool_params(x, x_bstride, d.B, d.N, d.D, d.Q, scale, x_dtype);
   p.cls = params + offs[0]; p.cls_bstride = 0; p.P = w.P; p.S = w.S; p.ML = w.ML; p.index = image_index;
   EP_TRY(pool_forward(p, st));
-  EP_TRY(project_forward(w.P, params + offs[1], d.B, d.D, Dp, d.Q, w.y, st));
-  EP_TRY(bn_forward_eval(w.y, d.B, Dp, bn_eps, running_mean, running_var, w.z, st));
+  // the value projection writes z itself: eval-mode BatchNorm is a fixed per-column map, folded into the contraction's epilogue
+  // (ep_side.h: store_acc_blocks) -- the arithmetic of ep_bn_eval_kernel, one launch less (EP_EVAL_FOLD=0: the round-5 chain)
+  static int fold = -1;
+  if (fold < 0) { const char* e = getenv("EP_EVAL_FOLD"); fold = e ? atoi(e) : 1; }
+  if (fold) {
+    const int Dq = Dp / d.Q;
+    GemmParams g{};
+    g.A = w.P; g.lda = (int64_t)d.Q * d.D; g.sAz = d.D;
+    g.B = params + offs[1]; g.ldb = d.D; g.sBz = (int64_t)Dq * d.D;
+    g.C = w.z; g.ldc = Dp; g.sCz = Dq;
+    g.M = d.B; g.N = Dq; g.K = d.D; g.alpha = 1.f; g.extA = d.D; g.extB = d.D;
+    g.bn_rm = running_mean; g.bn_rv = running_var; g.bn_eps = bn_eps; g.sBiasz = Dq;
+    EP_TRY(gemm(true, true, g, d.Q, st));
+  } else {
+    EP_TRY(project_forward(w.P, params + offs[1], d.B, d.D, Dp, d.Q, w.y, st));
+    EP_TRY(bn_forward_eval(w.y, d.B, Dp, bn_eps, running_mean, running_var, w.z, st));
+  }
   EP_TRY(linear_forward(w.z, params + offs[2], params + offs[3], d.B, Dp, d.C, logits, ldl, st));
   return 0;
 }

@@ -83,6 +83,10 @@ struct GemmParams {
   int nterms;                       // bf16 matrix-core kernels (planes, b3): 0 / 3 = three-term split at fp32 accuracy; 1 = ONE product of the
                                     // operands rounded to bf16, fp32 accumulation (the AMP-bf16 arithmetic mode: gemm_arith())
   int zn;                           // planes kernel: batch count of a 1-D (m_fast) launch, set by gemm_planes
+  // BatchNorm1d(affine=False) in EVAL mode folded into the epilogue (round 6, ep_head_eval_forward: the value projection writes
+  // z = (y - running_mean[col]) / sqrt(running_var[col] + eps) directly -- the arithmetic of ep_bn_eval_kernel, one launch less);
+  // indexed by the output column like `bias` (batched launches: z * sBiasz + col)
+  const float* bn_rm; const float* bn_rv; float bn_eps;
   int m_fast;                       // planes kernel: M-tiles fastest in the launch order (few M-tiles against a very long N: the
                                     // workgroups that share a weight tile then run together and it is fetched from HBM once)
 };

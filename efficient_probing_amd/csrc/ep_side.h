@@ -40,6 +40,11 @@ __device__ __forceinline__ void store_acc_blocks(const GemmParams& p, float* __r
       off[b][r] = (int64_t)(row < p.M ? row : p.M - 1) * p.ldc + colc;
       v[b][r] = p.alpha * acc[b][r] + bv;
     }
+    if (p.bn_rm) {                                     // eval-mode BatchNorm of the output column (GemmParams.bn_rm)
+      const float rm = p.bn_rm[(int64_t)z * p.sBiasz + colc], sd = sqrtf(p.bn_rv[(int64_t)z * p.sBiasz + colc] + p.bn_eps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[b][r] = (v[b][r] - rm) / sd;
+    }
   }
   if (p.accumulate) {
     float old[NB][4];
