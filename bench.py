@@ -743,6 +743,20 @@ def main():
         line["workload"] = cdesc + " [tokens stored as bf16, fp32 arithmetic]"
         line["classes"] = cC
         configs["c5_bf16"] = line
+        # ... and at the other published rows' shapes: MAE ViT-L/16, SigLIP2 SO400M (fp32 tokens) and the
+        # pre-dumped ViT-7B tokens as they fit 8 x 288 GB (bf16-stored)
+        for cname, stor in (("c3", "f32"), ("c4", "f32"), ("c5", "bf16")):
+            try:
+                qN, qD, _, qC, qdesc = WORKLOADS[cname]
+                torch.cuda.empty_cache()
+                line = secondary(qN, qD, 32, stor, 20, sC=qC, passes=True)
+                line["workload"] = qdesc.replace("EP q=8", "EP q=32") + (" [tokens stored as bf16]" if stor == "bf16" else "")
+                base = configs.get(cname if stor == "f32" else cname + "_bf16", {}).get("ms_per_step")
+                if base:
+                    line["ratio_to_q8_step"] = round(line["ms_per_step"] / base, 3)
+                configs[f"{cname}_q32" + ("_bf16" if stor == "bf16" else "")] = line
+            except Exception as e:
+                configs[f"{cname}_q32"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         # The published runs train under --amp bfloat16 (reference README.md:639-645, engine_finetune.py:52-55).  The same steps in
         # the AMP-bf16 arithmetic mode (ep_head_step.arith = EP_ARITH_BF16_AUTOCAST: the six contractions as ONE bf16 matrix-core
         # product with fp32 accumulation; token passes, softmax, BatchNorm, loss and optimizer unchanged) -- secondary objects,

@@ -629,9 +629,10 @@ static int mm2_launch_one(bool bwd, const PoolParams& p, int grid, hipStream_t s
 // fp32 tokens, shared query rows, 17 .. 32 queries, D = 128 k up to 1024 (two ring slots + the per-slot score / statistics
 // pieces must fit the 160 KiB, the register budget is 256 per wave at two waves per SIMD)
 bool mm2_supported(int D, int Q, int64_t cls_bstride, bool bwd) {
-  (void)bwd;
   if (cls_bstride != 0 || Q <= 16 || Q > 32 || D % 128 != 0 || D < 256) return false;
-  return D <= 1024;
+  // D = 1152 (SigLIP2 SO400M, round 6): the BACKWARD only -- 244 registers, 409 us in the step at 1024 x 256 against 586 us as two
+  // 16-query chunks; the forward instantiation spills 28 registers (256 + scratch) and is SLOWER than the chunks (659 against 568 us)
+  return D <= 1024 || (D == 1152 && bwd);
 }
 
 int mm2_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
@@ -643,6 +644,7 @@ int mm2_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {
     case 6: return mm2_launch_one<6>(bwd, p, grid, st);
     case 7: return mm2_launch_one<7>(bwd, p, grid, st);
     case 8: return mm2_launch_one<8>(bwd, p, grid, st);
+    case 9: return mm2_launch_one<9>(bwd, p, grid, st);      // round 6: SigLIP2 SO400M's 1152 (ring of two 72 KiB tiles, as D = 1024)
   }
   set_error("no 32-query matrix-core pooling kernel for D=%d", p.D);
   return EP_E_UNSUPPORTED;

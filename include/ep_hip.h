@@ -13,7 +13,12 @@
  *     library never allocates persistent memory and never frees caller memory.  Scratch is
  *     passed in explicitly; its size comes from the matching *_workspace_bytes() query.
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns
- *     without synchronising the device (safe to capture into a hipGraph).
+ *     without synchronising the device.  A call can be captured into a hipGraph (round 6:
+ *     tests/test_gpu_graph_capture.py captures whole ep_head_train_step calls and replays them bit-identically), with
+ *     two things to know: the FIRST call of a kind must run eagerly (it sets kernel attributes and creates the library's
+ *     events), and scalars are passed by VALUE -- a captured step replays with ITS lr / opt_step / planes_valid, so a
+ *     learning-rate schedule needs a re-capture per value (the loss scale is the exception: ep_head_step.scaler_state
+ *     lives on the device).  Replays measure the same device time as eager steps (the step is GPU-bound).
  *   - return value: 0 = ok; negative = invalid argument / unsupported shape (EP_E_*);
  *     positive = hipError_t of a failed launch.  Nothing throws across the boundary.
  *     ep_last_error_string() returns a thread-local description of the last failure.
@@ -317,8 +322,10 @@ typedef struct ep_head_step {
    * EP_ARITH_BF16_AUTOCAST (1): what the published runs' --amp bfloat16 does inside autocast (reference
    * engine_finetune.py:52-55): both operands rounded to bf16, ONE matrix-core product, fp32 accumulation -- the outputs stay
    * fp32 (autocast rounds them to bf16 as well), softmax / BatchNorm statistics / cross-entropy / the optimizer stay fp32, the
-   * token passes keep their arithmetic.  Needs (D / d_out / Q) % 32 == 0 (the contractions run against the weight planes);
-   * EP_E_UNSUPPORTED otherwise.  A secondary mode: never the default, never the headline number. */
+   * token passes keep their arithmetic.  Every slice width since round 6: where (D / d_out / Q) % 32 != 0 (256 x 768 at the
+   * protocol's 32 queries, SigLIP2 SO400M's 1152) dP = dy_q Wv_q -- the one contraction over a query's SLICE of the planes'
+   * permuted k-order -- runs on the thin-slice / single-product tile kernels instead.  A secondary mode: never the default,
+   * never the headline number. */
   int32_t arith;
   /* ABI v26: device-resident loss scale -- torch.cuda.amp.GradScaler (reference util/misc.py:260-286: scale(loss), unscale_,
    * step skipped on inf / nan, update()) without a host read per step.  scaler_state (device, 4 floats, NULL = off): two slots
