@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -Wno-unused-variable"
 objs=()
 maxjobs="${EP_BUILD_JOBS:-8}"
-for f in ep_pool ep_pool_stream ep_pool_bwd2 ep_pool_mfma ep_pool_mm ep_pool_mm2 ep_pool_mb ep_pool_mb_amp ep_pool_wide ep_pool_wideb ep_gemm ep_planes ep_planes_big ep_tail ep_optim ep_api ep_coca ep_abmilp ep_knn ep_siglip ep_aim ep_pool_imgq ep_simpool ep_cait ep_clip ep_dolg ep_cbam ep_dinovit; do
+for f in ep_pool ep_pool_stream ep_pool_bwd2 ep_pool_mfma ep_pool_mm ep_pool_mm2 ep_pool_mb ep_pool_mb_amp ep_pool_wide ep_pool_wideb ep_gemm ep_planes ep_planes_big ep_tail ep_dp_slice ep_optim ep_api ep_coca ep_abmilp ep_knn ep_siglip ep_aim ep_pool_imgq ep_simpool ep_cait ep_clip ep_dolg ep_cbam ep_dinovit; do
   src="${here}/${f}.hip"; obj="${here}/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${here}/ep_common.h" -nt "$obj" || "${here}/ep_internal.h" -nt "$obj" || "${here}/ep_pool_stream.h" -nt "$obj" || "${here}/ep_side.h" -nt "$obj" || "${here}/ep_inpass.h" -nt "$obj" || "${here}/ep_gemm_dma.h" -nt "$obj" || "${here}/ep_sidetask.h" -nt "$obj" || "${here}/ep_stream_dev.h" -nt "$obj" || "${here}/ep_lnaffine.h" -nt "$obj" || "${here}/ep_pool_imgq.h" -nt "$obj" || "${here}/ep_headkernels.h" -nt "$obj" || "${here}/ep_planes_dev.h" -nt "$obj" || "${here}/ep_wgrad3.h" -nt "$obj" || "${here}/../../include/ep_hip.h" -nt "$obj" || ( "$f" == ep_pool_mb_amp && "${here}/ep_pool_mb.hip" -nt "$obj" ) ]]; then
     echo "[build] hipcc ${f}.hip" >&2

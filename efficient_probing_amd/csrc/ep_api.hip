@@ -78,6 +78,8 @@ static int check_tokens_fwd(const void* x, int x_dtype, int64_t x_bstride, int B
 
 bool project_dp_thin_ok(int D, int Dp, int Q);           // ep_tail.hip: thin query slices (Dq <= 32)
 int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
+bool project_dp_slice_ok(const float* dy, const float* Wv, const float* dP, int D, int Dp, int Q);   // ep_dp_slice.hip: the same on the bf16 matrix cores (round 6)
+int project_dp_slice(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
 
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
@@ -292,7 +294,9 @@ static int project_backward(const float* dy, const float* y, const float* P, con
                             int Q, float* dP, float* dWv, float* ML, int accumulate, hipStream_t st) {
   const int Dq = Dp / Q;
   if (ML && y) EP_TRY(delta_rows(dy, y, B * Q, Dq, ML, st));
-  if (dP && project_dp_thin_ok(D, Dp, Q)) {
+  if (dP && project_dp_slice_ok(dy, Wv, dP, D, Dp, Q)) {
+    EP_TRY(project_dp_slice(dy, Wv, B, D, Dp, Q, dP, st));
+  } else if (dP && project_dp_thin_ok(D, Dp, Q)) {
     EP_TRY(project_dp_thin(dy, Wv, B, D, Dp, Q, dP, st));
   } else if (dP) {
     GemmParams g{};
@@ -923,28 +927,43 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       if (side2_on < 0) { const char* e = getenv("EP_SIDE2"); side2_on = e ? atoi(e) : 1; }
       hipStream_t side2 = side;
       if (side != st && side2_on && !plw && d.Q > 16) EP_TRY(get_side2_stream(&side2));
-      if (side != st) {
-        EP_TRY(get_events(ev, 4));
+      // ONE fork (round 6 experiment, EP_ONE_FORK: 0 = off, the default; 1 = with two side queues only; 2 = always): every event
+      // recorded on the step's own stream costs it ~6 us of idle queue (rocprofv3 timelines of the 32-query steps: three records
+      // and a join = ~30 us per step), so both side queues could fork once, behind BatchNorm backward.  Measured SLOWER: the
+      // classifier's weight gradient loses its head start and runs into the second pass -- 196 x 1024 Q = 32 0.787 / 0.795 ->
+      // 0.837 / 0.817 ms, 256 x 768 Q = 32 bf16 0.431 / 0.453 -> 0.469, fp32 0.721 / 0.713 -> 0.755 / 0.749; Q = 8 at 196 x 1024 and
+      // 256 x 1152 unchanged within noise.
+      static int one_fork_env = -1;
+      if (one_fork_env < 0) { const char* e = getenv("EP_ONE_FORK"); one_fork_env = e ? atoi(e) : 0; }
+      const bool one_fork = side != st && !plw && (one_fork_env == 2 || (one_fork_env == 1 && side2 != side));
+      if (side != st) EP_TRY(get_events(ev, 4));
+      if (side != st && !one_fork) {
         EP_HIP(hipEventRecord(ev[0], st));
         EP_HIP(hipStreamWaitEvent(side, ev[0], 0));
       }
-      EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
       struct SideHint { int old; explicit SideHint(int v) : old(t_wgrad_side) { t_wgrad_side = v; } ~SideHint() { t_wgrad_side = old; } };
       const SideHint hint(d.Q > 16 ? 0 : 1);                // (restored when this branch is left, error returns included)
-      if (plw) {
-        EP_TRY(wgrad_dwc_pl(w, d, s->grads + offs[2], s->accumulate, side));
-        EP_TRY(colsum(w.dlogits, d.B, d.C, w.ldl, s->accumulate, s->grads + offs[3], side));
-      } else {
-        EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
-                               s->accumulate, side));
-      }
+      auto classifier_side = [&]() -> int {                  // statistics fold, dWc, dbc: nothing before the optimizer reads them
+        EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
+        if (plw) {
+          EP_TRY(wgrad_dwc_pl(w, d, s->grads + offs[2], s->accumulate, side));
+          EP_TRY(colsum(w.dlogits, d.B, d.C, w.ldl, s->accumulate, s->grads + offs[3], side));
+        } else {
+          EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, nullptr, s->grads + offs[2], s->grads + offs[3],
+                                 s->accumulate, side));
+        }
+        return 0;
+      };
+      if (!one_fork) EP_TRY(classifier_side());
       if (plc) EP_TRY(linear_backward_dz_pl(w, d, st));
       else EP_TRY(linear_backward(w.dlogits, w.ldl, w.z, Wc, d.B, Dp, d.C, w.dz, nullptr, nullptr, 0, st));
       EP_TRY(bn_backward(w.dz, w.z, w.rstd, d.B, Dp, w.dy, w.bnpart, st));
       if (side != st) {
         EP_HIP(hipEventRecord(ev[1], st));
         EP_HIP(hipStreamWaitEvent(side2, ev[1], 0));
+        if (one_fork && side2 != side) EP_HIP(hipStreamWaitEvent(side, ev[1], 0));
       }
+      if (one_fork) EP_TRY(classifier_side());
       // (The weight gradient of v started only when dP is done, so that it runs beside the HBM-bound second pass instead of
       // beside dP: measured, the pass then takes 1070 instead of 555 us at 196 x 4096 -- the two kernels do not share CUs.)
       if (plw) EP_TRY(wgrad_dwv_pl(w, d, s->grads + offs[1], s->accumulate, side));

@@ -597,6 +597,13 @@ __global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p) {
   if constexpr (EP_B3_STAGES == 2) gemm_tile_b3g2<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
   else gemm_tile_b3g<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
 }
+// THIN outputs (N <= 32 per batch entry, K / K layout): the value projection at the published protocol's 32 queries is 32 batched
+// contractions of 24 / 32 columns (reference poolings/ep.py:40 with --ep_queries 32) -- on 64-column tiles more than half of the
+// staging and of the matrix instructions worked on padding (rocprofv3, in the step: 32 - 41 us).  64 x 32 tiles: wave = 32 x 16.
+__global__ __launch_bounds__(256) void ep_gemm_b3_thin_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
+  gemm_tile_b3g<true, true, 64, 32>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+}
 constexpr size_t B3_KERNEL_LDS = EP_B3_STAGES * W3_LDS_BYTES;
 template <bool A_K, bool B_K>
 static void b3_launch(const GemmParams& p, int batch, bool m32, hipStream_t st) {
@@ -668,6 +675,15 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
     const bool m32 = !(p.M % 64 == 0 || p.M >= 256) || tiles64 < 2L * cu_count();
     GemmParams q3 = p;
     if (t_arith == 1) q3.nterms = 1;
+    static int thin_on = -1;                                   // EP_GEMM_B3_THIN=0: 64-column tiles for thin outputs too
+    if (thin_on < 0) { const char* e = getenv("EP_GEMM_B3_THIN"); thin_on = e ? atoi(e) : 1; }
+    if (thin_on && a_k && b_k && p.N <= 32 && p.M >= 64) {
+      static bool attr_thin = false;
+      if (!attr_thin) { (void)hipFuncSetAttribute((const void*)ep_gemm_b3_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES); attr_thin = true; }
+      hipLaunchKernelGGL(ep_gemm_b3_thin_kernel, dim3((p.N + 31) / 32, (p.M + 63) / 64, batch), dim3(256), W3_LDS_BYTES, st, q3);
+      EP_LAUNCH_CHECK("ep_gemm_b3_thin_kernel");
+      return 0;
+    }
     if (!a_k) b3_launch<false, false>(q3, batch, m32, st);
     else if (b_k) b3_launch<true, true>(q3, batch, m32, st);
     else b3_launch<true, false>(q3, batch, m32, st);

@@ -97,13 +97,13 @@ __device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int row
 // C (+)= alpha * op(A) op(B)^T (+ bias) on one BMT x 64 tile.  A_K / B_K: the operand is contiguous along K (true) or along
 // its free dimension (false), as in ep_side.h: gemm_tile.  BMT = 64: 2 x 2 blocks per wave; 32: 1 x 2.  16-byte aligned
 // operands with leading dimensions (and K, for K-layout operands) multiples of 4 only.
-template <bool A_K, bool B_K, int BMT>
+template <bool A_K, bool B_K, int BMT, int BNT = 64>
 __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int by, int bz, char* lds) {
-  constexpr int MI = BMT / 32;
+  constexpr int MI = BMT / 32, NI = BNT / 32;        // 16 x 16 blocks per wave along M / N (BNT = 32: thin outputs, e.g. a 24-column query slice)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
-  const int m0 = by * BMT, n0 = bx * 64;
+  const int m0 = by * BMT, n0 = bx * BNT;
   const float* A = p.A + (int64_t)bz * p.sAz;
   const float* B = p.B + (int64_t)bz * p.sBz;
   float* C = p.C + (int64_t)bz * p.sCz;
@@ -113,13 +113,14 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
   // T-layout staging role: k-pair kp (0..15) x column quad mq (0..15); lanes run over mq first (coalesced rows)
   const int mq = tid & 15, kp = tid >> 4;
   const bool stA = A_K || 4 * mq < BMT;             // (T layout, 32-row tiles: half of the threads have no A work)
+  const bool stB = B_K || 4 * mq < BNT;
   const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
 
-  f4v acc[MI][2];
+  f4v acc[MI][NI];
 #pragma unroll
   for (int a = 0; a < MI; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NI; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + 31) / 32;
   const bool one = p.nterms == 1;
@@ -129,28 +130,28 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
     else w3_load_T(A, p.lda, extA, p.K, m0, k0, kp, stA ? mq : 0, xa);
   };
   auto loadB = [&](int k0) {
-    if constexpr (B_K) w3_load_K<64>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
-    else w3_load_T(B, p.ldb, extB, p.K, n0, k0, kp, mq, xb);
+    if constexpr (B_K) w3_load_K<BNT>(B, p.ldb, p.N, p.K, n0, k0, tid, xb);
+    else w3_load_T(B, p.ldb, extB, p.K, n0, k0, kp, stB ? mq : 0, xb);
   };
   loadA(0); loadB(0);
   for (int it = 0; it < nk; ++it) {
     if (it > 0) __syncthreads();                     // every wave has read tile it-1's fragments
     if constexpr (A_K) w3_stage_K<BMT>(imgA, xa, p.M, p.K, m0, it * 32, tid, one);
     else { if (stA) w3_stage_T(imgA, xa, extA, p.K, m0, it * 32, kp, mq, one); }
-    if constexpr (B_K) w3_stage_K<64>(imgB, xb, p.N, p.K, n0, it * 32, tid, one);
-    else w3_stage_T(imgB, xb, extB, p.K, n0, it * 32, kp, mq, one);
+    if constexpr (B_K) w3_stage_K<BNT>(imgB, xb, p.N, p.K, n0, it * 32, tid, one);
+    else { if (stB) w3_stage_T(imgB, xb, extB, p.K, n0, it * 32, kp, mq, one); }
     if (it + 1 < nk) { loadA((it + 1) * 32); loadB((it + 1) * 32); }     // in flight while this tile is multiplied
     __syncthreads();                                 // the plane images are complete
-    pl_u4 fa[MI][3], fb[2][3];
+    pl_u4 fa[MI][3], fb[NI][3];
     if (one) {                                       // AMP-bf16: bf16(a) x bf16(b), fp32 accumulation -- one product
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) fa[mi][0] = *reinterpret_cast<const pl_u4*>(imgA + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) fb[ni][0] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * 32 + ni * 16 + i16, kk));
+      for (int ni = 0; ni < NI; ++ni) fb[ni][0] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * (16 * NI) + ni * 16 + i16, kk));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
       continue;
     }
 #pragma unroll
@@ -159,10 +160,10 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
       for (int t = 0; t < 3; ++t)
         fa[mi][t] = *reinterpret_cast<const pl_u4*>(imgA + t * W3_IMG + w3_off(wm * (16 * MI) + mi * 16 + i16, kk));
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3_IMG + w3_off(wn * 32 + ni * 16 + i16, kk));
+        fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3_IMG + w3_off(wn * (16 * NI) + ni * 16 + i16, kk));
     // smallest terms first: lo x hi, hi x lo, mid x mid, then the 2^-8 pair, then hi x hi (as ep_planes.hip)
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr) {
@@ -170,17 +171,17 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
     }
   }
-  f4v blk[MI * 2]; int rb[MI * 2], cb[MI * 2];
+  f4v blk[MI * NI]; int rb[MI * NI], cb[MI * NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
+    for (int ni = 0; ni < NI; ++ni) {
+      blk[mi * NI + ni] = acc[mi][ni]; rb[mi * NI + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * NI + ni] = n0 + wn * (16 * NI) + ni * 16;
     }
-  store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
+  store_acc_blocks<MI * NI>(p, C, bz, rb, cb, blk, kk, i16);
   __syncthreads();                                   // LDS free for the caller's next tile
 }
 
