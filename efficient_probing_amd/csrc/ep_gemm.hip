@@ -552,12 +552,14 @@ bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k) {
 // Few output tiles and a very long K (weight gradients over all B N token rows): the tiles cannot fill the chip, so K is cut
 // into `splits` slices that run as the batch dimension into the caller's scratch and are summed in slice order
 // (ep_reduce_partials_kernel: deterministic).  Needs a contiguous C, no bias, one batch.
+static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k);
 static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st, bool* done) {
   *done = false;
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_SPLITK"); on = e ? atoi(e) : 1; }
   if (!on || !p.skws || p.bias || p.ldc != p.N || p.alpha != 1.0f || p.K < 8192 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
-  const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
+  const bool wide = b3_wide_ok(p, a_k, b_k);           // 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w): a quarter of the tiles
+  const long tiles = wide ? (long)((p.N + 127) / 128) * ((p.M + 127) / 128) : (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
   const long cus = cu_count();
   if (tiles >= 2 * cus) return 0;
   // the matrix pipe of a CU is shared by its workgroups: makespan ~ ceil(tiles * s / CUs) * (K / s); pick the s <= 16 with
@@ -569,6 +571,15 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
     if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < 1024) continue;
     const double cost = (double)((tiles * sp + cus - 1) / cus) / sp;
     if (cost < best * 0.95) { best = cost; splits = sp; }
+  }
+  if (wide && tiles * splits < 2 * cus) {
+    // the wide tile is one 4-wave workgroup with two barriers per K-tile: a CU needs TWO of them to keep its matrix pipe fed
+    // (the makespan model above counts whole rounds only) -- the smallest slice count that gives every CU two
+    for (int sp = splits + 1; sp <= 16; ++sp) {
+      if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < 1024) continue;
+      splits = sp;
+      if (tiles * sp >= 2 * cus) break;
+    }
   }
   if (splits < 2) return 0;
   const int kc = p.K / splits;
@@ -596,6 +607,21 @@ __global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
   if constexpr (EP_B3_STAGES == 2) gemm_tile_b3g2<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
   else gemm_tile_b3g<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+}
+// LONG weight gradients (T / T, K >= 4096) of at least 1024 x 1024 outputs: 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w).
+// Measured (ms per step, 256 images, 64 x 64 tiles -> wide): AbMILP 256 x 1152 18.22 -> 16.97 (AMP-bf16 mode 10.59 -> 9.79); at
+// D = 768 -- 36 wide tiles per gradient, one or two workgroups per CU after the K split -- it LOSES: DINOv2 block 20.3 -> 21.4,
+// DOLG 1.91 -> 1.98, AbMILP 8.75 -> 8.59: hence the size floor.  EP_GEMM_B3_WIDE=0: off; =2: from 256 x 256 (the first form).
+__global__ __launch_bounds__(256) void ep_gemm_b3_wide_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
+  gemm_tile_b3w(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+}
+static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EP_GEMM_B3_WIDE"); on = e ? atoi(e) : 1; }
+  const int floor_ = on == 2 ? 256 : 1024;
+  return on && gemm_b3_on() && !a_k && !b_k && !p.bias && !p.cs_out && p.M >= floor_ && p.N >= floor_ && p.K >= 4096 &&
+         vec_ok(p.A, p.lda, p.sAz, p.extA) && vec_ok(p.B, p.ldb, p.sBz, p.extB);
 }
 // THIN outputs (N <= 32 per batch entry, K / K layout): the value projection at the published protocol's 32 queries is 32 batched
 // contractions of 24 / 32 columns (reference poolings/ep.py:40 with --ep_queries 32) -- on 64-column tiles more than half of the
@@ -677,6 +703,13 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
     if (t_arith == 1) q3.nterms = 1;
     static int thin_on = -1;                                   // EP_GEMM_B3_THIN=0: 64-column tiles for thin outputs too
     if (thin_on < 0) { const char* e = getenv("EP_GEMM_B3_THIN"); thin_on = e ? atoi(e) : 1; }
+    if (b3_wide_ok(p, a_k, b_k)) {
+      static bool attr_wide = false;
+      if (!attr_wide) { (void)hipFuncSetAttribute((const void*)ep_gemm_b3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3W_LDS_BYTES); attr_wide = true; }
+      hipLaunchKernelGGL(ep_gemm_b3_wide_kernel, dim3((p.N + 127) / 128, (p.M + 127) / 128, batch), dim3(256), W3W_LDS_BYTES, st, q3);
+      EP_LAUNCH_CHECK("ep_gemm_b3_wide_kernel");
+      return 0;
+    }
     if (thin_on && a_k && b_k && p.N <= 32 && p.M >= 64) {
       static bool attr_thin = false;
       if (!attr_thin) { (void)hipFuncSetAttribute((const void*)ep_gemm_b3_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES); attr_thin = true; }

@@ -51,7 +51,8 @@ __device__ __forceinline__ void w3_load_T(const float* __restrict__ base, int64_
   }
 }
 // split and store this thread's 2 x 4 values into the three plane images of one operand (transposed: image rows = columns)
-__device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq, bool one = false) {
+__device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq, bool one = false,
+                                           int tstride = W3_IMG) {   // tstride: bytes between the three term images (128-row images: 2 W3_IMG)
   const bool cok = c0 + 4 * mq < ext;
   const bool k0ok = cok && k0 + 2 * kp < K, k1ok = cok && k0 + 2 * kp + 1 < K;
 #pragma unroll
@@ -61,8 +62,8 @@ __device__ __forceinline__ void w3_stage_T(char* img, const f4v (&x)[2], int ext
     const int o = w3_off(4 * mq + j, kp >> 2) + 4 * (kp & 3);
     *reinterpret_cast<unsigned*>(img + o) = h;
     if (one) continue;                               // AMP-bf16 (GemmParams.nterms == 1): the rounded operand only
-    *reinterpret_cast<unsigned*>(img + W3_IMG + o) = m;
-    *reinterpret_cast<unsigned*>(img + 2 * W3_IMG + o) = l;
+    *reinterpret_cast<unsigned*>(img + tstride + o) = m;
+    *reinterpret_cast<unsigned*>(img + 2 * tstride + o) = l;
   }
 }
 // ---- K layout (k contiguous): a thread takes 4 consecutive k of one row (two rows for 64-row tiles) ----------------------
@@ -392,6 +393,95 @@ __device__ __forceinline__ void gemm_tile_b3d(const GemmParams& p, int bx, int b
     }
   store_acc_blocks<MI * 2>(p, C, bz, rb, cb, blk, kk, i16);
   __syncthreads();                                    // LDS free for the caller's next tile
+}
+
+// The WIDE form for the long weight gradients of the matrix-core-bound heads (round 6): 128 x 128 output tile, both operands T
+// layout.  dW = dG^T X over the B N = 65536 token rows of the AbMILP / DINOv2-block / DOLG heads (reference poolings/abmilp.py:53-71,
+// poolings/dinov2_layers/block.py:86-113 under autograd) re-reads every operand column block once per tile of the other operand:
+// on 64 x 64 tiles the 1152 x 1152 x 65536 gradient pulls 10.6 GB through the L2 -> LDS path (16 KiB per K-tile and tile), and the
+// five of them in an AbMILP step at 256 x 1152 take 5 x 1.69 ms = 112 TFLOP/s fp32-equivalent (rocprofv3) -- operand-traffic
+// bound, not matrix bound (27 % of the bf16 pipe).  A 128 x 128 tile halves the bytes per FLOP and doubles the matrix work per
+// barrier pair (96 instead of 24 instructions per wave and K-tile).  Wave (wm, wn) of the 2 x 2 owns 64 x 64 = 4 x 4 blocks;
+// plane images of 128 rows (term stride 2 W3_IMG), one LDS stage of 60 KiB, the next K-tile's rows in flight in registers.
+constexpr int W3W_TS = 2 * W3_IMG;                                   // bytes per term image (128 rows)
+constexpr size_t W3W_LDS_BYTES = 6 * (size_t)W3W_TS;                 // A: h m l | B: h m l = 61440
+__device__ __forceinline__ void gemm_tile_b3w(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * 128, n0 = bx * 128;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  char* imgA = lds;
+  char* imgB = lds + 3 * W3W_TS;
+  const int mq = tid & 15, kp = tid >> 4;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  const int nk = (p.K + 31) / 32;
+  const bool one = p.nterms == 1;
+  f4v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  f4v xa[2][2], xb[2][2];                            // [64-column half][k of the pair]
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      w3_load_T(A, p.lda, extA, p.K, m0 + 64 * h, k0, kp, mq, xa[h]);
+      w3_load_T(B, p.ldb, extB, p.K, n0 + 64 * h, k0, kp, mq, xb[h]);
+    }
+  };
+  load(0);
+  for (int it = 0; it < nk; ++it) {
+    if (it > 0) __syncthreads();                     // every wave has read tile it-1's fragments
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      w3_stage_T(imgA + h * W3_IMG, xa[h], extA, p.K, m0 + 64 * h, it * 32, kp, mq, one, W3W_TS);
+      w3_stage_T(imgB + h * W3_IMG, xb[h], extB, p.K, n0 + 64 * h, it * 32, kp, mq, one, W3W_TS);
+    }
+    if (it + 1 < nk) load((it + 1) * 32);            // in flight while this tile is multiplied
+    __syncthreads();                                 // the plane images are complete
+    if (one) {
+      pl_u4 fb1[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fb1[ni] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * 64 + ni * 16 + i16, kk));
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const pl_u4 fa1 = *reinterpret_cast<const pl_u4*>(imgA + w3_off(wm * 64 + mi * 16 + i16, kk));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = pl_mfma(fa1, fb1[ni], acc[mi][ni]);
+      }
+      continue;
+    }
+    pl_u4 fb[4][3];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3W_TS + w3_off(wn * 64 + ni * 16 + i16, kk));
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      pl_u4 fa[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) fa[t] = *reinterpret_cast<const pl_u4*>(imgA + t * W3W_TS + w3_off(wm * 64 + mi * 16 + i16, kk));
+      // smallest terms first, as gemm_tile_b3g: lo x hi, hi x lo, mid x mid, mid x hi, hi x mid, hi x hi
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) {
+        const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = pl_mfma(fa[ta], fb[ni][tb], acc[mi][ni]);
+      }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {                   // the epilogue in four groups of four blocks (its loads and stores stay counted)
+    f4v blk[4]; int rb[4], cb[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) { blk[ni] = acc[mi][ni]; rb[ni] = m0 + wm * 64 + mi * 16; cb[ni] = n0 + wn * 64 + ni * 16; }
+    store_acc_blocks<4>(p, C, bz, rb, cb, blk, kk, i16);
+  }
 }
 
 // the weight-gradient form (both operands T layout): what the token passes run as side work

@@ -20,8 +20,12 @@ def rel_err(got, want):
 
 
 @pytest.mark.parametrize("shape", [(1024, 768, 1000), (1025, 768, 1000), (257, 64, 10), (96, 384, 100), (64, 128, 7), (4096, 1152, 1000),
-                                   (33, 768, 1000)],
-                         ids=["c2", "ragged_rows", "tiny_classes", "k96", "k64_c7", "so400m_b4096", "k33_f32_path"])
+                                   (33, 768, 1000),
+                                   # round 6: the 128 x 128 tile of long gradients (csrc/ep_wgrad3.h: gemm_tile_b3w; K >= 4096, outputs
+                                   # >= 1024 x 1024): whole tiles, ragged edges on both sides and a ragged K
+                                   (4096, 1152, 1024), (4100, 1156, 1100), (8192, 1024, 1280)],
+                         ids=["c2", "ragged_rows", "tiny_classes", "k96", "k64_c7", "so400m_b4096", "k33_f32_path",
+                              "wide_tile", "wide_tile_ragged", "wide_tile_k8192"])
 def test_classifier_weight_gradient_vs_fp64(shape):
     from efficient_probing_amd import functional as F_
     B, Dp, C_ = shape
@@ -32,7 +36,8 @@ def test_classifier_weight_gradient_vs_fp64(shape):
     _, dW, db = F_.linear_backward(dl, z, W, need_dz=False)
     want = dl.double().t() @ z.double()
     assert rel_err(dW, want) < 4e-6
-    np.testing.assert_allclose(db.cpu().numpy(), dl.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # (the bias gradient is a plain fp32 column sum over the B rows: its absolute error grows with the row count)
+    np.testing.assert_allclose(db.cpu().numpy(), dl.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5 * max(1.0, B / 1024))
     # accumulate: C += A^T B
     base = torch.randn_like(dW)
     acc = base.clone()
