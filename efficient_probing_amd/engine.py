@@ -161,7 +161,7 @@ class ProbeHeadEngine:
         import os
         want = overlap_comm if overlap_comm is not None else (os.environ.get("EP_OVERLAP_COMM", "0") == "1")
         self._pipelined = bool(want) and self._supports_comm_overlap() and self.accum_iter == 1 \
-            and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force") and self.arithmetic == "fp32"
+            and self.loss_scale == 1.0 and (self.world > 1 or overlap_comm == "force")
         self._pending = None
         # Deferred large update (one rank): the step updates cls_token, then v.weight / fc.* on the aux stream BESIDE the
         # next step's first token pass (which reads cls_token only).  Off by default -- between a train_step() and the
