@@ -79,7 +79,7 @@ static int check_tokens_fwd(const void* x, int x_dtype, int64_t x_bstride, int B
 bool project_dp_thin_ok(int D, int Dp, int Q);           // ep_tail.hip: thin query slices (Dq <= 32)
 int project_dp_thin(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
 bool project_dp_slice_ok(const float* dy, const float* Wv, const float* dP, int D, int Dp, int Q);   // ep_dp_slice.hip: the same on the bf16 matrix cores (round 6)
-int project_dp_slice(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st);
+int project_dp_slice(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st, const float* yv, float* ML);
 
 struct HeadWs {
   float *P, *S, *ML, *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy, *dP;
@@ -293,9 +293,11 @@ GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int
 static int project_backward(const float* dy, const float* y, const float* P, const float* Wv, int B, int D, int Dp,
                             int Q, float* dP, float* dWv, float* ML, int accumulate, hipStream_t st) {
   const int Dq = Dp / Q;
-  if (ML && y) EP_TRY(delta_rows(dy, y, B * Q, Dq, ML, st));
-  if (dP && project_dp_slice_ok(dy, Wv, dP, D, Dp, Q)) {
-    EP_TRY(project_dp_slice(dy, Wv, B, D, Dp, Q, dP, st));
+  const bool slice = dP && project_dp_slice_ok(dy, Wv, dP, D, Dp, Q);
+  const bool slice_delta = slice && ML && y && aligned16(y) && aligned16(ML);       // the delta rows inside the dP kernel (one launch less)
+  if (ML && y && !slice_delta) EP_TRY(delta_rows(dy, y, B * Q, Dq, ML, st));
+  if (slice) {
+    EP_TRY(project_dp_slice(dy, Wv, B, D, Dp, Q, dP, st, slice_delta ? y : nullptr, slice_delta ? ML : nullptr));
   } else if (dP && project_dp_thin_ok(D, Dp, Q)) {
     EP_TRY(project_dp_thin(dy, Wv, B, D, Dp, Q, dP, st));
   } else if (dP) {

@@ -24,7 +24,8 @@ constexpr int DPS_TRW = 16 * DPS_PITCH;             // ... per wave
 
 template <int NSUB>                                 // 64-column sub-tiles per workgroup: DCH = 64 NSUB
 __global__ __launch_bounds__(256) void ep_dp_slice_kernel(const float* __restrict__ dy, const float* __restrict__ Wv, int B, int D, int Dp,
-                                                         int Q, int DQ, int one, float* __restrict__ dP) {
+                                                         int Q, int DQ, int one, float* __restrict__ dP,
+                                                         const float* __restrict__ yv, float* __restrict__ ML) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,6 +55,23 @@ __global__ __launch_bounds__(256) void ep_dp_slice_kernel(const float* __restric
     float v[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = (k0 + e < DQ) ? v0[e] : 0.f; v[4 + e] = (k0 + 4 + e < DQ) ? v1[e] : 0.f; }
+    // the softmax-correction rows delta[b, q] = dy[b, q-slice] . y[b, q-slice] (ep_delta_kernel's sum, one launch less): the
+    // workgroups of the first column chunk hold exactly these dy values -- eight products per lane, the four lane groups of an
+    // image combined in fixed order
+    if (ML && blockIdx.y == 0) {
+      const float* ys = yv + (int64_t)q * DQ + (int64_t)(b < B ? b : B - 1) * Dp;
+      const f4v y0 = *reinterpret_cast<const f4v*>(ys + (k0 < DQ ? k0 : 0));
+      const f4v y1 = *reinterpret_cast<const f4v*>(ys + (k0 + 4 < DQ ? k0 + 4 : 0));
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc = fmaf(v[e], y0[e], acc); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc = fmaf(v[4 + e], y1[e], acc); }     // (v is zero at and beyond DQ)
+      const float a1 = __shfl_xor(acc, 16, 64);
+      const float s01 = acc + a1;                      // groups (0, 1) and (2, 3)
+      const float s23 = __shfl_xor(s01, 32, 64);
+      if (kk == 0 && b < B) ML[((int64_t)b * Q + q) * 4 + 2] = s01 + s23;
+    }
     pl_u4 bt[3];
     pl_split8(v, bt);
     // The 16 x 64 result of a sub-tile goes through a wave-private LDS tile (rows = images, 272-byte pitch) so that the global
@@ -105,7 +123,8 @@ bool project_dp_slice_ok(const float* dy, const float* Wv, const float* dP, int 
   return on && Q > 0 && Dp % Q == 0 && Dq >= 4 && Dq <= 32 && Dq % 4 == 0 && D % 64 == 0 && Dp % 4 == 0 && aligned16(dy) && aligned16(Wv) && aligned16(dP);
 }
 
-int project_dp_slice(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st) {
+// yv / ML (both or neither): also write delta[b, q] = dy[b, q-slice] . yv[b, q-slice] to ML[b, q, 2]
+int project_dp_slice(const float* dy, const float* Wv, int B, int D, int Dp, int Q, float* dP, hipStream_t st, const float* yv, float* ML) {
   const int Dq = Dp / Q;
   const int one = (gemm_arith() == 1) ? 1 : 0;
   const int nsub = D % 256 == 0 ? 4 : D % 128 == 0 ? 2 : 1;
@@ -115,11 +134,11 @@ int project_dp_slice(const float* dy, const float* Wv, int B, int D, int Dp, int
     case 4: {
       static bool attr = false;
       if (!attr) { (void)hipFuncSetAttribute((const void*)ep_dp_slice_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-      hipLaunchKernelGGL(ep_dp_slice_kernel<4>, grid, block, lds, st, dy, Wv, B, D, Dp, Q, Dq, one, dP);
+      hipLaunchKernelGGL(ep_dp_slice_kernel<4>, grid, block, lds, st, dy, Wv, B, D, Dp, Q, Dq, one, dP, yv, ML);
       break;
     }
-    case 2: hipLaunchKernelGGL(ep_dp_slice_kernel<2>, grid, block, lds, st, dy, Wv, B, D, Dp, Q, Dq, one, dP); break;
-    default: hipLaunchKernelGGL(ep_dp_slice_kernel<1>, grid, block, lds, st, dy, Wv, B, D, Dp, Q, Dq, one, dP); break;
+    case 2: hipLaunchKernelGGL(ep_dp_slice_kernel<2>, grid, block, lds, st, dy, Wv, B, D, Dp, Q, Dq, one, dP, yv, ML); break;
+    default: hipLaunchKernelGGL(ep_dp_slice_kernel<1>, grid, block, lds, st, dy, Wv, B, D, Dp, Q, Dq, one, dP, yv, ML); break;
   }
   EP_LAUNCH_CHECK("ep_dp_slice_kernel");
   return 0;

@@ -27,6 +27,13 @@ def test_dp_of_thin_slices_vs_fp64(shape):
     want = torch.einsum("bqc,qcd->bqd", dy.double().view(B, Q, Dq), Wv.double().view(Q, Dq, D))
     scale = float(want.abs().max())
     assert float((dP.double() - want).abs().max()) <= 4e-6 * scale
-    # the vector-ALU kernel of round 5 (exact fp32 FMAs) agrees to the same bound where it exists
     dP2, _ = F_.project_backward(dy, None, P, Wv, None, need_dP=True, need_dWv=False)
     assert torch.equal(dP, dP2)                               # run to run: the same bits
+    # with y and ML the same launch also leaves the softmax-correction rows delta[b, q] = dy_q . y_q in ML[b, q, 2]
+    y = torch.randn(B, D, device=DEV, generator=g)
+    ML = torch.full((B, Q, 4), 7.0, device=DEV)
+    dP3, _ = F_.project_backward(dy, y, P, Wv, ML, need_dP=True, need_dWv=False)
+    assert torch.equal(dP3, dP)
+    want_d = (dy.double() * y.double()).view(B, Q, Dq).sum(-1)
+    assert float((ML[:, :, 2].double() - want_d).abs().max()) <= 2e-6 * max(1.0, float(want_d.abs().max()))
+    assert bool((ML[:, :, [0, 1, 3]] == 7.0).all())           # the other three columns are not touched
