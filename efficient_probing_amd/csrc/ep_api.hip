@@ -796,7 +796,10 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       else EP_TRY(head_planes_split(d, w, Wv, Wc, st));
     }
     if (pl) {
-      EP_TRY(project_forward_pl(w, d, st));
+      // thin query slices (<= 32 columns: the protocol's 32 queries): the 64 x 32-tile kernel of ep_gemm.hip -- in the AMP-bf16 mode,
+      // the one that reaches here with such slices, as a single product -- instead of 64-column planes tiles that are half padding
+      if (Dp / d.Q <= 32 && d.B >= 64) EP_TRY(project_forward(w.P, Wv, d.B, d.D, Dp, d.Q, w.y, st));
+      else EP_TRY(project_forward_pl(w, d, st));
       // the planes of P^T (for dWv) are split on the side stream behind the value projection -- beside BatchNorm, logits, CE,
       // dz: started right behind the first pass the HBM-bound split slows the projection, which reads P too, from 225 to 331 us
       if (plw) {
