@@ -89,6 +89,7 @@ struct HeadWs {
                                                // (each on a 128-byte line of its own, zero between steps), give-up count
   uint16_t *plWv, *plWvT, *plWc, *plWcT;       // bf16 planes of the two weight matrices, both orientations (ep_planes.hip)
   uint16_t *ptP, *ptZ; float *dyT, *dlT;       // weight gradients on the planes kernel: planes of P^T and z^T, fp32 dy^T and dlogits^T
+  float *wgks_c, *wgks_v; size_t wgks_floats;  // K-slice scratch of the two weight gradients where they run on side queues (ep_gemm.hip)
   void* pool_ws; size_t pool_ws_bytes;
   void* opt_ws; size_t opt_ws_bytes;
   int ldl;
@@ -182,6 +183,18 @@ static HeadWs carve(const ep_head_dims& d, void* base) {
       w.dyT = take((size_t)Dp * d.B); w.dlT = take((size_t)d.C * d.B);
     }
   }
+  {
+    // K-slice scratch (GemmParams.skws) for dWc / dWv as launches of their own: only where a gradient is fewer than three 32-row
+    // tiles per CU -- up to 4 slices each
+    const size_t mnc = (size_t)d.C * Dp, mnv = (size_t)Dp * d.D;
+    const size_t tiles_c = (size_t)((Dp + 63) / 64) * ((d.C + 31) / 32), tiles_v = (size_t)((d.D + 63) / 64) * ((Dp / d.Q + 31) / 32) * d.Q;
+    static int ks_on = -1;                            // (EP_B3_SPLITK_WGS, off by default: ep_gemm.hip)
+    if (ks_on < 0) { const char* e = getenv("EP_B3_SPLITK_WGS"); ks_on = e ? atoi(e) : 0; }
+    const size_t need = (ks_on > 0 && (tiles_c < 768 || tiles_v < 768)) ? 4 * (mnc > mnv ? mnc : mnv) : 0;
+    w.wgks_floats = need;
+    w.wgks_c = need ? take(need) : nullptr;
+    w.wgks_v = need ? take(need) : nullptr;
+  }
   w.total = off;
   return w;
 }
@@ -270,6 +283,10 @@ static int project_forward(const float* P, const float* Wv, int B, int D, int Dp
 // the matrix-pipe-bound 32-query passes; there the bf16 x3 tile measured faster (0.7225 -> 0.714 ms fp32 tokens, 0.440 -> 0.435 ms
 // bf16, round 5), so that branch clears the hint for its calls.
 static thread_local int t_wgrad_side = 1;
+// K-slice scratch of the two weight gradients (set for the duration of the side-queue branch of ep_head_train_step): region 0 = dWc,
+// 1 = dWv -- they run concurrently on two queues
+static thread_local float* t_wgks[2] = {nullptr, nullptr};
+static thread_local size_t t_wgks_floats = 0;
 // dWv[q*Dq + c, d] (+)= sum_b dy[b, q*Dq + c] * P[b, q, d]   (Q batched T/T contractions over the batch)
 static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp, int Q, float* dWv, int accumulate) {
   const int Dq = Dp / Q;
@@ -279,6 +296,7 @@ static GemmParams dwv_gemm(const float* dy, const float* P, int B, int D, int Dp
   g.C = dWv; g.ldc = D; g.sCz = (int64_t)Dq * D;
   g.M = Dq; g.N = D; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = t_wgrad_side;
   g.nterms = gemm_arith() == 1 ? 1 : 0;            // (rides into the side tiles of the second token pass as well)
+  g.skws = t_wgks[1]; g.skws_floats = t_wgks[1] ? t_wgks_floats : 0;
   return g;
 }
 // dWc[c, k] (+)= sum_b dlogits[b, c] * z[b, k]
@@ -287,6 +305,7 @@ GemmParams dwc_gemm(const float* dl, int ldl, const float* z, int B, int Dp, int
   g.A = dl; g.lda = ldl; g.extA = ldl; g.B = z; g.ldb = Dp; g.extB = Dp; g.C = dWc; g.ldc = Dp;
   g.M = C; g.N = Dp; g.K = B; g.alpha = 1.f; g.accumulate = accumulate; g.side = t_wgrad_side;
   g.nterms = gemm_arith() == 1 ? 1 : 0;
+  g.skws = t_wgks[0]; g.skws_floats = t_wgks[0] ? t_wgks_floats : 0;
   return g;
 }
 
@@ -950,6 +969,10 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
       }
       struct SideHint { int old; explicit SideHint(int v) : old(t_wgrad_side) { t_wgrad_side = v; } ~SideHint() { t_wgrad_side = old; } };
       const SideHint hint(d.Q > 16 ? 0 : 1);                // (restored when this branch is left, error returns included)
+      // ... and, as launches of their own on the bf16 x3 tile (32 queries), with K slices (ep_gemm.hip): scratch per gradient
+      struct KsHint { explicit KsHint(float* c, float* v, size_t n) { t_wgks[0] = c; t_wgks[1] = v; t_wgks_floats = n; }
+                      ~KsHint() { t_wgks[0] = t_wgks[1] = nullptr; t_wgks_floats = 0; } };
+      const KsHint kshint(side != st ? w.wgks_c : nullptr, side != st ? w.wgks_v : nullptr, w.wgks_floats);
       auto classifier_side = [&]() -> int {                  // statistics fold, dWc, dbc: nothing before the optimizer reads them
         EP_TRY(ce_stats(w.rowstat, d.B, s->stats, side));
         if (plw) {

@@ -717,6 +717,35 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
       EP_LAUNCH_CHECK("ep_gemm_b3_thin_kernel");
       return 0;
     }
+    if (!a_k && p.skws && EP_B3_STAGES == 1) {
+      // SMALL weight gradients (the 1024-row gradients of the EP step where they run on side queues: 192 - 384 tiles, one or two
+      // workgroups per CU, every K-tile a latency chain with nothing beside it -- 43 / 61 us for dWc / dWv at 32 queries,
+      // EXPERIMENTS.md r6.1): K slices as extra batch entries of ONE launch, so that ~3 workgroups share a CU, summed in slice
+      // order by ep_reduce_partials_kernel (deterministic; on the side queue the extra launch is off the critical path).
+      // EP_B3_SPLITK_WGS: workgroups per CU aimed at (0 = off, the DEFAULT: measured neutral -- same-box, ms per step, off / 3 / 4:
+      // 196 x 1024 Q = 32 0.776 / 0.785 / 0.785, 256 x 768 Q = 32 bf16 0.4237 / 0.4256 / 0.430, fp32 0.708 / 0.705 / 0.711, 256 x 1152
+      // Q = 32 1.265 / 1.257 / 1.263: beside the contractions of the main queue the gradients are bound by what they share with
+      // them, not by their own occupancy.  The scratch is only carved with the switch on.)
+      static int target = -1;
+      if (target < 0) { const char* e = getenv("EP_B3_SPLITK_WGS"); target = e ? atoi(e) : 0; }
+      const long cus = cu_count();
+      const long tiles = (long)((p.N + 63) / 64) * ((p.M + (m32 ? 31 : 63)) / (m32 ? 32 : 64)) * batch;
+      const int64_t mn = (int64_t)p.M * p.N;
+      int S = 1;
+      if (target > 0 && tiles < target * cus && p.ldc == p.N && p.alpha == 1.0f && !p.bias && (batch == 1 || p.sCz == mn) && mn % 4 == 0)
+        for (int sp = 2; sp <= 8; sp *= 2) {
+          if (p.K % (sp * 32) != 0 || p.K / sp < 128 || (size_t)sp * batch * mn > p.skws_floats) break;
+          S = sp;
+          if (tiles * sp >= target * cus) break;
+        }
+      if (S > 1) {
+        q3.K = p.K / S; q3.ksplit = S; q3.ksA = (int64_t)q3.K * p.lda; q3.ksB = (int64_t)q3.K * p.ldb;
+        q3.C = p.skws; q3.sCz = mn; q3.ksC = (int64_t)batch * mn; q3.accumulate = 0; q3.skws = nullptr;
+        b3_launch<false, false>(q3, batch * S, m32, st);
+        EP_LAUNCH_CHECK("ep_gemm_b3_kernel (K slices)");
+        return reduce_partials(p.skws, S, (int)(batch * mn), 1.0f, p.accumulate, p.C, nullptr, st);
+      }
+    }
     if (!a_k) b3_launch<false, false>(q3, batch, m32, st);
     else if (b_k) b3_launch<true, true>(q3, batch, m32, st);
     else b3_launch<true, false>(q3, batch, m32, st);

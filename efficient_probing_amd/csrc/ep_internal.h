@@ -87,6 +87,10 @@ struct GemmParams {
   // z = (y - running_mean[col]) / sqrt(running_var[col] + eps) directly -- the arithmetic of ep_bn_eval_kernel, one launch less);
   // indexed by the output column like `bias` (batched launches: z * sBiasz + col)
   const float* bn_rm; const float* bn_rv; float bn_eps;
+  // bf16 x3 tile (ep_wgrad3.h), K split INSIDE one launch (round 6, small weight gradients on side queues): ksplit > 1 makes batch
+  // entry bz = zb * ksplit + ks contract slice ks of the K range -- operands offset by ks * ksA / ks * ksB elements, K = the slice
+  // length -- into the partial matrix C + zb * sCz + ks * ksC; the caller sums the slices in order (reduce_partials)
+  int ksplit; int64_t ksA, ksB, ksC;
   int m_fast;                       // planes kernel: M-tiles fastest in the launch order (few M-tiles against a very long N: the
                                     // workgroups that share a weight tile then run together and it is fetched from HBM once)
 };

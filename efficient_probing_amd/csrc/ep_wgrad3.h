@@ -105,9 +105,11 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int m0 = by * BMT, n0 = bx * BNT;
-  const float* A = p.A + (int64_t)bz * p.sAz;
-  const float* B = p.B + (int64_t)bz * p.sBz;
-  float* C = p.C + (int64_t)bz * p.sCz;
+  int zb = bz, ks = 0;                               // (GemmParams.ksplit: K slices as extra batch entries)
+  if (p.ksplit > 1) { zb = bz / p.ksplit; ks = bz - zb * p.ksplit; }
+  const float* A = p.A + (int64_t)zb * p.sAz + (int64_t)ks * p.ksA;
+  const float* B = p.B + (int64_t)zb * p.sBz + (int64_t)ks * p.ksB;
+  float* C = p.C + (int64_t)zb * p.sCz + (int64_t)ks * p.ksC;
   const int i16 = lane & 15, kk = lane >> 4;
   char* imgA = lds;
   char* imgB = lds + 3 * W3_IMG;
@@ -182,7 +184,7 @@ __device__ __forceinline__ void gemm_tile_b3g(const GemmParams& p, int bx, int b
     for (int ni = 0; ni < NI; ++ni) {
       blk[mi * NI + ni] = acc[mi][ni]; rb[mi * NI + ni] = m0 + wm * (16 * MI) + mi * 16; cb[mi * NI + ni] = n0 + wn * (16 * NI) + ni * 16;
     }
-  store_acc_blocks<MI * NI>(p, C, bz, rb, cb, blk, kk, i16);
+  store_acc_blocks<MI * NI>(p, C, zb, rb, cb, blk, kk, i16);
   __syncthreads();                                   // LDS free for the caller's next tile
 }
 
