@@ -732,7 +732,8 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
       const long tiles = (long)((p.N + 63) / 64) * ((p.M + (m32 ? 31 : 63)) / (m32 ? 32 : 64)) * batch;
       const int64_t mn = (int64_t)p.M * p.N;
       int S = 1;
-      if (target > 0 && tiles < target * cus && p.ldc == p.N && p.alpha == 1.0f && !p.bias && (batch == 1 || p.sCz == mn) && mn % 4 == 0)
+      if (target > 0 && tiles < target * cus && p.ldc == p.N && p.alpha == 1.0f && !p.bias && (batch == 1 || p.sCz == mn) && mn % 4 == 0 &&
+          (int64_t)batch * mn < (int64_t)0x7fffffff)
         for (int sp = 2; sp <= 8; sp *= 2) {
           if (p.K % (sp * 32) != 0 || p.K / sp < 128 || (size_t)sp * batch * mn > p.skws_floats) break;
           S = sp;
