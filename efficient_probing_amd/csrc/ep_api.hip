@@ -856,6 +856,12 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
     // pass.  dWc = dlogits^T z, the bias column sum and the statistics fold ride in the launch of dz = dlogits Wc (their
     // operands exist behind the loss kernel), dWv_q = dy_q^T P_q in the launch of dP = dy_q Wv_q (mode 1; otherwise it stays
     // with the pass) -- ep_planes.hip: ep_gemm_planes_side_kernel.  The pass then streams alone.  EP_CHAIN=0: the round-5 schedule.
+    // EP_WG2=1 (round 6 experiment): the two weight gradients as ONE launch of the paired-group tile between BatchNorm backward and
+    // the second pass (ep_gemm.hip: wgrad_pair) instead of side workgroups in the pass, which keeps only the bias sum and the
+    // statistics fold
+    static int wg2_on = -1;
+    if (wg2_on < 0) { const char* e = getenv("EP_WG2"); wg2_on = e ? atoi(e) : 0; }
+    const bool wg2 = wg2_on && wgrad_pair_ok(gWc) && wgrad_pair_ok(gWv);
     static int chain_on = -1;
     if (chain_on < 0) { const char* e = getenv("EP_CHAIN"); chain_on = e ? atoi(e) : 0; }
     if (chain_on && plc && gemm_side_ok(gWc, false, false) && gemm_side_ok(gWv, false, false)) {
@@ -936,8 +942,14 @@ int ep_head_train_step(const ep_head_step* s, void* ws, size_t ws_bytes, ep_stre
                                 in_pass ? nullptr : w.ML, 0, st));
       }
       SideTasks sd{};
-      side_add_gemm(sd, gWc, 1);
-      side_add_gemm(sd, gWv, d.Q);
+      if (wg2 && !fold) {
+        const GemmParams pair[2] = {gWc, gWv};
+        const int pb[2] = {1, d.Q};
+        EP_TRY(wgrad_pair(pair, pb, 2, st));
+      } else {
+        side_add_gemm(sd, gWc, 1);
+        side_add_gemm(sd, gWv, d.Q);
+      }
       sd.cs_src = w.dlogits; sd.cs_out = s->grads + offs[3]; sd.cs_B = d.B; sd.cs_ncol = d.C; sd.cs_ld = w.ldl;
       sd.cs_accumulate = s->accumulate; sd.n_colsum = (d.C + 15) / 16;
       sd.rowstat = w.rowstat; sd.stats = s->stats; sd.rs_B = d.B; sd.n_stats = 1;

@@ -642,6 +642,74 @@ static void b3_launch(const GemmParams& p, int batch, bool m32, hipStream_t st) 
   if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), B3_KERNEL_LDS, st, p);
   else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), B3_KERNEL_LDS, st, p);
 }
+// ---- up to two small T / T weight gradients in ONE launch on the paired-group tile (ep_wgrad3.h: gemm_tile_b3p): the EP step's
+// dWc = dlogits^T z and dWv_q = dy_q^T P_q as a launch of their own between BatchNorm backward and the second token pass ----
+struct PairJobs { GemmParams g[2]; int gx[2], gy[2], nb[2]; };
+__global__ __launch_bounds__(512) void ep_wgrad_pair_kernel(PairJobs j) {
+  extern __shared__ __attribute__((aligned(1024))) char lds_wp[];
+  int L = blockIdx.x, k = 0;
+  if (L >= j.nb[0]) { L -= j.nb[0]; k = 1; }
+  const int bx = L % j.gx[k], r = L / j.gx[k];
+  gemm_tile_b3p(j.g[k], bx, r % j.gy[k], r / j.gy[k], lds_wp);
+}
+__global__ __launch_bounds__(256) void ep_wgrad_free_kernel(PairJobs j) {
+  int L = blockIdx.x, k = 0;
+  if (L >= j.nb[0]) { L -= j.nb[0]; k = 1; }
+  const int bx = L % j.gx[k], r = L / j.gx[k];
+  gemm_tile_b3f(j.g[k], bx, r % j.gy[k], r / j.gy[k]);
+}
+__global__ __launch_bounds__(256, 2) void ep_wgrad_freek_kernel(PairJobs j) {
+  __shared__ __attribute__((aligned(16))) float red[3 * 64 * 16];
+  int L = blockIdx.x, k = 0;
+  if (L >= j.nb[0]) { L -= j.nb[0]; k = 1; }
+  const int bx = L % j.gx[k], r = L / j.gx[k];
+  gemm_tile_b3fk(j.g[k], bx, r % j.gy[k], r / j.gy[k], red);
+}
+bool wgrad_pair_ok(const GemmParams& p) {
+  return gemm_b3_on() && !p.bias && !p.cs_out && p.M > 0 && p.N > 0 && p.K >= 64 && vec_ok(p.A, p.lda, p.sAz, p.extA) && vec_ok(p.B, p.ldb, p.sBz, p.extB);
+}
+int wgrad_pair(const GemmParams* g, const int* batch, int n, hipStream_t st) {
+  EP_REQUIRE(n >= 1 && n <= 2, EP_E_ARG, "wgrad_pair: one or two contractions");
+  PairJobs j{};
+  int total = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (i < n) {
+      EP_REQUIRE(wgrad_pair_ok(g[i]), EP_E_ALIGN, "wgrad_pair: T / T contraction %d needs 16-byte aligned operands, K >= 64, no bias", i);
+      j.g[i] = g[i];
+      if (gemm_arith() == 1) j.g[i].nterms = 1;
+      { static int abl = -1; if (abl < 0) { const char* e = getenv("EP_WG2_ABLATE"); abl = e ? atoi(e) : 0; } j.g[i].ablate = abl; }   // diagnostics: 1 no matrix phase, 2 no staging, 4 no ring refills (results are wrong)
+      j.gx[i] = (g[i].N + 63) / 64; j.gy[i] = (g[i].M + 63) / 64; j.nb[i] = j.gx[i] * j.gy[i] * batch[i];
+    } else { j.g[i] = g[0]; j.gx[i] = j.gy[i] = 1; j.nb[i] = 0; }
+    total += j.nb[i];
+  }
+  static int form = -1;                              // EP_WG2_FORM: 1 = paired groups through LDS (gemm_tile_b3p), 2 = barrier-free waves
+  if (form < 0) { const char* e = getenv("EP_WG2_FORM"); form = e ? atoi(e) : 3; }      // (gemm_tile_b3f), 3 = ... with K dealt over a workgroup's waves (b3fk)
+  bool fk_ok = true;                                   // the K-dealt form: whole K-tiles, 32-bit byte offsets
+  for (int i = 0; i < n; ++i)
+    fk_ok &= g[i].K % 32 == 0 && ((int64_t)g[i].lda * 32 + g[i].M) * 4 < (int64_t)0x7fffffff && ((int64_t)g[i].ldb * 32 + g[i].N) * 4 < (int64_t)0x7fffffff;
+  if (form == 3 && !fk_ok) { hipLaunchKernelGGL(ep_wgrad_free_kernel, dim3(total), dim3(256), 0, st, j); EP_LAUNCH_CHECK("ep_wgrad_free_kernel"); return 0; }
+  if (form == 3) {
+    PairJobs q = j;
+    int tot = 0;
+    for (int i = 0; i < 2; ++i) {
+      if (i < n) { q.gx[i] = (g[i].N + 31) / 32; q.gy[i] = (g[i].M + 31) / 32; q.nb[i] = q.gx[i] * q.gy[i] * batch[i]; }
+      tot += q.nb[i];
+    }
+    hipLaunchKernelGGL(ep_wgrad_freek_kernel, dim3(tot), dim3(256), 0, st, q);
+    EP_LAUNCH_CHECK("ep_wgrad_freek_kernel");
+    return 0;
+  }
+  if (form == 2) {
+    hipLaunchKernelGGL(ep_wgrad_free_kernel, dim3(total), dim3(256), 0, st, j);
+    EP_LAUNCH_CHECK("ep_wgrad_free_kernel");
+    return 0;
+  }
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)ep_wgrad_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3P_LDS_BYTES); attr = true; }
+  hipLaunchKernelGGL(ep_wgrad_pair_kernel, dim3(total), dim3(512), W3P_LDS_BYTES, st, j);
+  EP_LAUNCH_CHECK("ep_wgrad_pair_kernel");
+  return 0;
+}
 static thread_local int t_arith = 0;
 int gemm_arith() { return t_arith; }
 void gemm_set_arith(int a) { t_arith = a; }

@@ -172,6 +172,9 @@ constexpr int IP_YPARTS = 4;                                   // K quarters of 
 // per-image query gradients: dq (B,Q,D) = p.scale * sum_n dS[b,q,n] k[b,n,:], NOT summed over the batch (per-image query rows)
 int pool_backward_per_image(const PoolParams& p, float* dq, hipStream_t st);
 bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k);
+// one or two SMALL T / T weight gradients (C (+)= A^T B, batched) in one launch of the paired-group tile (ep_wgrad3.h: gemm_tile_b3p)
+bool wgrad_pair_ok(const GemmParams& p);
+int wgrad_pair(const GemmParams* g, const int* batch, int n, hipStream_t st);
 const char* gemm_kernel_name(bool a_k, bool b_k, const GemmParams& p, int batch);   // what gemm() would launch (family name)
 bool gemm_b3_on();                                             // EP_GEMM_B3 (default 1): T / T contractions on the bf16 x3 tile
 int debug_force_generic(int on);

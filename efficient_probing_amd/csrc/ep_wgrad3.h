@@ -486,6 +486,332 @@ __device__ __forceinline__ void gemm_tile_b3w(const GemmParams& p, int bx, int b
   }
 }
 
+// The PAIRED form for SMALL weight gradients that have a CU to themselves (round 6): 8 waves = two groups of four on ONE 64 x 64
+// output tile, alternating K-tiles (the planes kernel's two parities, ep_planes.hip).  gemm_tile_b3g's K-tile is a serial chain --
+// raw rows -> split -> transposed LDS write -> barrier -> fragment reads -> 24 matrix instructions -> barrier -- that takes
+// ~1.2 us when nothing shares the CU (rocprofv3: dWc 38.8 us, dWv 47.4 us stand-alone at 1024 rows, EXPERIMENTS.md r6.1); here,
+// between two workgroup barriers, one group STAGES its next tile (vector ALU + LDS writes) while the other group MULTIPLIES its
+// current one (LDS reads + matrix pipe) on the same four SIMDs (wave w and w + 4 share SIMD w % 4).  Raw fp32 K-tiles come in by
+// LDS-DMA into a ring of four 16-KiB stages, three tiles ahead; each group owns one set of plane images (30 KiB).  Every output
+// element is the sum of the two groups' accumulators: group 1 hands its 16 blocks over through LDS, group 0 adds and stores.
+// Same split, same matrix-instruction order per K-tile as gemm_tile_b3g; the sum over K-tiles is taken as (even tiles) + (odd
+// tiles) -- a different, fixed order.  T / T layout, 16-byte aligned operands, 64-row tiles.
+constexpr int W3P_NSTG = 4;
+constexpr int W3P_RAW = 2 * 32 * 64 * 4;                              // one K-tile of both operands, raw fp32: 16384
+constexpr size_t W3P_LDS_BYTES = (size_t)W3P_NSTG * W3P_RAW + 2 * W3_LDS_BYTES;    // 65536 + 61440
+__device__ __forceinline__ void gemm_tile_b3p(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0 .. 7
+  const int grp = w >> 2, wg4 = w & 3;
+  const int wm = wg4 >> 1, wn = wg4 & 1;
+  const int m0 = by * 64, n0 = bx * 64;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  char* ring = lds;
+  char* imgA = lds + W3P_NSTG * W3P_RAW + grp * (int)W3_LDS_BYTES;
+  char* imgB = imgA + 3 * W3_IMG;
+  const int tg = tid & 255;                                           // thread of its group
+  const int mq = tg & 15, kp = tg >> 4;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  const int nk = (p.K + 31) / 32;
+  const bool one = p.nterms == 1;
+  // this wave's two DMA pieces of a K-tile: piece i = w + 8 j; i < 8: k-rows 4 i .. 4 i + 3 of the A tile, else of the B tile
+  const float* src[2]; int krow[2]; int64_t ldp[2]; int dst[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = w + 8 * j;
+    if (i < 8) {
+      const int c = m0 + 4 * (lane & 15);
+      krow[j] = 4 * i + (lane >> 4); ldp[j] = p.lda; src[j] = A + (c < extA ? c : 0); dst[j] = i * 1024;
+    } else {
+      const int c = n0 + 4 * (lane & 15);
+      krow[j] = 4 * (i - 8) + (lane >> 4); ldp[j] = p.ldb; src[j] = B + (c < extB ? c : 0); dst[j] = 8192 + (i - 8) * 1024;
+    }
+  }
+  auto issue = [&](int t) {                           // K-tile t (clamped: redundant, never out of range) into stage t % 4
+    const int tt = t < nk ? t : nk - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int k = tt * 32 + krow[j];
+      k = k < p.K ? k : p.K - 1;
+      __builtin_amdgcn_global_load_lds((pl_gptr_t)(src[j] + (int64_t)k * ldp[j]), (pl_lds_ptr_t)(ring + (t & 3) * W3P_RAW + dst[j]), 16, 0, 0);
+    }
+  };
+  f4v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  issue(0); issue(1); issue(2);
+  // interval i (between barriers i and i + 1): group i % 2 stages tile i, the other group multiplies tile i - 1
+  for (int i = 0; i <= nk; ++i) {
+    pl_dma_wait<4>();                                 // my pieces of tile i (tiles i + 1, i + 2 may be in flight)
+    pl_barrier();                                     // tile i landed everywhere; the images staged in interval i - 1 are complete;
+                                                      // the fragments read in interval i - 1 are consumed
+    if (!(p.ablate & 4)) issue(i + 3);                // into the stage tile i - 1 left (its rows were read in interval i - 1)
+    if ((i & 1) == grp) {
+      if (i < nk && !(p.ablate & 2)) {
+        const char* raw = ring + (i & 3) * W3P_RAW;
+        f4v xa[2], xb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          xa[h] = *reinterpret_cast<const f4v*>(raw + (2 * kp + h) * 256 + mq * 16);
+          xb[h] = *reinterpret_cast<const f4v*>(raw + 8192 + (2 * kp + h) * 256 + mq * 16);
+        }
+        w3_stage_T(imgA, xa, extA, p.K, m0, i * 32, kp, mq, one);
+        w3_stage_T(imgB, xb, extB, p.K, n0, i * 32, kp, mq, one);
+      }
+    } else if (i >= 1 && !(p.ablate & 1)) {
+      pl_u4 fa[2][3], fb[2][3];
+      if (one) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) fa[mi][0] = *reinterpret_cast<const pl_u4*>(imgA + w3_off(wm * 32 + mi * 16 + i16, kk));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[ni][0] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * 32 + ni * 16 + i16, kk));
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) fa[mi][t] = *reinterpret_cast<const pl_u4*>(imgA + t * W3_IMG + w3_off(wm * 32 + mi * 16 + i16, kk));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) fb[ni][t] = *reinterpret_cast<const pl_u4*>(imgB + t * W3_IMG + w3_off(wn * 32 + ni * 16 + i16, kk));
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+          const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+        }
+      }
+    }
+  }
+  pl_dma_wait<0>();                                   // the redundant tail pieces have landed: the ring serves the hand-over
+  pl_barrier();
+  f4v* hand = reinterpret_cast<f4v*>(ring) + (wg4 * 64 + lane) * 4;
+  if (grp == 1) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) hand[mi * 2 + ni] = acc[mi][ni];
+  }
+  pl_barrier();
+  if (grp == 1) return;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] += hand[mi * 2 + ni];
+  f4v blk[4]; int rb[4], cb[4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + wm * 32 + mi * 16; cb[mi * 2 + ni] = n0 + wn * 32 + ni * 16;
+    }
+  store_acc_blocks<4>(p, C, bz, rb, cb, blk, kk, i16);
+}
+
+// The BARRIER-FREE form (round 6, after the ablation of gemm_tile_b3p -- profiles / EXPERIMENTS.md r6.8: with one workgroup per CU
+// the bare barrier interval costs 0.33 us and the phases of the two groups add up instead of overlapping): every WAVE owns a
+// 32 x 32 output tile and needs nobody -- no LDS, no barrier.  A k-slow operand is loaded straight into the matrix instruction's
+// layout: lane (i16, kk) takes the eight values X[k0 + 8 kk + j][c0 + i16], j = 0 .. 7, as eight dword loads (16 consecutive
+// columns x 4 rows = four 64-byte segments per instruction, from L2), splits them in registers (pl_split8) and multiplies.  The next
+// K-tile's 32 loads are in flight while this one is split and multiplied.  Every operand block is loaded and split by the two waves
+// that share it (twice the vector work of the LDS forms) -- the price of independence; many waves per SIMD hide the rest.
+// T / T layout; any alignment of the columns (dword loads); the four waves of a workgroup cover a 64 x 64 tile so that their
+// loads share cache lines.
+__device__ __forceinline__ void w3f_load_block(const float* __restrict__ X, int64_t ld, int ext, int K, int c0, int k0, int i16, int kk,
+                                               float (&v)[8]) {
+  const int c = c0 + i16;
+  const float* col = X + (c < ext ? c : 0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + 8 * kk + j;
+    v[j] = col[(int64_t)(k < K ? k : K - 1) * ld];
+  }
+}
+__device__ __forceinline__ void w3f_mask_split(float (&v)[8], bool cok, int K, int k0, int kk, pl_u4 (&t)[3]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (cok && k0 + 8 * kk + j < K) ? v[j] : 0.f;
+  pl_split8(v, t);
+}
+__device__ __forceinline__ void gemm_tile_b3f(const GemmParams& p, int bx, int by, int bz) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int m0 = by * 64 + (w >> 1) * 32, n0 = bx * 64 + (w & 1) * 32;
+  if (m0 >= p.M || n0 >= p.N) return;                // (wave-uniform: a whole 32 x 32 tile outside the matrix)
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  const int nk = (p.K + 31) / 32;
+  const bool one = p.nterms == 1;
+  const bool ca0 = m0 + i16 < extA, ca1 = m0 + 16 + i16 < extA, cb0 = n0 + i16 < extB, cb1 = n0 + 16 + i16 < extB;
+  f4v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  float xa[2][2][8], xb[2][2][8];                    // [register set][block][j]
+  auto load = [&](int t, float (&ra)[2][8], float (&rb)[2][8]) {
+    const int k0 = (t < nk ? t : nk - 1) * 32;       // (clamped: redundant, never out of range)
+    w3f_load_block(A, p.lda, extA, p.K, m0, k0, i16, kk, ra[0]);
+    w3f_load_block(A, p.lda, extA, p.K, m0 + 16, k0, i16, kk, ra[1]);
+    w3f_load_block(B, p.ldb, extB, p.K, n0, k0, i16, kk, rb[0]);
+    w3f_load_block(B, p.ldb, extB, p.K, n0 + 16, k0, i16, kk, rb[1]);
+  };
+  auto step = [&](int t, float (&ra)[2][8], float (&rb)[2][8]) {
+    pl_u4 fa[2][3], fb[2][3];
+    w3f_mask_split(ra[0], ca0, p.K, t * 32, kk, fa[0]);
+    w3f_mask_split(ra[1], ca1, p.K, t * 32, kk, fa[1]);
+    w3f_mask_split(rb[0], cb0, p.K, t * 32, kk, fb[0]);
+    w3f_mask_split(rb[1], cb1, p.K, t * 32, kk, fb[1]);
+    if (one) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
+      return;
+    }
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {                 // smallest terms first, as gemm_tile_b3g
+      const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+    }
+  };
+  load(0, xa[0], xb[0]);
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    load(t + 1, xa[1], xb[1]);
+    step(t, xa[0], xb[0]);
+    load(t + 2, xa[0], xb[0]);
+    step(t + 1, xa[1], xb[1]);
+  }
+  if (t < nk) step(t, xa[0], xb[0]);
+  f4v blk[4]; int rb[4], cb[4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) { blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + mi * 16; cb[mi * 2 + ni] = n0 + ni * 16; }
+  store_acc_blocks<4>(p, C, bz, rb, cb, blk, kk, i16);
+}
+
+// ... and with the K range dealt over the four waves of a workgroup (K-tile t to wave t % 4), the workgroup owning ONE 32 x 32
+// output tile: a 1024-row gradient of 1000 x 768 is then 768 workgroups = 3072 waves of 8 K-tiles each instead of 1536 waves of
+// 32 -- the wave's serial chain (load, split, multiply) is a quarter as long and three waves per SIMD cover each other.  The four
+// partial tiles meet in LDS at the end (16 KiB, one barrier), summed in wave order.
+__device__ __forceinline__ void gemm_tile_b3fk(const GemmParams& p, int bx, int by, int bz, float* red) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int m0 = by * 32, n0 = bx * 32;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  const int nk = (p.K + 31) / 32;
+  const bool one = p.nterms == 1;
+  const bool ca0 = m0 + i16 < extA, ca1 = m0 + 16 + i16 < extA, cb0 = n0 + i16 < extB, cb1 = n0 + 16 + i16 < extB;
+  f4v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  float xa[2][2][8], xb[2][2][8];
+  // Row k0 + j of an operand is a UNIFORM base (scalar arithmetic) plus one per-lane 32-bit BYTE offset (8 kk ld + column) that never
+  // changes: global_load_dword with an SGPR base.  (The first form computed a 64-bit product per load, 32 per K-tile: ~770 of the
+  // ~1600 vector cycles of a wave's K-tile -- rocprofv3: 43 us for the EP step's two gradients at 1024 rows.)  Needs K % 32 == 0
+  // and 32-bit offsets (wgrad_pair_ok checks both).
+  const bool full = m0 + 32 <= extA && n0 + 32 <= extB;                  // (uniform) no column of the tile is masked
+  const int colA = m0 + i16, colB = n0 + i16;
+  const unsigned boA0 = 4u * (unsigned)(8 * kk * (int)p.lda + (colA < extA ? colA : 0)), boA1 = 4u * (unsigned)(8 * kk * (int)p.lda + (colA + 16 < extA ? colA + 16 : 0));
+  const unsigned boB0 = 4u * (unsigned)(8 * kk * (int)p.ldb + (colB < extB ? colB : 0)), boB1 = 4u * (unsigned)(8 * kk * (int)p.ldb + (colB + 16 < extB ? colB + 16 : 0));
+  auto ldf = [](const float* base, unsigned bo) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + bo); };
+  auto load = [&](int t, float (&ra)[2][8], float (&rb)[2][8]) {
+    const int k0 = (t < nk ? t : nk - 1) * 32;
+    const float* Ak = A + (int64_t)k0 * p.lda;
+    const float* Bk = B + (int64_t)k0 * p.ldb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* ar = Ak + (int64_t)j * p.lda;       // uniform
+      const float* br = Bk + (int64_t)j * p.ldb;
+      ra[0][j] = ldf(ar, boA0); ra[1][j] = ldf(ar, boA1);
+      rb[0][j] = ldf(br, boB0); rb[1][j] = ldf(br, boB1);
+    }
+  };
+  auto step = [&](int t, float (&ra)[2][8], float (&rb)[2][8]) {
+    pl_u4 fa[2][3], fb[2][3];
+    if (!full) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ra[0][j] = ca0 ? ra[0][j] : 0.f; ra[1][j] = ca1 ? ra[1][j] : 0.f;
+        rb[0][j] = cb0 ? rb[0][j] : 0.f; rb[1][j] = cb1 ? rb[1][j] : 0.f;
+      }
+    }
+    pl_split8(ra[0], fa[0]); pl_split8(ra[1], fa[1]); pl_split8(rb[0], fb[0]); pl_split8(rb[1], fb[1]);
+    if (one) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][0], fb[ni][0], acc[mi][ni]);
+      return;
+    }
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int ta = pr == 0 ? 2 : (pr == 1 || pr >= 4) ? 0 : 1, tb = pr == 0 ? 0 : pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = pl_mfma(fa[mi][ta], fb[ni][tb], acc[mi][ni]);
+    }
+  };
+  int t = w;                                          // this wave's K-tiles: w, w + 4, ...
+  if (t < nk) load(t, xa[0], xb[0]);
+  for (; t + 4 < nk; t += 8) {
+    load(t + 4, xa[1], xb[1]);
+    step(t, xa[0], xb[0]);
+    if (t + 8 < nk) load(t + 8, xa[0], xb[0]);
+    step(t + 4, xa[1], xb[1]);
+  }
+  if (t < nk) step(t, xa[0], xb[0]);
+  // the four partial tiles: waves 1 .. 3 hand theirs over, wave 0 sums them in wave order and stores
+  f4v* mine = reinterpret_cast<f4v*>(red) + ((w - 1) * 64 + lane) * 4;
+  if (w > 0) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) mine[mi * 2 + ni] = acc[mi][ni];
+  }
+  __syncthreads();
+  if (w > 0) return;
+#pragma unroll
+  for (int ww = 0; ww < 3; ++ww) {
+    const f4v* o = reinterpret_cast<const f4v*>(red) + (ww * 64 + lane) * 4;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] += o[mi * 2 + ni];
+  }
+  f4v blk[4]; int rb[4], cb[4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) { blk[mi * 2 + ni] = acc[mi][ni]; rb[mi * 2 + ni] = m0 + mi * 16; cb[mi * 2 + ni] = n0 + ni * 16; }
+  store_acc_blocks<4>(p, C, bz, rb, cb, blk, kk, i16);
+}
+
 // the weight-gradient form (both operands T layout): what the token passes run as side work
 template <int BMT>
 __device__ __forceinline__ void gemm_tile_b3(const GemmParams& p, int bx, int by, int bz, char* lds) {
