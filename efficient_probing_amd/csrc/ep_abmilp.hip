@@ -171,21 +171,77 @@ __global__ __launch_bounds__(256) void ep_wcolsum_kernel(const float* __restrict
     partial[(int64_t)blockIdx.y * ncol + col] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 
-// out[0] (+)= sum_i v[i]   (one workgroup, fixed order)
+// out[0] (+)= sum_i v[i]   (one workgroup, fixed order; eight independent 16-byte loads per thread in flight: as a chain of
+// dependent scalar loads the 65536 row gradients of a 256-image step took 60 us)
 __global__ __launch_bounds__(256) void ep_sum_kernel(const float* __restrict__ v, int64_t n, int accumulate,
                                                    float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(v) % 16 == 0) ? n / 4 : 0;
+  const f4* v4 = reinterpret_cast<const f4*>(v);
+  int64_t i = threadIdx.x;
+  for (; i + 7 * 256 < n4; i += 8 * 256) {
+    f4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = v4[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (t[u].x + t[u].y) + (t[u].z + t[u].w);
+  }
+  for (; i < n4; i += 256) { const f4 t = v4[i]; s += (t.x + t.y) + (t.z + t.w); }
+  for (int64_t j = 4 * n4 + threadIdx.x; j < n; j += 256) s += v[j];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) { const float t = (red[0] + red[1]) + (red[2] + red[3]); out[0] = accumulate ? out[0] + t : t; }
 }
 
+// The predictor's tanh layer backward in ONE read of H (round 6; before: a weighted column sum, the element-wise kernel and a
+// plain column sum -- 1.2 GB of traffic per 256-image step at D = 1152 instead of 0.6):
+//   pw2[rs][col] = sum_{r in chunk rs} ds[r] H[r, col]            (dw2 partials; H = tanh output)
+//   H[r, col]   <- dG = ds[r] w2[col] (1 - H[r, col]^2)
+//   pb1[rs][col] = sum_{r in chunk rs} dG[r, col]                 (db1 partials)
+// grid (ceil(ncol/64), RS), 256 threads = 64 columns x 4 row lanes, the chunking and the summation order of ep_wcolsum_kernel.
+__global__ __launch_bounds__(256) void ep_tanh_bwd_sums_kernel(float* __restrict__ H, const float* __restrict__ ds,
+                                                             const float* __restrict__ w2, int64_t rows, int ncol,
+                                                             float* __restrict__ pw2, float* __restrict__ pb1) {
+  __shared__ float sm[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (col < ncol) {
+    const float wc = w2[col];
+    int64_t r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+      float h[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { h[u] = H[(r + 4 * u) * ncol + col]; g[u] = ds[r + 4 * u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dg = g[u] * wc * (1.0f - h[u] * h[u]);
+        H[(r + 4 * u) * ncol + col] = dg;
+        if (u & 1) { a1 = fmaf(g[u], h[u], a1); b1 += dg; } else { a0 = fmaf(g[u], h[u], a0); b0 += dg; }
+      }
+    }
+    for (; r < r1; r += 4) {
+      const float h = H[r * ncol + col], g = ds[r];
+      const float dg = g * wc * (1.0f - h * h);
+      H[r * ncol + col] = dg;
+      a0 = fmaf(g, h, a0); b0 += dg;
+    }
+  }
+  sm[0][ty][tx] = a0 + a1; sm[1][ty][tx] = b0 + b1;
+  __syncthreads();
+  if (ty == 0 && col < ncol) {
+    pw2[(int64_t)blockIdx.y * ncol + col] = (sm[0][0][tx] + sm[0][1][tx]) + (sm[0][2][tx] + sm[0][3][tx]);
+    pb1[(int64_t)blockIdx.y * ncol + col] = (sm[1][0][tx] + sm[1][1][tx]) + (sm[1][2][tx] + sm[1][3][tx]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct AbWs {
-  float *QKV, *SA, *O, *Xa, *H, *s, *a, *da, *ds, *dXa, *dS, *dQKV, *part, *stage, *skws;
+  float *QKV, *SA, *O, *Xa, *H, *s, *a, *da, *ds, *dXa, *dS, *dQKV, *part, *part2, *stage, *skws;
   size_t skws_floats;
   // contractions on the bf16-plane kernel (ep_planes.hip): planes of the three weight matrices (qkv natural; proj_w, w1 both
   // orientations)
@@ -228,7 +284,7 @@ static AbWs ab_carve(const ep_abmilp_dims& d, void* base, bool head) {
   w.QKV = take(BN * 3 * D); w.SA = take(BN * d.N); w.O = take(BN * D); w.Xa = take(BN * D); w.H = take(BN * D);
   w.s = take(BN); w.a = take(BN); w.da = take(BN); w.ds = take(BN);
   w.dXa = take(BN * D); w.dS = take(BN * d.N); w.dQKV = take(BN * 3 * D);
-  w.part = take((size_t)WCS_RS * D); w.stage = take(16 * D);
+  w.part = take((size_t)WCS_RS * D); w.part2 = take((size_t)WCS_RS * D); w.stage = take(16 * D);
   w.skws_floats = (size_t)16 * D * D; w.skws = take(w.skws_floats);     // split-K slices of the D x D weight gradients
   if (ab_planes()) {
     auto take16 = [&](size_t n) { return reinterpret_cast<uint16_t*>(take((n + 1) / 2)); };
@@ -352,11 +408,21 @@ static int ab_backward_core(const ep_abmilp_dims& d, const float* x, const ep_ab
                      (int64_t)N, D, w.da);
   hipLaunchKernelGGL(ep_abmilp_ds_kernel, dim3(d.B), dim3(256), 0, st, w.a, w.da, N, w.ds);
   EP_LAUNCH_CHECK("abmilp backward kernels (1)");
-  EP_TRY(wcolsum(w.H, w.ds, BN, D, acc, gr.w2, w, st));                              // dw2 = sum_r ds[r] H[r,:]
   hipLaunchKernelGGL(ep_sum_kernel, dim3(1), dim3(256), 0, st, w.ds, (int64_t)BN, acc, gr.b2);
-  hipLaunchKernelGGL(ep_tanh_bwd_kernel, dim3(eg), dim3(256), 0, st, w.H, w.ds, pr.w2, (int64_t)BN, D / 4);   // H <- dG
-  EP_LAUNCH_CHECK("abmilp backward kernels (2)");
-  EP_TRY(wcolsum(w.H, nullptr, BN, D, acc, gr.b1, w, st));
+  static int fused_tanh = -1;                // EP_ABMILP_TANH_FUSED=0: the three kernels of rounds 1 - 5
+  if (fused_tanh < 0) { const char* e = getenv("EP_ABMILP_TANH_FUSED"); fused_tanh = e ? atoi(e) : 1; }
+  if (fused_tanh) {
+    // dw2 = sum_r ds[r] H[r,:], H <- dG, db1 = sum_r dG[r,:] in one read of H
+    hipLaunchKernelGGL(ep_tanh_bwd_sums_kernel, dim3((D + 63) / 64, WCS_RS), dim3(256), 0, st, w.H, w.ds, pr.w2, (int64_t)BN, D, w.part, w.part2);
+    EP_LAUNCH_CHECK("ep_tanh_bwd_sums_kernel");
+    EP_TRY(reduce_partials(w.part, WCS_RS, D, 1.0f, acc, gr.w2, w.stage, st));
+    EP_TRY(reduce_partials(w.part2, WCS_RS, D, 1.0f, acc, gr.b1, w.stage, st));
+  } else {
+    EP_TRY(wcolsum(w.H, w.ds, BN, D, acc, gr.w2, w, st));                            // dw2 = sum_r ds[r] H[r,:]
+    hipLaunchKernelGGL(ep_tanh_bwd_kernel, dim3(eg), dim3(256), 0, st, w.H, w.ds, pr.w2, (int64_t)BN, D / 4);   // H <- dG
+    EP_LAUNCH_CHECK("abmilp backward kernels (2)");
+    EP_TRY(wcolsum(w.H, nullptr, BN, D, acc, gr.b1, w, st));
+  }
   {
     GemmParams g = mk(w.H, D, w.Xa, D, gr.w1, D, D, D, BN); g.accumulate = acc;       // dW1 = dG^T Xa
     g.skws = w.skws; g.skws_floats = w.skws_floats;

@@ -602,19 +602,37 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
 #ifndef EP_B3_STAGES
 #define EP_B3_STAGES 1
 #endif
+// Launched 1-D; tile V of the (batch entry, M-tile, N-tile) numbering, N fastest.  xcd (b3_launch): V = (L % 8) * (grid / 8) + L / 8,
+// so that XCD L % 8 works through WHOLE batch entries (the images of a batched attention product, the K slices of a weight
+// gradient) and the tiles that share an entry's operands share one L2; otherwise V = L, the launch order.
 template <bool A_K, bool B_K, int BMT>
-__global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p, int gx, int gy, unsigned ntiles, int xcd) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
-  if constexpr (EP_B3_STAGES == 2) gemm_tile_b3g2<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
-  else gemm_tile_b3g<A_K, B_K, BMT>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+  const unsigned L = blockIdx.x;
+  const unsigned V = xcd ? (L % 8u) * (gridDim.x / 8u) + L / 8u : L;
+  if (V >= ntiles) return;
+  const int bx = __builtin_amdgcn_readfirstlane((int)(V % (unsigned)gx)), by = __builtin_amdgcn_readfirstlane((int)((V / (unsigned)gx) % (unsigned)gy)),
+            bz = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(gx * gy)));
+  if constexpr (EP_B3_STAGES == 2) gemm_tile_b3g2<A_K, B_K, BMT>(p, bx, by, bz, lds_b3);
+  else gemm_tile_b3g<A_K, B_K, BMT>(p, bx, by, bz, lds_b3);
 }
 // LONG weight gradients (T / T, K >= 4096) of at least 1024 x 1024 outputs: 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w).
 // Measured (ms per step, 256 images, 64 x 64 tiles -> wide): AbMILP 256 x 1152 18.22 -> 16.97 (AMP-bf16 mode 10.59 -> 9.79); at
 // D = 768 -- 36 wide tiles per gradient, one or two workgroups per CU after the K split -- it LOSES: DINOv2 block 20.3 -> 21.4,
 // DOLG 1.91 -> 1.98, AbMILP 8.75 -> 8.59: hence the size floor.  EP_GEMM_B3_WIDE=0: off; =2: from 256 x 256 (the first form).
-__global__ __launch_bounds__(256) void ep_gemm_b3_wide_kernel(GemmParams p) {
+// Tile order (round 6): 1-D launch, workgroup L runs on XCD L % 8 and takes tile V = (L % 8) * (grid / 8) + L / 8 of the
+// (K slice, M-tile, N-tile) numbering, N fastest: an XCD works through WHOLE K slices, so the 9 x 9 ... 27 x 9 tiles that share
+// a slice's operand panels share one L2.  In launch order (tiles of a slice dealt round-robin over the eight L2s) every XCD
+// held ~10 tiles of each of ~6 slices and the panels -- 2 x 9 x 302 MB per 1152 x 1152 gradient -- came from HBM.
+// EP_B3_WIDE_XCD=0: launch order.
+__global__ __launch_bounds__(256) void ep_gemm_b3_wide_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int xcd) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
-  gemm_tile_b3w(p, blockIdx.x, blockIdx.y, blockIdx.z, lds_b3);
+  const unsigned L = blockIdx.x;
+  const unsigned V = xcd ? (L % 8u) * (gridDim.x / 8u) + L / 8u : L;
+  if (V >= ntiles) return;
+  const int bx = __builtin_amdgcn_readfirstlane((int)(V % (unsigned)ntn)), by = __builtin_amdgcn_readfirstlane((int)((V / (unsigned)ntn) % (unsigned)mtn)),
+            bz = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(mtn * ntn)));
+  gemm_tile_b3w(p, bx, by, bz, lds_b3);
 }
 static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k) {
   static int on = -1;
@@ -639,8 +657,21 @@ static void b3_launch(const GemmParams& p, int batch, bool m32, hipStream_t st) 
     (void)hipFuncSetAttribute((const void*)ep_gemm_b3_kernel<A_K, B_K, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_KERNEL_LDS);
     attr_set = true;
   }
-  if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3((p.N + 63) / 64, (p.M + 31) / 32, batch), dim3(256), B3_KERNEL_LDS, st, p);
-  else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3((p.N + 63) / 64, (p.M + 63) / 64, batch), dim3(256), B3_KERNEL_LDS, st, p);
+  // XCD-grouped order for launches of SEVERAL entries that fill the chip (round 6: the six per-image attention products of the
+  // AbMILP step -- 256 x 256 x 1152 per image, 16 - 72 tiles each -- streamed every image's operands into up to eight L2s: 0.27 -
+  // 0.55 ms per 39 GFLOP product; AMP-bf16 step at 256 x 1152 8.30 -> 7.95 ms, fp32 16.33 -> 16.15, DINOv2 block 19.8 -> 19.5).
+  // EP_B3_XCD=0: launch order everywhere; =2: grouped for every launch.
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("EP_B3_XCD"); mode = e ? atoi(e) : 1; }
+  const int gx = (p.N + 63) / 64, gy = m32 ? (p.M + 31) / 32 : (p.M + 63) / 64;
+  const unsigned ntiles = (unsigned)gx * (unsigned)gy * (unsigned)batch;
+  // (default rule: per-image batches and the K slices of long weight gradients.  The EP step's own batched launches -- 8 / 32 query
+  // slices, 1024-row gradients -- measured equal or 0.3 - 1 % slower grouped and keep the launch order.)
+  const int xcd = mode == 2 || (mode == 1 && gx * gy > 1 && ntiles >= 2u * (unsigned)cu_count() &&
+                                (batch >= 64 || (batch > 1 && !A_K && p.K >= 2048)));
+  const unsigned grid = xcd ? 8u * ((ntiles + 7u) / 8u) : ntiles;
+  if (m32) hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 32>), dim3(grid), dim3(256), B3_KERNEL_LDS, st, p, gx, gy, ntiles, xcd);
+  else hipLaunchKernelGGL((ep_gemm_b3_kernel<A_K, B_K, 64>), dim3(grid), dim3(256), B3_KERNEL_LDS, st, p, gx, gy, ntiles, xcd);
 }
 // ---- up to two small T / T weight gradients in ONE launch on the paired-group tile (ep_wgrad3.h: gemm_tile_b3p): the EP step's
 // dWc = dlogits^T z and dWv_q = dy_q^T P_q as a launch of their own between BatchNorm backward and the second token pass ----
@@ -774,7 +805,11 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
     if (b3_wide_ok(p, a_k, b_k)) {
       static bool attr_wide = false;
       if (!attr_wide) { (void)hipFuncSetAttribute((const void*)ep_gemm_b3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3W_LDS_BYTES); attr_wide = true; }
-      hipLaunchKernelGGL(ep_gemm_b3_wide_kernel, dim3((p.N + 127) / 128, (p.M + 127) / 128, batch), dim3(256), W3W_LDS_BYTES, st, q3);
+      static int xcd = -1;
+      if (xcd < 0) { const char* e = getenv("EP_B3_WIDE_XCD"); xcd = e ? atoi(e) : 1; }
+      const int mtn = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
+      const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
+      hipLaunchKernelGGL(ep_gemm_b3_wide_kernel, dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
       EP_LAUNCH_CHECK("ep_gemm_b3_wide_kernel");
       return 0;
     }

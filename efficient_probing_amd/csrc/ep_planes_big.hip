@@ -108,7 +108,7 @@ __device__ __forceinline__ void pbg_dma(const char* base, unsigned off, unsigned
 #pragma clang diagnostic pop
 
 template <int NST, int NT>
-__global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles) {
+__global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int nfast) {
   constexpr int PBG_STB = PbgGeom<NT>::stb, PBG_NPC = PbgGeom<NT>::npc, NM = PbgGeom<NT>::nm;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p
   if (V >= ntiles) return;
   // (the divisions run on the vector ALU: hand the results back to scalar registers, or every address built from them is a
   // vector value that has to be read back lane 0 by lane 0 for each DMA instruction)
-  const int mt = __builtin_amdgcn_readfirstlane((int)(V % (unsigned)mtn)), nt = __builtin_amdgcn_readfirstlane((int)((V / (unsigned)mtn) % (unsigned)ntn)),
+  // nfast (planes_big_launch_nt): the N-tiles of one M-tile are neighbours -- the order for activations larger than the weights
+  const int mt = __builtin_amdgcn_readfirstlane((int)(nfast ? (V / (unsigned)ntn) % (unsigned)mtn : V % (unsigned)mtn)),
+            nt = __builtin_amdgcn_readfirstlane((int)(nfast ? V % (unsigned)ntn : (V / (unsigned)mtn) % (unsigned)ntn)),
             z = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(mtn * ntn)));
   const int m0 = mt * 128, n0 = nt * 128;
   const int nk = (p.K + BK - 1) / BK;
@@ -426,6 +428,14 @@ static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st)
   const int mtn = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
   const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
   const unsigned grid = 8u * ((ntiles + 7u) / 8u);
+  // Tile order inside an XCD's range.  M fastest (round 5) keeps one WEIGHT tile in the XCD's L2 while the activations stream
+  // past it: right for the EP step (1024 rows against 4096 x 4096 weights).  With 65536 token rows against a 1152-wide layer
+  // (AbMILP, the DINOv2 block) it makes every XCD read ALL activations once per N-tile -- 9 / 27 x 302 MB per contraction from
+  // HBM; N fastest reads an activation tile once and its other N-tiles hit the L2 (the weights, <= 8 MB, stay resident).
+  // Taken when the activations are at least four times the weights.  EP_PBG_ORDER=0 / 1 forces M / N fastest (A/B runs).
+  static int order = -2;
+  if (order == -2) { const char* e = getenv("EP_PBG_ORDER"); order = e ? atoi(e) : -1; }
+  const int nfast = order >= 0 ? order : ((double)p.M * 4.0 >= 4.0 * (double)p.N * 2.0 * NT && ntn > 1) ? 1 : 0;
 #if EP_PBG_CLK
   static unsigned long long* dbg = nullptr;
   static unsigned long long host[8192 * 8];
@@ -433,7 +443,7 @@ static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st)
   GemmParams q = p;
   q.skws = reinterpret_cast<float*>(dbg);
   if (ntiles <= 8192) {
-    hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, q, mtn, ntn, ntiles);
+    hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, q, mtn, ntn, ntiles, nfast);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host, dbg, (size_t)ntiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double c = 0, r = 0;
@@ -445,7 +455,7 @@ static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st)
     return;
   }
 #endif
-  hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, p, mtn, ntn, ntiles);
+  hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, p, mtn, ntn, ntiles, nfast);
 }
 void planes_big_launch(const GemmParams& p, int batch, hipStream_t st) {
   if (p.nterms == 1 || gemm_arith() == 1) planes_big_launch_nt<1>(p, batch, st); else planes_big_launch_nt<3>(p, batch, st);
