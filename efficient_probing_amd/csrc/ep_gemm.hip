@@ -634,6 +634,16 @@ __global__ __launch_bounds__(256) void ep_gemm_b3_wide_kernel(GemmParams p, int 
             bz = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(mtn * ntn)));
   gemm_tile_b3w(p, bx, by, bz, lds_b3);
 }
+// ... and its single-product form (AMP-bf16): 40 KiB, one barrier per K-tile, three workgroups per CU
+__global__ __launch_bounds__(256, 3) void ep_gemm_b3_wide1_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int xcd) {
+  extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
+  const unsigned L = blockIdx.x;
+  const unsigned V = xcd ? (L % 8u) * (gridDim.x / 8u) + L / 8u : L;
+  if (V >= ntiles) return;
+  const int bx = __builtin_amdgcn_readfirstlane((int)(V % (unsigned)ntn)), by = __builtin_amdgcn_readfirstlane((int)((V / (unsigned)ntn) % (unsigned)mtn)),
+            bz = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(mtn * ntn)));
+  gemm_tile_b3w1(p, bx, by, bz, lds_b3);
+}
 static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_B3_WIDE"); on = e ? atoi(e) : 1; }
@@ -809,6 +819,11 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
       if (xcd < 0) { const char* e = getenv("EP_B3_WIDE_XCD"); xcd = e ? atoi(e) : 1; }
       const int mtn = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
       const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
+      static int one_form = -1;                                // EP_B3_WIDE1=0: the three-term tile with its run-time single-term branch
+      if (one_form < 0) { const char* e = getenv("EP_B3_WIDE1"); one_form = e ? atoi(e) : 1; }
+      if (q3.nterms == 1 && one_form)
+        hipLaunchKernelGGL(ep_gemm_b3_wide1_kernel, dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W1_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
+      else
       hipLaunchKernelGGL(ep_gemm_b3_wide_kernel, dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
       EP_LAUNCH_CHECK("ep_gemm_b3_wide_kernel");
       return 0;

@@ -107,8 +107,8 @@ __device__ __forceinline__ void pbg_dma(const char* base, unsigned off, unsigned
 }
 #pragma clang diagnostic pop
 
-template <int NST, int NT>
-__global__ __launch_bounds__(256, 1) void ep_gemm_planes_big_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int nfast) {
+template <int NST, int NT, int WGS = 1>
+__global__ __launch_bounds__(256, WGS) void ep_gemm_planes_big_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int nfast) {
   constexpr int PBG_STB = PbgGeom<NT>::stb, PBG_NPC = PbgGeom<NT>::npc, NM = PbgGeom<NT>::nm;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
@@ -419,12 +419,12 @@ bool planes_big_wanted(const GemmParams& p, int batch) {
   return (tiles >= 192 && p.K >= 2048) || (tiles >= 2048 && p.K >= 512);
 }
 
-template <int NT>
+template <int NT, int WGS>
 static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st) {
-  constexpr int NST = NT == 1 ? 4 : EP_PBG_NST;      // (single term: 24 KiB stages, four of them)
+  constexpr int NST = NT == 1 ? (WGS == 2 ? 3 : 4) : EP_PBG_NST;   // (single term: 24 KiB stages; two workgroups per CU: three each)
   constexpr int lds = NST * PbgGeom<NT>::stb;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_big_kernel<NST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ep_gemm_planes_big_kernel<NST, NT, WGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   const int mtn = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
   const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
   const unsigned grid = 8u * ((ntiles + 7u) / 8u);
@@ -443,7 +443,7 @@ static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st)
   GemmParams q = p;
   q.skws = reinterpret_cast<float*>(dbg);
   if (ntiles <= 8192) {
-    hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, q, mtn, ntn, ntiles, nfast);
+    hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT, WGS>), dim3(grid), dim3(256), lds, st, q, mtn, ntn, ntiles, nfast);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host, dbg, (size_t)ntiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double c = 0, r = 0;
@@ -455,10 +455,16 @@ static void planes_big_launch_nt(const GemmParams& p, int batch, hipStream_t st)
     return;
   }
 #endif
-  hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT>), dim3(grid), dim3(256), lds, st, p, mtn, ntn, ntiles, nfast);
+  hipLaunchKernelGGL((ep_gemm_planes_big_kernel<NST, NT, WGS>), dim3(grid), dim3(256), lds, st, p, mtn, ntn, ntiles, nfast);
 }
 void planes_big_launch(const GemmParams& p, int batch, hipStream_t st) {
-  if (p.nterms == 1 || gemm_arith() == 1) planes_big_launch_nt<1>(p, batch, st); else planes_big_launch_nt<3>(p, batch, st);
+  // single-term form: its K-tile is 8 matrix instructions per wave against the same DMA issue, fragment reads and barrier as the
+  // three-term form's 48 -- one wave per SIMD leaves the matrix pipe idle most of the time, so TWO workgroups share a CU
+  // (212 VGPRs, 72 KiB of LDS each).  EP_PBG_AMP_WGS=1: one workgroup with a four-stage ring (round 5).
+  static int wgs = -1;
+  if (wgs < 0) { const char* e = getenv("EP_PBG_AMP_WGS"); wgs = e ? atoi(e) : 2; }
+  if (p.nterms == 1 || gemm_arith() == 1) { if (wgs == 2) planes_big_launch_nt<1, 2>(p, batch, st); else planes_big_launch_nt<1, 1>(p, batch, st); }
+  else planes_big_launch_nt<3, 1>(p, batch, st);
 }
 
 }  // namespace ep

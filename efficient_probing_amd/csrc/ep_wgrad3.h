@@ -486,6 +486,85 @@ __device__ __forceinline__ void gemm_tile_b3w(const GemmParams& p, int bx, int b
   }
 }
 
+// The wide tile for ONE product of the bf16-rounded operands (the AMP-bf16 arithmetic mode, GemmParams.nterms == 1; round 6).
+// gemm_tile_b3w with a run-time `one` keeps its 60 KiB of plane images and 248 registers: two workgroups per CU, each K-tile a
+// chain of two barriers around 16 matrix instructions per wave (rocprofv3, AbMILP step at 256 x 1152: 0.55 ms per 1152 x 1152 x
+// 65536 gradient, 18 % of the matrix pipe).  Here only the rounded operand is staged -- 20 KiB per K-tile -- into TWO image sets,
+// so tile it + 1 is written while tile it is multiplied and ONE barrier per K-tile remains; 40 KiB and <= 128 registers let
+// three to four workgroups share a CU.  Same rounding, same per-tile instruction order as the `one` branch of gemm_tile_b3w.
+constexpr size_t W3W1_LDS_BYTES = 2 * 2 * (size_t)W3W_TS;            // two sets of (A | B) = 40960
+__device__ __forceinline__ void w3_stage_T1(char* img, const f4v (&x)[2], int ext, int K, int c0, int k0, int kp, int mq) {
+  const bool cok = c0 + 4 * mq < ext;
+  const bool k0ok = cok && k0 + 2 * kp < K, k1ok = cok && k0 + 2 * kp + 1 < K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    *reinterpret_cast<unsigned*>(img + w3_off(4 * mq + j, kp >> 2) + 4 * (kp & 3)) = pl_pack_rne(k0ok ? x[0][j] : 0.f, k1ok ? x[1][j] : 0.f);
+}
+__device__ __forceinline__ void gemm_tile_b3w1(const GemmParams& p, int bx, int by, int bz, char* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * 128, n0 = bx * 128;
+  const float* A = p.A + (int64_t)bz * p.sAz;
+  const float* B = p.B + (int64_t)bz * p.sBz;
+  float* C = p.C + (int64_t)bz * p.sCz;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int mq = tid & 15, kp = tid >> 4;
+  const int extA = p.extA < p.M ? p.extA : p.M, extB = p.extB < p.N ? p.extB : p.N;
+  const int nk = (p.K + 31) / 32;
+  f4v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+  f4v xa[2][2], xb[2][2];                            // [64-column half][k of the pair]
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      w3_load_T(A, p.lda, extA, p.K, m0 + 64 * h, k0, kp, mq, xa[h]);
+      w3_load_T(B, p.ldb, extB, p.K, n0 + 64 * h, k0, kp, mq, xb[h]);
+    }
+  };
+  auto stage = [&](int t) {                          // the rows in registers (K-tile t) -> image set t & 1
+    char* imgA = lds + (t & 1) * (2 * W3W_TS);
+    char* imgB = imgA + W3W_TS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      w3_stage_T1(imgA + h * W3_IMG, xa[h], extA, p.K, m0 + 64 * h, t * 32, kp, mq);
+      w3_stage_T1(imgB + h * W3_IMG, xb[h], extB, p.K, n0 + 64 * h, t * 32, kp, mq);
+    }
+  };
+  load(0);
+  stage(0);
+  if (nk > 1) load(32);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) {
+      stage(it + 1);                                 // set (it + 1) & 1: last read in iteration it - 1, before the barrier that ended it
+      if (it + 2 < nk) load((it + 2) * 32);
+    }
+    const char* imgA = lds + (it & 1) * (2 * W3W_TS);
+    const char* imgB = imgA + W3W_TS;
+    pl_u4 fb1[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb1[ni] = *reinterpret_cast<const pl_u4*>(imgB + w3_off(wn * 64 + ni * 16 + i16, kk));
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const pl_u4 fa1 = *reinterpret_cast<const pl_u4*>(imgA + w3_off(wm * 64 + mi * 16 + i16, kk));
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = pl_mfma(fa1, fb1[ni], acc[mi][ni]);
+    }
+    __syncthreads();                                 // tile it + 1's images are complete; everyone has read tile it's
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    f4v blk[4]; int rb[4], cb[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) { blk[ni] = acc[mi][ni]; rb[ni] = m0 + wm * 64 + mi * 16; cb[ni] = n0 + wn * 64 + ni * 16; }
+    store_acc_blocks<4>(p, C, bz, rb, cb, blk, kk, i16);
+  }
+}
+
 // The PAIRED form for SMALL weight gradients that have a CU to themselves (round 6): 8 waves = two groups of four on ONE 64 x 64
 // output tile, alternating K-tiles (the planes kernel's two parities, ep_planes.hip).  gemm_tile_b3g's K-tile is a serial chain --
 // raw rows -> split -> transposed LDS write -> barrier -> fragment reads -> 24 matrix instructions -> barrier -- that takes

@@ -269,3 +269,50 @@ def test_coca_and_abmilp_heads_in_the_amp_mode(fam_case):
             # (LARS steps the 1-D tensors by lr x gradient without a trust ratio, and several of this head's bias gradients are
             # sums of cancelling terms -- tests/test_gpu_abmilp.py CANCELLING: their drift is not normalised)
             assert float((a - b).norm() / a.norm()) < (3e-2 if a.dim() > 1 else 1e-1)
+
+
+# ---- round 6: the long weight gradients of the matrix-core-bound heads in the AMP mode run on the single-product form of the
+# 128 x 128 tile (csrc/ep_wgrad3.h: gemm_tile_b3w1; reference poolings/abmilp.py:53-71 under autograd inside autocast) ----
+_WIDE1_CHILD = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/golden"]
+from cases import AbmilpCase, make_abmilp_inputs
+import test_gpu_abmilp as T
+from efficient_probing_amd.engine import AbmilpHeadEngine as E
+case = AbmilpCase("wide1", B=16, N=256, D=1024, C=10, seed=11, sharp=False)
+inp = make_abmilp_inputs(case)
+x, t = torch.from_numpy(inp["x_buf"]).cuda(), torch.from_numpy(inp["targets"]).cuda()
+g = {}
+for mode in ("fp32", "bf16_autocast"):
+    eng = E(T.native_head(case, inp)[0], optimizer="sgd", lr=0.0, arithmetic=mode)
+    eng.forward_backward(x, t)
+    g[mode] = [p.grad.detach().double().cpu() for p in eng.params_list]
+    if mode == "bf16_autocast":
+        print("sha", hashlib.sha256(eng.flat_g.cpu().numpy().tobytes()).hexdigest())
+for a, b in zip(g["fp32"], g["bf16_autocast"]):
+    print("rel", a.dim(), float((a - b).norm() / max(float(a.norm()), 1e-30)), float(a.norm()))
+"""
+
+
+def test_long_weight_gradients_on_the_single_product_wide_tile():
+    """16 images of 256 x 1024 tokens: 4096 token rows put dW1, dWp (1024 x 1024) and dWqkv (3072 x 1024) on the wide tile.
+    (a) the AMP-mode gradients of the matrices stay within bf16 rounding of the fp32 mode's (an indexing error is O(1));
+    (b) the tile's own single-product form and the three-term tile's run-time branch (EP_B3_WIDE1=0) give the same bits:
+    same rounding, same order of the matrix instructions.  (The switch is read once per process: children.)"""
+    import os, subprocess, sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(tests)
+    sha = {}
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _WIDE1_CHILD, tests], cwd=root, env=dict(os.environ, EP_B3_WIDE1=v, PYTHONPATH=root),
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = r.stdout.strip().splitlines()
+        sha[v] = [l for l in lines if l.startswith("sha")][0]
+        rels = [l.split() for l in lines if l.startswith("rel")]
+        assert len(rels) == 9
+        for _, dim, rel, norm in rels:
+            if int(dim) > 1 and float(norm) > 0:
+                assert 1e-6 < float(rel) < 2e-2, (v, rels)
+    assert sha["1"] == sha["0"], sha
