@@ -786,7 +786,12 @@ bool gemm_b3_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
   static long min_tiles = -1;
   if (min_tiles < 0) { const char* e = getenv("EP_GEMM_B3_MIN_TILES"); min_tiles = e ? atol(e) : 512; }
   const long tiles64 = (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64) * batch;
-  return min_tiles > 0 && tiles64 >= min_tiles && p.K >= 256;
+  // K floor 128 since round 6 (EP_GEMM_B3_MIN_K; 256 before): dP = dy_q Wv_q at 256 x 1152 (K = 144, 2304 tiles) 79.9 -> 37.4 us
+  // (rocprofv3); the step gains less -- 0.764 -> 0.759 ms, bf16-stored tokens 0.507 -> 0.499 -- because the weight gradients of
+  // the second queue then overlap the second token pass for longer (277 -> 311 us).  Every other head and shape: equal.
+  static int min_k = -1;
+  if (min_k < 0) { const char* e = getenv("EP_GEMM_B3_MIN_K"); min_k = e ? atoi(e) : 128; }
+  return min_tiles > 0 && tiles64 >= min_tiles && p.K >= min_k;
 }
 
 const char* gemm_kernel_name(bool a_k, bool b_k, const GemmParams& p, int batch) {
