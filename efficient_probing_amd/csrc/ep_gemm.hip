@@ -552,13 +552,13 @@ bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k) {
 // Few output tiles and a very long K (weight gradients over all B N token rows): the tiles cannot fill the chip, so K is cut
 // into `splits` slices that run as the batch dimension into the caller's scratch and are summed in slice order
 // (ep_reduce_partials_kernel: deterministic).  Needs a contiguous C, no bias, one batch.
-static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k);
+static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k, int batch);
 static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st, bool* done) {
   *done = false;
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_SPLITK"); on = e ? atoi(e) : 1; }
   if (!on || !p.skws || p.bias || p.ldc != p.N || p.alpha != 1.0f || p.K < 8192 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
-  const bool wide = b3_wide_ok(p, a_k, b_k);           // 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w): a quarter of the tiles
+  const bool wide = b3_wide_ok(p, a_k, b_k, 1);        // 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w): a quarter of the tiles
   const long tiles = wide ? (long)((p.N + 127) / 128) * ((p.M + 127) / 128) : (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
   const long cus = cu_count();
   if (tiles >= 2 * cus) return 0;
@@ -625,6 +625,7 @@ __global__ __launch_bounds__(256) void ep_gemm_b3_kernel(GemmParams p, int gx, i
 // a slice's operand panels share one L2.  In launch order (tiles of a slice dealt round-robin over the eight L2s) every XCD
 // held ~10 tiles of each of ~6 slices and the panels -- 2 x 9 x 302 MB per 1152 x 1152 gradient -- came from HBM.
 // EP_B3_WIDE_XCD=0: launch order.
+template <bool A_K, bool B_K>
 __global__ __launch_bounds__(256) void ep_gemm_b3_wide_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int xcd) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
   const unsigned L = blockIdx.x;
@@ -632,9 +633,10 @@ __global__ __launch_bounds__(256) void ep_gemm_b3_wide_kernel(GemmParams p, int 
   if (V >= ntiles) return;
   const int bx = __builtin_amdgcn_readfirstlane((int)(V % (unsigned)ntn)), by = __builtin_amdgcn_readfirstlane((int)((V / (unsigned)ntn) % (unsigned)mtn)),
             bz = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(mtn * ntn)));
-  gemm_tile_b3w(p, bx, by, bz, lds_b3);
+  gemm_tile_b3w<A_K, B_K>(p, bx, by, bz, lds_b3);
 }
 // ... and its single-product form (AMP-bf16): 40 KiB, one barrier per K-tile, three workgroups per CU
+template <bool A_K, bool B_K>
 __global__ __launch_bounds__(256, 3) void ep_gemm_b3_wide1_kernel(GemmParams p, int mtn, int ntn, unsigned ntiles, int xcd) {
   extern __shared__ __attribute__((aligned(1024))) char lds_b3[];
   const unsigned L = blockIdx.x;
@@ -642,13 +644,34 @@ __global__ __launch_bounds__(256, 3) void ep_gemm_b3_wide1_kernel(GemmParams p, 
   if (V >= ntiles) return;
   const int bx = __builtin_amdgcn_readfirstlane((int)(V % (unsigned)ntn)), by = __builtin_amdgcn_readfirstlane((int)((V / (unsigned)ntn) % (unsigned)mtn)),
             bz = __builtin_amdgcn_readfirstlane((int)(V / (unsigned)(mtn * ntn)));
-  gemm_tile_b3w1(p, bx, by, bz, lds_b3);
+  gemm_tile_b3w1<A_K, B_K>(p, bx, by, bz, lds_b3);
 }
-static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k) {
+template <bool A_K, bool B_K>
+static void b3_wide_launch(const GemmParams& q3, int batch, hipStream_t st) {
+  static bool attr_wide = false;
+  if (!attr_wide) { (void)hipFuncSetAttribute((const void*)ep_gemm_b3_wide_kernel<A_K, B_K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3W_LDS_BYTES); attr_wide = true; }
+  static int xcd = -1;
+  if (xcd < 0) { const char* e = getenv("EP_B3_WIDE_XCD"); xcd = e ? atoi(e) : 1; }
+  const int mtn = (q3.M + 127) / 128, ntn = (q3.N + 127) / 128;
+  const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
+  static int one_form = -1;                                // EP_B3_WIDE1=0: the three-term tile with its run-time single-term branch
+  if (one_form < 0) { const char* e = getenv("EP_B3_WIDE1"); one_form = e ? atoi(e) : 1; }
+  if (q3.nterms == 1 && one_form)
+    hipLaunchKernelGGL((ep_gemm_b3_wide1_kernel<A_K, B_K>), dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W1_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
+  else
+    hipLaunchKernelGGL((ep_gemm_b3_wide_kernel<A_K, B_K>), dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
+}
+static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k, int batch) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_B3_WIDE"); on = e ? atoi(e) : 1; }
+  if (!on || !gemm_b3_on() || p.cs_out || p.ksplit > 1) return false;
+  // PER-IMAGE products (>= 64 batch entries of at least 128 x 128 outputs, any layout; round 6, r6.10): the attention products of
+  // the AbMILP head -- S = q k^T, O = A v, dA, dv, dq, dk at 256 x 256 x 1152 / 256 x 1152 x 256 per image -- on 64 x 64 tiles were
+  // bound by the L2 -> LDS fill of their fp32 operands.  EP_GEMM_B3_WIDE=3: the weight gradients only.
+  if (on != 3 && batch >= 64 && p.M >= 128 && p.N >= 128 && p.K >= 64)
+    return vec_ok(p.A, p.lda, p.sAz, a_k ? p.K : p.extA) && vec_ok(p.B, p.ldb, p.sBz, b_k ? p.K : p.extB);
   const int floor_ = on == 2 ? 256 : 1024;
-  return on && gemm_b3_on() && !a_k && !b_k && !p.bias && !p.cs_out && p.M >= floor_ && p.N >= floor_ && p.K >= 4096 &&
+  return !a_k && !b_k && !p.bias && p.M >= floor_ && p.N >= floor_ && p.K >= 4096 &&
          vec_ok(p.A, p.lda, p.sAz, p.extA) && vec_ok(p.B, p.ldb, p.sBz, p.extB);
 }
 // THIN outputs (N <= 32 per batch entry, K / K layout): the value projection at the published protocol's 32 queries is 32 batched
@@ -817,19 +840,10 @@ int gemm(bool a_k, bool b_k, const GemmParams& p, int batch, hipStream_t st) {
     if (t_arith == 1) q3.nterms = 1;
     static int thin_on = -1;                                   // EP_GEMM_B3_THIN=0: 64-column tiles for thin outputs too
     if (thin_on < 0) { const char* e = getenv("EP_GEMM_B3_THIN"); thin_on = e ? atoi(e) : 1; }
-    if (b3_wide_ok(p, a_k, b_k)) {
-      static bool attr_wide = false;
-      if (!attr_wide) { (void)hipFuncSetAttribute((const void*)ep_gemm_b3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3W_LDS_BYTES); attr_wide = true; }
-      static int xcd = -1;
-      if (xcd < 0) { const char* e = getenv("EP_B3_WIDE_XCD"); xcd = e ? atoi(e) : 1; }
-      const int mtn = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
-      const unsigned ntiles = (unsigned)mtn * (unsigned)ntn * (unsigned)batch;
-      static int one_form = -1;                                // EP_B3_WIDE1=0: the three-term tile with its run-time single-term branch
-      if (one_form < 0) { const char* e = getenv("EP_B3_WIDE1"); one_form = e ? atoi(e) : 1; }
-      if (q3.nterms == 1 && one_form)
-        hipLaunchKernelGGL(ep_gemm_b3_wide1_kernel, dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W1_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
-      else
-      hipLaunchKernelGGL(ep_gemm_b3_wide_kernel, dim3(8u * ((ntiles + 7u) / 8u)), dim3(256), W3W_LDS_BYTES, st, q3, mtn, ntn, ntiles, xcd);
+    if (b3_wide_ok(p, a_k, b_k, batch) && (a_k || !b_k)) {               // (T / K does not occur)
+      if (!a_k) b3_wide_launch<false, false>(q3, batch, st);
+      else if (b_k) b3_wide_launch<true, true>(q3, batch, st);
+      else b3_wide_launch<true, false>(q3, batch, st);
       EP_LAUNCH_CHECK("ep_gemm_b3_wide_kernel");
       return 0;
     }

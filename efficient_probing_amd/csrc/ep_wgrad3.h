@@ -78,7 +78,8 @@ __device__ __forceinline__ void w3_load_K(const float* __restrict__ base, int64_
   }
 }
 template <int RT>
-__device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int rows, int K, int r0, int k0, int tid, bool one = false) {
+__device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int rows, int K, int r0, int k0, int tid, bool one = false,
+                                           int tstride = W3_IMG) {
 #pragma unroll
   for (int r = 0; r < RT / 32; ++r) {
     const int idx = tid + 256 * r, lrow = idx >> 3, kq = idx & 7;
@@ -90,8 +91,8 @@ __device__ __forceinline__ void w3_stage_K(char* img, const f4v (&x)[2], int row
     const int o = w3_off(lrow, kq >> 1) + 8 * (kq & 1);
     *reinterpret_cast<w3_u2*>(img + o) = w3_u2{h0, h1};
     if (one) continue;
-    *reinterpret_cast<w3_u2*>(img + W3_IMG + o) = w3_u2{m0, m1};
-    *reinterpret_cast<w3_u2*>(img + 2 * W3_IMG + o) = w3_u2{l0, l1};
+    *reinterpret_cast<w3_u2*>(img + tstride + o) = w3_u2{m0, m1};
+    *reinterpret_cast<w3_u2*>(img + 2 * tstride + o) = w3_u2{l0, l1};
   }
 }
 
@@ -407,6 +408,9 @@ __device__ __forceinline__ void gemm_tile_b3d(const GemmParams& p, int bx, int b
 // plane images of 128 rows (term stride 2 W3_IMG), one LDS stage of 60 KiB, the next K-tile's rows in flight in registers.
 constexpr int W3W_TS = 2 * W3_IMG;                                   // bytes per term image (128 rows)
 constexpr size_t W3W_LDS_BYTES = 6 * (size_t)W3W_TS;                 // A: h m l | B: h m l = 61440
+// A_K / B_K (round 6, late): the K-contiguous layouts too -- the per-image attention products of the AbMILP head (S = q k^T,
+// O = A v, dq, dk, dv, dA: 256 x 256 x 1152 / 256 x 1152 x 256 per image) ran on 64 x 64 tiles, L2 -> LDS fill bound.
+template <bool A_K = false, bool B_K = false>
 __device__ __forceinline__ void gemm_tile_b3w(const GemmParams& p, int bx, int by, int bz, char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -427,12 +431,14 @@ __device__ __forceinline__ void gemm_tile_b3w(const GemmParams& p, int bx, int b
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
-  f4v xa[2][2], xb[2][2];                            // [64-column half][k of the pair]
+  f4v xa[2][2], xb[2][2];                            // [64-column half][k of the pair]  (K layout: [64-row half][row of the pair])
   auto load = [&](int k0) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      w3_load_T(A, p.lda, extA, p.K, m0 + 64 * h, k0, kp, mq, xa[h]);
-      w3_load_T(B, p.ldb, extB, p.K, n0 + 64 * h, k0, kp, mq, xb[h]);
+      if constexpr (A_K) w3_load_K<64>(A, p.lda, p.M, p.K, m0 + 64 * h, k0, tid, xa[h]);
+      else w3_load_T(A, p.lda, extA, p.K, m0 + 64 * h, k0, kp, mq, xa[h]);
+      if constexpr (B_K) w3_load_K<64>(B, p.ldb, p.N, p.K, n0 + 64 * h, k0, tid, xb[h]);
+      else w3_load_T(B, p.ldb, extB, p.K, n0 + 64 * h, k0, kp, mq, xb[h]);
     }
   };
   load(0);
@@ -440,8 +446,10 @@ __device__ __forceinline__ void gemm_tile_b3w(const GemmParams& p, int bx, int b
     if (it > 0) __syncthreads();                     // every wave has read tile it-1's fragments
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      w3_stage_T(imgA + h * W3_IMG, xa[h], extA, p.K, m0 + 64 * h, it * 32, kp, mq, one, W3W_TS);
-      w3_stage_T(imgB + h * W3_IMG, xb[h], extB, p.K, n0 + 64 * h, it * 32, kp, mq, one, W3W_TS);
+      if constexpr (A_K) w3_stage_K<64>(imgA + h * W3_IMG, xa[h], p.M, p.K, m0 + 64 * h, it * 32, tid, one, W3W_TS);
+      else w3_stage_T(imgA + h * W3_IMG, xa[h], extA, p.K, m0 + 64 * h, it * 32, kp, mq, one, W3W_TS);
+      if constexpr (B_K) w3_stage_K<64>(imgB + h * W3_IMG, xb[h], p.N, p.K, n0 + 64 * h, it * 32, tid, one, W3W_TS);
+      else w3_stage_T(imgB + h * W3_IMG, xb[h], extB, p.K, n0 + 64 * h, it * 32, kp, mq, one, W3W_TS);
     }
     if (it + 1 < nk) load((it + 1) * 32);            // in flight while this tile is multiplied
     __syncthreads();                                 // the plane images are complete
@@ -500,6 +508,7 @@ __device__ __forceinline__ void w3_stage_T1(char* img, const f4v (&x)[2], int ex
   for (int j = 0; j < 4; ++j)
     *reinterpret_cast<unsigned*>(img + w3_off(4 * mq + j, kp >> 2) + 4 * (kp & 3)) = pl_pack_rne(k0ok ? x[0][j] : 0.f, k1ok ? x[1][j] : 0.f);
 }
+template <bool A_K = false, bool B_K = false>
 __device__ __forceinline__ void gemm_tile_b3w1(const GemmParams& p, int bx, int by, int bz, char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -521,8 +530,10 @@ __device__ __forceinline__ void gemm_tile_b3w1(const GemmParams& p, int bx, int 
   auto load = [&](int k0) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      w3_load_T(A, p.lda, extA, p.K, m0 + 64 * h, k0, kp, mq, xa[h]);
-      w3_load_T(B, p.ldb, extB, p.K, n0 + 64 * h, k0, kp, mq, xb[h]);
+      if constexpr (A_K) w3_load_K<64>(A, p.lda, p.M, p.K, m0 + 64 * h, k0, tid, xa[h]);
+      else w3_load_T(A, p.lda, extA, p.K, m0 + 64 * h, k0, kp, mq, xa[h]);
+      if constexpr (B_K) w3_load_K<64>(B, p.ldb, p.N, p.K, n0 + 64 * h, k0, tid, xb[h]);
+      else w3_load_T(B, p.ldb, extB, p.K, n0 + 64 * h, k0, kp, mq, xb[h]);
     }
   };
   auto stage = [&](int t) {                          // the rows in registers (K-tile t) -> image set t & 1
@@ -530,8 +541,10 @@ __device__ __forceinline__ void gemm_tile_b3w1(const GemmParams& p, int bx, int 
     char* imgB = imgA + W3W_TS;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      w3_stage_T1(imgA + h * W3_IMG, xa[h], extA, p.K, m0 + 64 * h, t * 32, kp, mq);
-      w3_stage_T1(imgB + h * W3_IMG, xb[h], extB, p.K, n0 + 64 * h, t * 32, kp, mq);
+      if constexpr (A_K) w3_stage_K<64>(imgA + h * W3_IMG, xa[h], p.M, p.K, m0 + 64 * h, t * 32, tid, true);
+      else w3_stage_T1(imgA + h * W3_IMG, xa[h], extA, p.K, m0 + 64 * h, t * 32, kp, mq);
+      if constexpr (B_K) w3_stage_K<64>(imgB + h * W3_IMG, xb[h], p.N, p.K, n0 + 64 * h, t * 32, tid, true);
+      else w3_stage_T1(imgB + h * W3_IMG, xb[h], extB, p.K, n0 + 64 * h, t * 32, kp, mq);
     }
   };
   load(0);

@@ -280,7 +280,7 @@ sys.path[:0] = [sys.argv[1], sys.argv[1] + "/golden"]
 from cases import AbmilpCase, make_abmilp_inputs
 import test_gpu_abmilp as T
 from efficient_probing_amd.engine import AbmilpHeadEngine as E
-case = AbmilpCase("wide1", B=16, N=256, D=1024, C=10, seed=11, sharp=False)
+case = AbmilpCase("wide1", B=64, N=256, D=1024, C=10, seed=11, sharp=False)
 inp = make_abmilp_inputs(case)
 x, t = torch.from_numpy(inp["x_buf"]).cuda(), torch.from_numpy(inp["targets"]).cuda()
 g = {}
@@ -296,8 +296,10 @@ for a, b in zip(g["fp32"], g["bf16_autocast"]):
 
 
 def test_long_weight_gradients_on_the_single_product_wide_tile():
-    """16 images of 256 x 1024 tokens: 4096 token rows put dW1, dWp (1024 x 1024) and dWqkv (3072 x 1024) on the wide tile.
-    (a) the AMP-mode gradients of the matrices stay within bf16 rounding of the fp32 mode's (an indexing error is O(1));
+    """64 images of 256 x 1024 tokens: 16384 token rows put dW1, dWp (1024 x 1024) and dWqkv (3072 x 1024) on the wide tile (K slices
+    included), and 64 batch entries put the six per-image attention products (K/K, K/T and T/T layouts) on it as well.
+    (a) the AMP-mode gradients of the matrices stay within bf16 rounding of the fp32 mode's (an indexing error is O(1); the fp32 mode
+    at this batch size is pinned against the oracle in tests/test_gpu_abmilp.py);
     (b) the tile's own single-product form and the three-term tile's run-time branch (EP_B3_WIDE1=0) give the same bits:
     same rounding, same order of the matrix instructions.  (The switch is read once per process: children.)"""
     import os, subprocess, sys
