@@ -5,7 +5,10 @@ f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "pool_" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]]
+if len(idx) < 3:                      # heads without a token pass (AbMILP, DINOv2 block, DOLG): a step ends with the optimizer's update
+    idx = [i + 1 for i, r in enumerate(rows) if "opt_update" in r["Kernel_Name"]][:-1]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else min(20, len(idx) - 6)
+k = max(0, min(k, len(idx) - 2))
 a, b = idx[k], idx[k + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b + 1]:
