@@ -4,7 +4,8 @@ import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "pool_" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]]
+isfwd = lambda r: "pool_" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]
+idx = [i for i, r in enumerate(rows) if isfwd(r) and not (i > 0 and isfwd(rows[i - 1]))]     # (a pass in query chunks: its first launch)
 if len(idx) < 3:                      # heads without a token pass (AbMILP, DINOv2 block, DOLG): a step ends with the optimizer's update
     idx = [i + 1 for i, r in enumerate(rows) if "opt_update" in r["Kernel_Name"]][:-1]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else min(20, len(idx) - 6)
