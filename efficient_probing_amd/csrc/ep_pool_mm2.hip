@@ -122,14 +122,15 @@ __device__ __forceinline__ void m2_dma_tile(const char* src, unsigned limit, cha
 // k-steps) keep the dependent chain off the critical path when the SIMD partner is not issuing; `mid` (the ring refill)
 // goes behind the first MFMAs.  A operand: lane (i = token, kk): chunk 4*(NB*kq + g) + kk of row i.  The operands are read
 // in two halves (the second into the first's registers).
-template <int NB, typename F>
-__device__ __forceinline__ void m2_scores(const char* tile, const int (&aoff)[NB], const float (&bq)[NB][4], char* spart, int w, int lane,
+// (`aoff(g)`: byte offset of operand g -- a table in registers, or recomputed per tile where the registers are short: D = 1152)
+template <int NB, typename AO, typename F>
+__device__ __forceinline__ void m2_scores(const char* tile, AO&& aoff, const float (&bq)[NB][4], char* spart, int w, int lane,
                                           F&& mid) {
   f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   constexpr int H = NB / 2;
   f4 xa[H];
 #pragma unroll
-  for (int g = 0; g < H; ++g) xa[g] = *reinterpret_cast<const f4*>(tile + aoff[g]);
+  for (int g = 0; g < H; ++g) xa[g] = *reinterpret_cast<const f4*>(tile + aoff(g));
 #pragma unroll
   for (int g = 0; g < H; ++g) {
     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].x, bq[g][0], a0, 0, 0, 0);
@@ -140,7 +141,7 @@ __device__ __forceinline__ void m2_scores(const char* tile, const int (&aoff)[NB
   }
   f4 xb[NB - H];
 #pragma unroll
-  for (int g = 0; g < NB - H; ++g) xb[g] = *reinterpret_cast<const f4*>(tile + aoff[H + g]);
+  for (int g = 0; g < NB - H; ++g) xb[g] = *reinterpret_cast<const f4*>(tile + aoff(H + g));
 #pragma unroll
   for (int g = 0; g < NB - H; ++g) {
     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].x, bq[H + g][0], a0, 0, 0, 0);
@@ -250,6 +251,32 @@ __device__ __forceinline__ void m2_pool_mfma(const float (&xa)[4][NB], const f4&
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3][blk], wgt.w, acc[blk], 0, 0, 0);
 }
+// blocks LO .. LO + CNT - 1 only (the b32 layout): D = 1152 pools its 18 blocks in two halves through ONE set of 36 operand
+// registers -- all 72 at once is what made the forward instantiation spill (round 6)
+template <int NB, int LO, int CNT>
+__device__ __forceinline__ void m2_pool_load_part(const char* tile, const M2Pool<NB>& o, int kq, float (&xa)[4][CNT]) {
+  static_assert(!M2Pool<NB>::WIDE, "b32 layout only");
+  constexpr int ROWB = 256 * NB;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int b = 0; b < CNT; ++b) {
+      const int cb = NB * kq + LO + b;
+      const int uni = 4 * s * ROWB + 64 * ((cb & ~3) | ((cb & 3) ^ s));
+      xa[s][b] = *reinterpret_cast<const float*>(tile + uni + o.pb[0]);
+    }
+}
+template <int NB, int LO, int CNT>
+__device__ __forceinline__ void m2_pool_mfma_part(const float (&xa)[4][CNT], const f4& wgt, f4 (&acc)[NB]) {
+#pragma unroll
+  for (int b = 0; b < CNT; ++b) acc[LO + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][b], wgt.x, acc[LO + b], 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < CNT; ++b) acc[LO + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][b], wgt.y, acc[LO + b], 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < CNT; ++b) acc[LO + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[2][b], wgt.z, acc[LO + b], 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < CNT; ++b) acc[LO + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3][b], wgt.w, acc[LO + b], 0, 0, 0);
+}
 __device__ __forceinline__ float m2_sel(const f4& v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
 
 // ---------------------------------------------------------------------------------------
@@ -286,16 +313,22 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_fwd_kernel(PoolPara
   if constexpr (EP_MM2_CLK != 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
   // B operand of the score MFMAs: query qj over the wave's D-quarter, pre-scaled like the reference (ep.py:39)
+  // SLIM (D = 1152, round 6): 72 query + 72 accumulator registers leave no room for the 18 operand offsets and all 72 pooling
+  // operands of a tile at two waves per SIMD (the first instantiation spilled 28 registers: 659 us against 568 us as two 16-query
+  // chunks).  Here the score offsets are recomputed per tile (3 vector instructions per operand) and the 18 pooled blocks go
+  // through ONE set of 36 operand registers in two halves.
+  constexpr bool SLIM = NG >= 9;
   float bq[NB][4];
-  int aoff[NB];
+  int aoff[SLIM ? 1 : NB];
 #pragma unroll
   for (int g = 0; g < NB; ++g) {
     f4 v = {0.f, 0.f, 0.f, 0.f};
     if (qj < Q) v = *reinterpret_cast<const f4*>(p.cls + (int64_t)qj * D + 16 * NB * kq + 16 * g + 4 * kk);
     v = v * p.scale;
     bq[g][0] = v.x; bq[g][1] = v.y; bq[g][2] = v.z; bq[g][3] = v.w;
-    aoff[g] = j * ROWB + (((4 * NB * kq + 4 * g + kk) ^ j) << 4);
+    if constexpr (!SLIM) aoff[g] = j * ROWB + (((4 * NB * kq + 4 * g + kk) ^ j) << 4);
   }
+  const int arow = j * ROWB, acb = 4 * NB * kq + kk;      // (SLIM: operand g sits at arow + (((acb + 4 g) ^ j) << 4))
   M2Pool<NB> po;
   m2_pool_offsets<NB>(kq, j, kk, po);
   unsigned soff[NG];
@@ -326,7 +359,7 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_fwd_kernel(PoolPara
   f4 acc[NB];
   float m_j = -INFINITY, mL_j = -INFINITY, lsum = 0.f;     // per lane: running max / partial sum of query qj
   f4 wgt = {0.f, 0.f, 0.f, 0.f};                          // softmax weights in k-slot order (late half: of the pending tile)
-  float xa[4][NB];                                        // pooling operands (late half: of the pending tile)
+  float xa[4][SLIM ? 1 : NB];                             // pooling operands (late half: of the pending tile)
   // online softmax of tile (b, n0) from the summed score block -> wgt; the raw scores go to S (one wave of the block per tile)
   auto softmax = [&](const f4& sc, int b, int n0, int nvalid, int t) {
     if (t == 0) {
@@ -391,7 +424,23 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_fwd_kernel(PoolPara
       const char* tile = ring + cslot * SLOT;
       cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
       if constexpr (EP_MM2_ABLATE == 1) { produce(); m2_barrier(); continue; }
-      m2_scores<NB>(tile, aoff, bq, spart, w, lane, produce);
+      if constexpr (SLIM) {
+        int cbv = acb;
+        asm volatile("" : "+v"(cbv));               // (opaque per tile: keeps the 18 offsets out of registers)
+        m2_scores<NB>(tile, [&](int g) { return arow + (((cbv + 4 * g) ^ j) << 4); }, bq, spart, w, lane, produce);
+        m2_barrier();                               // all partial score blocks are in the scratch
+        const f4 sc = m2_gather(spart, qb, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int HB = NB / 2;
+        float xh[4][HB];
+        m2_pool_load_part<NB, 0, HB>(tile, po, kq, xh);          // in flight under the softmax arithmetic
+        softmax(sc, b, n0, nvalid, t);
+        m2_pool_mfma_part<NB, 0, HB>(xh, wgt, acc);
+        m2_pool_load_part<NB, HB, NB - HB>(tile, po, kq, xh);    // (the slot stays valid until the next iteration's barrier)
+        m2_pool_mfma_part<NB, HB, NB - HB>(xh, wgt, acc);
+      }
+      if constexpr (!SLIM) {
+      m2_scores<NB>(tile, [&](int g) { return aoff[g]; }, bq, spart, w, lane, produce);
       M2_STAMP(1)
       if constexpr (PIPE) { if (t > 0) m2_pool_mfma<NB>(xa, wgt, acc); }       // the pending tile: one matrix phase per iteration
       m2_barrier();                                 // all partial score blocks are in the scratch
@@ -411,8 +460,9 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_fwd_kernel(PoolPara
       M2_STAMP(4)
       if (!late) m2_pool_mfma<NB>(xa, wgt, acc);
       M2_STAMP(5)
+      }
     }
-    if (late) m2_pool_mfma<NB>(xa, wgt, acc);
+    if constexpr (!SLIM) { if (late) m2_pool_mfma<NB>(xa, wgt, acc); }
     if constexpr (EP_MM2_ABLATE != 1) {             // image b is complete in acc / m_j / lsum: normalise and store
       const float l = m2_q4_sum(lsum);
       const float inv = 1.0f / l;
@@ -551,7 +601,7 @@ __global__ __launch_bounds__(M2_NW * 64, 1) void ep_pool_mm2_bwd_kernel(PoolPara
         next_item(tile, small);
         const int n0 = t * M2_TT;
         const int nvalid = (N - n0) < M2_TT ? (N - n0) : M2_TT;
-        m2_scores<NB>(tile, aoff, bq, spart, w, lane, produce);      // dA partial blocks
+        m2_scores<NB>(tile, [&](int g) { return aoff[g]; }, bq, spart, w, lane, produce);      // dA partial blocks
         if constexpr (PIPE) { if (t > 0) m2_pool_mfma<NB>(xa, wgt, gacc); }
         m2_barrier();
         if constexpr (!PIPE) { if (late && t > 0) m2_pool_mfma<NB>(xa, wgt, gacc); }
@@ -632,7 +682,11 @@ bool mm2_supported(int D, int Q, int64_t cls_bstride, bool bwd) {
   if (cls_bstride != 0 || Q <= 16 || Q > 32 || D % 128 != 0 || D < 256) return false;
   // D = 1152 (SigLIP2 SO400M, round 6): the BACKWARD only -- 244 registers, 409 us in the step at 1024 x 256 against 586 us as two
   // 16-query chunks; the forward instantiation spills 28 registers (256 + scratch) and is SLOWER than the chunks (659 against 568 us)
-  return D <= 1024 || (D == 1152 && bwd);
+  // (... round 6, later: the SLIM forward -- offsets recomputed, pooling operands in two halves: 233 registers -- fits: 256 x 1152 at 32
+  // queries, same box, 1.262 -> 1.117 ms per step; EP_POOL_MM2_FWD9=0: chunks)
+  static int fwd9 = -1;
+  if (fwd9 < 0) { const char* e = getenv("EP_POOL_MM2_FWD9"); fwd9 = e ? atoi(e) : 1; }
+  return D <= 1024 || (D == 1152 && (bwd || fwd9));
 }
 
 int mm2_launch(bool bwd, const PoolParams& p, int grid, hipStream_t st) {

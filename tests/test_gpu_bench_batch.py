@@ -247,7 +247,10 @@ Q32 = [((64, 196, 1024, 32), "f32"), ((64, 196, 1024, 32), "bf16"), ((48, 256, 1
        ((72, 256, 768, 32), "f32"), ((40, 197, 768, 32), "f32"), ((40, 197, 768, 32), "bf16"), ((33, 77, 384, 32), "f32"), ((33, 77, 512, 24), "f32"),
        ((24, 50, 4096, 32), "bf16"), ((48, 100, 768, 32), "bf16"), ((40, 64, 1152, 24), "f32"), ((16, 40, 2048, 20), "f32"),
        # the single-read bf16 pass (ep_pool_mbq) also takes D = 384 and any 17 .. 31 queries -- only 32 / 24 at other widths were pinned
-       ((33, 77, 384, 32), "bf16"), ((20, 50, 384, 17), "bf16"), ((20, 50, 384, 31), "bf16"), ((24, 64, 256, 20), "bf16")]
+       ((33, 77, 384, 32), "bf16"), ((20, 50, 384, 17), "bf16"), ((20, 50, 384, 31), "bf16"), ((24, 64, 256, 20), "bf16"),
+       # round 6: the single-read FORWARD at D = 1152 (ep_pool_mm2_fwd_kernel<9>: offsets recomputed per tile, pooling operands in two
+       # halves) -- ragged token counts (no multiple of 16, of 4) and more images than workgroups
+       ((70, 197, 1152, 32), "f32"), ((300, 50, 1152, 32), "f32"), ((9, 33, 1152, 19), "f32")]
 
 
 @pytest.mark.parametrize("case", Q32, ids=[f"{s[0]}x{s[1]}x{s[2]}_q{s[3]}_{t}" for s, t in Q32])
