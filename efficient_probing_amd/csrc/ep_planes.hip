@@ -429,7 +429,11 @@ static bool planes_wide(const GemmParams& p, int batch) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("EP_PLANES_WIDE"); force = e ? atoi(e) : -1; }
   if (force >= 0) return force != 0;
-  return (long)((p.N + 127) / 128) * ((p.M + 63) / 64) * batch >= 2 * 256;
+  const long wide = (long)((p.N + 127) / 128) * ((p.M + 63) / 64) * batch, narrow = (long)((p.N + 63) / 64) * ((p.M + 63) / 64) * batch;
+  // ... or when the 64 x 64 tiles need a SECOND round of the chip that the wide ones do not (one 12-wave workgroup per CU): dz at
+  // 1024 x 1152 (SigLIP2 SO400M) is 288 narrow tiles on 256 CUs -- 32 - 44 us in the step against 20 for the logits (rocprofv3)
+  const long cus = cu_count();
+  return wide >= 2 * 256 || (narrow > cus && wide <= cus);
 }
 
 template <int NB, int NT>
