@@ -572,6 +572,22 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
     const double cost = (double)((tiles * sp + cus - 1) / cus) / sp;
     if (cost < best * 0.95) { best = cost; splits = sp; }
   }
+  static int one_model = -1;                       // EP_SPLITK_WIDE1=0: the two-per-CU rule below for the single-product tile too
+  if (one_model < 0) { const char* e = getenv("EP_SPLITK_WIDE1"); one_model = e ? atoi(e) : 1; }
+  if (wide && one_model && (gemm_arith() == 1 || p.nterms == 1)) {
+    // the single-product wide tile (gemm_tile_b3w1) is latency-bound, THREE workgroups per CU: makespan ~ ceil(tiles * s / (3 CUs)) * (K / s).
+    // dWqkv of the AbMILP step (243 tiles): 4 slices = 972 workgroups = 1.27 rounds of 768 under the rule below; 8 slices = 2.53
+    // rounds of half the length.
+    const long slots = 3 * cus;
+    double bc = (double)((tiles + slots - 1) / slots);
+    int bs = 1;
+    for (int sp = 2; sp <= 16; ++sp) {
+      if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < 1024) continue;
+      const double cost = (double)((tiles * sp + slots - 1) / slots) / sp;
+      if (cost < bc * 0.95) { bc = cost; bs = sp; }
+    }
+    splits = bs;
+  } else
   if (wide && tiles * splits < 2 * cus) {
     // the wide tile is one 4-wave workgroup with two barriers per K-tile: a CU needs TWO of them to keep its matrix pipe fed
     // (the makespan model above counts whole rounds only) -- the smallest slice count that gives every CU two
