@@ -220,6 +220,7 @@ constexpr int CLIP_NT = 9;    // pos_embed | qkv.weight qkv.bias | proj.weight p
 struct ClipWs {
   float *tstat, *xbar, *t0, *q0, *w, *u, *sb, *s0, *P, *S, *ML, *ML2, *mix, *A, *Apos, *Ppr, *vin, *o;
   float *dO, *dvin, *dPpr, *dAp, *dS, *ds0, *du, *dwp, *dw, *dq0, *dt0, *cpart;
+  float* skws; size_t skws_floats;                   // K-slice scratch of the two position-embedding gradients (gemm_split_k)
   void* pool_ws; size_t pool_ws_bytes;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
@@ -256,6 +257,7 @@ static ClipWs clip_carve(const ep_clip_dims& d, void* base, bool head) {
   w.dO = take(B * D); w.dvin = take(B * H * D); w.dPpr = take(B * H * D); w.dAp = take(B * H * N); w.dS = take(B * H * N);
   w.ds0 = take(B * H); w.du = take(B * H * D); w.dwp = take(B * H * D); w.dw = take(B * H * D); w.dq0 = take(B * D);
   w.dt0 = take(B * D); w.cpart = take((size_t)2 * CLIP_RS * D);
+  w.skws_floats = (size_t)16 * N * D; w.skws = take(w.skws_floats);
   if (head) {
     w.ldl = (d.C + 3) / 4 * 4;
     w.y = take(B * D); w.z = take(B * D); w.rstd = take(D);
@@ -414,7 +416,10 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   hipLaunchKernelGGL(ep_clip_dppr_kernel, dim3(eh), dim3(256), 0, st, w.dvin, pr.norm_w, nhd, D, w.dPpr);
   EP_LAUNCH_CHECK("ep_clip value backward kernels");
   // Apos = A pos[1:] :  d pos[1:] = A^T dvin ; dAp = dvin pos[1:]^T
-  { GemmParams g = kg(w.A, N, w.dvin, D, dposN, D, N, D, BH); g.accumulate = acc; EP_TRY(aux_side_gemm(ax, g, 1)); }
+  // (d pos[1:]: N x D outputs -- 48 tiles -- summed over all B H rows: K slices, or one long latency chain on a fifth of the chip.
+  // Round 6: the two of them took 153 + 128 us on the side queue and the optimizer waited 140 us for it, rocprofv3.)
+  { GemmParams g = kg(w.A, N, w.dvin, D, dposN, D, N, D, BH); g.accumulate = acc; g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(aux_side_gemm(ax, g, 1)); }
   EP_TRY(gemm(true, true, kg(w.dvin, D, posN, D, w.dAp, N, BH, N, D), 1, st));
   hipLaunchKernelGGL(ep_clip_delta_kernel, dim3((BH + 3) / 4), dim3(256), 0, st, w.dPpr, w.Ppr, w.dvin, w.xbar, pos0, w.A, w.dAp,
                      w.mix, BH, H, D, N, w.ML2, w.ds0);
@@ -431,7 +436,8 @@ static int clip_backward_core(const ep_clip_dims& d, const void* x, int x_dtype,
   EP_TRY(clip_colred(w.w, (const float*)nullptr, 1, w.ds0, 1, BH, D, 0,
                      (float*)nullptr, 1, dpos0, w.cpart, st));
   EP_LAUNCH_CHECK("ep_clip key backward kernels");
-  { GemmParams g = kg(w.dS, N, w.w, D, dposN, D, N, D, BH); g.accumulate = 1; EP_TRY(aux_side_gemm(ax, g, 1)); }   // (behind the first dposN term: same stream)
+  { GemmParams g = kg(w.dS, N, w.w, D, dposN, D, N, D, BH); g.accumulate = 1; g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(aux_side_gemm(ax, g, 1)); }   // (behind the first dposN term: same stream, so the scratch is free again)
   // w_h = scale q0_h Wk_h :  dq0_h = scale dw_h Wk_h^T ; dWk_h = scale q0_h^T dw_h ; d bk = 0
   {
     GemmParams g = kg(w.dw, (int64_t)H * D, Wk, D, w.dq0, D, B, dh, D);

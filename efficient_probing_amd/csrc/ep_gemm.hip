@@ -557,19 +557,29 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
   *done = false;
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_SPLITK"); on = e ? atoi(e) : 1; }
-  if (!on || !p.skws || p.bias || p.ldc != p.N || p.alpha != 1.0f || p.K < 8192 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
+  if (!on || !p.skws || p.bias || p.ldc != p.N || p.alpha != 1.0f || p.K < 2048 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
   const bool wide = b3_wide_ok(p, a_k, b_k, 1);        // 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w): a quarter of the tiles
   const long tiles = wide ? (long)((p.N + 127) / 128) * ((p.M + 127) / 128) : (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
   const long cus = cu_count();
   if (tiles >= 2 * cus) return 0;
+  static int few_model = -1;                           // EP_SPLITK_FEW=0: the CU model and the K >= 8192 floor for every tile count
+  if (few_model < 0) { const char* e = getenv("EP_SPLITK_FEW"); few_model = e ? atoi(e) : 1; }
+  const bool few = few_model && !wide && !a_k && !b_k && tiles * 4 <= cus;
+  if (p.K < 8192 && !few) return 0;
+  const int min_slice = few ? 512 : 1024;              // rows per slice
   // the matrix pipe of a CU is shared by its workgroups: makespan ~ ceil(tiles * s / CUs) * (K / s); pick the s <= 16 with
   // the smallest one (ties: fewer slices) among those that divide K into whole K-tiles and fit the scratch
   const int64_t mn = (int64_t)p.M * p.N;
   int splits = 1;
-  double best = (double)((tiles + cus - 1) / cus);
+  // (VERY few tiles -- at most a quarter of the CUs, e.g. the 256 x 768 position-embedding gradient of the CLIP head over its
+  // 4096 B H rows: 48 tiles, each a 128-K-tile latency chain, 130 - 165 us for 1.6 GFLOP on the side queue with the optimizer
+  // waiting for it.  The bf16 x3 tile is latency-bound there and three workgroups share a CU without slowing each other, so the
+  // slices are counted against 3 CUs' worth of slots, from K = 2048, down to 512 rows per slice.)
+  const long slots = few ? 3 * cus : cus;
+  double best = (double)((tiles + slots - 1) / slots);
   for (int sp = 2; sp <= 16; ++sp) {
-    if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < 1024) continue;
-    const double cost = (double)((tiles * sp + cus - 1) / cus) / sp;
+    if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < min_slice) continue;
+    const double cost = (double)((tiles * sp + slots - 1) / slots) / sp;
     if (cost < best * 0.95) { best = cost; splits = sp; }
   }
   static int one_model = -1;                       // EP_SPLITK_WIDE1=0: the two-per-CU rule below for the single-product tile too

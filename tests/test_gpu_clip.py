@@ -186,18 +186,20 @@ def test_full_width_per_image_query_kernel_vs_generic_kernels(shape):
         np.testing.assert_allclose(a, g, rtol=rtol, atol=2e-5 * max(1e-3, float(np.abs(g).max())))
 
 
-def test_gradients_of_a_batch_with_many_image_head_rows_vs_float64():
+@pytest.mark.parametrize("B", [96, 640], ids=["rows384", "rows2560_k_slices"])
+def test_gradients_of_a_batch_with_many_image_head_rows_vs_float64(B):
     """B = 96 images of 8 x 8 tokens: 384 (image, head) rows put the column reductions of the backward on several row chunks --
     every gradient against the oracle in float64 (floor 1e-4 of the tensor's scale: the gradients of this head are sums of
-    batch-cancelling rows)."""
+    batch-cancelling rows).  B = 640 (round 6): 2560 rows put the two position-embedding gradients -- two 64 x 64 tiles summed over
+    all rows -- on K slices (csrc/ep_gemm.hip: gemm_split_k, the few-tile rule)."""
     from efficient_probing_amd import functional as F_
-    case = ClipCase("rows", B=96, N=64, D=128, C=20, seed=9, sharp=True)
+    case = ClipCase("rows", B=B, N=64, D=128, C=20, seed=9, sharp=True)
     inp = make_clip_inputs(case)
     head, plist = native_head(case, inp)
     x, t = tokens(case, inp["x_buf"]), torch.from_numpy(inp["targets"]).to(DEV)
     loss, _ = F_.cross_entropy_loss(head(x), t)
     loss.backward()
-    truth = f64_reference(ClipCase("rows", B=96, N=64, D=128, C=20, seed=9, sharp=True, steps=1), inp)[0]
+    truth = f64_reference(ClipCase("rows", B=B, N=64, D=128, C=20, seed=9, sharp=True, steps=1), inp)[0]
     assert loss.item() == pytest.approx(truth["loss"], rel=2e-5)
     for n, p, tr in zip(CLIP_PARAM_NAMES, plist, truth["grads"]):
         scale = max(float(np.abs(tr).max()), 1e-12)
