@@ -33,10 +33,10 @@ int cu_count() {
 // reused (events carry no data; the library otherwise keeps no state).
 int get_events(hipEvent_t* out, int n) {
   constexpr int MAX_DEV = 16;          // events belong to the device that was current when they were created
-  static thread_local hipEvent_t pool[MAX_DEV][6] = {};
+  static thread_local hipEvent_t pool[MAX_DEV][8] = {};
   int dev = 0;
   EP_HIP(hipGetDevice(&dev));
-  EP_REQUIRE(dev >= 0 && dev < MAX_DEV && n <= 6, EP_E_ARG, "get_events: device %d / %d events not supported", dev, n);
+  EP_REQUIRE(dev >= 0 && dev < MAX_DEV && n <= 8, EP_E_ARG, "get_events: device %d / %d events not supported", dev, n);
   for (int i = 0; i < n; ++i) {
     if (!pool[dev][i]) EP_HIP(hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming));
     out[i] = pool[dev][i];
@@ -387,20 +387,23 @@ int side_run_standalone(const SideTasks& sd, hipStream_t st) {
   return 0;
 }
 
-int aux_side_begin(AuxSide& a, hipStream_t st, hipStream_t aux) {
+int aux_side_begin(AuxSide& a, hipStream_t st, hipStream_t aux, bool two) {
   static int early_env = -1;
   if (early_env < 0) { const char* e = getenv("EP_WGRAD_EARLY"); early_env = e ? atoi(e) : 1; }
+  static int two_env = -1;                            // EP_AUX_TWO=0: one side queue for every head
+  if (two_env < 0) { const char* e = getenv("EP_AUX_TWO"); two_env = e ? atoi(e) : 1; }
   a = AuxSide{};
   a.st = st; a.side = aux ? aux : st;
   a.early = early_env && a.side != st;
-  if (a.side != st) EP_TRY(get_events(a.ev, 6));
+  if (a.side != st) EP_TRY(get_events(a.ev, 8));
+  if (two && two_env && a.early) EP_TRY(get_side2_stream(&a.side2));
   return 0;
 }
-static int aux_side_sync(AuxSide& a) {                // aux waits for everything enqueued on `st` so far
-  hipEvent_t e = a.ev[a.nev % 5];                     // (ev[5] is the join's; re-recording an event whose earlier wait is already
+static int aux_side_sync(AuxSide& a, hipStream_t target = nullptr) {   // `target` (default: the aux stream) waits for everything enqueued on `st` so far
+  hipEvent_t e = a.ev[a.nev % 5];                     // (ev[5] / ev[6] are the joins'; re-recording an event whose earlier wait is already
   ++a.nev;                                            // enqueued is legal: a wait refers to the record in front of it)
   EP_HIP(hipEventRecord(e, a.st));
-  EP_HIP(hipStreamWaitEvent(a.side, e, 0));
+  EP_HIP(hipStreamWaitEvent(target ? target : a.side, e, 0));
   return 0;
 }
 // An early contraction runs beside the chain in front of the pass, not beside the pass: the `side` hint (which keeps a
@@ -414,8 +417,11 @@ static GemmParams aux_early_params(const GemmParams& g) {
 }
 int aux_side_fork(AuxSide& a, const SideTasks& sd) {
   if (!a.early || a.launched >= sd.n_gemm) return 0;
-  EP_TRY(aux_side_sync(a));
-  for (; a.launched < sd.n_gemm; ++a.launched) EP_TRY(gemm(false, false, aux_early_params(sd.g[a.launched]), sd.gz[a.launched], a.side));
+  hipStream_t target = a.side;
+  if (a.side2 && (a.nfork & 1)) { target = a.side2; a.used2 = true; }
+  ++a.nfork;
+  EP_TRY(aux_side_sync(a, target));
+  for (; a.launched < sd.n_gemm; ++a.launched) EP_TRY(gemm(false, false, aux_early_params(sd.g[a.launched]), sd.gz[a.launched], target));
   return 0;
 }
 int aux_side_rest(AuxSide& a, const SideTasks& sd) {
@@ -457,6 +463,10 @@ int aux_side_join(AuxSide& a) {
   if (a.side == a.st) return 0;
   EP_HIP(hipEventRecord(a.ev[5], a.side));
   EP_HIP(hipStreamWaitEvent(a.st, a.ev[5], 0));
+  if (a.used2) {
+    EP_HIP(hipEventRecord(a.ev[6], a.side2));
+    EP_HIP(hipStreamWaitEvent(a.st, a.ev[6], 0));
+  }
   return 0;
 }
 

@@ -260,6 +260,7 @@ struct CaitWs {
   float *P, *S, *ML, *ML2, *mix, *csc, *tstat, *ya0, *ya, *z1, *c1, *stat2, *h2, *pre, *h1, *m2, *c2, *statf;
   float *dc2, *dm2, *dh1, *dh2, *dc1, *dz1, *dya, *dya0, *dP;
   float *chat, *un0, *lnstat, *q, *u, *wq, *sc, *vc, *dvc, *dw, *du, *dq, *dun0, *dchat, *dcsum, *Wvs, *bo, *dWvs, *dbo, *scr, *cpart;
+  float* skws; size_t skws_floats;                   // K-slice scratch of the two long-K MLP contractions (ep_gemm.hip: gemm_split_k)
   void* pool_ws; size_t pool_ws_bytes;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
@@ -298,6 +299,7 @@ static CaitWs cait_carve(const ep_cait_dims& d, void* base, bool head) {
   w.dya = take(B * D); w.dya0 = take(B * D); w.dP = take(B * H * D);
   w.chat = take(D); w.un0 = take(D); w.lnstat = take(4); w.q = take(D); w.u = take(H * D); w.wq = take(H * D); w.sc = take(32);
   w.vc = take(D); w.dvc = take(D); w.dw = take(H * D); w.du = take(H * D); w.dq = take(D); w.dun0 = take(D); w.dchat = take(D); w.cpart = take((size_t)CAIT_RS * D);
+  w.skws_floats = (size_t)4 * d.B * D; w.skws = take(w.skws_floats);
   w.dcsum = take(D); w.Wvs = take(D * D); w.bo = take(D); w.dWvs = take(D * D); w.dbo = take(D); w.scr = take(2 * D);
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.H);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
@@ -381,7 +383,8 @@ static int cait_forward_core(const ep_cait_dims& d, const void* x, int x_dtype, 
   { GemmParams g = cgm(w.h2, D, pr.fc1_w, D, w.pre, Hd, B, Hd, D); g.bias = pr.fc1_b; EP_TRY(gemm(true, true, g, 1, st)); }
   const int64_t n4 = (int64_t)B * Hd / 4;
   hipLaunchKernelGGL(ep_gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.h1);
-  { GemmParams g = cgm(w.h1, Hd, pr.fc2_w, Hd, w.m2, D, B, D, Hd); g.bias = pr.fc2_b; EP_TRY(gemm(true, true, g, 1, st)); }
+  { GemmParams g = cgm(w.h1, Hd, pr.fc2_w, Hd, w.m2, D, B, D, Hd); g.bias = pr.fc2_b; g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(gemm(true, true, g, 1, st)); }
   hipLaunchKernelGGL(ep_cait_res_kernel, dim3(eg), dim3(256), 0, st, w.c1, (int64_t)D, pr.gamma_2, w.m2, nd, D, w.c2);
   EP_TRY(token_stats(w.c2, 0, D, B, 1, D, d.final_eps, w.statf, st));
   hipLaunchKernelGGL(ep_rowln_apply_kernel, dim3(eg), dim3(256), 0, st, w.c2, w.statf, pr.norm_w, pr.norm_b, nd, D, out);
@@ -430,7 +433,8 @@ static int cait_backward_core(const ep_cait_dims& d, const void* x, int x_dtype,
   if (!side_add_colsum(sd, w.dh1, B, Hd, Hd, acc, gr.fc1_b)) EP_TRY(colsum(w.dh1, B, Hd, Hd, acc, gr.fc1_b, st));
   side_add_gemm(sd, gW1, 1);
   EP_TRY(aux_side_fork(ax, sd));                     // dW1 = dpre^T h2
-  EP_TRY(gemm(true, false, cgm(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
+  { GemmParams g = cgm(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd); g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(gemm(true, false, g, 1, st)); }                                                          // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.c1, w.stat2, pr.n2_w, w.dc2, B, D, w.dc1);
   EP_TRY(lnaffine_grad(w.dh2, w.c1, w.stat2, B, D, acc, gr.n2_w,
                      gr.n2_b, st));

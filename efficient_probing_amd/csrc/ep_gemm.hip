@@ -553,11 +553,32 @@ bool gemm_side_ok(const GemmParams& p, bool a_k, bool b_k) {
 // into `splits` slices that run as the batch dimension into the caller's scratch and are summed in slice order
 // (ep_reduce_partials_kernel: deterministic).  Needs a contiguous C, no bias, one batch.
 static bool b3_wide_ok(const GemmParams& p, bool a_k, bool b_k, int batch);
+// out = (accumulate ? out : 0) + sum of the K slices in slice order (+ bias[col]): the slice sum of an ACTIVATION x WEIGHT contraction
+// (gemm_split_k, the long-K rule), whose bias and residual the slices cannot carry themselves.  n4 / ncol4: float4 counts.
+__global__ __launch_bounds__(256) void ep_splitk_sum_bias_kernel(const float* __restrict__ part, int nparts, int64_t n4,
+                                                               const float* __restrict__ bias, int ncol4, int accumulate,
+                                                               float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f4* p4 = reinterpret_cast<const f4*>(part);
+  f4 s = p4[i];
+  for (int k = 1; k < nparts; ++k) s += p4[(int64_t)k * n4 + i];
+  if (bias) s += reinterpret_cast<const f4*>(bias)[i % ncol4];
+  if (accumulate) s += reinterpret_cast<const f4*>(out)[i];
+  reinterpret_cast<f4*>(out)[i] = s;
+}
 static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st, bool* done) {
   *done = false;
   static int on = -1;
   if (on < 0) { const char* e = getenv("EP_GEMM_SPLITK"); on = e ? atoi(e) : 1; }
-  if (!on || !p.skws || p.bias || p.ldc != p.N || p.alpha != 1.0f || p.K < 2048 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
+  // LONG-K activation x weight contractions (round 6, r6.15): the MLP layers of the SigLIP / V-JEPA / CaiT heads contract 1024 rows over
+  // the hidden width 3072 into 768 columns -- 192 tiles of 64 x 64, each a 96-K-tile latency chain: 60 us forward (fc2) and 50 - 100 us
+  // backward (dpre W1) for 4.8 GFLOP.  With a slice scratch from the caller they run as K slices on the bf16 x3 tile (three
+  // workgroups per CU), summed in slice order together with bias and residual.  EP_SPLITK_LONG=0: off.
+  static int long_rule = -1;
+  if (long_rule < 0) { const char* e = getenv("EP_SPLITK_LONG"); long_rule = e ? atoi(e) : 1; }
+  const bool lng = long_rule && a_k && p.N % 4 == 0 && (!p.bias || (aligned16(p.bias) && p.sBiasz == 0));
+  if (!on || !p.skws || (p.bias && !lng) || p.ldc != p.N || p.alpha != 1.0f || p.K < 2048 || ((int64_t)p.M * p.N) % 4 != 0) return 0;
   const bool wide = b3_wide_ok(p, a_k, b_k, 1);        // 128 x 128 tiles (ep_wgrad3.h: gemm_tile_b3w): a quarter of the tiles
   const long tiles = wide ? (long)((p.N + 127) / 128) * ((p.M + 127) / 128) : (long)((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
   const long cus = cu_count();
@@ -565,8 +586,10 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
   static int few_model = -1;                           // EP_SPLITK_FEW=0: the CU model and the K >= 8192 floor for every tile count
   if (few_model < 0) { const char* e = getenv("EP_SPLITK_FEW"); few_model = e ? atoi(e) : 1; }
   const bool few = few_model && !wide && !a_k && !b_k && tiles * 4 <= cus;
-  if (p.K < 8192 && !few) return 0;
-  const int min_slice = few ? 512 : 1024;              // rows per slice
+  const bool longk = lng && tiles < cus && gemm_b3_on();
+  if (a_k && !longk) return 0;
+  if (p.K < 8192 && !few && !longk) return 0;
+  const int min_slice = (few || longk) ? 512 : 1024;   // rows per slice
   // the matrix pipe of a CU is shared by its workgroups: makespan ~ ceil(tiles * s / CUs) * (K / s); pick the s <= 16 with
   // the smallest one (ties: fewer slices) among those that divide K into whole K-tiles and fit the scratch
   const int64_t mn = (int64_t)p.M * p.N;
@@ -575,7 +598,7 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
   // 4096 B H rows: 48 tiles, each a 128-K-tile latency chain, 130 - 165 us for 1.6 GFLOP on the side queue with the optimizer
   // waiting for it.  The bf16 x3 tile is latency-bound there and three workgroups share a CU without slowing each other, so the
   // slices are counted against 3 CUs' worth of slots, from K = 2048, down to 512 rows per slice.)
-  const long slots = few ? 3 * cus : cus;
+  const long slots = (few || longk) ? 3 * cus : cus;
   double best = (double)((tiles + slots - 1) / slots);
   for (int sp = 2; sp <= 16; ++sp) {
     if ((size_t)sp * mn > p.skws_floats || p.K % (sp * BK) != 0 || p.K / sp < min_slice) continue;
@@ -613,8 +636,16 @@ static int gemm_split_k(bool a_k, bool b_k, const GemmParams& p, hipStream_t st,
   q.K = kc; q.C = p.skws; q.ldc = p.N; q.sCz = mn; q.accumulate = 0; q.skws = nullptr;
   q.sAz = a_k ? kc : (int64_t)kc * p.lda;
   q.sBz = b_k ? kc : (int64_t)kc * p.ldb;
+  if (longk) q.bias = nullptr;
   EP_TRY(gemm(a_k, b_k, q, splits, st));
-  EP_TRY(reduce_partials(p.skws, splits, (int)mn, 1.0f, p.accumulate, p.C, nullptr, st));
+  if (longk) {
+    const int64_t n4 = mn / 4;
+    hipLaunchKernelGGL(ep_splitk_sum_bias_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.skws, splits, n4, p.bias, p.N / 4,
+                       p.accumulate, p.C);
+    EP_LAUNCH_CHECK("ep_splitk_sum_bias_kernel");
+  } else {
+    EP_TRY(reduce_partials(p.skws, splits, (int)mn, 1.0f, p.accumulate, p.C, nullptr, st));
+  }
   *done = true;
   return 0;
 }

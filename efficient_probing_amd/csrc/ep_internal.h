@@ -232,12 +232,14 @@ int side_run_standalone(const SideTasks& sd, hipStream_t st);
 // contractions: side_add_gemm(sd, ...) + fork; rest() once the column sums' sources exist; before_pass() in front of the
 // pass launch; join() in front of the first consumer of a side result.  aux == st or null: everything inline on `st`.
 struct AuxSide {
-  hipStream_t st = nullptr, side = nullptr;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool early = false, rest_done = false;
-  int launched = 0, nev = 0;
+  hipStream_t st = nullptr, side = nullptr, side2 = nullptr;   // side2: the library's second side queue (begin(..., two = true))
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool early = false, rest_done = false, used2 = false;
+  int launched = 0, nev = 0, nfork = 0;
 };
-int aux_side_begin(AuxSide& a, hipStream_t st, hipStream_t aux);
+// two: successive forks alternate between the aux stream and a second side queue (heads whose four or five gradient contractions
+// of 45 - 80 us each queue up on ONE stream and run into the second token pass, which starves them: V-JEPA, SigLIP)
+int aux_side_begin(AuxSide& a, hipStream_t st, hipStream_t aux, bool two = false);
 int aux_side_fork(AuxSide& a, const SideTasks& sd);        // early: aux waits for `st` so far, then runs sd.g[launched .. n_gemm)
 int aux_side_rest(AuxSide& a, const SideTasks& sd);        // early: the column sums and statistics of `sd`, now
 int aux_side_before_pass(AuxSide& a, const SideTasks& sd); // whatever of `sd` has not been launched (not early: all of it)

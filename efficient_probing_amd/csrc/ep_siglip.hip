@@ -21,6 +21,7 @@ namespace ep {
 // ---------------------------------------------------------------------------------------------
 struct SigWs {
   float *P, *S, *ML, *ya, *z1, *pre, *h1, *dh1, *dz1, *dya, *dP, *q, *u, *du, *dq;
+  float* skws; size_t skws_floats;                   // K-slice scratch of the two long-K MLP contractions (ep_gemm.hip: gemm_split_k)
   void* pool_ws; size_t pool_ws_bytes;
   size_t pool_total;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
@@ -52,6 +53,7 @@ static SigWs sig_carve(const ep_siglip_dims& d, void* base, bool head) {
   w.ya = take(B * D); w.z1 = take(B * D); w.pre = take(B * Hd); w.h1 = take(B * Hd); w.dh1 = take(B * Hd);
   w.dz1 = take(B * D); w.dya = take(B * D); w.dP = take(B * d.H * D);
   w.q = take(D); w.u = take((size_t)d.H * D); w.du = take((size_t)d.H * D); w.dq = take(D);
+  w.skws_floats = 4 * B * D; w.skws = take(w.skws_floats);
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.H);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
   w.pool_total = off;
@@ -121,7 +123,8 @@ static int sig_forward_core(const ep_siglip_dims& d, const void* x, int x_dtype,
   hipLaunchKernelGGL(ep_gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.h1);
   EP_LAUNCH_CHECK("ep_gelu_kernel");
   EP_HIP(hipMemcpyAsync(out, w.z1, (size_t)d.B * D * sizeof(float), hipMemcpyDeviceToDevice, st));      // residual
-  { GemmParams g = mkg(w.h1, Hd, pr.fc2_w, Hd, out, D, d.B, D, Hd); g.bias = pr.fc2_b; g.accumulate = 1; EP_TRY(gemm(true, true, g, 1, st)); }
+  { GemmParams g = mkg(w.h1, Hd, pr.fc2_w, Hd, out, D, d.B, D, Hd); g.bias = pr.fc2_b; g.accumulate = 1;
+    g.skws = w.skws; g.skws_floats = w.skws_floats; EP_TRY(gemm(true, true, g, 1, st)); }
   return 0;
 }
 
@@ -158,7 +161,8 @@ static int sig_backward_core(const ep_siglip_dims& d, const void* x, int x_dtype
   side_add_gemm(sd, gW1, 1);
   EP_TRY(fork());
   EP_HIP(hipMemcpyAsync(w.dz1, dout, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-  { GemmParams g = mkg(w.dh1, Hd, pr.fc1_w, D, w.dz1, D, B, D, Hd); g.accumulate = 1; EP_TRY(gemm(true, false, g, 1, st)); }   // dz1 = dout + dpre W1
+  { GemmParams g = mkg(w.dh1, Hd, pr.fc1_w, D, w.dz1, D, B, D, Hd); g.accumulate = 1; g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(gemm(true, false, g, 1, st)); }   // dz1 = dout + dpre W1
   side_add_gemm(sd, gWp, 1);
   EP_TRY(fork());
   EP_TRY(gemm(true, false, mkg(w.dz1, D, pr.proj_w, D, w.dya, D, B, D, D), 1, st));                 // dya = dz1 Wp
@@ -213,6 +217,7 @@ constexpr int JEPA_NT = 17;   // query | n1.w n1.b | q.w q.b | kv.w kv.b | proj.
 struct JepaWs {
   float *P, *S, *ML, *tstat, *ya, *q1, *qstat, *h2, *pre, *h1, *dh1, *dh2, *dq1, *dya, *dP, *q, *u, *wq, *dw, *du, *dq, *Wvs, *bo,
       *dWvs, *dbo, *bq0;
+  float* skws; size_t skws_floats;                   // (as SigWs)
   void* pool_ws; size_t pool_ws_bytes;
   float *y, *z, *rstd, *logits, *dlogits, *rowstat, *bnpart, *dz, *dy;
   void* opt_ws; size_t opt_ws_bytes;
@@ -243,6 +248,7 @@ static JepaWs jepa_carve(const ep_jepa_dims& d, void* base, bool head) {
   w.q = take(D); w.u = take((size_t)d.H * D); w.wq = take((size_t)d.H * D); w.dw = take((size_t)d.H * D);
   w.du = take((size_t)d.H * D); w.dq = take(D); w.Wvs = take(D * D); w.bo = take(D); w.dWvs = take(D * D); w.dbo = take(D);
   w.bq0 = take(D);
+  w.skws_floats = 4 * B * D; w.skws = take(w.skws_floats);
   w.pool_ws_bytes = pool_workspace_bytes(d.B, d.N, d.D, d.H);
   w.pool_ws = take(w.pool_ws_bytes / sizeof(float));
   if (head) {
@@ -316,7 +322,8 @@ static int jepa_forward_core(const ep_jepa_dims& d, const void* x, int x_dtype, 
   hipLaunchKernelGGL(ep_gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.pre, n4, w.h1);
   EP_LAUNCH_CHECK("ep_jepa forward kernels");
   EP_HIP(hipMemcpyAsync(out, w.q1, (size_t)nd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  { GemmParams g = mkg(w.h1, Hd, pr.fc2_w, Hd, out, D, B, D, Hd); g.bias = pr.fc2_b; g.accumulate = 1; EP_TRY(gemm(true, true, g, 1, st)); }
+  { GemmParams g = mkg(w.h1, Hd, pr.fc2_w, Hd, out, D, B, D, Hd); g.bias = pr.fc2_b; g.accumulate = 1;
+    g.skws = w.skws; g.skws_floats = w.skws_floats; EP_TRY(gemm(true, true, g, 1, st)); }
   return 0;
 }
 
@@ -329,9 +336,11 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   if (!tokstat) tokstat = w.tstat;
   // The weight-gradient contractions feed nothing before the optimizer (dWv: the small kernels behind the second pass); the
   // token-pass kernel of this head takes no side workgroups: the aux stream, each contraction as early as its operands exist
-  // (AuxSide, ep_internal.h).  At 256 x 768, 1024 images: 1.367 -> 1.27 ms per step.
+  // (AuxSide, ep_internal.h).  At 256 x 768, 1024 images: 1.367 -> 1.27 ms per step.  Round 6: successive forks alternate between the
+  // aux stream and the library's second side queue -- on one queue the five contractions (45 - 80 us each) ran into the second pass,
+  // which starved the last one (236 us) and the optimizer waited ~95 us for it: 1.266 -> 1.209 ms (EP_AUX_TWO=0: one queue).
   AuxSide ax;
-  EP_TRY(aux_side_begin(ax, st, aux));
+  EP_TRY(aux_side_begin(ax, st, aux, true));
   GemmParams gW2 = mkg(dout, D, w.h1, Hd, gr.fc2_w, Hd, D, Hd, B); gW2.accumulate = acc; gW2.side = 1;
   GemmParams gW1 = mkg(w.dh1, Hd, w.h2, D, gr.fc1_w, D, Hd, D, B); gW1.accumulate = acc; gW1.side = 1;
   GemmParams gWp = mkg(w.dq1, D, w.ya, D, gr.proj_w, D, D, D, B); gWp.accumulate = acc; gWp.side = 1;
@@ -347,7 +356,8 @@ static int jepa_backward_core(const ep_jepa_dims& d, const void* x, int x_dtype,
   EP_LAUNCH_CHECK("ep_gelu_bwd_kernel");
   side_add_gemm(sd, gW1, 1);
   EP_TRY(aux_side_fork(ax, sd));                     // dW1 = dpre^T h2
-  EP_TRY(gemm(true, false, mkg(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd), 1, st));               // dh2 = dpre W1
+  { GemmParams g = mkg(w.dh1, Hd, pr.fc1_w, D, w.dh2, D, B, D, Hd); g.skws = w.skws; g.skws_floats = w.skws_floats;
+    EP_TRY(gemm(true, false, g, 1, st)); }                                                          // dh2 = dpre W1
   hipLaunchKernelGGL(ep_rowln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.dh2, w.q1, w.qstat, pr.n2_w, dout, B, D, w.dq1);
   side_add_gemm(sd, gWp, 1);
   EP_TRY(aux_side_fork(ax, sd));                     // dWp = dq1^T ya
